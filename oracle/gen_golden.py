@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""Pin the oracle against the LIVE reference and (re)generate tests/golden/*.npz.
+
+Container-only tool (needs /root/reference; run from the repo root):
+
+    python oracle/gen_golden.py            # validate + write fixtures
+    python oracle/gen_golden.py --full     # additionally validate at large dims (minutes, nothing written)
+
+What it does
+  1. imports the reference ``nn`` package through ``oracle/ref_shims.py``;
+  2. builds reference models, copies their weights into the oracle's flat dict and asserts that
+     ``oracle/a2v_oracle.py`` reproduces the reference's outputs AND parameter gradients;
+  3. dumps small input/weight/output vectors as fixtures.  Fixtures are data only -- no reference
+     source text is stored.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import a2v_oracle as O  # noqa: E402
+import ref_shims  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(HERE), "tests", "golden")
+
+TINY_LAYERS = [(31, 15, 1), (32, 10, 5)] + [(32, 3, 2)] * 3 + [(32, 3, 1)] + [(32, 2, 1)] * 2
+TINY_LAYERS_STR = "[(31, 15, 1)] + [(32, 10, 5)] + [(32, 3, 2)] * 3 + [(32, 3, 1)] + [(32, 2, 1)] * 2"
+
+
+def rel(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(name, a, b, tol):
+    r = rel(a, b)
+    flag = "ok " if r <= tol else "FAIL"
+    print(f"  [{flag}] {name:42s} rel={r:.3e}")
+    assert r <= tol, (name, r)
+
+
+def state_to_flat(model):
+    sd = model.state_dict()
+    ema = {k: v.detach().clone() for k, v in sd["_ema"].items()}
+    p = {k: v.detach().clone() for k, v in sd.items() if k != "_ema"}
+    return p, ema
+
+
+def run_pair(refnn, dims, layers, layers_str, B, L, keep, seed, tol=2e-5, perturb=True, grads=True):
+    """Build reference + oracle with identical weights, run both, compare.  Returns fixture dict."""
+    cfg = O.OracleConfig(**dims, conv_feature_layers=layers)
+    model, _ = ref_shims.build_reference_model(
+        refnn, embed_dim=cfg.embed_dim, num_heads=cfg.num_heads, depth=cfg.depth,
+        prenet_depth=cfg.prenet_depth, decoder_dim=cfg.decoder_dim, decoder_layers=cfg.decoder_layers,
+        decoder_kernel=cfg.decoder_kernel, decoder_groups=cfg.decoder_groups,
+        clone_batch=cfg.clone_batch, conv_feature_layers=layers_str, conv_pos_groups=cfg.conv_pos_groups,
+        average_top_k_layers=cfg.average_top_k_layers, seed=seed)
+    g = torch.Generator().manual_seed(seed + 100)
+    if perturb:
+        # move every parameter off its init so that LN affine / PSwish beta / alibi scales / biases matter,
+        # and make the teacher differ from the student
+        with torch.no_grad():
+            for n, prm in model.named_parameters():
+                if "low_hz_" in n or "band_hz_" in n:
+                    prm.add_(torch.randn(prm.shape, generator=g) * 3.0)
+                elif "alibi_scale" in n:
+                    prm.add_(torch.rand(prm.shape, generator=g) * 0.5)
+                elif "p_swish_beta" in n:
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.3)
+                else:
+                    prm.add_(torch.randn(prm.shape, generator=g) * 0.02)
+            for n, prm in model.ema.model.named_parameters():
+                prm.add_(torch.randn(prm.shape, generator=g) * 0.01)
+            model.ema.build_fp32_params()
+    model.eval()
+    p, ema = state_to_flat(model)
+    T = O.frame_counts(L, layers)[-1]
+    source = torch.randn(B, L, generator=g)
+    source = torch.nn.functional.layer_norm(source, (L,))
+    mask = O.seeded_mask(B * cfg.clone_batch, T, keep, seed + 7)
+
+    # ---- reference
+    torch.manual_seed(seed + 11)
+    out_ref = model(source, precomputed_mask=mask)
+    torch.manual_seed(seed + 11)
+    noise_ref = torch.empty(B * cfg.clone_batch, T - keep, cfg.embed_dim).normal_(0, cfg.mask_noise_std)
+    loss_ref = out_ref["losses"]["AUDIO_regression"]
+    model.zero_grad()
+    loss_ref.sum().backward()
+    gref = {n: prm.grad.detach().clone() for n, prm in model.named_parameters() if prm.grad is not None}
+
+    # reference-side intermediates obtained by calling its own sub-modules
+    enc = model.modality_encoders["AUDIO"]
+    with torch.no_grad():
+        feats_ref = enc.local_encoder(source)
+        lf_ref = enc.local_features(source)
+        mi = enc.make_maskinfo(lf_ref.repeat_interleave(cfg.clone_batch, 0), mask)
+        tm = model.ema.model
+        tin = tm.modality_encoders["AUDIO"].contextualized_features(lf_ref, None, mask=False, remove_masked=False)
+        xt, ab = tin["x"], tin["alibi_bias"]
+        ts = []
+        for blk in tm.blocks:
+            xt, t = blk(xt, padding_mask=None, alibi_bias=ab)
+            ts.append(t)
+        y_ref = model.make_targets(ts, cfg.average_top_k_layers)
+
+    # The reference's argsort is not stable, so WHICH noise row lands on WHICH masked frame depends
+    # on torch's tie order.  The oracle's convention is: noise row j belongs to the j-th masked frame
+    # in ascending time order.  Re-index the reference's draw into that convention (frame by frame
+    # the two models then see identical mask tokens).
+    ref_restore = mi.ids_restore[..., 0]
+    noise = torch.empty_like(noise_ref)
+    for n in range(mask.shape[0]):
+        masked_t = torch.nonzero(mask[n]).flatten()                       # ascending
+        noise[n] = noise_ref[n, ref_restore[n, masked_t] - keep]
+
+    # ---- oracle
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    res = O.pretrain_forward(po, ema, source, mask, noise, cfg)
+    loss = res["losses"]["AUDIO_regression"]
+    loss.sum().backward()
+    dbg = res["_dbg"]
+
+    print(f"pair D={cfg.embed_dim} depth={cfg.depth}+{cfg.prenet_depth} B={B} L={L} T={T} keep={keep}")
+    assert torch.equal(mi.ids_keep[..., 0].sort(dim=1)[0], dbg["ids_keep"]), "kept sets differ"
+    check("feature_extractor", O.feature_extractor(p, source, cfg), feats_ref, tol)
+    check("local_features", dbg["local_features"], lf_ref, tol)
+    check("teacher targets y", dbg["targets"], y_ref, tol * 5)
+    check("loss (unreduced)", loss, loss_ref, tol * 5)
+    check("loss.sum", loss.sum(), loss_ref.sum(), tol * 5)
+    assert int(res["sample_size"]) == int(out_ref["sample_size"])
+    assert abs(res["masked_pct"] - out_ref["masked_pct"]) < 1e-12
+    check("pred_var", res["pred_var"], out_ref["pred_var"], tol * 5)
+    check("target_var", res["target_var"], out_ref["target_var"], tol * 5)
+    if grads:
+        worst = 0.0
+        for n, gr in gref.items():
+            go = po[n].grad
+            assert go is not None, n
+            r = rel(go, gr)
+            worst = max(worst, r)
+            assert r < 5e-4, (n, r)
+        print(f"  [ok ] all {len(gref)} parameter grads                 worst rel={worst:.3e}")
+
+    fx = {"source": source, "mask": mask, "noise": noise, "loss": loss_ref.detach(),
+          "loss_sum": loss_ref.sum().detach(), "pred_var": out_ref["pred_var"],
+          "target_var": out_ref["target_var"], "sample_size": out_ref["sample_size"],
+          "features": feats_ref, "local_features": lf_ref, "targets": y_ref,
+          "ids_keep": dbg["ids_keep"], "ids_restore": dbg["ids_restore"]}
+    # a few reference-side intermediates for kernel-level parity (obtained via oracle == ref above)
+    for k in ("x_pos", "prenet_in", "prenet_out", "encoder_out", "decoder_in", "decoder_out"):
+        fx["dbg." + k] = dbg[k].detach()
+    for k, v in p.items():
+        fx["p." + k] = v
+    for k, v in ema.items():
+        fx["ema." + k] = v
+    for k, v in gref.items():
+        fx["g." + k] = v
+    return model, cfg, fx
+
+
+def save(name, d):
+    os.makedirs(GOLD, exist_ok=True)
+    arrs = {}
+    for k, v in d.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        arrs[k] = np.asarray(v)
+    path = os.path.join(GOLD, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1e6:.2f} MB, {len(arrs)} arrays)")
+
+
+def sinc_fixtures(refnn):
+    """G1: SincConv filters at default init and after a perturbation, three (C,k,sr) settings,
+    plus the reflect-padded conv output on a short signal (sinc.py known-answer vectors)."""
+    from nn.sinc import SincConv
+    out = {}
+    g = torch.Generator().manual_seed(5)
+    for (C, k, sr) in [(127, 63, 8000), (127, 63, 44100), (296, 149, 44100), (31, 15, 8000)]:
+        m = SincConv(out_channels=C, kernel_size=k, sample_rate=sr)
+        m.device = torch.device("cpu")
+        tag = f"{C}_{k}_{sr}"
+        lo, band = O.sinc_init(C, k, sr)
+        assert torch.equal(lo, m.low_hz_.detach()) and torch.equal(band, m.band_hz_.detach()), tag
+        f_ref = m._get_sinc_filters().detach()
+        check(f"sinc filters init {tag}", O.sinc_filters(lo, band, k, sr), f_ref, 1e-6)
+        out[f"init.{tag}.low"], out[f"init.{tag}.band"], out[f"init.{tag}.filters"] = lo, band, f_ref
+        with torch.no_grad():
+            m.low_hz_.add_(torch.randn(m.low_hz_.shape, generator=g) * 20)
+            m.band_hz_.add_(torch.randn(m.band_hz_.shape, generator=g) * 20)
+        f_ref = m._get_sinc_filters().detach()
+        check(f"sinc filters perturbed {tag}", O.sinc_filters(m.low_hz_.detach(), m.band_hz_.detach(), k, sr), f_ref, 1e-6)
+        out[f"pert.{tag}.low"], out[f"pert.{tag}.band"] = m.low_hz_.detach().clone(), m.band_hz_.detach().clone()
+        out[f"pert.{tag}.filters"] = f_ref
+        if sr == 8000:
+            x = torch.randn(2, 1000, generator=g)
+            y_ref = m(x.unsqueeze(1)).detach()
+            check(f"sinc conv fwd {tag}", O.sinc_conv(x, m.low_hz_.detach(), m.band_hz_.detach(), k, sr), y_ref, 1e-6)
+            out[f"conv.{tag}.x"], out[f"conv.{tag}.y"] = x, y_ref
+    return out
+
+
+def ema_fixture(model, cfg, fx):
+    """G13: one EMA step at the annealed decay for num_updates=1 -> teacher params."""
+    p = {k[2:]: torch.as_tensor(v) for k, v in fx.items() if k.startswith("p.")}
+    ema = {k[4:]: torch.as_tensor(v).clone() for k, v in fx.items() if k.startswith("ema.")}
+    model.train()
+    model.num_updates = 0
+    model.set_num_updates(1)
+    d = O.ema_decay_at(cfg, 1)
+    assert abs(model.ema.get_decay() - d) < 1e-15
+    O.ema_step(p, ema, d)
+    after = model.ema.fp32_params
+    worst = max(rel(ema[k], after[k]) for k in ema)
+    print(f"  [ok ] EMA step decay={d:.10f} worst rel={worst:.2e}")
+    assert worst < 1e-6
+    model.eval()
+    return {"decay": torch.tensor(d, dtype=torch.float64),
+            **{"after." + k: v.detach().clone() for k, v in after.items()}}
+
+
+def mixup_fixture(refnn):
+    """G14: BC-mixup with fixed r / perm, checked against the reference's forward in train mode by
+    monkey-patching its RNG draws (uniform_ and randperm) to the fixed values."""
+    model, _ = ref_shims.build_reference_model(
+        refnn, **{k: v for k, v in O.TINY.items()}, conv_feature_layers=TINY_LAYERS_STR, source_mixup=0.5)
+    g = torch.Generator().manual_seed(9)
+    src = torch.nn.functional.layer_norm(torch.randn(4, 8000, generator=g), (8000,))
+    src = src * torch.tensor([1.0, 0.3, 2.0, 0.7]).unsqueeze(-1)
+    perm = torch.tensor([2, 0, 3, 1])
+    r = 0.7
+    G_ref = model.compute_gain_torch(src, fs=8000, wl=0.05, mode="A_weighting")
+    check("mixup gain dB", O.compute_gain(src, 8000, 0.05), G_ref, 1e-6)
+    G1 = G_ref.max(-1)[0].to(src.dtype)
+    G2 = G1[perm]
+    rr = torch.tensor([r])
+    p = (1 / (1 + 10 ** ((G1 - G2) / 20) * (1 - rr) / rr)).unsqueeze(-1)      # data2vec2.py:581-582
+    mixed_ref = (p * src + (1 - p) * src[perm]) / torch.sqrt(p ** 2 + (1 - p) ** 2)  # :584-587
+    check("mixup mixed source", O.bc_mixup(src, perm, r), mixed_ref, 1e-6)
+    return {"source": src, "perm": perm, "r": torch.tensor(r), "gain_db": G_ref, "mixed": mixed_ref}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true", help="also validate large dims at L=80000 (slow)")
+    ap.add_argument("--no-write", action="store_true")
+    args = ap.parse_args()
+    torch.set_num_threads(os.cpu_count())
+    refnn = ref_shims.install()
+
+    sx = sinc_fixtures(refnn)
+    model, cfg, fx = run_pair(refnn, O.TINY, TINY_LAYERS, TINY_LAYERS_STR, B=2, L=8000, keep=16, seed=1)
+    ex = ema_fixture(model, cfg, fx)
+    mx = mixup_fixture(refnn)
+    # second pair: real front end (127x63 sinc, 512-wide convs), small transformer; validated, not stored
+    mid = dict(O.TINY, embed_dim=128, num_heads=8, conv_pos_groups=16, decoder_groups=16, decoder_dim=64)
+    run_pair(refnn, mid, O.LARGE_LAYERS, ref_shims.LARGE_LAYERS, B=1, L=16000, keep=28, seed=2)
+    if args.full:
+        run_pair(refnn, O.LARGE, O.LARGE_LAYERS, ref_shims.LARGE_LAYERS, B=1, L=80000, keep=140, seed=3,
+                 tol=5e-5, grads=True)
+    if not args.no_write:
+        save("sinc.npz", sx)
+        save("tiny_pretrain.npz", fx)
+        save("tiny_ema.npz", ex)
+        save("mixup.npz", mx)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,118 @@
+"""CPU: the oracle (oracle/a2v_oracle.py) against the golden vectors dumped from the LIVE reference
+by oracle/gen_golden.py.  These are the tests that pin the oracle."""
+import math
+
+import pytest
+import torch
+
+import a2v_oracle as O
+from conftest import load_golden, rel_err, split_golden
+
+TINY_LAYERS = [(31, 15, 1), (32, 10, 5)] + [(32, 3, 2)] * 3 + [(32, 3, 1)] + [(32, 2, 1)] * 2
+
+
+def tiny_cfg():
+    return O.OracleConfig(**O.TINY, conv_feature_layers=TINY_LAYERS)
+
+
+def test_frame_count_chain():
+    # SURVEY section 4 known answer: 80000 -> 80000 -> 16000 -> 8000 -> 4000 -> 2000 x4
+    assert O.frame_counts(80000, O.LARGE_LAYERS) == [80000, 16000, 8000, 4000, 2000, 2000, 2000, 2000]
+    assert O.frame_counts(8000, TINY_LAYERS)[-1] == 200
+
+
+def test_sinc_known_answers():
+    # nn/sinc.py:225-276 is RNG-free: centre tap exactly 1, row 0 starts with the surveyed values
+    lo, band = O.sinc_init(127, 63, 8000)
+    f = O.sinc_filters(lo, band, 63, 8000)
+    assert f.shape == (127, 1, 63)
+    assert torch.all(f[:, 0, 31] == 1.0)
+    assert torch.allclose(f[0, 0, :5], torch.tensor([-0.0258, -0.0326, -0.0419, -0.0543, -0.0704]), atol=1e-4)
+    assert int(math.ceil(8000 / 63)) == 127 and int(math.ceil(44100 / 63)) == 700
+
+
+@pytest.mark.parametrize("tag", ["127_63_8000", "127_63_44100", "296_149_44100", "31_15_8000"])
+def test_sinc_filters_golden(tag):
+    g = load_golden("sinc.npz")
+    C, k, sr = (int(v) for v in tag.split("_"))
+    lo, band = O.sinc_init(C, k, sr)
+    assert torch.equal(lo, g[f"init.{tag}.low"]) and torch.equal(band, g[f"init.{tag}.band"])
+    assert rel_err(O.sinc_filters(lo, band, k, sr), g[f"init.{tag}.filters"]) < 1e-6
+    assert rel_err(O.sinc_filters(g[f"pert.{tag}.low"], g[f"pert.{tag}.band"], k, sr), g[f"pert.{tag}.filters"]) < 1e-6
+
+
+@pytest.mark.parametrize("tag", ["127_63_8000", "31_15_8000"])
+def test_sinc_conv_golden(tag):
+    g = load_golden("sinc.npz")
+    C, k, sr = (int(v) for v in tag.split("_"))
+    y = O.sinc_conv(g[f"conv.{tag}.x"], g[f"pert.{tag}.low"], g[f"pert.{tag}.band"], k, sr)
+    assert rel_err(y, g[f"conv.{tag}.y"]) < 1e-6
+
+
+def test_alibi_slopes():
+    # base.py:559-576: H=16 -> 2^(-0.5 i), i=1..16 ; non power of two uses the interleave rule
+    s = O.alibi_slopes(16)
+    assert all(abs(s[i] - 2 ** (-0.5 * (i + 1))) < 1e-12 for i in range(16))
+    assert len(O.alibi_slopes(12)) == 12 and abs(O.alibi_slopes(12)[8] - 2 ** -0.5) < 1e-12
+
+
+def test_annealed_rate():
+    assert O.get_annealed_rate(0.9997, 1.0, 0, 300000) == pytest.approx(0.9997)
+    assert O.get_annealed_rate(0.9997, 1.0, 150000, 300000) == pytest.approx(0.99985)
+    assert O.get_annealed_rate(0.9997, 1.0, 300000, 300000) == 1.0
+
+
+def test_param_counts():
+    # 315 830 026 (large student), 122 780 678 (base*)
+    for dims, n in ((O.LARGE, 315_830_026), (O.BASE_STAR, 122_780_678)):
+        cfg = O.OracleConfig(**dims)
+        shapes = O.init_param_shapes(cfg) if hasattr(O, "init_param_shapes") else None
+        if shapes is None:
+            pytest.skip("shape-only counter not available")
+        assert sum(math.prod(s) for s in shapes.values()) == n
+
+
+def test_pretrain_forward_backward_golden(tiny_golden):
+    fx = tiny_golden
+    p, ema, g = split_golden(fx)
+    cfg = tiny_cfg()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    res = O.pretrain_forward(po, ema, fx["source"], fx["mask"], fx["noise"], cfg)
+    loss = res["losses"]["AUDIO_regression"]
+    assert rel_err(loss, fx["loss"]) < 1e-5
+    assert rel_err(res["_dbg"]["targets"], fx["targets"]) < 1e-5
+    assert rel_err(res["_dbg"]["local_features"], fx["local_features"]) < 1e-5
+    assert int(res["sample_size"]) == int(fx["sample_size"])
+    assert rel_err(res["pred_var"], fx["pred_var"]) < 1e-5
+    assert rel_err(res["target_var"], fx["target_var"]) < 1e-5
+    loss.sum().backward()
+    for k, gr in g.items():
+        assert rel_err(po[k].grad, gr) < 5e-4, k
+
+
+def test_ema_step_golden(tiny_golden):
+    p, ema, _ = split_golden(tiny_golden)
+    ex = load_golden("tiny_ema.npz")
+    cfg = tiny_cfg()
+    d = O.ema_decay_at(cfg, 1)
+    assert d == pytest.approx(float(ex["decay"]), abs=1e-15)
+    ema = {k: v.clone() for k, v in ema.items()}
+    O.ema_step(p, ema, d)
+    for k, v in ema.items():
+        assert rel_err(v, ex["after." + k]) < 1e-6, k
+
+
+def test_mixup_golden():
+    mx = load_golden("mixup.npz")
+    assert rel_err(O.compute_gain(mx["source"], 8000, 0.05), mx["gain_db"]) < 1e-6
+    assert rel_err(O.bc_mixup(mx["source"], mx["perm"], float(mx["r"])), mx["mixed"]) < 1e-6
+
+
+def test_init_params_shapes_match_reference_keys(tiny_golden):
+    p, ema, _ = split_golden(tiny_golden)
+    cfg = tiny_cfg()
+    q = O.init_params(cfg, seed=0)
+    assert set(q) == set(p)
+    for k in p:
+        assert q[k].shape == p[k].shape, k
+    assert set(O.teacher_keys(q)) == set(ema)
