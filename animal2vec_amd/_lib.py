@@ -1,0 +1,82 @@
+"""ctypes binding of liba2v_hip.so -- the C-ABI boundary of the MI355X hot path (include/a2v.h).
+
+The library is REQUIRED: there is no CPU or torch fallback anywhere in the product path.  If the
+shared object is missing or a symbol cannot be resolved, importing the ops fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liba2v_hip.so")
+
+F32, BF16 = 0, 1
+EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM = 1, 2, 4, 8, 16, 32
+
+_p, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+
+# name -> argtypes (mirrors include/a2v.h one to one; tests/test_abi.py cross-checks both)
+SIGNATURES = {
+    "a2v_conv_gemm": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _ll, _p, _ll, _i, _p, _p, _ll,
+                      _p, _p, _i, _i, _i, _i, _i, _p],
+    "a2v_conv_wgrad": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
+                       _i, _p],
+    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "a2v_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _f, _i, _p],
+    "a2v_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _p],
+    "a2v_instnorm_targets": [_i, C.POINTER(_p), _i, _p, _p, _p, _i, _i, _i, _f, _p],
+    "a2v_colsum": [_i, _p, _p, _ll, _i, _ll, _p],
+    "a2v_sinc_filters_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _p],
+    "a2v_sinc_filters_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _p],
+    "a2v_sinc_fused_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
+    "a2v_sinc_fused_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "a2v_gather_tokens": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "a2v_scatter_tokens": [_i, _p, _p, _p, _i, _i, _i, _i, _p],
+    "a2v_clone_reduce": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "a2v_decoder_input": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "a2v_d2v_loss": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
+    "a2v_ema_update": [_p, _p, _ll, _f, _p],
+    "a2v_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p],
+    "a2v_sumsq": [_p, _ll, _p, _p],
+    "a2v_pack_weight": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
+    "a2v_unpack_wgrad": [_p, _p, _i, _i, _i, _i, _p],
+    "a2v_col2im": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _p],
+    "a2v_cast2d": [_i, _i, _p, _p, _ll, _i, _ll, _ll, _p],
+    "a2v_abi_version": [],
+}
+
+_lib = None
+
+
+class A2VError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load liba2v_hip.so (never builds, never falls back)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise A2VError(
+            f"{LIB_PATH} is missing: the HIP extension is mandatory (run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `python animal2vec_amd/build.py`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise A2VError(f"liba2v_hip.so does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        if rc <= -1000:
+            raise A2VError(f"{what}: HIP launch error {-(rc + 1000)}")
+        raise A2VError(f"{what}: {({-1: 'bad argument', -2: 'bad dtype'}).get(rc, rc)}")

@@ -1,0 +1,65 @@
+"""Builds liba2v_hip.so (hipcc, gfx950 only) in-tree.  No JIT cache: the .so travels with the repo."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "build")
+LIB = os.path.join(HERE, "liba2v_hip.so")
+SOURCES = ["a2v_gemm.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    hdr = os.path.join(CSRC, "a2v_common.h")
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src, hdr]):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

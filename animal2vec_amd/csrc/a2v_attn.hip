@@ -1,0 +1,581 @@
+// Fused multi-head attention with analytic ALiBi for gfx950 (reference modules.py:368-410 +
+// base.py:292-314,553-698).  The (N,H,S,S) bias tensor of the reference is never built: the bias is
+//     -slope_h * max(alibi_scale_h, 0) * |pos[n,i] - pos[n,j]|
+// computed in-register from the original frame indices of the (possibly masked-out) tokens.
+//
+// Forward  : flash style, 64 query rows per workgroup (4 waves x 16), 64-key tiles through LDS.
+//            Products are issued "swapped" (S^T = K Q^T, O^T = V^T P^T) so that a query row lives on
+//            one lane column: softmax statistics are lane-local (+2 shuffles) and P never leaves
+//            registers (its accumulator layout IS the next MFMA's B operand, k order permuted).
+// Backward : one workgroup per 64-key block, loops over query tiles ("key on the lane"): dK^T, dV^T
+//            accumulate in registers, only dS crosses LDS once for dQ, dQ is summed across key
+//            blocks with fp32 atomics; d(alibi_scale) is reduced per head.
+// qkv layout (N,S,3,H,HD) = the qkv Linear's output; O / dO layout (N,S,H*HD).
+// T = bf16 -> v_mfma_f32_16x16x32_bf16 ; T = float -> v_mfma_f32_16x16x4_f32 (parity mode).
+#include "a2v_common.h"
+#include <type_traits>
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+template <typename T> struct AT {   // LDS tile addressing for [64][HD] tiles
+  // row-read image (ds_read_b128 of 8 contiguous d): XOR swizzle of 16-B chunks
+  // tr-read image (4 rows x 16 cols blocks): XOR swizzle of 32-B blocks
+};
+
+template <int HD> __device__ __forceinline__ int rowimg_off(int r, int chunk) {   // bf16, 16-B chunk index
+  constexpr int NCH = HD / 8;
+  return r * (HD * 2) + (((chunk ^ ((r >> 1) & (NCH - 1))) & (NCH - 1)) << 4);
+}
+template <int HD> __device__ __forceinline__ int trimg_off(int r, int col) {     // bf16 element (r,col)
+  constexpr int NB = HD / 16;
+  return r * (HD * 2) + ((((col >> 4) ^ ((r >> 1) & (NB - 1))) & (NB - 1)) << 5) + ((col & 15) << 1);
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile_lo, const char* tile_hi) {
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)tile_lo);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)tile_hi);
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+struct AttnArgs {
+  const void* qkv; void* out; float* lse;
+  const int* pos;                 // (N,S) original frame index or nullptr (= arange)
+  const float* slopes;            // (H)
+  const float* alibi_scale;       // (H) learned, clamped at 0 here
+  int N, S, H;
+  float scale;
+};
+
+#define FP32_PITCH(HD) ((HD) + 4)
+
+// =============================================================================================
+//                                            forward
+// =============================================================================================
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  constexpr bool BF = std::is_same<T, bf16>::value;
+  constexpr int ND = HD / 16;                 // 16-wide d blocks
+  constexpr int TILE_BYTES = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
+  __shared__ __attribute__((aligned(16))) char sK[TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char sV[TILE_BYTES];
+  __shared__ float sPos[64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;                 // elements between tokens in qkv
+  const T* qkv = (const T*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  const float coef = -a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f);
+
+  const int q = q0 + wid * 16 + fr;                          // this lane's query row
+  const int qc = q < S ? q : S - 1;
+  const float pos_q = a.pos ? (float)a.pos[(long long)n * S + qc] : (float)qc;
+
+  // Q fragments (B operand of S^T = K Q^T): lane (q=fr, g) holds Q[q][8g+jj (+32ks)]
+  bf16x8 qf_b[BF ? HD / 32 : 1];
+  float qf_f[BF ? 1 : HD / 4];
+  if constexpr (BF) {
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) qf_b[ks] = *(const bf16x8*)(qkv + (long long)qc * rowstride + ks * 32 + g * 8);
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < HD / 4; ++ks) qf_f[ks] = qkv[(long long)qc * rowstride + ks * 4 + g];
+  }
+
+  f32x4 o[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntile = (S + 63) / 64;
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int kv0 = kt * 64;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage K and V tiles (zero fill past S)
+    if constexpr (BF) {
+      constexpr int NCH = HD / 8;                        // 16-B chunks per row
+      for (int c = tid; c < 64 * NCH; c += 256) {
+        const int r = c / NCH, ch = c % NCH;
+        uint4 kz = {0u, 0u, 0u, 0u}, vz = {0u, 0u, 0u, 0u};
+        if (kv0 + r < S) {
+          const T* base = qkv + (long long)(kv0 + r) * rowstride + ch * 8;
+          kz = *(const uint4*)(base + (long long)H * HD);
+          vz = *(const uint4*)(base + 2LL * H * HD);
+        }
+        *(uint4*)(sK + rowimg_off<HD>(r, ch)) = kz;
+        *(uint4*)(sV + trimg_off<HD>(r, ch * 8)) = vz;
+      }
+    } else {
+      constexpr int NCH = HD / 4;
+      for (int c = tid; c < 64 * NCH; c += 256) {
+        const int r = c / NCH, ch = c % NCH;
+        uint4 kz = {0u, 0u, 0u, 0u}, vz = {0u, 0u, 0u, 0u};
+        if (kv0 + r < S) {
+          const T* base = qkv + (long long)(kv0 + r) * rowstride + ch * 4;
+          kz = *(const uint4*)(base + (long long)H * HD);
+          vz = *(const uint4*)(base + 2LL * H * HD);
+        }
+        *(uint4*)((float*)sK + r * FP32_PITCH(HD) + ch * 4) = kz;
+        *(uint4*)((float*)sV + r * FP32_PITCH(HD) + ch * 4) = vz;
+      }
+    }
+    if (tid < 64) {
+      const int kv = kv0 + tid;
+      sPos[tid] = kv < S ? (a.pos ? (float)a.pos[(long long)n * S + kv] : (float)kv) : 0.f;
+    }
+    __syncthreads();
+
+    // ---- S^T tiles: s[j][r] = score(kv = kv0+16j+4g+r, q)
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (BF) {
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(sK + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf_b[ks], acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < HD / 4; ++ks) {
+          const float kf = ((const float*)sK)[(16 * j + fr) * FP32_PITCH(HD) + ks * 4 + g];
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf, qf_f[ks], acc, 0, 0, 0);
+        }
+      }
+      s[j] = acc;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kvl = 16 * j + 4 * g + r;
+        float v = s[j][r] * a.scale + coef * fabsf(pos_q - sPos[kvl]);
+        v = (kv0 + kvl < S) ? v : -INFINITY;
+        s[j][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __expf(s[j][r] - m_new);
+        s[j][r] = p;
+        ps += p;
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] *= alpha;
+
+    // ---- O^T += V^T P^T
+    if constexpr (BF) {
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pf[r] = (bf16)s[2 * st][r]; pf[4 + r] = (bf16)s[2 * st + 1][r]; }
+        const int qq = (lane & 15) >> 2, pp = lane & 3;
+        const int r_lo = 32 * st + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const bf16x8 vf = tr_frag(sV + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sV + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+          o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[i], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kvl = 16 * j + 4 * g + r;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) {
+            const float vf = ((const float*)sV)[kvl * FP32_PITCH(HD) + 16 * i + fr];
+            o[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf, s[j][r], o[i], 0, 0, 0);
+          }
+        }
+    }
+  }
+  // ---- finish: O = O^T / l ; lse = m + log(l)
+  float l_tot = l_run;
+  l_tot += __shfl_xor(l_tot, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q < S) {
+    T* orow = (T*)a.out + ((long long)n * S + q) * ((long long)H * HD) + (long long)h * HD;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      f32x4 v = o[i] * inv;
+      Vec4<T>::store(orow + 16 * i + 4 * g, v);
+    }
+    if (g == 0 && a.lse) a.lse[((long long)n * H + h) * S + q] = m_run + __logf(l_tot);
+  }
+}
+
+// =============================================================================================
+//                                            backward
+// =============================================================================================
+// delta[n,h,s] = sum_d dO[n,s,h,d] * O[n,s,h,d]
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o, const T* __restrict__ d_o,
+                                                         float* __restrict__ delta, int N, int S, int H) {
+  const long long total = (long long)N * S * H;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int h = (int)(i % H);
+    const long long ns = i / H;
+    const T* po = o + ns * ((long long)H * HD) + (long long)h * HD;
+    const T* pd = d_o + ns * ((long long)H * HD) + (long long)h * HD;
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; d += 4) {
+      const f32x4 x = Vec4<T>::load(po + d), y = Vec4<T>::load(pd + d);
+      acc += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+    }
+    const int n = (int)(ns / S), s = (int)(ns - (long long)n * S);
+    delta[((long long)n * H + h) * S + s] = acc;
+  }
+}
+
+struct AttnBwdArgs {
+  const void* qkv; const void* d_out; const float* lse; const float* delta;
+  void* dqkv;               // (N,S,3,H,HD): k and v slots written here
+  float* dq32;              // (N,S,H,HD) fp32, zeroed by the caller, accumulated with atomics
+  float* dalibi;            // (H) fp32 accumulated: d loss / d alibi_scale_h
+  const int* pos; const float* slopes; const float* alibi_scale;
+  int N, S, H;
+  float scale;
+};
+
+template <typename T, int HD>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+  constexpr bool BF = std::is_same<T, bf16>::value;
+  constexpr int ND = HD / 16;
+  constexpr int TILE_BYTES = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
+  constexpr int DS_BYTES = BF ? 64 * 64 * 2 : 64 * 68 * 4;
+  // dynamic LDS carve-up (all offsets multiples of 16 B)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sQ = smem;                                   // [q][d] row image
+  char* const sDO = sQ + TILE_BYTES;                       // [q][d] row image of dO
+  char* const sKt = sDO + TILE_BYTES;                      // K tile for dQ (tr image for bf16)
+  char* const sDS = sKt + TILE_BYTES;                      // dS [q][kv]
+  float* const sLse = (float*)(sDS + DS_BYTES);
+  float* const sDelta = sLse + 64;
+  float* const sPosQ = sDelta + 64;
+  char* const sQt = (char*)(sPosQ + 64);                   // bf16 only: tr image of Q
+  char* const sDOt = sQt + TILE_BYTES;                     // bf16 only: tr image of dO
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int kv0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const long long orow = (long long)H * HD;
+  const T* qkv = (const T*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  const T* dO = (const T*)a.d_out + (long long)n * S * orow + (long long)h * HD;
+  const float slope = a.slopes[h];
+  const float asc = a.alibi_scale[h];
+  const float coef = -slope * fmaxf(asc, 0.f);
+
+  const int kv = kv0 + wid * 16 + fr;            // this lane's key column
+  const int kvc = kv < S ? kv : S - 1;
+  const bool kv_ok = kv < S;
+  const float pos_kv = a.pos ? (float)a.pos[(long long)n * S + kvc] : (float)kvc;
+
+  // K / V fragments as B operands (k = d, col = kv): lane (kv=fr, g)
+  bf16x8 kf_b[BF ? HD / 32 : 1], vf_b[BF ? HD / 32 : 1];
+  float kf_f[BF ? 1 : HD / 4], vf_f[BF ? 1 : HD / 4];
+  if constexpr (BF) {
+#pragma unroll
+    for (int ks = 0; ks < HD / 32; ++ks) {
+      kf_b[ks] = *(const bf16x8*)(qkv + (long long)kvc * rowstride + (long long)H * HD + ks * 32 + g * 8);
+      vf_b[ks] = *(const bf16x8*)(qkv + (long long)kvc * rowstride + 2LL * H * HD + ks * 32 + g * 8);
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < HD / 4; ++ks) {
+      kf_f[ks] = qkv[(long long)kvc * rowstride + (long long)H * HD + ks * 4 + g];
+      vf_f[ks] = qkv[(long long)kvc * rowstride + 2LL * H * HD + ks * 4 + g];
+    }
+  }
+  // K tile of the whole block for the dQ product
+  if constexpr (BF) {
+    constexpr int NCH = HD / 8;
+    for (int c = tid; c < 64 * NCH; c += 256) {
+      const int r = c / NCH, ch = c % NCH;
+      uint4 kz = {0u, 0u, 0u, 0u};
+      if (kv0 + r < S) kz = *(const uint4*)(qkv + (long long)(kv0 + r) * rowstride + (long long)H * HD + ch * 8);
+      *(uint4*)(sKt + trimg_off<HD>(r, ch * 8)) = kz;
+    }
+  } else {
+    constexpr int NCH = HD / 4;
+    for (int c = tid; c < 64 * NCH; c += 256) {
+      const int r = c / NCH, ch = c % NCH;
+      uint4 kz = {0u, 0u, 0u, 0u};
+      if (kv0 + r < S) kz = *(const uint4*)(qkv + (long long)(kv0 + r) * rowstride + (long long)H * HD + ch * 4);
+      *(uint4*)((float*)sKt + r * FP32_PITCH(HD) + ch * 4) = kz;
+    }
+  }
+
+  f32x4 dk[ND], dv[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  float dal = 0.f;
+
+  const int ntile = (S + 63) / 64;
+  for (int qt = 0; qt < ntile; ++qt) {
+    const int q0 = qt * 64;
+    __syncthreads();
+    // ---- stage Q and dO tiles (+ lse, delta, pos)
+    if constexpr (BF) {
+      constexpr int NCH = HD / 8;
+      for (int c = tid; c < 64 * NCH; c += 256) {
+        const int r = c / NCH, ch = c % NCH;
+        uint4 qz = {0u, 0u, 0u, 0u}, dz = {0u, 0u, 0u, 0u};
+        if (q0 + r < S) {
+          qz = *(const uint4*)(qkv + (long long)(q0 + r) * rowstride + ch * 8);
+          dz = *(const uint4*)(dO + (long long)(q0 + r) * orow + ch * 8);
+        }
+        *(uint4*)(sQ + rowimg_off<HD>(r, ch)) = qz;
+        *(uint4*)(sQt + trimg_off<HD>(r, ch * 8)) = qz;
+        *(uint4*)(sDO + rowimg_off<HD>(r, ch)) = dz;
+        *(uint4*)(sDOt + trimg_off<HD>(r, ch * 8)) = dz;
+      }
+    } else {
+      constexpr int NCH = HD / 4;
+      for (int c = tid; c < 64 * NCH; c += 256) {
+        const int r = c / NCH, ch = c % NCH;
+        uint4 qz = {0u, 0u, 0u, 0u}, dz = {0u, 0u, 0u, 0u};
+        if (q0 + r < S) {
+          qz = *(const uint4*)(qkv + (long long)(q0 + r) * rowstride + ch * 4);
+          dz = *(const uint4*)(dO + (long long)(q0 + r) * orow + ch * 4);
+        }
+        *(uint4*)((float*)sQ + r * FP32_PITCH(HD) + ch * 4) = qz;
+        *(uint4*)((float*)sDO + r * FP32_PITCH(HD) + ch * 4) = dz;
+      }
+    }
+    if (tid < 64) {
+      const int qq = q0 + tid;
+      const bool ok = qq < S;
+      const long long si = ((long long)n * H + h) * S + (ok ? qq : 0);
+      sLse[tid] = ok ? a.lse[si] : INFINITY;     // exp(x - inf) = 0 -> padded query rows contribute nothing
+      sDelta[tid] = ok ? a.delta[si] : 0.f;
+      sPosQ[tid] = ok ? (a.pos ? (float)a.pos[(long long)n * S + qq] : (float)qq) : 0.f;
+    }
+    __syncthreads();
+
+    // ---- S, P, dP, dS for the 4 query sub-blocks; rows q = 16i+4g+r, col kv = fr
+    f32x4 p[4], ds[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (BF) {
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) {
+          const bf16x8 qa = *(const bf16x8*)(sQ + rowimg_off<HD>(16 * i + fr, ks * 4 + g));
+          const bf16x8 da = *(const bf16x8*)(sDO + rowimg_off<HD>(16 * i + fr, ks * 4 + g));
+          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf_b[ks], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf_b[ks], pacc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < HD / 4; ++ks) {
+          const float qa = ((const float*)sQ)[(16 * i + fr) * FP32_PITCH(HD) + ks * 4 + g];
+          const float da = ((const float*)sDO)[(16 * i + fr) * FP32_PITCH(HD) + ks * 4 + g];
+          sacc = __builtin_amdgcn_mfma_f32_16x16x4f32(qa, kf_f[ks], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_16x16x4f32(da, vf_f[ks], pacc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ql = 16 * i + 4 * g + r;
+        const float dist = fabsf(sPosQ[ql] - pos_kv);
+        const float sc = sacc[r] * a.scale + coef * dist;
+        const float pv = kv_ok ? __expf(sc - sLse[ql]) : 0.f;
+        const float dsv = pv * (pacc[r] - sDelta[ql]);
+        p[i][r] = pv;
+        ds[i][r] = dsv;
+        dal -= dsv * dist;
+      }
+    }
+    // ---- dS -> LDS (for dQ), as [q][kv]
+    if constexpr (BF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * i + 4 * g + r;
+          const int col = wid * 16 + fr;
+          *(bf16*)(sDS + ql * 128 + ((((col >> 3) ^ ((ql >> 1) & 7)) & 7) << 4) + ((col & 7) << 1)) = (bf16)ds[i][r];
+        }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ((float*)sDS)[(16 * i + 4 * g + r) * 68 + wid * 16 + fr] = ds[i][r];
+    }
+
+    // ---- dV^T += dO^T P ; dK^T += Q^T dS      (k = q, permuted order shared by both operands)
+    if constexpr (BF) {
+      const int qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf, df;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[r] = (bf16)p[2 * st][r]; pf[4 + r] = (bf16)p[2 * st + 1][r];
+          df[r] = (bf16)ds[2 * st][r]; df[4 + r] = (bf16)ds[2 * st + 1][r];
+        }
+        const int r_lo = 32 * st + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const bf16x8 dof = tr_frag(sDOt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sDOt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+          const bf16x8 qf = tr_frag(sQt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sQt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+          dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[i], 0, 0, 0);
+          dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, df, dk[i], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * j + 4 * g + r;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) {
+            const float dof = ((const float*)sDO)[ql * FP32_PITCH(HD) + 16 * i + fr];
+            const float qf = ((const float*)sQ)[ql * FP32_PITCH(HD) + 16 * i + fr];
+            dv[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(dof, p[j][r], dv[i], 0, 0, 0);
+            dk[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(qf, ds[j][r], dk[i], 0, 0, 0);
+          }
+        }
+    }
+    __syncthreads();   // dS tile complete
+
+    // ---- dQ[q rows 16*wid..][d] += dS K * scale : A = dS rows, B = K (k = kv, col = d)
+    f32x4 dq[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (BF) {
+      const int qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int rq = wid * 16 + fr;
+        const int ch = ks * 4 + g;
+        const bf16x8 af = *(const bf16x8*)(sDS + rq * 128 + (((ch ^ ((rq >> 1) & 7)) & 7) << 4));
+        const int r_lo = 32 * ks + 8 * g + qq, r_hi = r_lo + 4;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const bf16x8 kf = tr_frag(sKt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sKt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+          dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, dq[i], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        const float af = ((const float*)sDS)[(wid * 16 + fr) * 68 + ks * 4 + g];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const float kf = ((const float*)sKt)[(ks * 4 + g) * FP32_PITCH(HD) + 16 * i + fr];
+          dq[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, kf, dq[i], 0, 0, 0);
+        }
+      }
+    }
+    // D: row q = q0 + 16*wid + 4g + r, col d = 16i + fr
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq2 = q0 + wid * 16 + 4 * g + r;
+      if (qq2 < S) {
+        float* dst = a.dq32 + (((long long)n * S + qq2) * H + h) * HD;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) atomicAdd(dst + 16 * i + fr, dq[i][r] * a.scale);
+      }
+    }
+  }
+  // ---- write dK, dV: D rows d = 16i+4g+r, col kv = fr
+  if (kv_ok) {
+    T* dkv = (T*)a.dqkv + ((long long)n * S + kv) * rowstride + (long long)h * HD;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      f32x4 kk = dk[i] * a.scale;
+      Vec4<T>::store(dkv + (long long)H * HD + 16 * i + 4 * g, kk);
+      Vec4<T>::store(dkv + 2LL * H * HD + 16 * i + 4 * g, dv[i]);
+    }
+  }
+  // ---- d alibi_scale_h = slope_h * [scale_h >= 0] * sum dS * (-dist)
+  dal = wave_sum(dal);
+  if (lane == 0 && a.dalibi && asc >= 0.f) atomicAdd(a.dalibi + h, dal * slope);
+}
+
+// =============================================================================================
+template <typename T, int HD>
+static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
+  dim3 grid((a.S + 63) / 64, a.H, a.N);
+  hipLaunchKernelGGL((attn_fwd_kernel<T, HD>), grid, dim3(256), 0, st, a);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const int* pos, const float* slopes,
+                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, hipStream_t stream) {
+  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale) return A2V_ERR_ARG;
+  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale};
+  if (dtype == A2V_BF16) {
+    if (HD == 64) return attn_fwd_launch<bf16, 64>(a, stream);
+    if (HD == 32) return attn_fwd_launch<bf16, 32>(a, stream);
+    return A2V_ERR_ARG;
+  }
+  if (dtype == A2V_F32) {
+    if (HD == 64) return attn_fwd_launch<float, 64>(a, stream);
+    if (HD == 32) return attn_fwd_launch<float, 32>(a, stream);
+    if (HD == 16) return attn_fwd_launch<float, 16>(a, stream);
+    return A2V_ERR_ARG;
+  }
+  return A2V_ERR_DTYPE;
+}
+
+template <typename T, int HD>
+static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, hipStream_t st) {
+  const long long total = (long long)a.N * a.S * a.H;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3(g), dim3(256), 0, st, (const T*)out, (const T*)a.d_out, delta, a.N, a.S, a.H);
+  dim3 grid((a.S + 63) / 64, a.H, a.N);
+  constexpr bool BF = std::is_same<T, bf16>::value;
+  constexpr int TILE = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
+  constexpr int LDS = (BF ? 5 : 3) * TILE + (BF ? 64 * 64 * 2 : 64 * 68 * 4) + 3 * 64 * 4;
+  (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  hipLaunchKernelGGL((attn_bwd_kernel<T, HD>), grid, dim3(256), LDS, st, a);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+// dq32 must be zero on entry; delta is (N,H,S) fp32 scratch.  dQ is left in dq32 (fp32, (N,S,H,HD));
+// the caller casts it into the q slot of dqkv (a2v_cast2d).
+extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse,
+                                 float* delta, void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
+                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, hipStream_t stream) {
+  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || !dq32) return A2V_ERR_ARG;
+  AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale};
+  if (dtype == A2V_BF16) {
+    if (HD == 64) return attn_bwd_launch<bf16, 64>(a, out, delta, stream);
+    if (HD == 32) return attn_bwd_launch<bf16, 32>(a, out, delta, stream);
+    return A2V_ERR_ARG;
+  }
+  if (dtype == A2V_F32) {
+    if (HD == 64) return attn_bwd_launch<float, 64>(a, out, delta, stream);
+    if (HD == 32) return attn_bwd_launch<float, 32>(a, out, delta, stream);
+    if (HD == 16) return attn_bwd_launch<float, 16>(a, out, delta, stream);
+    return A2V_ERR_ARG;
+  }
+  return A2V_ERR_DTYPE;
+}

@@ -1,0 +1,116 @@
+// Shared device helpers for the animal2vec gfx950 (MI355X / CDNA4) kernels.
+// Wavefront = 64 lanes everywhere; no 32-lane idioms.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define A2V_OK 0
+#define A2V_ERR_ARG (-1)
+#define A2V_ERR_DTYPE (-2)
+#define A2V_ERR_LAUNCH (-3)
+
+// dtype codes used across the C ABI
+#define A2V_F32 0
+#define A2V_BF16 1
+
+#define A2V_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return -(int)(1000 + (int)e__);   \
+  } while (0)
+
+template <typename T> struct Cvt;
+template <> struct Cvt<float> {
+  static __device__ __forceinline__ float to(float v) { return v; }
+  static __device__ __forceinline__ float from(float v) { return v; }
+};
+template <> struct Cvt<bf16> {
+  static __device__ __forceinline__ float to(bf16 v) { return (float)v; }
+  static __device__ __forceinline__ bf16 from(float v) { return (bf16)v; }
+};
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return Cvt<T>::to(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { *p = Cvt<T>::from(v); }
+
+// 4-wide vector load/store as floats (T = float: 16 B, T = bf16: 8 B); pointers must be aligned.
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+  static __device__ __forceinline__ f32x4 load(const float* p) { return *(const f32x4*)p; }
+  static __device__ __forceinline__ void store(float* p, f32x4 v) { *(f32x4*)p = v; }
+};
+template <> struct Vec4<bf16> {
+  static __device__ __forceinline__ f32x4 load(const bf16* p) {
+    bf16x4 v = *(const bf16x4*)p;
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+  }
+  static __device__ __forceinline__ void store(bf16* p, f32x4 v) {
+    bf16x4 r = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+    *(bf16x4*)p = r;
+  }
+};
+
+// 8-wide (T = bf16: one 16-B access; T = float: two)
+template <typename T> struct Vec8;
+template <> struct Vec8<bf16> {
+  static __device__ __forceinline__ void load(const bf16* p, float* o) {
+    bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+  }
+  static __device__ __forceinline__ void store(bf16* p, const float* o) {
+    bf16x8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+    *(bf16x8*)p = v;
+  }
+};
+template <> struct Vec8<float> {
+  static __device__ __forceinline__ void load(const float* p, float* o) {
+    f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+  }
+  static __device__ __forceinline__ void store(float* p, const float* o) {
+    f32x4 a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]};
+    *(f32x4*)p = a; *(f32x4*)(p + 4) = b;
+  }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// exact (erf) GELU, as torch.nn.GELU() default
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: ids that share (id % 8) run on one XCD
+// (round-robin dispatch), so give each XCD a contiguous chunk of the tile space.
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  const int q = n >> 3, r = n & 7, x = id & 7, loc = id >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+}
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,434 @@
+// HBM-bound index / elementwise kernels of the animal2vec pretraining path: token gather under
+// clone-batch masking (never materialising the clone_batch-fold copy), decoder input assembly,
+// fused masked MSE loss + gradient + variance statistics, EMA, Adam, weight packing, col2im.
+// All rows are channels-last; every thread moves 16 bytes where the layout allows it.
+#include "a2v_common.h"
+
+// ---------------------------------------------------------------------------------- gather tokens
+// out[n,k,:] = a[n/cb, ids[n,k], :] (+ b[n, ids[n,k], :])        reference base.py:244,447,277-280
+template <typename T>
+__global__ __launch_bounds__(256) void gather_tokens_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                            const int* __restrict__ ids, T* __restrict__ out, int N,
+                                                            int K, int D, int Ta, int cb) {
+  const int vecs = D / 8;
+  const long long total = (long long)N * K * vecs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vecs);
+    const long long nk = i / vecs;
+    const int n = (int)(nk / K);
+    const int t = ids[nk];
+    float x[8];
+    Vec8<T>::load(a + ((long long)(n / cb) * Ta + t) * D + v * 8, x);
+    if (b) {
+      float y[8];
+      Vec8<T>::load(b + ((long long)n * Ta + t) * D + v * 8, y);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] += y[j];
+    }
+    Vec8<T>::store(out + nk * D + v * 8, x);
+  }
+}
+
+// dpos[n,t,:] = restore[n,t] < K ? dtok[n, restore[n,t], :] : 0        (scatter of kept-token grads)
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_tokens_kernel(const T* __restrict__ dtok, const int* __restrict__ restore,
+                                                             T* __restrict__ dpos, int N, int K, int D, int Tn) {
+  const int vecs = D / 8;
+  const long long total = (long long)N * Tn * vecs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vecs);
+    const long long nt = i / vecs;
+    const int n = (int)(nt / Tn);
+    const int r = restore[nt];
+    float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < K) Vec8<T>::load(dtok + ((long long)n * K + r) * D + v * 8, x);
+    Vec8<T>::store(dpos + nt * D + v * 8, x);
+  }
+}
+
+// dfeat[b,t,:] = sum_{c<cb, n=b*cb+c, kept(n,t)} ( dxm[n,t,:] + dtok[n, restore[n,t], :] )
+// gradient of: x.repeat_interleave(cb) -> {x*(1-mask) -> pos-conv input ; gather kept tokens}
+template <typename T>
+__global__ __launch_bounds__(256) void clone_reduce_kernel(const T* __restrict__ dxm, const T* __restrict__ dtok,
+                                                           const int* __restrict__ restore, T* __restrict__ dfeat,
+                                                           int B, int cb, int K, int D, int Tn) {
+  const int vecs = D / 8;
+  const long long total = (long long)B * Tn * vecs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vecs);
+    const long long bt = i / vecs;
+    const int b = (int)(bt / Tn), t = (int)(bt - (long long)b * Tn);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < cb; ++c) {
+      const int n = b * cb + c;
+      const int r = restore[(long long)n * Tn + t];
+      if (r < K) {
+        float x[8], y[8];
+        Vec8<T>::load(dxm + ((long long)n * Tn + t) * D + v * 8, x);
+        Vec8<T>::load(dtok + ((long long)n * K + r) * D + v * 8, y);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += x[j] + y[j];
+      }
+    }
+    Vec8<T>::store(dfeat + bt * D + v * 8, acc);
+  }
+}
+
+// decoder input (base.py:162-192): out[n,t,:] = r<K ? x[n,r,:] : noise[n,r-K,:], r = restore[n,t]
+template <typename T>
+__global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict__ x, const float* __restrict__ noise,
+                                                            const int* __restrict__ restore, T* __restrict__ out, int N,
+                                                            int K, int D, int Tn) {
+  const int vecs = D / 8;
+  const long long total = (long long)N * Tn * vecs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vecs);
+    const long long nt = i / vecs;
+    const int n = (int)(nt / Tn);
+    const int r = restore[nt];
+    float o[8];
+    if (r < K)
+      Vec8<T>::load(x + ((long long)n * K + r) * D + v * 8, o);
+    else
+      Vec8<float>::load(noise + ((long long)n * (Tn - K) + (r - K)) * D + v * 8, o);
+    Vec8<T>::store(out + nt * D + v * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------------------------- d2v loss
+// data2vec2.py:850-864,904-909,1005-1021 + compute_var statistics (:1095-1110) in one pass.
+//   masked rows:  l = (x - y[n/cb])^2 * scale ; dx = 2*(x-y)*scale*gscale ; kept rows: dx = 0
+// stats (double): [0..D) sum x, [D..2D) sum x^2, [2D..3D) sum y, [3D..4D) sum y^2, [4D] loss sum,
+// [4D+1] masked-row count.  One wave per row; lane-owned columns accumulate over a row block.
+template <typename T>
+__global__ __launch_bounds__(256) void d2v_loss_kernel(const T* __restrict__ x, const float* __restrict__ y,
+                                                       const unsigned char* __restrict__ mask, T* __restrict__ dx,
+                                                       float* __restrict__ loss_rows, double* __restrict__ stats, int N,
+                                                       int Tn, int D, int cb, float scale, float gscale,
+                                                       int rows_per_wave) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long long row0 = ((long long)blockIdx.x * 4 + wid) * rows_per_wave;
+  const long long rows = (long long)N * Tn;
+  const int nch = (D + 511) / 512;
+  for (int c = 0; c < nch; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sxx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float sy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, syy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ls = 0.f, cnt = 0.f;
+    for (int rr = 0; rr < rows_per_wave; ++rr) {
+      const long long row = row0 + rr;
+      if (row >= rows || col >= D) break;
+      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (mask[row]) {
+        const int n = (int)(row / Tn);
+        const int t = (int)(row - (long long)n * Tn);
+        float xv[8], yv[8];
+        Vec8<T>::load(x + row * D + col, xv);
+        Vec8<float>::load(y + ((long long)(n / cb) * Tn + t) * D + col, yv);
+        float l8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = xv[j] - yv[j];
+          l8[j] = d * d * scale;
+          ls += l8[j];
+          o[j] = 2.f * d * scale * gscale;
+          sx[j] += xv[j]; sxx[j] += xv[j] * xv[j];
+          sy[j] += yv[j]; syy[j] += yv[j] * yv[j];
+        }
+        if (loss_rows) Vec8<float>::store(loss_rows + row * D + col, l8);
+        if (c == 0 && lane == 0) cnt += 1.f;
+      } else if (loss_rows) {
+        Vec8<float>::store(loss_rows + row * D + col, o);
+      }
+      if (dx) Vec8<T>::store(dx + row * D + col, o);
+    }
+    if (col < D) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(stats + col + j, (double)sx[j]);
+        atomicAdd(stats + D + col + j, (double)sxx[j]);
+        atomicAdd(stats + 2 * D + col + j, (double)sy[j]);
+        atomicAdd(stats + 3 * D + col + j, (double)syy[j]);
+      }
+    }
+    ls = wave_sum(ls);
+    if (lane == 0) {
+      atomicAdd(stats + 4 * D, (double)ls);
+      if (c == 0) atomicAdd(stats + 4 * D + 1, (double)cnt);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- optimizer-side
+// EMA teacher (fairseq EMAModule.step): e = e*d + (1-d)*p  (fp32), 4 floats per thread
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, long long n,
+                                                  float d) {
+  const long long nv = n / 4;
+  const float om = 1.f - d;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 a = *(const f32x4*)(e + i * 4), b = *(const f32x4*)(p + i * 4);
+    a = a * d + b * om;
+    *(f32x4*)(e + i * 4) = a;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long long i = nv * 4 + threadIdx.x;
+    e[i] = e[i] * d + p[i] * om;
+  }
+}
+
+// fairseq Adam (decoupled weight decay applied before the step), flat fp32 buffers
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float step_size,
+                                                   float gscale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * gscale;
+    const float mi = m[i] * b1 + gr * (1.f - b1);
+    const float vi = v[i] * b2 + gr * gr * (1.f - b2);
+    float pi = p[i];
+    pi -= wd * lr * pi;
+    pi -= step_size * mi / (sqrtf(vi) + eps);
+    m[i] = mi; v[i] = vi; p[i] = pi;
+  }
+}
+
+// sum of squares of a flat fp32 buffer (gradient norm), double accumulator
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n, double* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) s += x[i] * x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (double)(red[0] + red[1] + red[2] + red[3]));
+}
+
+// ---------------------------------------------------------------------------------- weight packing
+// Source: reference parameter layout w[(g*N + n)][ci][j]  (C_out, Cg, k), fp32.
+// mode 0: out[g][n][j*Cgp + ci]            forward operand (K contiguous), Cgp >= Cg zero padded
+// mode 1: out[g][ci][j*Np + n] = w[g,n,ci,k-1-j]   stride-1 dgrad-as-conv operand (flipped taps)
+// mode 2: out[j*Cgp + ci][n]               (G==1) dA = dY * Wmat operand, rows kk, N contiguous
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restrict__ w, T* __restrict__ out, int G, int N,
+                                                          int Cg, int k, int Cgp, int Np, int mode, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float val = 0.f;
+    if (mode == 0) {
+      const int ci = (int)(i % Cgp);
+      const int j = (int)((i / Cgp) % k);
+      const long long gn = i / ((long long)Cgp * k);
+      if (ci < Cg) val = w[(gn * Cg + ci) * k + j];
+    } else if (mode == 1) {
+      const int n = (int)(i % Np);
+      const int j = (int)((i / Np) % k);
+      const int ci = (int)((i / ((long long)Np * k)) % Cg);
+      const int g = (int)(i / ((long long)Np * k * Cg));
+      if (n < N) val = w[(((long long)g * N + n) * Cg + ci) * k + (k - 1 - j)];
+    } else {
+      const int n = (int)(i % Np);
+      const int ci = (int)((i / Np) % Cgp);
+      const int j = (int)(i / ((long long)Np * Cgp));
+      if (n < N && ci < Cg) val = w[((long long)n * Cg + ci) * k + j];
+    }
+    out[i] = Cvt<T>::from(val);
+  }
+}
+
+// gw[(g*N+n)][ci][j] += packed[g][n][j*Cgp + ci]     (fp32 both)
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ gw,
+                                                           int Cg, int k, int Cgp, long long total) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i % k);
+    const int ci = (int)((i / k) % Cg);
+    const long long gn = i / ((long long)k * Cg);
+    gw[i] += packed[(gn * k + j) * Cgp + ci];
+  }
+}
+
+// col2im for the strided dense convs' input gradient:
+//   dX[b,u,ci] = sum_{t,j : t*s - p + j = u} dA[(b,t)][j*C + ci]
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dA, T* __restrict__ dX, int B, int T_in,
+                                                     int T_out, int C, int k, int s, int p, long long lda) {
+  const int vecs = C / 8;
+  const long long total = (long long)B * T_in * vecs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vecs);
+    const long long bu = i / vecs;
+    const int b = (int)(bu / T_in), u = (int)(bu - (long long)b * T_in);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < k; ++j) {
+      const int num = u + p - j;
+      if (num < 0 || num % s) continue;
+      const int t = num / s;
+      if (t >= T_out) continue;
+      float x[8];
+      Vec8<T>::load(dA + ((long long)b * T_out + t) * lda + (long long)j * C + v * 8, x);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] += x[q];
+    }
+    Vec8<T>::store(dX + bu * C + v * 8, acc);
+  }
+}
+
+// 2-D cast/copy with strides: out[m][0..C) (ldo) = in[m][0..C) (ldi)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast2d_kernel(const TI* __restrict__ in, TO* __restrict__ out, long long M, int C,
+                                                     long long ldi, long long ldo) {
+  const int vecs = C / 4;
+  const long long total = M * vecs;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(i % vecs);
+    const long long m = i / vecs;
+    Vec4<TO>::store(out + m * ldo + v * 4, Vec4<TI>::load(in + m * ldi + v * 4));
+  }
+}
+
+// =============================================================================================
+static inline int grid_for(long long total, int cap = 8192) {
+  long long g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32) \
+  if (dtype == A2V_BF16) { CALL_BF16; } else if (dtype == A2V_F32) { CALL_F32; } else return A2V_ERR_DTYPE;
+
+extern "C" int a2v_gather_tokens(int dtype, const void* a, const void* b, const int* ids, void* out, int N, int K, int D,
+                                 int Ta, int cb, hipStream_t st) {
+  if (N <= 0 || K <= 0 || D % 8 || cb <= 0) return A2V_ERR_ARG;
+  const int g = grid_for((long long)N * K * (D / 8));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(gather_tokens_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, ids, (bf16*)out, N, K, D, Ta, cb),
+             hipLaunchKernelGGL(gather_tokens_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, ids, (float*)out, N, K, D, Ta, cb));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_scatter_tokens(int dtype, const void* dtok, const int* restore, void* dpos, int N, int K, int D, int Tn,
+                                  hipStream_t st) {
+  if (N <= 0 || K <= 0 || D % 8) return A2V_ERR_ARG;
+  const int g = grid_for((long long)N * Tn * (D / 8));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(scatter_tokens_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dtok, restore, (bf16*)dpos, N, K, D, Tn),
+             hipLaunchKernelGGL(scatter_tokens_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dtok, restore, (float*)dpos, N, K, D, Tn));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_clone_reduce(int dtype, const void* dxm, const void* dtok, const int* restore, void* dfeat, int B, int cb,
+                                int K, int D, int Tn, hipStream_t st) {
+  if (B <= 0 || K <= 0 || D % 8 || cb <= 0) return A2V_ERR_ARG;
+  const int g = grid_for((long long)B * Tn * (D / 8));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(clone_reduce_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dxm, (const bf16*)dtok, restore, (bf16*)dfeat, B, cb, K, D, Tn),
+             hipLaunchKernelGGL(clone_reduce_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dxm, (const float*)dtok, restore, (float*)dfeat, B, cb, K, D, Tn));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K,
+                                 int D, int Tn, hipStream_t st) {
+  if (N <= 0 || K <= 0 || K > Tn || D % 8) return A2V_ERR_ARG;
+  const int g = grid_for((long long)N * Tn * (D / 8));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(decoder_input_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, noise, restore, (bf16*)out, N, K, D, Tn),
+             hipLaunchKernelGGL(decoder_input_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, noise, restore, (float*)out, N, K, D, Tn));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsigned char* mask, void* dx, float* loss_rows,
+                            double* stats, int N, int Tn, int D, int cb, float scale, float gscale, hipStream_t st) {
+  if (N <= 0 || Tn <= 0 || D % 8 || cb <= 0 || !stats) return A2V_ERR_ARG;
+  const int rpw = 32;
+  const long long rows = (long long)N * Tn;
+  const int g = (int)((rows + 4 * rpw - 1) / (4 * rpw));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(d2v_loss_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, y, mask, (bf16*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw),
+             hipLaunchKernelGGL(d2v_loss_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, y, mask, (float*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_ema_update(float* ema, const float* p, long long n, float decay, hipStream_t st) {
+  if (n <= 0 || (((uintptr_t)ema | (uintptr_t)p) & 15)) return A2V_ERR_ARG;
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, ema, p, n, decay);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                             float eps, float weight_decay, int step, float grad_scale, hipStream_t st) {
+  if (n <= 0 || step <= 0) return A2V_ERR_ARG;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
+                     step_size, grad_scale);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_sumsq(const float* x, long long n, double* out, hipStream_t st) {
+  if (n <= 0) return A2V_ERR_ARG;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, st, x, n, out);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_pack_weight(int dtype, const float* w, void* out, int G, int N, int Cg, int k, int Cgp, int Np, int mode,
+                               hipStream_t st) {
+  if (G <= 0 || N <= 0 || Cg <= 0 || k <= 0 || Cgp < Cg || Np < N || mode < 0 || mode > 2) return A2V_ERR_ARG;
+  if (mode == 2 && G != 1) return A2V_ERR_ARG;
+  long long total;
+  if (mode == 0) total = (long long)G * N * k * Cgp;
+  else if (mode == 1) total = (long long)G * Cg * k * Np;
+  else total = (long long)k * Cgp * Np;
+  const int g = grid_for(total);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(g), dim3(256), 0, st, w, (bf16*)out, G, N, Cg, k, Cgp, Np, mode, total),
+             hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(g), dim3(256), 0, st, w, (float*)out, G, N, Cg, k, Cgp, Np, mode, total));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_unpack_wgrad(const float* packed, float* gw, int GN, int Cg, int k, int Cgp, hipStream_t st) {
+  if (GN <= 0 || Cg <= 0 || k <= 0 || Cgp < Cg) return A2V_ERR_ARG;
+  const long long total = (long long)GN * Cg * k;
+  hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(total)), dim3(256), 0, st, packed, gw, Cg, k, Cgp, total);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, int C, int k, int s, int p,
+                          long long lda, hipStream_t st) {
+  if (B <= 0 || C % 8 || lda % 8 || s <= 0) return A2V_ERR_ARG;
+  const int g = grid_for((long long)B * T_in * (C / 8));
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dA, (bf16*)dX, B, T_in, T_out, C, k, s, p, lda),
+             hipLaunchKernelGGL(col2im_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dA, (float*)dX, B, T_in, T_out, C, k, s, p, lda));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+// in_dtype / out_dtype: A2V_F32 or A2V_BF16
+extern "C" int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out, long long M, int C, long long ldi,
+                          long long ldo, hipStream_t st) {
+  if (M <= 0 || C <= 0 || C % 4 || ldi % 4 || ldo % 4) return A2V_ERR_ARG;
+  const int g = grid_for(M * (C / 4));
+  if (in_dtype == A2V_F32 && out_dtype == A2V_BF16)
+    hipLaunchKernelGGL((cast2d_kernel<float, bf16>), dim3(g), dim3(256), 0, st, (const float*)in, (bf16*)out, M, C, ldi, ldo);
+  else if (in_dtype == A2V_F32 && out_dtype == A2V_F32)
+    hipLaunchKernelGGL((cast2d_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)in, (float*)out, M, C, ldi, ldo);
+  else if (in_dtype == A2V_BF16 && out_dtype == A2V_F32)
+    hipLaunchKernelGGL((cast2d_kernel<bf16, float>), dim3(g), dim3(256), 0, st, (const bf16*)in, (float*)out, M, C, ldi, ldo);
+  else if (in_dtype == A2V_BF16 && out_dtype == A2V_BF16)
+    hipLaunchKernelGGL((cast2d_kernel<bf16, bf16>), dim3(g), dim3(256), 0, st, (const bf16*)in, (bf16*)out, M, C, ldi, ldo);
+  else
+    return A2V_ERR_DTYPE;
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_abi_version(void) { return 1; }

@@ -1,0 +1,645 @@
+// Implicit-GEMM family for gfx950: every dense contraction of the animal2vec hot path.
+//
+//   NT:  C[m][g*N+n] = epi( sum_kk A_g[m][kk] * B_g[n][kk] )          (Linear fwd/dgrad, conv fwd/dgrad)
+//   TN:  W[g][n][kk] += sum_m  P[m][g*N+n] * A_g[m][kk]               (Linear / conv weight gradient)
+//
+// A is an *implicit im2col view* of a channels-last activation tensor (B, T_in, pitch):
+//   A_g[m=(b,t)][kk=(j,ci)] = X[b][t*stride - pad + j][g*goff + ci]   (0 outside [0,T_in))
+// so a Linear is taps=1, a dense strided Conv1d is G=1, a grouped Conv1d walks `goff` per group.
+// Weights are pre-packed as B[g][n][kk] with kk = j*Cg + ci (K-contiguous).
+//
+// bf16 mode : v_mfma_f32_16x16x32_bf16, fp32 accumulate, 128x128x64 tiles, 4 waves (2x2), double-
+//             buffered LDS fed through registers (the implicit gather needs per-lane predication),
+//             XOR-swizzled 16-B chunks for conflict-free ds_read_b128, XCD-aware tile order.
+// fp32 mode : v_mfma_f32_16x16x4_f32 (bitwise fmaf chain) -- the parity mode.
+// TN bf16 reads both operands with ds_read_b64_tr_b16 (hardware transpose) from row-major tiles.
+#include "a2v_common.h"
+
+struct ConvA {
+  const void* ptr;
+  long long pitch;       // elements between consecutive source rows
+  long long bstride;     // elements between batch items (T_in * pitch normally)
+  int goff;              // channel offset per group
+  int T_in, T_out;       // rows per batch item: source / GEMM-M
+  int stride, pad, taps, Cg;
+  // clone-batch view (reference base.py:244,464): GEMM batch item b reads source item b / bdiv and
+  // rows with rowmask[b*T_in + row] != 0 read as zero -- x.repeat_interleave(cb) * (1 - mask) is
+  // never materialised.
+  const unsigned char* rowmask;
+  int bdiv;
+};
+
+struct GemmArgs {
+  ConvA a;
+  const void* B; long long ldb; long long b_gstride;
+  void* C; long long ldc; int c_goff;
+  void* C2;                      // optional: pre-activation copy (same layout as C)
+  const void* R; long long ldr;  // residual (RES) or pre-activation for GELU_BWD
+  const float* bias;             // [G*N] fp32
+  float* colsum;                 // [G*N] fp32, atomically accumulated column sums of the output
+  int M, N, K, G;
+  int flags;
+};
+
+enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32 };
+
+struct WgradArgs {
+  ConvA a;                       // implicit A (M x K per group)
+  const void* P; long long ldp; int p_goff;   // dY: P[m][g*p_goff + n]
+  float* W; long long ldw; long long w_gstride;  // fp32 [G][N][ldw], accumulated with atomics
+  int M, N, K, G;
+  int m_chunk;                   // rows of M handled by one split (multiple of the M step)
+};
+
+// ----------------------------------------------------------------------------------------------
+// Per-thread description of one 16-byte chunk this thread stages from the implicit A operand.
+struct ARow {
+  const char* base;   // points at X[b / bdiv][0][g*goff] (bytes)
+  const unsigned char* mrow;   // rowmask + b*T_in, or nullptr
+  int t0;             // t*stride - pad
+  bool valid;
+};
+
+template <typename T>
+__device__ __forceinline__ ARow make_arow(const ConvA& a, int m, int M, int g) {
+  ARow r;
+  r.valid = m < M;
+  const int mm = r.valid ? m : 0;
+  const int b = mm / a.T_out, t = mm - b * a.T_out;
+  r.base = (const char*)a.ptr + ((long long)(b / a.bdiv) * a.bstride + (long long)g * a.goff) * (long long)sizeof(T);
+  r.mrow = a.rowmask ? a.rowmask + (long long)b * a.T_in : nullptr;
+  r.t0 = t * a.stride - a.pad;
+  return r;
+}
+
+// load the 16-B chunk holding A[m][kk .. kk+16/sizeof(T)) or zeros
+template <typename T>
+__device__ __forceinline__ uint4 load_a_chunk(const ConvA& a, const ARow& r, int kk, int K) {
+  uint4 z = {0u, 0u, 0u, 0u};
+  if (!r.valid || kk >= K) return z;
+  const int j = kk / a.Cg, ci = kk - j * a.Cg;
+  const int row = r.t0 + j;
+  if (row < 0 || row >= a.T_in) return z;
+  if (r.mrow && r.mrow[row]) return z;
+  return *(const uint4*)(r.base + ((long long)row * a.pitch + ci) * (long long)sizeof(T));
+}
+
+// ----------------------------------------------------------------------------------------------
+// Shared epilogue: one wave owns a 64x64 fp32 sub-tile staged in LDS (pitch 68 floats).
+template <typename T>
+__device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, int lane, int m_base, int n_base,
+                                              int grp) {
+  // stage[r][c] r,c in [0,64)
+  const int cq = (lane & 15) * 4;
+  const int n = n_base + cq;                 // column inside the group
+  const bool ncol_ok = n < g.N;              // N % 4 == 0 is required
+  const long long ccol = (long long)grp * g.c_goff + n;
+  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+  if ((g.flags & F_BIAS) && ncol_ok) bias4 = *(const f32x4*)(g.bias + (long long)grp * g.N + n);
+  f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+  T* C = (T*)g.C;
+  T* C2 = (T*)g.C2;
+  const T* R = (const T*)g.R;
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const int r = it * 4 + (lane >> 4);
+    const int m = m_base + r;
+    f32x4 v = *(const f32x4*)(stage + r * 68 + cq);
+    if (m < g.M && ncol_ok) {
+      v += bias4;
+      if (g.flags & F_STORE_PRE) Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, v);
+      if (g.flags & F_GELU) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
+      }
+      if (g.flags & F_RES) v += Vec4<T>::load(R + (long long)m * g.ldr + ccol);
+      if (g.flags & F_GELU_BWD) {
+        f32x4 h = Vec4<T>::load(R + (long long)m * g.ldr + ccol);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] *= gelu_grad_f(h[i]);
+      }
+      Vec4<T>::store(C + (long long)m * g.ldc + ccol, v);
+      if (g.flags & F_COLSUM) {
+        // sum what was actually written (rounded to T), so bias grads match the stored gradient
+#pragma unroll
+        for (int i = 0; i < 4; ++i) cs[i] += Cvt<T>::to(Cvt<T>::from(v[i]));
+      }
+    }
+  }
+  if (g.flags & F_COLSUM) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float s = cs[i];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      cs[i] = s;
+    }
+    if (lane < 16 && ncol_ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(g.colsum + (long long)grp * g.N + n + i, cs[i]);
+    }
+  }
+}
+
+// =============================================================================================
+//                                   bf16  NT   (128 x 128 x 64)
+// =============================================================================================
+#define NT_BM 128
+#define NT_BN 128
+#define NT_BK 64
+#define NT_THREADS 256
+#define NT_LDS_BYTES 69632   // max(2*(16K+16K) pipeline, 4 waves * 64*68*4 epilogue staging)
+
+// byte offset of 16-B chunk `c` (0..7) of row `r` inside a [rows][64] bf16 tile (128-B rows)
+__device__ __forceinline__ int swz128(int r, int c) { return r * 128 + ((c ^ ((r >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#define sA_(b) (smem + (b) * 16384)
+#define sB_(b) (smem + 32768 + (b) * 16384)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_n = (g.N + NT_BN - 1) / NT_BN;
+  const int tiles_m = (g.M + NT_BM - 1) / NT_BM;
+  const int ntile = tiles_m * tiles_n;
+  const int id = xcd_remap(blockIdx.x, ntile);
+  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  const int grp = blockIdx.y;
+  const int m0 = tm * NT_BM, n0 = tn * NT_BN;
+
+  // ---- staging assignment: 4 chunks of A and 4 of B per thread per k-tile
+  const int crow = tid >> 3, cchunk = tid & 7;
+  const ARow ar0 = make_arow<bf16>(g.a, m0 + crow, g.M, grp);
+  const ARow ar1 = make_arow<bf16>(g.a, m0 + crow + 32, g.M, grp);
+  const ARow ar2 = make_arow<bf16>(g.a, m0 + crow + 64, g.M, grp);
+  const ARow ar3 = make_arow<bf16>(g.a, m0 + crow + 96, g.M, grp);
+  const char* bbase = (const char*)g.B + ((long long)grp * g.b_gstride) * 2;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+#define NT_LOAD_B(i) \
+  ((n0 + crow + 32 * (i) < g.N && kk_ < g.K) ? *(const uint4*)(bbase + ((long long)(n0 + crow + 32 * (i)) * g.ldb + kk_) * 2) : zero4)
+#define load_tile(kt)                                                   \
+  {                                                                     \
+    const int kk_ = (kt) * NT_BK + cchunk * 8;                          \
+    ra0 = load_a_chunk<bf16>(g.a, ar0, kk_, g.K);                       \
+    ra1 = load_a_chunk<bf16>(g.a, ar1, kk_, g.K);                       \
+    ra2 = load_a_chunk<bf16>(g.a, ar2, kk_, g.K);                       \
+    ra3 = load_a_chunk<bf16>(g.a, ar3, kk_, g.K);                       \
+    rb0 = NT_LOAD_B(0); rb1 = NT_LOAD_B(1); rb2 = NT_LOAD_B(2); rb3 = NT_LOAD_B(3); \
+  }
+#define store_tile(buf_)                                                \
+  {                                                                     \
+    *(uint4*)(sA_(buf_) + swz128(crow, cchunk)) = ra0;                  \
+    *(uint4*)(sA_(buf_) + swz128(crow + 32, cchunk)) = ra1;             \
+    *(uint4*)(sA_(buf_) + swz128(crow + 64, cchunk)) = ra2;             \
+    *(uint4*)(sA_(buf_) + swz128(crow + 96, cchunk)) = ra3;             \
+    *(uint4*)(sB_(buf_) + swz128(crow, cchunk)) = rb0;                  \
+    *(uint4*)(sB_(buf_) + swz128(crow + 32, cchunk)) = rb1;             \
+    *(uint4*)(sB_(buf_) + swz128(crow + 64, cchunk)) = rb2;             \
+    *(uint4*)(sB_(buf_) + swz128(crow + 96, cchunk)) = rb3;             \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + NT_BK - 1) / NT_BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = wm * 64 + i * 16 + fr;
+        fa[i] = *(const bf16x8*)(sA_(buf) + swz128(r, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = wn * 64 + j * 16 + fr;
+        fb[j] = *(const bf16x8*)(sB_(buf) + swz128(r, ks * 4 + fq));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue through a per-wave LDS stage (64 x 68 floats)
+  float* stage = (float*)smem + wid * (64 * 68);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(i * 16 + fq * 4 + r) * 68 + j * 16 + fr] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_epilogue<bf16>(g, stage, lane, m0 + wm * 64, n0 + wn * 64, grp);
+}
+
+#undef load_tile
+#undef store_tile
+// =============================================================================================
+//                                   fp32  NT   (128 x 128 x 16)   -- parity mode
+// =============================================================================================
+#define F32_BK 16
+#define F32_PITCH 20   // floats per LDS row (16 + 4 pad, keeps 16-B alignment)
+
+__global__ __launch_bounds__(NT_THREADS) void gemm_nt_f32_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#define fA_(b) ((float*)smem + (b) * 128 * F32_PITCH)
+#define fB_(b) ((float*)smem + (2 + (b)) * 128 * F32_PITCH)
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_n = (g.N + NT_BN - 1) / NT_BN;
+  const int tiles_m = (g.M + NT_BM - 1) / NT_BM;
+  const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  const int grp = blockIdx.y;
+  const int m0 = tm * NT_BM, n0 = tn * NT_BN;
+
+  // 128 rows x 4 chunks (of 4 floats) = 512 chunks per operand -> 2 per thread
+  const int crow = tid >> 2, cchunk = tid & 3;
+  const ARow ar0 = make_arow<float>(g.a, m0 + crow, g.M, grp);
+  const ARow ar1 = make_arow<float>(g.a, m0 + crow + 64, g.M, grp);
+  const char* bbase = (const char*)g.B + ((long long)grp * g.b_gstride) * 4;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+  uint4 ra0, ra1, rb0, rb1;
+#define F32_LOAD_B(i) \
+  ((n0 + crow + 64 * (i) < g.N && kk_ < g.K) ? *(const uint4*)(bbase + ((long long)(n0 + crow + 64 * (i)) * g.ldb + kk_) * 4) : zero4)
+#define load_tile(kt)                                   \
+  {                                                     \
+    const int kk_ = (kt) * F32_BK + cchunk * 4;         \
+    ra0 = load_a_chunk<float>(g.a, ar0, kk_, g.K);      \
+    ra1 = load_a_chunk<float>(g.a, ar1, kk_, g.K);      \
+    rb0 = F32_LOAD_B(0); rb1 = F32_LOAD_B(1);           \
+  }
+#define store_tile(buf_)                                                   \
+  {                                                                        \
+    *(uint4*)(fA_(buf_) + crow * F32_PITCH + cchunk * 4) = ra0;            \
+    *(uint4*)(fA_(buf_) + (crow + 64) * F32_PITCH + cchunk * 4) = ra1;     \
+    *(uint4*)(fB_(buf_) + crow * F32_PITCH + cchunk * 4) = rb0;            \
+    *(uint4*)(fB_(buf_) + (crow + 64) * F32_PITCH + cchunk * 4) = rb1;     \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (g.K + F32_BK - 1) / F32_BK;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = fA_(buf)[(wm * 64 + i * 16 + fr) * F32_PITCH + ks * 4 + fq];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = fB_(buf)[(wn * 64 + j * 16 + fr) * F32_PITCH + ks * 4 + fq];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  float* stage = (float*)smem + wid * (64 * 68);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(i * 16 + fq * 4 + r) * 68 + j * 16 + fr] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_epilogue<float>(g, stage, lane, m0 + wm * 64, n0 + wn * 64, grp);
+}
+
+#undef load_tile
+#undef store_tile
+// =============================================================================================
+//                         bf16  TN  (weight gradient)   128(n) x 128(kk), M step 64
+// =============================================================================================
+// LDS tile [64 rows m][128 cols] bf16 (256-B rows); 32-B column blocks XOR-swizzled by row so the
+// ds_read_b64_tr_b16 lane groups (rows 8g+q, q=0..3) land on distinct banks.
+__device__ __forceinline__ int tn_f(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }
+__device__ __forceinline__ int tn_off(int r, int col) {   // byte offset of element (r, col)
+  return r * 256 + ((((col >> 4) ^ tn_f(r)) & 7) << 5) + ((col & 15) << 1);
+}
+
+#define TN_MSTEP 64
+
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#define sP_(b) (smem + (b) * 16384)
+#define sQ_(b) (smem + 32768 + (b) * 16384)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_k = (g.K + 127) / 128;
+  const int tn_ = blockIdx.x / tiles_k, tk = blockIdx.x - tn_ * tiles_k;
+  const int grp = blockIdx.y;
+  const int n0 = tn_ * 128, k0 = tk * 128;
+  const int mbeg = blockIdx.z * g.m_chunk;
+  const int mend = min(g.M, mbeg + g.m_chunk);
+
+  // staging: tile = 64 rows x 16 chunks(16 B) = 1024 chunks per operand, 4 per thread
+  const int crow = tid >> 4, cchunk = tid & 15;   // rows crow + 16*i
+  const bf16* P = (const bf16*)g.P;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+  uint4 rp0, rp1, rp2, rp3, rq0, rq1, rq2, rq3;
+  const int pn = n0 + cchunk * 8;
+#define TN_LOAD_P(i) \
+  ((mt_ + crow + 16 * (i) < mend && pn < g.N) ? *(const uint4*)(P + (long long)(mt_ + crow + 16 * (i)) * g.ldp + (long long)grp * g.p_goff + pn) : zero4)
+#define TN_LOAD_Q(i) load_a_chunk<bf16>(g.a, make_arow<bf16>(g.a, mt_ + crow + 16 * (i), mend, grp), k0 + cchunk * 8, g.K)
+#define load_tile(mt)                                                          \
+  {                                                                            \
+    const int mt_ = (mt);                                                      \
+    rp0 = TN_LOAD_P(0); rp1 = TN_LOAD_P(1); rp2 = TN_LOAD_P(2); rp3 = TN_LOAD_P(3); \
+    rq0 = TN_LOAD_Q(0); rq1 = TN_LOAD_Q(1); rq2 = TN_LOAD_Q(2); rq3 = TN_LOAD_Q(3); \
+  }
+#define TN_OFF(r) ((r) * 256 + ((((cchunk >> 1) ^ tn_f(r)) & 7) << 5) + ((cchunk & 1) << 4))
+#define store_tile(buf_)                                   \
+  {                                                        \
+    *(uint4*)(sP_(buf_) + TN_OFF(crow)) = rp0;             \
+    *(uint4*)(sP_(buf_) + TN_OFF(crow + 16)) = rp1;        \
+    *(uint4*)(sP_(buf_) + TN_OFF(crow + 32)) = rp2;        \
+    *(uint4*)(sP_(buf_) + TN_OFF(crow + 48)) = rp3;        \
+    *(uint4*)(sQ_(buf_) + TN_OFF(crow)) = rq0;             \
+    *(uint4*)(sQ_(buf_) + TN_OFF(crow + 16)) = rq1;        \
+    *(uint4*)(sQ_(buf_) + TN_OFF(crow + 32)) = rq2;        \
+    *(uint4*)(sQ_(buf_) + TN_OFF(crow + 48)) = rq3;        \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nsteps = (mend - mbeg + TN_MSTEP - 1) / TN_MSTEP;
+  if (nsteps <= 0) return;
+  load_tile(mbeg);
+  store_tile(0);
+  __syncthreads();
+
+  const int gq = lane >> 4;           // lane group 0..3 -> k rows 8*gq .. 8*gq+7
+  const int q = (lane & 15) >> 2, p = lane & 3;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) load_tile(mbeg + (st + 1) * TN_MSTEP);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+      const int r_lo = ks * 32 + 8 * gq + q;       // rows for elements 0..3
+      const int r_hi = r_lo + 4;                   // rows for elements 4..7
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = wm * 64 + i * 16 + 4 * p;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sP_(buf) + tn_off(r_lo, col)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sP_(buf) + tn_off(r_hi, col)));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        fa[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + 4 * p;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sQ_(buf) + tn_off(r_lo, col)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sQ_(buf) + tn_off(r_hi, col)));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        fb[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+  // accumulate: D[row=(lane>>4)*4+r][col=lane&15] -> W[g][n][kk]
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wm * 64 + i * 16 + fq * 4 + r;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k0 + wn * 64 + j * 16 + fr;
+        if (kk < g.K) atomicAdd(g.W + (long long)grp * g.w_gstride + (long long)n * g.ldw + kk, acc[i][j][r]);
+      }
+    }
+}
+
+#undef load_tile
+#undef store_tile
+// fp32 TN: 128(n) x 128(kk), M step 16, v_mfma_f32_16x16x4_f32
+#define TNF_PITCH 132
+__global__ __launch_bounds__(256) void gemm_tn_f32_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+#define fP_(b) ((float*)smem + (b) * 16 * TNF_PITCH)
+#define fQ_(b) ((float*)smem + (2 + (b)) * 16 * TNF_PITCH)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_k = (g.K + 127) / 128;
+  const int tn_ = blockIdx.x / tiles_k, tk = blockIdx.x - tn_ * tiles_k;
+  const int grp = blockIdx.y;
+  const int n0 = tn_ * 128, k0 = tk * 128;
+  const int mbeg = blockIdx.z * g.m_chunk;
+  const int mend = min(g.M, mbeg + g.m_chunk);
+  // tile 16 rows x 32 chunks (4 floats) = 512 chunks -> 2 per thread
+  const int crow = tid >> 5, cchunk = tid & 31;   // rows crow + 8*i
+  const float* P = (const float*)g.P;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+  uint4 rp0, rp1, rq0, rq1;
+  const int pn = n0 + cchunk * 4;
+#define TNF_LOAD_P(i) \
+  ((mt_ + crow + 8 * (i) < mend && pn < g.N) ? *(const uint4*)(P + (long long)(mt_ + crow + 8 * (i)) * g.ldp + (long long)grp * g.p_goff + pn) : zero4)
+#define TNF_LOAD_Q(i) load_a_chunk<float>(g.a, make_arow<float>(g.a, mt_ + crow + 8 * (i), mend, grp), k0 + cchunk * 4, g.K)
+#define load_tile(mt)                               \
+  {                                                 \
+    const int mt_ = (mt);                           \
+    rp0 = TNF_LOAD_P(0); rp1 = TNF_LOAD_P(1);       \
+    rq0 = TNF_LOAD_Q(0); rq1 = TNF_LOAD_Q(1);       \
+  }
+#define store_tile(buf_)                                                   \
+  {                                                                        \
+    *(uint4*)(fP_(buf_) + crow * TNF_PITCH + cchunk * 4) = rp0;            \
+    *(uint4*)(fP_(buf_) + (crow + 8) * TNF_PITCH + cchunk * 4) = rp1;      \
+    *(uint4*)(fQ_(buf_) + crow * TNF_PITCH + cchunk * 4) = rq0;            \
+    *(uint4*)(fQ_(buf_) + (crow + 8) * TNF_PITCH + cchunk * 4) = rq1;      \
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nsteps = (mend - mbeg + 15) / 16;
+  if (nsteps <= 0) return;
+  load_tile(mbeg);
+  store_tile(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) load_tile(mbeg + (st + 1) * 16);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = fP_(buf)[(ks * 4 + fq) * TNF_PITCH + wm * 64 + i * 16 + fr];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = fQ_(buf)[(ks * 4 + fq) * TNF_PITCH + wn * 64 + j * 16 + fr];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wm * 64 + i * 16 + fq * 4 + r;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k0 + wn * 64 + j * 16 + fr;
+        if (kk < g.K) atomicAdd(g.W + (long long)grp * g.w_gstride + (long long)n * g.ldw + kk, acc[i][j][r]);
+      }
+    }
+}
+
+#undef load_tile
+#undef store_tile
+// =============================================================================================
+//                                         C ABI
+// =============================================================================================
+static int check_conv(const ConvA& a, int esz) {
+  const int per16 = 16 / esz;
+  if (a.Cg <= 0 || a.Cg % per16 || a.pitch % per16 || a.goff % per16 || a.bstride % per16) return A2V_ERR_ARG;
+  if (a.taps <= 0 || a.stride <= 0 || a.T_in <= 0 || a.T_out <= 0) return A2V_ERR_ARG;
+  if (((uintptr_t)a.ptr) & 15) return A2V_ERR_ARG;
+  return A2V_OK;
+}
+
+extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                             int T_out, int stride, int pad, int taps, int Cg, const unsigned char* rowmask, int bdiv,
+                             const void* Bw, long long ldb,
+                             long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
+                             long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
+                             hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || G <= 0) return A2V_ERR_ARG;
+  if (dtype != A2V_F32 && dtype != A2V_BF16) return A2V_ERR_DTYPE;
+  const int esz = dtype == A2V_F32 ? 4 : 2;
+  GemmArgs g;
+  g.a = ConvA{A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, rowmask, bdiv < 1 ? 1 : bdiv};
+  int rc = check_conv(g.a, esz);
+  if (rc) return rc;
+  if (K != taps * Cg) return A2V_ERR_ARG;
+  if (N % 4 || ldc % 4 || c_goff % 4 || (ldb * esz) % 16 || (b_gstride * esz) % 16) return A2V_ERR_ARG;
+  if ((flags & (F_RES | F_GELU_BWD)) && (!R || ldr % 4)) return A2V_ERR_ARG;
+  if ((flags & F_BIAS) && !bias) return A2V_ERR_ARG;
+  if ((flags & F_STORE_PRE) && !C2) return A2V_ERR_ARG;
+  if ((flags & F_COLSUM) && !colsum) return A2V_ERR_ARG;
+  g.B = Bw; g.ldb = ldb; g.b_gstride = b_gstride;
+  g.C = C; g.ldc = ldc; g.c_goff = c_goff; g.C2 = C2; g.R = R; g.ldr = ldr;
+  g.bias = bias; g.colsum = colsum; g.M = M; g.N = N; g.K = K; g.G = G; g.flags = flags;
+  const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
+  dim3 grid(tiles, G, 1);
+  if (dtype == A2V_BF16) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(NT_THREADS), NT_LDS_BYTES, stream, g);
+  } else {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(NT_THREADS), NT_LDS_BYTES, stream, g);
+  }
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                              int T_out, int stride, int pad, int taps, int Cg, const unsigned char* rowmask, int bdiv,
+                              const void* P, long long ldp,
+                              int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
+                              hipStream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || G <= 0) return A2V_ERR_ARG;
+  if (dtype != A2V_F32 && dtype != A2V_BF16) return A2V_ERR_DTYPE;
+  const int esz = dtype == A2V_F32 ? 4 : 2;
+  WgradArgs g;
+  g.a = ConvA{A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, rowmask, bdiv < 1 ? 1 : bdiv};
+  int rc = check_conv(g.a, esz);
+  if (rc) return rc;
+  if (K != taps * Cg) return A2V_ERR_ARG;
+  const int per16 = 16 / esz;
+  if (N % per16 || ldp % per16 || p_goff % per16 || (((uintptr_t)P) & 15)) return A2V_ERR_ARG;
+  g.P = P; g.ldp = ldp; g.p_goff = p_goff; g.W = W; g.ldw = ldw; g.w_gstride = w_gstride;
+  g.M = M; g.N = N; g.K = K; g.G = G;
+  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  const int step = dtype == A2V_BF16 ? TN_MSTEP : 16;
+  // split M so that the grid has ~>= 1024 workgroups, each split a multiple of the M step
+  int splits = 1024 / (tiles * G);
+  if (splits < 1) splits = 1;
+  int max_splits = cdiv(M, step * 4);
+  if (max_splits < 1) max_splits = 1;
+  if (splits > max_splits) splits = max_splits;
+  int chunk = cdiv(cdiv(M, splits), step) * step;
+  splits = cdiv(M, chunk);
+  g.m_chunk = chunk;
+  dim3 grid(tiles, G, splits);
+  if (dtype == A2V_BF16) {
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+      attr = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, grid, dim3(256), 65536, stream, g);
+  } else {
+    hipLaunchKernelGGL(gemm_tn_f32_kernel, grid, dim3(256), 64 * TNF_PITCH * 4, stream, g);
+  }
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}

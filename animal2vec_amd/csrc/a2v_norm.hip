@@ -1,0 +1,342 @@
+// HBM-bound normalisation kernels (channels-last rows): LayerNorm fwd/bwd (optional residual add
+// in, optional exact-GELU out, optional column sums out), the instance-norm teacher-target builder
+// (reference data2vec2.py:1023-1066) and column sums.  One wave (64 lanes) owns one row; each lane
+// keeps its 8-element chunks in registers (16-B loads for bf16, 2x16-B for fp32); statistics in fp32.
+#include "a2v_common.h"
+
+#define LN_MAXCHUNK 4     // C <= 4*512 = 2048
+#define LN_ROWS_PER_WAVE 8
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            T* __restrict__ sum_out, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, long long M, int C,
+                                                            long long ldx, long long ldy, float eps, int act) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < C) {
+      Vec8<T>::load(x + row * ldx + col, v[c]);
+      if (res) {
+        float r[8];
+        Vec8<T>::load(res + row * ldx + col, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[c][i] += r[i];
+      }
+      if (sum_out) Vec8<T>::store(sum_out + row * ldx + col, v[c]);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += v[c][i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < C) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+    if (col < C) {
+      float o[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float t = (v[c][i] - mean) * rstd;
+        if (gamma) t = t * gamma[col + i] + beta[col + i];
+        if (act == 1) t = gelu_f(t);
+        o[i] = t;
+      }
+      Vec8<T>::store(y + row * ldy + col, o);
+    }
+  }
+}
+
+// Backward of y = act(LN(x)*gamma+beta).  dx; dgamma/dbeta and (optionally) column sums of dx are
+// accumulated with one atomic per column per workgroup (each lane owns fixed columns).
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            const float* __restrict__ mean_in,
+                                                            const float* __restrict__ rstd_in, T* __restrict__ dx,
+                                                            const T* __restrict__ dres, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dxsum,
+                                                            long long M, int C, long long ldx, long long lddy,
+                                                            int act) {
+  __shared__ float red[4][64 * 8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float ag[NCH][8], ab[NCH][8], as_[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; as_[c][i] = 0.f; }
+
+  const long long row0 = ((long long)blockIdx.x * 4 + wid) * LN_ROWS_PER_WAVE;
+  for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+    const long long row = row0 + rr;
+    if (row >= M) break;
+    const float mean = mean_in[row], rstd = rstd_in[row];
+    float xh[NCH][8], g[NCH][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < C) {
+        float xv[8], dv[8];
+        Vec8<T>::load(x + row * ldx + col, xv);
+        Vec8<T>::load(dy + row * lddy + col, dv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float h = (xv[i] - mean) * rstd;
+          const float ga = gamma ? gamma[col + i] : 1.f;
+          float d = dv[i];
+          if (act == 1) d *= gelu_grad_f(gamma ? h * ga + beta[col + i] : h);
+          ag[c][i] += d * h;
+          ab[c][i] += d;
+          const float dg = d * ga;
+          xh[c][i] = h;
+          g[c][i] = dg;
+          s1 += dg;
+          s2 += dg * h;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { xh[c][i] = 0.f; g[c][i] = 0.f; }
+      }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < C) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = rstd * (g[c][i] - s1 - xh[c][i] * s2);
+        if (dres) {
+          float r[8];
+          Vec8<T>::load(dres + row * ldx + col, r);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += r[i];
+        }
+        Vec8<T>::store(dx + row * ldx + col, o);
+        if (dxsum) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) as_[c][i] += Cvt<T>::to(Cvt<T>::from(o[i]));
+        }
+      }
+    }
+  }
+  // cross-wave reduction of the per-column partials, then one atomic per column
+  const int nvec = (dgamma ? 2 : 0) + (dxsum ? 1 : 0);
+  for (int which = 0; which < 3; ++which) {
+    if (which < 2 && !dgamma) continue;
+    if (which == 2 && !dxsum) continue;
+    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) red[wid][lane * 8 + i] = which == 0 ? ag[c][i] : (which == 1 ? ab[c][i] : as_[c][i]);
+      __syncthreads();
+      // 512 columns of this chunk, 256 threads -> 2 each
+      for (int k = threadIdx.x; k < 512; k += 256) {
+        const int col = c * 512 + k;
+        if (col < C) atomicAdd(dst + col, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+      }
+    }
+  }
+  (void)nvec;
+}
+
+// ---------------------------------------------------------------------------------- instance norm
+// stats over T per (layer, batch, channel): mean and rstd (biased variance, eps) -- two passes over
+// the (L2-resident) column strip for accuracy.
+struct PtrList { const void* p[32]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_stats_kernel(PtrList layers, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, int B, int Tn, int D,
+                                                             float eps) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int b = blockIdx.y, l = blockIdx.z;
+  const T* base = (const T*)layers.p[l] + (long long)b * Tn * D;
+  const bool ok = c < D;
+  float s = 0.f;
+  for (int t = wid; t < Tn; t += 4) s += ok ? ldf(base + (long long)t * D + c) : 0.f;
+  red[wid][lane] = s;
+  __syncthreads();
+  const float mu = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)Tn;
+  __syncthreads();
+  float q = 0.f;
+  for (int t = wid; t < Tn; t += 4) {
+    const float d = ok ? ldf(base + (long long)t * D + c) - mu : 0.f;
+    q += d * d;
+  }
+  red[wid][lane] = q;
+  __syncthreads();
+  if (wid == 0 && ok) {
+    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)Tn;
+    const long long o = ((long long)l * B + b) * D + c;
+    mean[o] = mu;
+    rstd[o] = rsqrtf(var + eps);
+  }
+}
+
+// y[b,t,c] = (1/L) * sum_l (x_l[b,t,c] - mean[l,b,c]) * rstd[l,b,c]   (fp32 out)
+template <typename T>
+__global__ __launch_bounds__(256) void instnorm_apply_kernel(PtrList layers, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ y,
+                                                             int L, int B, int Tn, int D) {
+  const long long nvec = (long long)B * Tn * D / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    const long long e = i * 4;
+    const int c = (int)(e % D);
+    const int b = (int)(e / ((long long)Tn * D));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+      const f32x4 v = Vec4<T>::load((const T*)layers.p[l] + e);
+      const long long o = ((long long)l * B + b) * D + c;
+      const f32x4 mu = *(const f32x4*)(mean + o), rs = *(const f32x4*)(rstd + o);
+      acc += (v - mu) * rs;
+    }
+    const float inv = 1.f / (float)L;
+    acc *= inv;
+    *(f32x4*)(y + e) = acc;
+  }
+}
+
+// column sums: out[c] += sum_m x[m][c]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long long M,
+                                                     int C, long long ld, int rows_per_block) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const long long m0 = (long long)blockIdx.y * rows_per_block;
+  const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+  float s = 0.f;
+  if (c < C)
+    for (long long m = m0 + wid; m < m1; m += 4) s += ldf(x + m * ld + c);
+  red[wid][lane] = s;
+  __syncthreads();
+  if (wid == 0 && c < C) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+}
+
+// =============================================================================================
+template <typename T>
+static int ln_fwd_launch(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out,
+                         float* mean, float* rstd, long long M, int C, long long ldx, long long ldy, float eps, int act,
+                         hipStream_t st) {
+  const int nch = (C + 511) / 512;
+  dim3 grid((unsigned)((M + 3) / 4)), blk(256);
+#define LN_F(N)                                                                                                      \
+  hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
+                     (T*)sum_out, mean, rstd, M, C, ldx, ldy, eps, act)
+  switch (nch) {
+    case 1: LN_F(1); break;
+    case 2: LN_F(2); break;
+    case 3: LN_F(3); break;
+    case 4: LN_F(4); break;
+    default: return A2V_ERR_ARG;
+  }
+#undef LN_F
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta,
+                                 void* y, void* sum_out, float* mean, float* rstd, long long M, int C, long long ldx,
+                                 long long ldy, float eps, int act, hipStream_t stream) {
+  if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || C > 512 * LN_MAXCHUNK) return A2V_ERR_ARG;
+  if ((gamma == nullptr) != (beta == nullptr)) return A2V_ERR_ARG;
+  if (dtype == A2V_BF16) return ln_fwd_launch<bf16>(x, res, gamma, beta, y, sum_out, mean, rstd, M, C, ldx, ldy, eps, act, stream);
+  if (dtype == A2V_F32) return ln_fwd_launch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, M, C, ldx, ldy, eps, act, stream);
+  return A2V_ERR_DTYPE;
+}
+
+template <typename T>
+static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, void* dx, const void* dres, float* dgamma, float* dbeta, float* dxsum,
+                         long long M, int C, long long ldx, long long lddy, int act, hipStream_t st) {
+  const int nch = (C + 511) / 512;
+  dim3 grid((unsigned)((M + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE))), blk(256);
+#define LN_B(N)                                                                                                  \
+  hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), grid, blk, 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, \
+                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act)
+  switch (nch) {
+    case 1: LN_B(1); break;
+    case 2: LN_B(2); break;
+    case 3: LN_B(3); break;
+    case 4: LN_B(4); break;
+    default: return A2V_ERR_ARG;
+  }
+#undef LN_B
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* beta,
+                                 const float* mean, const float* rstd, void* dx, const void* dres, float* dgamma,
+                                 float* dbeta, float* dxsum, long long M, int C, long long ldx, long long lddy, int act,
+                                 hipStream_t stream) {
+  if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || lddy % 8 || C > 512 * LN_MAXCHUNK) return A2V_ERR_ARG;
+  if ((gamma == nullptr) != (beta == nullptr)) return A2V_ERR_ARG;
+  if ((dgamma == nullptr) != (dbeta == nullptr)) return A2V_ERR_ARG;
+  if (dtype == A2V_BF16) return ln_bwd_launch<bf16>(dy, x, gamma, beta, mean, rstd, dx, dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, stream);
+  if (dtype == A2V_F32) return ln_bwd_launch<float>(dy, x, gamma, beta, mean, rstd, dx, dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, stream);
+  return A2V_ERR_DTYPE;
+}
+
+extern "C" int a2v_instnorm_targets(int dtype, const void* const* layers, int L, float* mean_ws, float* rstd_ws,
+                                    float* y, int B, int Tn, int D, float eps, hipStream_t stream) {
+  if (L <= 0 || L > 32 || B <= 0 || Tn <= 0 || D <= 0 || D % 4) return A2V_ERR_ARG;
+  PtrList pl;
+  for (int i = 0; i < 32; ++i) pl.p[i] = i < L ? layers[i] : nullptr;
+  dim3 g1((D + 63) / 64, B, L), blk(256);
+  long long nvec = (long long)B * Tn * D / 4;
+  int g2 = (int)((nvec + 255) / 256);
+  if (g2 > 4096) g2 = 4096;
+  if (dtype == A2V_BF16) {
+    hipLaunchKernelGGL(instnorm_stats_kernel<bf16>, g1, blk, 0, stream, pl, mean_ws, rstd_ws, B, Tn, D, eps);
+    hipLaunchKernelGGL(instnorm_apply_kernel<bf16>, dim3(g2), blk, 0, stream, pl, mean_ws, rstd_ws, y, L, B, Tn, D);
+  } else if (dtype == A2V_F32) {
+    hipLaunchKernelGGL(instnorm_stats_kernel<float>, g1, blk, 0, stream, pl, mean_ws, rstd_ws, B, Tn, D, eps);
+    hipLaunchKernelGGL(instnorm_apply_kernel<float>, dim3(g2), blk, 0, stream, pl, mean_ws, rstd_ws, y, L, B, Tn, D);
+  } else
+    return A2V_ERR_DTYPE;
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_colsum(int dtype, const void* x, float* out, long long M, int C, long long ld, hipStream_t stream) {
+  if (M <= 0 || C <= 0) return A2V_ERR_ARG;
+  int rows = 512;
+  dim3 grid((C + 63) / 64, (unsigned)((M + rows - 1) / rows)), blk(256);
+  if (dtype == A2V_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, stream, (const bf16*)x, out, M, C, ld, rows);
+  else if (dtype == A2V_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, stream, (const float*)x, out, M, C, ld, rows);
+  else
+    return A2V_ERR_DTYPE;
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}

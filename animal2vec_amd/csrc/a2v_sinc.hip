@@ -1,0 +1,439 @@
+// SincConv front end for gfx950 (reference nn/sinc.py + nn/utils.py:1105-1117,1430-1431):
+//   a2v_sinc_filters_fwd/bwd : band-pass FIR synthesis from (low_hz_, band_hz_) and its gradient
+//   a2v_sinc_fused_fwd       : reflect-pad + conv1d(1->C,k) + channel LayerNorm + PSwish in ONE pass;
+//                              the (B,C,L) fp32 intermediate of the reference (40.6 MB/clip) never
+//                              exists -- output is written once, channels-last (B,L,Cp).
+//   a2v_sinc_fused_bwd       : recomputes the conv tile, back-propagates PSwish/LN, and reduces the
+//                              filter gradient dW[c][tap] = sum_t dconv[t][c] * xpad[t+tap] on the
+//                              matrix cores; per-channel parameter gradients ride in registers.
+// The convolution runs on v_mfma_f32_16x16x4_f32 (exact fp32, like the reference's .float() conv).
+#include "a2v_common.h"
+
+#define SINC_FP 66          // LDS pitch (floats) of one filter row: conflict-free A/B reads
+#define SINC_MAXK 64        // taps padded to 64 (k <= 63)
+#define SINC_CP 128         // padded channel count handled by one pass (C <= 128)
+
+// ---------------------------------------------------------------------------------- filter synthesis
+// filters[c][j], c < Cp (rows >= C are zero), j < k;  n_ (k/2), window (k/2) as in sinc.py:264-276
+__global__ void sinc_filters_fwd_kernel(const float* __restrict__ low_hz, const float* __restrict__ band_hz,
+                                        const float* __restrict__ n_, const float* __restrict__ window,
+                                        float* __restrict__ filt, int C, int Cp, int k, float min_low, float min_band,
+                                        float nyq) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Cp) return;
+  float* f = filt + (long long)c * k;
+  if (c >= C) {
+    for (int j = 0; j < k; ++j) f[j] = 0.f;
+    return;
+  }
+  const int half = k / 2;
+  const float low = min_low + fabsf(low_hz[c]);                                    // sinc.py:184
+  const float high = fminf(fmaxf(low + min_band + fabsf(band_hz[c]), min_low), nyq);  // :187-191
+  const float band = high - low;                                                   // :192
+  const float inv = 1.f / (2.f * band);
+  for (int j = 0; j < half; ++j) {
+    const float n = n_[j];
+    const float v = (sinf(high * n) - sinf(low * n)) / n * 2.f * window[j];        // :204
+    f[j] = v * inv;                                                                // :218
+    f[k - 1 - j] = v * inv;                                                        // :210 flip
+  }
+  f[half] = 2.f * band * inv;                                                      // :207
+}
+
+// dlow[c], dband[c] (written, not accumulated) from dfilt[c][j]
+__global__ void sinc_filters_bwd_kernel(const float* __restrict__ low_hz, const float* __restrict__ band_hz,
+                                        const float* __restrict__ n_, const float* __restrict__ window,
+                                        const float* __restrict__ dfilt, float* __restrict__ dlow,
+                                        float* __restrict__ dband, int C, int k, float min_low, float min_band,
+                                        float nyq) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int half = k / 2;
+  const float lo_p = low_hz[c], ba_p = band_hz[c];
+  const float low = min_low + fabsf(lo_p);
+  const float pre = low + min_band + fabsf(ba_p);
+  const float high = fminf(fmaxf(pre, min_low), nyq);
+  const bool inrange = pre >= min_low && pre <= nyq;
+  const float band = high - low;
+  const float* df = dfilt + (long long)c * k;
+  float g_high = 0.f, g_low = 0.f;
+  for (int j = 0; j < half; ++j) {
+    const float n = n_[j], w = window[j];
+    const float G = df[j] + df[k - 1 - j];
+    const float F = (sinf(high * n) - sinf(low * n)) * w / (n * band);
+    g_high += G * (w * cosf(high * n) / band - F / band);
+    g_low += G * (-w * cosf(low * n) / band + F / band);
+  }
+  const float gh = inrange ? g_high : 0.f;
+  const float sl = lo_p > 0.f ? 1.f : (lo_p < 0.f ? -1.f : 0.f);
+  const float sb = ba_p > 0.f ? 1.f : (ba_p < 0.f ? -1.f : 0.f);
+  dlow[c] = sl * (g_low + gh);
+  dband[c] = sb * gh;
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int L) {
+  if (i < 0) i = -i;
+  if (i >= L) i = 2 * (L - 1) - i;
+  return i;
+}
+
+// ---------------------------------------------------------------------------------- fused forward
+// Workgroup = 4 waves; each wave owns 16 consecutive samples per tile, the block walks `tiles_per_blk`
+// tiles of 64 samples.  Orientation: D[row = channel][col = time] so a time step's 128 channels sit in
+// ONE lane column -> LayerNorm statistics are in-lane sums + 2 shuffles.
+template <typename T>
+__global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __restrict__ x, const float* __restrict__ filt,
+                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                             const float* __restrict__ ps_a, const float* __restrict__ ps_b,
+                                                             T* __restrict__ y, float* __restrict__ mean_out,
+                                                             float* __restrict__ rstd_out, int B, int L, int C, int k,
+                                                             float eps, int tiles_per_blk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sF = (float*)smem;                         // [128][SINC_FP]
+  float* sPar = sF + SINC_CP * SINC_FP;             // [4][128]: ln_w, ln_b, ps_a, ps_b
+  float* sX = sPar + 4 * SINC_CP;                   // [64 + 64] padded signal of the current tile
+  T* sOut = (T*)(sX + 128);                         // [4 waves][16][SINC_CP + 8]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int half = k / 2;
+
+  for (int i = tid; i < SINC_CP * SINC_MAXK; i += 256) {
+    const int c = i >> 6, j = i & 63;
+    sF[c * SINC_FP + j] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
+  }
+  for (int i = tid; i < SINC_CP; i += 256) {
+    const bool ok = i < C;
+    sPar[i] = ok ? ln_w[i] : 0.f;
+    sPar[SINC_CP + i] = ok ? ln_b[i] : 0.f;
+    sPar[2 * SINC_CP + i] = ok ? ps_a[i] : 0.f;
+    sPar[3 * SINC_CP + i] = ok ? ps_b[i] : 0.f;
+  }
+  const int tiles_per_clip = (L + 63) / 64;
+  const long long ntiles = (long long)B * tiles_per_clip;
+  T* myOut = sOut + wid * 16 * (SINC_CP + 8);
+
+  for (int it = 0; it < tiles_per_blk; ++it) {
+    const long long tile = (long long)blockIdx.x * tiles_per_blk + it;
+    if (tile >= ntiles) break;
+    const int b = (int)(tile / tiles_per_clip);
+    const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
+    __syncthreads();
+    if (tid < 128) sX[tid] = x[(long long)b * L + reflect_idx(t0 - half + tid, L)];
+    __syncthreads();
+
+    f32x4 acc[8];
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tl = wid * 16 + fr;                     // local time of this lane
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const float xb = sX[tl + ks * 4 + g];            // B[k=tap][col=t]
+#pragma unroll
+      for (int jc = 0; jc < 8; ++jc) {
+        const float wa = sF[(16 * jc + fr) * SINC_FP + ks * 4 + g];   // A[row=c][k=tap]
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xb, acc[jc], 0, 0, 0);
+      }
+    }
+    // acc[jc][r] = conv[c = 16jc+4g+r][t = t0+tl]
+    float s = 0.f;
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += (16 * jc + 4 * g + r < C) ? acc[jc][r] : 0.f;
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[jc][r] - mean;
+        q += (16 * jc + 4 * g + r < C) ? d * d : 0.f;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    const int t = t0 + tl;
+    if (g == 0 && t < L && mean_out) {
+      mean_out[(long long)b * L + t] = mean;
+      rstd_out[(long long)b * L + t] = rstd;
+    }
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) {
+      const int c0 = 16 * jc + 4 * g;
+      const f32x4 w = *(const f32x4*)(sPar + c0), bb = *(const f32x4*)(sPar + SINC_CP + c0);
+      const f32x4 pa = *(const f32x4*)(sPar + 2 * SINC_CP + c0), pb = *(const f32x4*)(sPar + 3 * SINC_CP + c0);
+      f32x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float yl = (acc[jc][r] - mean) * rstd * w[r] + bb[r];
+        const float sg = 1.f / (1.f + __expf(-pb[r] * yl));
+        o[r] = (c0 + r < C) ? yl * pa[r] * sg : 0.f;                    // utils.py:1431
+      }
+      Vec4<T>::store(myOut + fr * (SINC_CP + 8) + c0, o);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // coalesced store of this wave's 16 rows x 128 channels (8 elements per lane per pass)
+    constexpr int LPR = SINC_CP / 8;                 // lanes per row = 16
+#pragma unroll
+    for (int pass = 0; pass < 16 / (64 / LPR); ++pass) {
+      const int rrow = pass * (64 / LPR) + lane / LPR;
+      const int cc = (lane % LPR) * 8;
+      const int tt = t0 + wid * 16 + rrow;
+      if (tt < L) {
+        float v[8];
+        Vec8<T>::load(myOut + rrow * (SINC_CP + 8) + cc, v);
+        Vec8<T>::store(y + ((long long)b * L + tt) * SINC_CP + cc, v);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- fused backward
+// Orientation: D[row = time][col = channel]: a lane owns channels {fr + 16 jc}, so per-channel
+// parameter gradients accumulate in registers over all tiles of the block; the dconv accumulator
+// layout is directly the A operand (k = time, order permuted) of dW = dconv^T . Xpad.
+// grads: dfilt [Cp][k] fp32 (atomic), dpar [4][128] fp32 (atomic): d ln_w, d ln_b, d ps_a, d ps_b
+template <typename T>
+__global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ filt,
+                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                             const float* __restrict__ ps_a, const float* __restrict__ ps_b,
+                                                             const T* __restrict__ dy, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, float* __restrict__ dfilt,
+                                                             float* __restrict__ dpar, int B, int L, int C, int k,
+                                                             int tiles_per_blk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sF = (float*)smem;                         // [128][SINC_FP]
+  float* sX = sF + SINC_CP * SINC_FP;               // [128]
+  float* sMean = sX + 128;                          // [64]
+  float* sRstd = sMean + 64;                        // [64]
+  T* sDy = (T*)(sRstd + 64);                        // [64][SINC_CP + 8]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int half = k / 2;
+
+  for (int i = tid; i < SINC_CP * SINC_MAXK; i += 256) {
+    const int c = i >> 6, j = i & 63;
+    sF[c * SINC_FP + j] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
+  }
+  // per-lane channel parameters: channels c = fr + 16 jc
+  float pw[8], pb_[8], pa[8], pbs[8];
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc) {
+    const int c = fr + 16 * jc;
+    const bool ok = c < C;
+    pw[jc] = ok ? ln_w[c] : 0.f; pb_[jc] = ok ? ln_b[c] : 0.f;
+    pa[jc] = ok ? ps_a[c] : 0.f; pbs[jc] = ok ? ps_b[c] : 0.f;
+  }
+  float gw[8], gb[8], ga[8], gbs[8];
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc) { gw[jc] = 0.f; gb[jc] = 0.f; ga[jc] = 0.f; gbs[jc] = 0.f; }
+  f32x4 dW[8][4];                                   // [jc][jt]: rows c = 16jc+4g+r, cols tap = 16jt+fr
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dW[jc][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int tiles_per_clip = (L + 63) / 64;
+  const long long ntiles = (long long)B * tiles_per_clip;
+  const float invC = 1.f / (float)C;
+
+  for (int it = 0; it < tiles_per_blk; ++it) {
+    const long long tile = (long long)blockIdx.x * tiles_per_blk + it;
+    if (tile >= ntiles) break;
+    const int b = (int)(tile / tiles_per_clip);
+    const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
+    __syncthreads();
+    if (tid < 128) sX[tid] = x[(long long)b * L + reflect_idx(t0 - half + tid, L)];
+    if (tid < 64) {
+      const int t = t0 + tid;
+      sMean[tid] = t < L ? mean_in[(long long)b * L + t] : 0.f;
+      sRstd[tid] = t < L ? rstd_in[(long long)b * L + t] : 0.f;
+    }
+    for (int i = tid; i < 64 * (SINC_CP / 8); i += 256) {
+      const int r = i / (SINC_CP / 8), cc = (i % (SINC_CP / 8)) * 8;
+      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (t0 + r < L) Vec8<T>::load(dy + ((long long)b * L + t0 + r) * SINC_CP + cc, v);
+      Vec8<T>::store(sDy + r * (SINC_CP + 8) + cc, v);
+    }
+    __syncthreads();
+
+    // conv recompute: D[row t = 4g+r][col c = fr+16jc]; A = X[t=fr][tap], B = filt[c][tap]
+    f32x4 acc[8];
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {
+      const float xa = sX[wid * 16 + fr + ks * 4 + g];
+#pragma unroll
+      for (int jc = 0; jc < 8; ++jc) {
+        const float wb = sF[(16 * jc + fr) * SINC_FP + ks * 4 + g];
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[jc], 0, 0, 0);
+      }
+    }
+    // back-prop through PSwish and LN.  values indexed [jc][r]: t = 16wid+4g+r, c = fr+16jc
+    f32x4 dh[8], hh[8];
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) {
+      const bool cok = fr + 16 * jc < C;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tl = wid * 16 + 4 * g + r;
+        const float h = (acc[jc][r] - sMean[tl]) * sRstd[tl];
+        const float yl = h * pw[jc] + pb_[jc];
+        const float sg = 1.f / (1.f + __expf(-pbs[jc] * yl));
+        float dz = cok ? Cvt<T>::to(sDy[tl * (SINC_CP + 8) + fr + 16 * jc]) : 0.f;
+        if (t0 + tl >= L) dz = 0.f;
+        ga[jc] += dz * yl * sg;
+        gbs[jc] += dz * yl * pa[jc] * sg * (1.f - sg) * yl;
+        const float dyl = dz * pa[jc] * (sg + yl * pbs[jc] * sg * (1.f - sg));
+        gw[jc] += dyl * h;
+        gb[jc] += dyl;
+        const float d = dyl * pw[jc];
+        dh[jc][r] = d;
+        hh[jc][r] = cok ? h : 0.f;
+        s1[r] += d;
+        s2[r] += d * hh[jc][r];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+      s1[r] *= invC; s2[r] *= invC;
+    }
+    // dconv[t][c] = rstd * (dh - mean(dh) - h * mean(dh*h)), zero for padded channel / time
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc) {
+      const bool cok = fr + 16 * jc < C;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tl = wid * 16 + 4 * g + r;
+        const float v = sRstd[tl] * (dh[jc][r] - s1[r] - hh[jc][r] * s2[r]);
+        dh[jc][r] = (cok && t0 + tl < L) ? v : 0.f;
+      }
+    }
+    // dW[c][tap] += sum_t dconv[t][c] * xpad[t + tap]: k-step r has k-slot g <-> t = 16wid+4g+r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tl = wid * 16 + 4 * g + r;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float xb = sX[tl + 16 * jt + fr];          // B[k=t][col=tap]
+#pragma unroll
+        for (int jc = 0; jc < 8; ++jc)
+          dW[jc][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[jc][r], xb, dW[jc][jt], 0, 0, 0);
+      }
+    }
+  }
+  // flush: filter gradient rows c = 16jc+4g+r, cols tap = 16jt+fr
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * jc + 4 * g + r;
+      if (c >= C) continue;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int tap = 16 * jt + fr;
+        if (tap < k) atomicAdd(dfilt + (long long)c * k + tap, dW[jc][jt][r]);
+      }
+    }
+  // per-channel parameter grads: reduce over the 4 lane groups (same fr), then atomics
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc) {
+    float a0 = gw[jc], a1 = gb[jc], a2 = ga[jc], a3 = gbs[jc];
+    a0 += __shfl_xor(a0, 16, 64); a0 += __shfl_xor(a0, 32, 64);
+    a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
+    a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
+    a3 += __shfl_xor(a3, 16, 64); a3 += __shfl_xor(a3, 32, 64);
+    const int c = fr + 16 * jc;
+    if (g == 0 && c < C) {
+      atomicAdd(dpar + c, a0);
+      atomicAdd(dpar + SINC_CP + c, a1);
+      atomicAdd(dpar + 2 * SINC_CP + c, a2);
+      atomicAdd(dpar + 3 * SINC_CP + c, a3);
+    }
+  }
+}
+
+// =============================================================================================
+extern "C" int a2v_sinc_filters_fwd(const float* low_hz, const float* band_hz, const float* n_, const float* window,
+                                    float* filt, int C, int Cp, int k, float min_low_hz, float min_band_hz,
+                                    float sample_rate, hipStream_t st) {
+  if (C <= 0 || Cp < C || k < 3 || !(k & 1)) return A2V_ERR_ARG;
+  hipLaunchKernelGGL(sinc_filters_fwd_kernel, dim3((Cp + 63) / 64), dim3(64), 0, st, low_hz, band_hz, n_, window, filt, C,
+                     Cp, k, min_low_hz, min_band_hz, sample_rate * 0.5f);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_sinc_filters_bwd(const float* low_hz, const float* band_hz, const float* n_, const float* window,
+                                    const float* dfilt, float* dlow, float* dband, int C, int k, float min_low_hz,
+                                    float min_band_hz, float sample_rate, hipStream_t st) {
+  if (C <= 0 || k < 3 || !(k & 1)) return A2V_ERR_ARG;
+  hipLaunchKernelGGL(sinc_filters_bwd_kernel, dim3((C + 63) / 64), dim3(64), 0, st, low_hz, band_hz, n_, window, dfilt, dlow,
+                     dband, C, k, min_low_hz, min_band_hz, sample_rate * 0.5f);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+static int sinc_tiles_per_block(long long ntiles) {
+  int tpb = (int)((ntiles + 2047) / 2048);
+  if (tpb < 1) tpb = 1;
+  return tpb;
+}
+
+// y: (B, L, 128) channels-last, channels >= C zero.  filt: (>=C rows, k) fp32 from a2v_sinc_filters_fwd.
+extern "C" int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
+                                  const float* ps_alpha, const float* ps_beta, void* y, float* mean, float* rstd, int B,
+                                  int L, int C, int k, float eps, hipStream_t st) {
+  if (B <= 0 || L < 128 || C <= 0 || C > SINC_CP || k > 63 || !(k & 1)) return A2V_ERR_ARG;
+  const long long ntiles = (long long)B * ((L + 63) / 64);
+  const int tpb = sinc_tiles_per_block(ntiles);
+  const int grid = (int)((ntiles + tpb - 1) / tpb);
+  const int esz = dtype == A2V_BF16 ? 2 : 4;
+  const int lds = (SINC_CP * SINC_FP + 4 * SINC_CP + 128) * 4 + 4 * 16 * (SINC_CP + 8) * esz;
+  if (dtype == A2V_BF16) {
+    (void)hipFuncSetAttribute((const void*)sinc_fused_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(sinc_fused_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
+                       (bf16*)y, mean, rstd, B, L, C, k, eps, tpb);
+  } else if (dtype == A2V_F32) {
+    (void)hipFuncSetAttribute((const void*)sinc_fused_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(sinc_fused_fwd_kernel<float>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
+                       (float*)y, mean, rstd, B, L, C, k, eps, tpb);
+  } else
+    return A2V_ERR_DTYPE;
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+// dfilt (C rows used, k) and dpar (4 x 128) are ACCUMULATED (atomics): zero them first.
+extern "C" int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
+                                  const float* ps_alpha, const float* ps_beta, const void* dy, const float* mean,
+                                  const float* rstd, float* dfilt, float* dpar, int B, int L, int C, int k,
+                                  hipStream_t st) {
+  if (B <= 0 || L < 128 || C <= 0 || C > SINC_CP || k > 63 || !(k & 1)) return A2V_ERR_ARG;
+  const long long ntiles = (long long)B * ((L + 63) / 64);
+  int tpb = (int)((ntiles + 1023) / 1024);
+  if (tpb < 1) tpb = 1;
+  const int grid = (int)((ntiles + tpb - 1) / tpb);
+  const int esz = dtype == A2V_BF16 ? 2 : 4;
+  const int lds = (SINC_CP * SINC_FP + 128 + 128) * 4 + 64 * (SINC_CP + 8) * esz;
+  if (dtype == A2V_BF16) {
+    (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(sinc_fused_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
+                       (const bf16*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpb);
+  } else if (dtype == A2V_F32) {
+    (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(sinc_fused_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
+                       (const float*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpb);
+  } else
+    return A2V_ERR_DTYPE;
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}

@@ -1,0 +1,337 @@
+"""Torch-tensor front door of the C ABI (include/a2v.h).  PyTorch is plumbing here: it owns device
+memory and the stream; every op below is a hand-written HIP kernel in liba2v_hip.so.  No op has a
+fallback: without the library, or on a CPU tensor, they raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, check
+
+
+def _L():
+    return _lib.load()
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.bfloat16:
+        return BF16
+    if t.dtype == torch.float32:
+        return F32
+    raise TypeError(f"unsupported activation dtype {t.dtype}")
+
+
+def ptr(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.A2VError("a2v ops need device tensors (no CPU path exists)")
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def per16(t: torch.Tensor) -> int:
+    return 16 // t.element_size()
+
+
+# ----------------------------------------------------------------------------------------------
+#                                         GEMM family
+# ----------------------------------------------------------------------------------------------
+def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, a_pitch, a_bstride,
+              a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
+              gelu=False, gelu_bwd=False, pre_out=None, colsum=None):
+    flags = 0
+    if bias is not None:
+        flags |= EPI_BIAS
+    if gelu:
+        flags |= EPI_GELU
+    if res is not None and not gelu_bwd:
+        flags |= EPI_RES
+    if gelu_bwd:
+        flags |= EPI_GELU_BWD
+    if pre_out is not None:
+        flags |= EPI_STORE_PRE
+    if colsum is not None:
+        flags |= EPI_COLSUM
+    rc = _L().a2v_conv_gemm(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg,
+                            ptr(rowmask), bdiv, ptr(w), ldb, b_gstride, ptr(out), ldc, c_goff, ptr(pre_out),
+                            ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
+                            stream())
+    check(rc, "a2v_conv_gemm")
+    return out
+
+
+def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None):
+    """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w/out/res row-major 2-D (leading dims from strides)."""
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+    if out is None:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+    r = gelu_bwd_aux if gelu_bwd_aux is not None else res
+    return conv_gemm(x, w, out, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
+                     ldb=w.stride(0), ldc=out.stride(0), bias=bias, res=r, ldr=r.stride(0) if r is not None else 0,
+                     gelu=gelu, gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum)
+
+
+def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=None, rowmask=None, bdiv=1,
+              n_batch=None, res=None, colsum=None):
+    """Channels-last Conv1d as implicit GEMM.  x (Bsrc,T_in,Cp); w_packed (G, n_out/G, k*Cg);
+    out (B,T_out,n_out) with B = n_batch or Bsrc."""
+    Bsrc, T_in, Cp = x.shape
+    B = n_batch if n_batch is not None else Bsrc
+    G = groups
+    Cg = w_packed.shape[-1] // k
+    N = n_out // G
+    if out is None:
+        out = torch.empty(B, T_out, n_out, dtype=x.dtype, device=x.device)
+    return conv_gemm(x, w_packed, out, M=B * T_out, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride,
+                     pad=pad, taps=k, Cg=Cg, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=Cg if G > 1 else 0,
+                     rowmask=rowmask, bdiv=bdiv, ldb=w_packed.stride(-2), b_gstride=w_packed.stride(0) if G > 1 else 0,
+                     ldc=n_out, c_goff=N, bias=bias, res=res, ldr=n_out if res is not None else 0, colsum=colsum)
+
+
+def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, a_pitch, a_bstride, a_goff=0,
+               rowmask=None, bdiv=1, ldp, p_goff=0, ldw, w_gstride=0):
+    rc = _L().a2v_conv_wgrad(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg,
+                             ptr(rowmask), bdiv, ptr(dy), ldp, p_goff, ptr(gw), ldw, w_gstride, M, N, K, G, stream())
+    check(rc, "a2v_conv_wgrad")
+    return gw
+
+
+def linear_wgrad(x, dy, gw):
+    """gw[N,K] (fp32) += dy[M,N]^T @ x[M,K]"""
+    M, K = x.shape
+    N = dy.shape[1]
+    assert gw.dtype == torch.float32 and gw.shape == (N, K)
+    return conv_wgrad(x, dy, gw, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
+                      ldp=dy.stride(0), ldw=gw.stride(0))
+
+
+def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=None, bdiv=1, n_batch=None):
+    """gw_packed (G, N, k*Cg) fp32 += implicit-im2col(x)^T dy."""
+    Bsrc, T_in, Cp = x.shape
+    B = n_batch if n_batch is not None else Bsrc
+    G = groups
+    Cg = gw_packed.shape[-1] // k
+    N = gw_packed.shape[-2]
+    n_out = dy.shape[-1]
+    return conv_wgrad(x, dy, gw_packed, M=B * T_out, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride, pad=pad,
+                      taps=k, Cg=Cg, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=Cg if G > 1 else 0,
+                      rowmask=rowmask, bdiv=bdiv, ldp=n_out, p_goff=N, ldw=gw_packed.stride(-2),
+                      w_gstride=gw_packed.stride(0) if G > 1 else 0)
+
+
+# ----------------------------------------------------------------------------------------------
+#                                         attention
+# ----------------------------------------------------------------------------------------------
+def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True):
+    """qkv (N,S,3*H*HD) -> out (N,S,H*HD), lse (N,H,S)"""
+    N, S, W = qkv.shape
+    HD = W // (3 * H)
+    out = torch.empty(N, S, H * HD, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
+    rc = _L().a2v_attention_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
+                                HD, HD ** -0.5, stream())
+    check(rc, "a2v_attention_fwd")
+    return out, lse
+
+
+def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi):
+    """-> dqkv (N,S,3*H*HD).  dalibi (H) fp32 is accumulated."""
+    N, S, W = qkv.shape
+    HD = W // (3 * H)
+    dqkv = torch.empty_like(qkv)
+    dq32 = torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
+    delta = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
+    rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(delta), ptr(dqkv), ptr(dq32),
+                                ptr(dalibi), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, stream())
+    check(rc, "a2v_attention_bwd")
+    cast2d(dq32, dqkv.view(N * S, W)[:, : H * HD])
+    return dqkv
+
+
+# ----------------------------------------------------------------------------------------------
+#                                         normalisation
+# ----------------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=None, sum_out=None):
+    """x (..., C) contiguous rows.  Returns y, mean, rstd."""
+    C_ = x.shape[-1]
+    M = x.numel() // C_
+    y = out if out is not None else torch.empty_like(x)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rc = _L().a2v_layernorm_fwd(dt(x), ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(y), ptr(sum_out), ptr(mean),
+                                ptr(rstd), M, C_, C_, C_, eps, act, stream())
+    check(rc, "a2v_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, *, act=0, dgamma=None, dbeta=None, dxsum=None, dres=None, out=None):
+    C_ = x.shape[-1]
+    M = x.numel() // C_
+    dx = out if out is not None else torch.empty_like(x)
+    rc = _L().a2v_layernorm_bwd(dt(x), ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dres),
+                                ptr(dgamma), ptr(dbeta), ptr(dxsum), M, C_, C_, C_, act, stream())
+    check(rc, "a2v_layernorm_bwd")
+    return dx
+
+
+def instnorm_targets(layers: Sequence[torch.Tensor], eps=1e-5):
+    """make_targets: mean over layers of instance_norm over T.  layers: list of (B,T,D) -> fp32 (B,T,D)"""
+    L = len(layers)
+    B, T, D = layers[0].shape
+    dev = layers[0].device
+    arr = (C.c_void_p * L)(*[ptr(t) for t in layers])
+    mean = torch.empty(L * B * D, dtype=torch.float32, device=dev)
+    rstd = torch.empty(L * B * D, dtype=torch.float32, device=dev)
+    y = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+    rc = _L().a2v_instnorm_targets(dt(layers[0]), arr, L, ptr(mean), ptr(rstd), ptr(y), B, T, D, eps, stream())
+    check(rc, "a2v_instnorm_targets")
+    return y
+
+
+def colsum(x2d, out):
+    M, C_ = x2d.shape
+    rc = _L().a2v_colsum(dt(x2d), ptr(x2d), ptr(out), M, C_, x2d.stride(0), stream())
+    check(rc, "a2v_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+#                                         sinc front end
+# ----------------------------------------------------------------------------------------------
+def sinc_filters_fwd(low_hz, band_hz, n_, window, *, C_, Cp, k, min_low_hz, min_band_hz, sample_rate):
+    filt = torch.empty(Cp, k, dtype=torch.float32, device=low_hz.device)
+    rc = _L().a2v_sinc_filters_fwd(ptr(low_hz), ptr(band_hz), ptr(n_), ptr(window), ptr(filt), C_, Cp, k,
+                                   float(min_low_hz), float(min_band_hz), float(sample_rate), stream())
+    check(rc, "a2v_sinc_filters_fwd")
+    return filt
+
+
+def sinc_filters_bwd(low_hz, band_hz, n_, window, dfilt, *, C_, k, min_low_hz, min_band_hz, sample_rate):
+    dlow = torch.empty(C_, dtype=torch.float32, device=low_hz.device)
+    dband = torch.empty(C_, dtype=torch.float32, device=low_hz.device)
+    rc = _L().a2v_sinc_filters_bwd(ptr(low_hz), ptr(band_hz), ptr(n_), ptr(window), ptr(dfilt), ptr(dlow), ptr(dband),
+                                   C_, k, float(min_low_hz), float(min_band_hz), float(sample_rate), stream())
+    check(rc, "a2v_sinc_filters_bwd")
+    return dlow, dband
+
+
+def sinc_fused_fwd(x, filt, ln_w, ln_b, ps_a, ps_b, *, C_, k, dtype, eps=1e-5, save_stats=True):
+    B, L = x.shape
+    y = torch.empty(B, L, 128, dtype=dtype, device=x.device)
+    mean = torch.empty(B, L, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = torch.empty(B, L, dtype=torch.float32, device=x.device) if save_stats else None
+    rc = _L().a2v_sinc_fused_fwd(dt(y), ptr(x), ptr(filt), ptr(ln_w), ptr(ln_b), ptr(ps_a), ptr(ps_b), ptr(y), ptr(mean),
+                                 ptr(rstd), B, L, C_, k, eps, stream())
+    check(rc, "a2v_sinc_fused_fwd")
+    return y, mean, rstd
+
+
+def sinc_fused_bwd(x, filt, ln_w, ln_b, ps_a, ps_b, dy, mean, rstd, dfilt, dpar, *, C_, k):
+    B, L = x.shape
+    rc = _L().a2v_sinc_fused_bwd(dt(dy), ptr(x), ptr(filt), ptr(ln_w), ptr(ln_b), ptr(ps_a), ptr(ps_b), ptr(dy), ptr(mean),
+                                 ptr(rstd), ptr(dfilt), ptr(dpar), B, L, C_, k, stream())
+    check(rc, "a2v_sinc_fused_bwd")
+
+
+# ----------------------------------------------------------------------------------------------
+#                                         tokens / loss / optimizer
+# ----------------------------------------------------------------------------------------------
+def gather_tokens(a, ids, *, cb=1, b=None):
+    """out[n,k,:] = a[n//cb, ids[n,k], :] (+ b[n, ids[n,k], :]);  a (Ba,Ta,D), ids (N,K) int32"""
+    N, K = ids.shape
+    Ta, D = a.shape[1], a.shape[2]
+    out = torch.empty(N, K, D, dtype=a.dtype, device=a.device)
+    rc = _L().a2v_gather_tokens(dt(a), ptr(a), ptr(b), ptr(ids), ptr(out), N, K, D, Ta, cb, stream())
+    check(rc, "a2v_gather_tokens")
+    return out
+
+
+def scatter_tokens(dtok, restore, T):
+    N, K, D = dtok.shape
+    out = torch.empty(N, T, D, dtype=dtok.dtype, device=dtok.device)
+    rc = _L().a2v_scatter_tokens(dt(dtok), ptr(dtok), ptr(restore), ptr(out), N, K, D, T, stream())
+    check(rc, "a2v_scatter_tokens")
+    return out
+
+
+def clone_reduce(dxm, dtok, restore, cb):
+    N, T, D = dxm.shape
+    K = dtok.shape[1]
+    out = torch.empty(N // cb, T, D, dtype=dxm.dtype, device=dxm.device)
+    rc = _L().a2v_clone_reduce(dt(dxm), ptr(dxm), ptr(dtok), ptr(restore), ptr(out), N // cb, cb, K, D, T, stream())
+    check(rc, "a2v_clone_reduce")
+    return out
+
+
+def decoder_input(x, noise, restore):
+    N, K, D = x.shape
+    T = restore.shape[1]
+    out = torch.empty(N, T, D, dtype=x.dtype, device=x.device)
+    rc = _L().a2v_decoder_input(dt(x), ptr(x), ptr(noise), ptr(restore), ptr(out), N, K, D, T, stream())
+    check(rc, "a2v_decoder_input")
+    return out
+
+
+def d2v_loss(x, y, mask_u8, cb, *, stats, want_dx=True, gscale=1.0, loss_rows=None):
+    """x (N,T,D), y (B,T,D) fp32, mask (N,T) uint8.  stats: double[4D+2] accumulated."""
+    N, T, D = x.shape
+    dx = torch.empty_like(x) if want_dx else None
+    rc = _L().a2v_d2v_loss(dt(x), ptr(x), ptr(y), ptr(mask_u8), ptr(dx), ptr(loss_rows), ptr(stats), N, T, D, cb,
+                           D ** -0.5, gscale, stream())
+    check(rc, "a2v_d2v_loss")
+    return dx
+
+
+def ema_update(ema, p, decay):
+    rc = _L().a2v_ema_update(ptr(ema), ptr(p), ema.numel(), decay, stream())
+    check(rc, "a2v_ema_update")
+
+
+def adam_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    rc = _L().a2v_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                            grad_scale, stream())
+    check(rc, "a2v_adam_step")
+
+
+def sumsq(x, out):
+    rc = _L().a2v_sumsq(ptr(x), x.numel(), ptr(out), stream())
+    check(rc, "a2v_sumsq")
+
+
+def pack_weight(w, out, *, G, N, Cg, k, Cgp=None, Np=None, mode=0):
+    """w: fp32 param (G*N, Cg, k) (or (N,K) Linear with k=1) -> packed operand in out's dtype."""
+    Cgp = Cg if Cgp is None else Cgp
+    Np = N if Np is None else Np
+    rc = _L().a2v_pack_weight(dt(out), ptr(w), ptr(out), G, N, Cg, k, Cgp, Np, mode, stream())
+    check(rc, "a2v_pack_weight")
+    return out
+
+
+def unpack_wgrad(packed, gw, *, GN, Cg, k, Cgp):
+    rc = _L().a2v_unpack_wgrad(ptr(packed), ptr(gw), GN, Cg, k, Cgp, stream())
+    check(rc, "a2v_unpack_wgrad")
+
+
+def col2im(dA, *, B, T_in, T_out, C_, k, s, p):
+    dX = torch.empty(B, T_in, C_, dtype=dA.dtype, device=dA.device)
+    rc = _L().a2v_col2im(dt(dA), ptr(dA), ptr(dX), B, T_in, T_out, C_, k, s, p, dA.stride(-2), stream())
+    check(rc, "a2v_col2im")
+    return dX
+
+
+def cast2d(src, dst):
+    """dst[m, :C] = src[m, :C] with dtype conversion; 2-D views with unit inner stride."""
+    M, C_ = src.shape
+    rc = _L().a2v_cast2d(dt(src), dt(dst), ptr(src), ptr(dst), M, C_, src.stride(0), dst.stride(0), stream())
+    check(rc, "a2v_cast2d")
+    return dst

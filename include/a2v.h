@@ -1,0 +1,161 @@
+/* animal2vec MI355X hot path -- C ABI of liba2v_hip.so (gfx950).
+ *
+ * Drop-in boundary.  The reference (livingingroups/animal2vec) has no native code at all: every
+ * device op of its pretraining path is a stock torch op issued from Python.  Each entry point below
+ * therefore replaces a *Python call site* of the reference (cited as file:line, paths relative to the
+ * reference root) rather than an existing FFI symbol.  The reference-side binding a maintainer would
+ * add is the ctypes stub shown in INTEGRATION.md (animal2vec_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch types.  All pointers are DEVICE pointers.
+ *  - dtype: 0 = fp32 storage + v_mfma_f32_16x16x4_f32 (parity mode), 1 = bf16 storage +
+ *    v_mfma_f32_16x16x32_bf16 with fp32 accumulation (throughput mode).  Parameters, biases,
+ *    statistics and gradients of parameters are always fp32.
+ *  - activations are channels-last: (batch, time, channels) row-major.
+ *  - ownership: the caller owns every buffer (incl. workspaces and tensors saved for backward);
+ *    kernels never allocate, free or retain pointers.
+ *  - every call is asynchronous on `stream`, re-entrant and graph-capturable (no sync, no alloc).
+ *  - return value: 0 on success, <0 on error (-1 bad argument, -2 bad dtype, -(1000+hipError_t) on a
+ *    launch failure).  No exceptions cross the ABI.
+ */
+#ifndef A2V_H
+#define A2V_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
+
+#define A2V_F32 0
+#define A2V_BF16 1
+
+/* epilogue flags of a2v_conv_gemm */
+#define A2V_EPI_BIAS 1      /* + bias[g*N+n] */
+#define A2V_EPI_GELU 2      /* exact erf GELU (torch.nn.GELU) */
+#define A2V_EPI_RES 4       /* + R[m][.] (residual / gradient accumulation) */
+#define A2V_EPI_GELU_BWD 8  /* * gelu'(R[m][.]) : R holds the saved pre-activation */
+#define A2V_EPI_STORE_PRE 16 /* also store the pre-activation (acc + bias) to C2 */
+#define A2V_EPI_COLSUM 32   /* atomically add column sums of the output to colsum (bias gradient) */
+
+/* ---------------------------------------------------------------- implicit-GEMM (MFMA) family
+ * C[m][g*c_goff + n] = epi( sum_kk A_g[m][kk] * Bw[g][n][kk] ),  kk = tap*Cg + ci,
+ * A_g[m=(b,t)][kk] = X[b / bdiv][t*stride - pad + tap][g*a_goff + ci]   (0 outside [0,T_in), and 0
+ * where rowmask[b*T_in + row] != 0).
+ * Replaces: F.linear in AltAttention/Mlp/project_features/decoder.proj (nn/modalities/modules.py:371,
+ * 408; timm Mlp; nn/modalities/audio.py:87; modules.py:191), nn.Conv1d of the feature extractor
+ * (nn/utils.py:1085-1090), the grouped positional/decoder convs (audio.py:97-103, modules.py:143-149)
+ * and their autograd input gradients; with rowmask/bdiv also x.repeat_interleave(cb)*(1-mask)
+ * (nn/modalities/base.py:244,464). */
+int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in, int T_out,
+                  int stride, int pad, int taps, int Cg, const unsigned char* rowmask, int bdiv, const void* Bw,
+                  long long ldb, long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
+                  long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
+                  a2v_stream_t stream);
+
+/* W[g][n][kk] += sum_m P[m][g*p_goff + n] * A_g[m][kk]   (fp32 atomics; zero W first)
+ * Replaces autograd's weight gradients of the ops above. */
+int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in, int T_out,
+                   int stride, int pad, int taps, int Cg, const unsigned char* rowmask, int bdiv, const void* P,
+                   long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
+                   a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- attention with analytic ALiBi
+ * qkv (N,S,3,H,HD); out (N,S,H*HD); lse (N,H,S) fp32; pos (N,S) int32 original frame index or NULL
+ * (= arange); slopes (H) fp32; alibi_scale (H) fp32 (clamped at 0 inside).
+ * Replaces AltAttention.forward's q@k^T + alibi + softmax + @v (modules.py:391-407) together with
+ * get_alibi_bias / masked_alibi (base.py:292-314,553-698): no (N,H,S,S) tensor is ever built. */
+int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const int* pos, const float* slopes,
+                      const float* alibi_scale, int N, int S, int H, int HD, float scale, a2v_stream_t stream);
+/* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dq32 (N,S,H,HD) fp32 must be zero on entry and
+ * receives dQ; dalibi (H) fp32 accumulates d loss / d alibi_scale. */
+int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse, float* delta,
+                      void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
+                      const float* alibi_scale, int N, int S, int H, int HD, float scale, a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- normalisation
+ * y = act( LN(x [+ res]) * gamma + beta ), act 0 none / 1 GELU; optional sum_out = x + res;
+ * optional mean/rstd (M) fp32 saved for backward.
+ * Replaces Fp32LayerNorm / nn.LayerNorm call sites: nn/utils.py:1105-1115, audio.py:86,106,
+ * modules.py:85,152,330,333. */
+int a2v_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
+                      void* sum_out, float* mean, float* rstd, long long M, int C, long long ldx, long long ldy,
+                      float eps, int act, a2v_stream_t stream);
+/* dx [+ dres]; dgamma/dbeta (C) and dxsum (C, column sums of dx) are accumulated with atomics. */
+int a2v_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* beta,
+                      const float* mean, const float* rstd, void* dx, const void* dres, float* dgamma, float* dbeta,
+                      float* dxsum, long long M, int C, long long ldx, long long lddy, int act, a2v_stream_t stream);
+/* y (B,T,D) fp32 = mean_l instance_norm_T(layers[l])   -- make_targets, nn/data2vec2.py:1023-1066.
+ * layers: HOST array of L device pointers (B,T,D); mean_ws/rstd_ws (L*B*D) fp32 scratch. */
+int a2v_instnorm_targets(int dtype, const void* const* layers, int L, float* mean_ws, float* rstd_ws, float* y, int B,
+                         int T, int D, float eps, a2v_stream_t stream);
+int a2v_colsum(int dtype, const void* x, float* out, long long M, int C, long long ld, a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- SincConv front end (nn/sinc.py)
+ * filters (Cp,k) fp32 from (low_hz_, band_hz_) -- SincConv._get_sinc_filters, sinc.py:181-223;
+ * n_ / window are the module buffers of sinc.py:264-276. */
+int a2v_sinc_filters_fwd(const float* low_hz, const float* band_hz, const float* n_, const float* window, float* filt,
+                         int C, int Cp, int k, float min_low_hz, float min_band_hz, float sample_rate,
+                         a2v_stream_t stream);
+int a2v_sinc_filters_bwd(const float* low_hz, const float* band_hz, const float* n_, const float* window,
+                         const float* dfilt, float* dlow, float* dband, int C, int k, float min_low_hz,
+                         float min_band_hz, float sample_rate, a2v_stream_t stream);
+/* x (B,L) fp32 -> y (B,L,128) channels-last: reflect pad + conv1d + LayerNorm(C) + PSwish in one
+ * pass -- SincConv.forward (sinc.py:107-159) + ConvFeatureExtractionModel block 0 tail
+ * (nn/utils.py:1105-1117) + PSwish.forward (utils.py:1430-1431). mean/rstd (B,L) saved for backward. */
+int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
+                       const float* ps_alpha, const float* ps_beta, void* y, float* mean, float* rstd, int B, int L,
+                       int C, int k, float eps, a2v_stream_t stream);
+/* dfilt (C,k) and dpar (4,128: d ln_w, d ln_b, d ps_alpha, d ps_beta) are accumulated: zero first. */
+int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
+                       const float* ps_alpha, const float* ps_beta, const void* dy, const float* mean,
+                       const float* rstd, float* dfilt, float* dpar, int B, int L, int C, int k, a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- masking / token plumbing
+ * out[n,k,:] = a[n/cb, ids[n,k], :] (+ b[n, ids[n,k], :])  -- make_maskinfo gather + x_unmasked +
+ * gather_unmasked(x_pos) (base.py:244,447,277-280). */
+int a2v_gather_tokens(int dtype, const void* a, const void* b, const int* ids, void* out, int N, int K, int D, int Ta,
+                      int cb, a2v_stream_t stream);
+int a2v_scatter_tokens(int dtype, const void* dtok, const int* restore, void* dpos, int N, int K, int D, int T,
+                       a2v_stream_t stream);
+int a2v_clone_reduce(int dtype, const void* dxm, const void* dtok, const int* restore, void* dfeat, int B, int cb,
+                     int K, int D, int T, a2v_stream_t stream);
+/* decoder_input (base.py:162-192): out[n,t] = restore<K ? x[n,restore] : noise[n,restore-K] */
+int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K, int D,
+                      int T, a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- loss (data2vec2.py:850-864,904-909,
+ * 1005-1021) + compute_var sums (:1095-1110).  stats: double[4*D+2] accumulated (zero first):
+ * sum x, sum x^2, sum y, sum y^2, loss sum, masked-row count. dx may be NULL; loss_rows (N,T,D)
+ * fp32 unreduced loss (0 on kept rows) may be NULL. */
+int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsigned char* mask, void* dx, float* loss_rows,
+                 double* stats, int N, int T, int D, int cb, float scale, float gscale, a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- optimizer side
+ * EMA teacher: fairseq EMAModule.step driven from data2vec2.py:386-410, flat fp32 buffers. */
+int a2v_ema_update(float* ema, const float* p, long long n, float decay, a2v_stream_t stream);
+/* fairseq Adam (configs/MeerKAT/a2v_large_pretrain_best.yaml:64-79). */
+int a2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, float grad_scale, a2v_stream_t stream);
+int a2v_sumsq(const float* x, long long n, double* out, a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- layout helpers
+ * w: reference parameter layout (G*N, Cg, k) fp32.  mode 0: [g][n][tap*Cgp+ci]; mode 1: flipped /
+ * transposed [g][ci][tap*Np+n] (input-gradient-as-convolution operand, and W^T for Linear);
+ * mode 2 (G==1): [tap*Cgp+ci][n]. */
+int a2v_pack_weight(int dtype, const float* w, void* out, int G, int N, int Cg, int k, int Cgp, int Np, int mode,
+                    a2v_stream_t stream);
+int a2v_unpack_wgrad(const float* packed, float* gw, int GN, int Cg, int k, int Cgp, a2v_stream_t stream);
+int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, int C, int k, int s, int p,
+               long long lda, a2v_stream_t stream);
+int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out, long long M, int C, long long ldi,
+               long long ldo, a2v_stream_t stream);
+
+/* library version / build info */
+int a2v_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* A2V_H */

@@ -1,0 +1,437 @@
+"""GPU parity of every C-ABI op against plain fp32 PyTorch-on-CPU references (and oracle functions).
+
+Tolerances (relative L2, ||a-b|| / ||b||):
+  fp32 mode  : 2e-5  (exact-fp32 MFMA; only summation order differs)
+  bf16 mode  : 1e-2  (inputs are pre-rounded to bf16, so the error is output rounding 2^-9 + fp32 accumulate)
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import a2v_oracle as O
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype, scale=1.0):
+    return (2e-5 if dtype == torch.float32 else 1e-2) * scale
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from animal2vec_amd import ops as o
+    return o
+
+
+def rnd(*shape, dtype, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(*shape, generator=g) * scale
+    return x.to(dtype).float()      # value representable in dtype, held as fp32 on CPU
+
+
+def dev(x, dtype):
+    return x.to(device="cuda", dtype=dtype).contiguous()
+
+
+# ------------------------------------------------------------------------------------------ linear
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 136), (77, 48, 72), (1000, 384, 1024), (64, 3072, 1024)])
+def test_linear_plain(ops, dtype, M, N, K):
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, seed=3)
+    y = ops.linear(dev(x, dtype), dev(w, dtype), dev(b, torch.float32))
+    assert rel_err(y.float(), x @ w.t() + b) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_epilogues(ops, dtype):
+    M, N, K = 200, 160, 96
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, seed=3)
+    r = rnd(M, N, dtype=dtype, seed=4)
+    xd, wd, bd, rd = dev(x, dtype), dev(w, dtype), dev(b, torch.float32), dev(r, dtype)
+    pre = x @ w.t() + b
+    # bias + gelu + stored pre-activation
+    pre_out = torch.empty(M, N, dtype=dtype, device="cuda")
+    y = ops.linear(xd, wd, bd, gelu=True, pre_out=pre_out)
+    assert rel_err(pre_out.float(), pre) < tol(dtype)
+    assert rel_err(y.float(), F.gelu(pre)) < tol(dtype)
+    # bias + residual
+    y = ops.linear(xd, wd, bd, res=rd)
+    assert rel_err(y.float(), pre + r) < tol(dtype)
+    # gelu backward epilogue + column sums
+    cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+    y = ops.linear(xd, wd, None, gelu_bwd_aux=rd, colsum=cs)
+    rr = r.clone().requires_grad_(True)
+    F.gelu(rr).backward(x @ w.t())
+    assert rel_err(y.float(), rr.grad) < tol(dtype)
+    assert rel_err(cs, y.float().sum(0)) < 1e-4
+
+
+# ------------------------------------------------------------------------------------------ convs
+def to_cl(x_bct, cp, dtype):
+    B, C_, T = x_bct.shape
+    out = torch.zeros(B, T, cp)
+    out[:, :, :C_] = x_bct.transpose(1, 2)
+    return dev(out, dtype)
+
+
+def pack_ref(w, G, cgp):
+    """(Cout, Cg, k) -> (G, N, k*cgp) forward operand"""
+    Cout, Cg, k = w.shape
+    p = torch.zeros(Cout, k, cgp)
+    p[:, :, :Cg] = w.permute(0, 2, 1)
+    return p.reshape(G, Cout // G, k * cgp)
+
+
+CONVS = [  # Cin, Cout, k, stride, pad_left, groups, T
+    (127, 64, 10, 5, 3, 1, 400),
+    (64, 96, 3, 2, 1, 1, 201),
+    (64, 64, 3, 1, 1, 1, 150),
+    (64, 64, 2, 1, 0, 1, 150),
+    (128, 128, 19, 1, 9, 16, 200),
+    (128, 96, 7, 1, 3, 16, 130),
+    (96, 96, 7, 1, 3, 16, 130),
+]
+
+
+def conv_ref(x, w, k, s, pl, G, T_out):
+    T = x.shape[-1]
+    pr = max(0, (T_out - 1) * s + k - pl - T)
+    return F.conv1d(F.pad(x, (pl, pr)), w, stride=s, groups=G)[..., :T_out]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv_fwd_and_wgrad(ops, dtype, cfg):
+    Cin, Cout, k, s, pl, G, T = cfg
+    B = 3
+    Cg = Cin // G
+    cgp = (Cg + 7) // 8 * 8
+    cp = cgp * G if G > 1 else cgp
+    x = rnd(B, Cin, T, dtype=dtype, seed=5)
+    w = rnd(Cout, Cg, k, dtype=dtype, seed=6, scale=(Cg * k) ** -0.5)
+    bias = rnd(Cout, dtype=torch.float32, seed=7)
+    if s == 1:
+        T_out = T
+    else:
+        T_out = (T + 2 * pl - k) // s + 1
+    ref = conv_ref(x, w, k, s, pl, G, T_out) + bias.view(1, -1, 1)
+    xcl = to_cl(x, cp, dtype)
+    wp = dev(pack_ref(w, G, cgp), dtype)
+    y = ops.conv1d_cl(xcl, wp, dev(bias, torch.float32), k=k, stride=s, pad=pl, groups=G, T_out=T_out, n_out=Cout)
+    assert rel_err(y.float().transpose(1, 2), ref) < tol(dtype)
+    # the device-side packer agrees with the reference packing
+    wp2 = torch.empty_like(wp)
+    ops.pack_weight(dev(w, torch.float32), wp2, G=G, N=Cout // G, Cg=Cg, k=k, Cgp=cgp, mode=0)
+    assert torch.equal(wp2.float().cpu(), wp.float().cpu())
+    # weight gradient
+    dy = rnd(B, Cout, T_out, dtype=dtype, seed=8)
+    wr = w.clone().requires_grad_(True)
+    conv_ref(x, wr, k, s, pl, G, T_out).backward(dy)
+    gw = torch.zeros(G, Cout // G, k * cgp, dtype=torch.float32, device="cuda")
+    ops.conv1d_cl_wgrad(xcl, to_cl(dy, Cout, dtype), gw, k=k, stride=s, pad=pl, groups=G, T_out=T_out)
+    gw_un = torch.zeros(Cout, Cg, k, dtype=torch.float32, device="cuda")
+    ops.unpack_wgrad(gw, gw_un, GN=Cout, Cg=Cg, k=k, Cgp=cgp)
+    assert rel_err(gw_un, wr.grad) < tol(dtype, 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_clone_mask_view(ops, dtype):
+    """x.repeat_interleave(cb) * (1 - mask) -> grouped conv, without materialising the clones"""
+    B, cb, T, D, G, k = 2, 3, 96, 64, 4, 19
+    x = rnd(B, T, D, dtype=dtype, seed=1)
+    w = rnd(D, D // G, k, dtype=dtype, seed=2, scale=0.05)
+    mask = (torch.rand(B * cb, T, generator=torch.Generator().manual_seed(3)) < 0.8).to(torch.uint8)
+    xm = x.repeat_interleave(cb, 0) * (1 - mask.float().unsqueeze(-1))
+    ref = F.conv1d(xm.transpose(1, 2), w, padding=k // 2, groups=G).transpose(1, 2)
+    wp = dev(pack_ref(w, G, D // G), dtype)
+    y = ops.conv1d_cl(dev(x, dtype), wp, None, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D,
+                      rowmask=mask.cuda(), bdiv=cb, n_batch=B * cb)
+    assert rel_err(y.float(), ref) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_dgrad_paths(ops, dtype):
+    # stride-1 grouped conv: input gradient as a convolution with flipped/transposed weights (pack mode 1)
+    B, T, D, G, k = 2, 120, 64, 4, 7
+    Cg = D // G
+    x = rnd(B, D, T, dtype=dtype, seed=1).requires_grad_(True)
+    w = rnd(D, Cg, k, dtype=dtype, seed=2, scale=0.1)
+    dy = rnd(B, D, T, dtype=dtype, seed=3)
+    F.conv1d(x, w, padding=k // 2, groups=G).backward(dy)
+    wt = torch.empty(G, Cg, k * Cg, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(w, torch.float32), wt, G=G, N=Cg, Cg=Cg, k=k, mode=1)
+    dx = ops.conv1d_cl(to_cl(dy, D, dtype), wt, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D)
+    assert rel_err(dx.float().transpose(1, 2), x.grad) < tol(dtype, 2)
+    # strided dense conv: dA = dY @ Wmat (pack mode 2) then col2im
+    Cin, Cout, k, s, p = 64, 96, 10, 5, 3
+    T = 200
+    T_out = (T + 2 * p - k) // s + 1
+    x = rnd(B, Cin, T, dtype=dtype, seed=4).requires_grad_(True)
+    w = rnd(Cout, Cin, k, dtype=dtype, seed=5, scale=0.05)
+    dy = rnd(B, Cout, T_out, dtype=dtype, seed=6)
+    F.conv1d(x, w, stride=s, padding=p).backward(dy)
+    wm = torch.empty(k * Cin, Cout, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(w, torch.float32), wm, G=1, N=Cout, Cg=Cin, k=k, mode=2)
+    dA = ops.linear(to_cl(dy, Cout, dtype).view(B * T_out, Cout), wm)
+    dx = ops.col2im(dA, B=B, T_in=T, T_out=T_out, C_=Cin, k=k, s=s, p=p)
+    assert rel_err(dx.float().transpose(1, 2), x.grad) < tol(dtype, 2)
+    # Linear: dX = dY @ W via W^T from pack mode 1, dW via wgrad
+    M, N, K = 150, 96, 64
+    xx, ww, dd = rnd(M, K, dtype=dtype, seed=7), rnd(N, K, dtype=dtype, seed=8), rnd(M, N, dtype=dtype, seed=9)
+    wT = torch.empty(K, N, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(ww, torch.float32), wT, G=1, N=N, Cg=K, k=1, mode=1)
+    assert rel_err(ops.linear(dev(dd, dtype), wT).float(), dd @ ww) < tol(dtype)
+    gw = torch.zeros(N, K, dtype=torch.float32, device="cuda")
+    ops.linear_wgrad(dev(xx, dtype), dev(dd, dtype), gw)
+    assert rel_err(gw, dd.t() @ xx) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_wgrad_large_m(ops, dtype):
+    M, N, K = 5000, 256, 192
+    x, dy = rnd(M, K, dtype=dtype, seed=1), rnd(M, N, dtype=dtype, seed=2)
+    gw = torch.zeros(N, K, dtype=torch.float32, device="cuda")
+    ops.linear_wgrad(dev(x, dtype), dev(dy, dtype), gw)
+    assert rel_err(gw, dy.t() @ x) < tol(dtype)
+
+
+# ------------------------------------------------------------------------------------------ attention
+def attn_ref(qkv, pos, slopes, scale_h, H):
+    N, S, W = qkv.shape
+    hd = W // (3 * H)
+    q, k, v = qkv.reshape(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = O.alibi_bias_from_positions(pos.long(), H, scale_h.view(1, 1, H, 1, 1))
+    att = (q * hd ** -0.5) @ k.transpose(-2, -1) + bias
+    att = att.softmax(-1)
+    return (att @ v).transpose(1, 2).reshape(N, S, H * hd)
+
+
+@pytest.mark.parametrize("dtype,hd", [(torch.float32, 16), (torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 32)])
+@pytest.mark.parametrize("S", [37, 140, 200])
+def test_attention_fwd_bwd(ops, dtype, hd, S):
+    N, H = 3, 4
+    qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=1).requires_grad_(True)
+    g = torch.Generator().manual_seed(2)
+    pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = (torch.rand(H, generator=g) + 0.5).requires_grad_(True)
+    ref = attn_ref(qkv, pos, slopes, sc, H)
+    do = rnd(N, S, H * hd, dtype=dtype, seed=3)
+    ref.backward(do)
+    qd = dev(qkv.detach(), dtype)
+    out, lse = ops.attention_fwd(qd, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H)
+    assert rel_err(out.float(), ref) < tol(dtype, 2)
+    dal = torch.zeros(H, dtype=torch.float32, device="cuda")
+    dqkv = ops.attention_bwd(qd, out, dev(do, dtype), lse, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, dal)
+    t = tol(dtype, 3)
+    assert rel_err(dqkv.float(), qkv.grad) < t
+    assert rel_err(dal, sc.grad) < max(t, 2e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_attention_teacher_arange_long(ops, dtype):
+    N, H, hd, S = 1, 2, 64, 700
+    qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=4)
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = torch.tensor([1.3, -0.2])          # negative learned scale is clamped to 0
+    pos = torch.arange(S).unsqueeze(0).int()
+    ref = attn_ref(qkv, pos, slopes, sc, H)
+    out, _ = ops.attention_fwd(dev(qkv, dtype), None, slopes.cuda(), sc.cuda(), H, need_lse=False)
+    assert rel_err(out.float(), ref) < tol(dtype, 2)
+
+
+# ------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C_,act,affine", [(64, 0, True), (512, 1, True), (1024, 0, True), (768, 1, False), (32, 1, True)])
+def test_layernorm_fwd_bwd(ops, dtype, C_, act, affine):
+    M = 203
+    x = rnd(M, C_, dtype=dtype, seed=1).requires_grad_(True)
+    w = (rnd(C_, dtype=torch.float32, seed=2) * 0.2 + 1).requires_grad_(affine)
+    b = (rnd(C_, dtype=torch.float32, seed=3) * 0.2).requires_grad_(affine)
+    y = F.layer_norm(x, (C_,), w if affine else None, b if affine else None, 1e-5)
+    if act:
+        y = F.gelu(y)
+    dy = rnd(M, C_, dtype=dtype, seed=4)
+    y.backward(dy)
+    wd = dev(w.detach(), torch.float32) if affine else None
+    bd = dev(b.detach(), torch.float32) if affine else None
+    xd = dev(x.detach(), dtype)
+    yd, mean, rstd = ops.layernorm_fwd(xd, wd, bd, 1e-5, act=act)
+    assert rel_err(yd.float(), y) < tol(dtype)
+    dg = torch.zeros(C_, device="cuda") if affine else None
+    db = torch.zeros(C_, device="cuda") if affine else None
+    dxs = torch.zeros(C_, device="cuda")
+    dx = ops.layernorm_bwd(dev(dy, dtype), xd, wd, bd, mean, rstd, act=act, dgamma=dg, dbeta=db, dxsum=dxs)
+    assert rel_err(dx.float(), x.grad) < tol(dtype, 2)
+    assert rel_err(dxs, dx.float().sum(0)) < 1e-3
+    if affine:
+        assert rel_err(dg, w.grad) < tol(dtype, 2)
+        assert rel_err(db, b.grad) < tol(dtype, 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_residual_in(ops, dtype):
+    M, C_ = 100, 128
+    x, r = rnd(M, C_, dtype=dtype, seed=1), rnd(M, C_, dtype=dtype, seed=2)
+    w, b = torch.ones(C_), torch.zeros(C_)
+    y, _, _ = ops.layernorm_fwd(dev(x, dtype), w.cuda(), b.cuda(), 1e-5, res=dev(r, dtype), save_stats=False)
+    assert rel_err(y.float(), F.layer_norm(x + r, (C_,))) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_instnorm_targets(ops, dtype):
+    B, T, D, Ln = 2, 200, 64, 3
+    ts = [rnd(B, T, D, dtype=dtype, seed=10 + i) * (i + 1) + i for i in range(Ln)]
+    ref = O.make_targets([t.clone() for t in ts], Ln)
+    y = ops.instnorm_targets([dev(t, dtype) for t in ts])
+    assert rel_err(y, ref) < 2e-5     # statistics and output are fp32 in both modes
+
+
+# ------------------------------------------------------------------------------------------ sinc
+@pytest.mark.parametrize("C_,k,sr", [(127, 63, 8000), (31, 15, 8000), (127, 63, 44100)])
+def test_sinc_filters_fwd_bwd(ops, C_, k, sr):
+    lo, band = O.sinc_init(C_, k, sr)
+    g = torch.Generator().manual_seed(1)
+    lo = (lo + torch.randn(lo.shape, generator=g) * 10).requires_grad_(True)
+    band = (band + torch.randn(band.shape, generator=g) * 10).requires_grad_(True)
+    ref = O.sinc_filters(lo, band, k, sr)[:, 0]
+    win, n_ = O.sinc_window_and_n(k, sr)
+    kw = dict(C_=C_, k=k, min_low_hz=50.0, min_band_hz=float(math.ceil(sr / k)), sample_rate=sr)
+    args = (lo.detach().flatten().cuda(), band.detach().flatten().cuda(), n_.flatten().cuda(), win.cuda())
+    f = ops.sinc_filters_fwd(*args, Cp=128, **kw)
+    assert rel_err(f[:C_], ref) < 1e-5 and float(f[C_:].abs().max() if C_ < 128 else 0) == 0
+    df = torch.randn(C_, k, generator=g)
+    ref.backward(df)
+    dlow, dband = ops.sinc_filters_bwd(*args, df.cuda(), **kw)
+    assert rel_err(dlow, lo.grad.flatten()) < 1e-3
+    assert rel_err(dband, band.grad.flatten()) < 1e-3
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C_,k,L", [(127, 63, 1000), (31, 15, 640)])
+def test_sinc_fused_fwd_bwd(ops, dtype, C_, k, L):
+    B, sr = 2, 8000
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, L, generator=g)
+    lo, band = O.sinc_init(C_, k, sr)
+    filt = O.sinc_filters(lo, band, k, sr)[:, 0].clone().requires_grad_(True)
+    lw = (torch.randn(C_, generator=g) * 0.2 + 1).requires_grad_(True)
+    lb = (torch.randn(C_, generator=g) * 0.2).requires_grad_(True)
+    pa = (torch.randn(C_, generator=g) * 0.2 + 2).requires_grad_(True)
+    pb = (torch.randn(C_, generator=g) * 0.3).requires_grad_(True)
+    pad = k // 2
+    conv = F.conv1d(F.pad(x.unsqueeze(1), (pad, pad), mode="reflect"), filt.unsqueeze(1))
+    yl = O.channel_layer_norm(conv, lw, lb)
+    ref = O.pswish(yl, pa.view(1, -1, 1), pb.view(1, -1, 1))             # (B,C,L)
+    dyr = rnd(B, C_, L, dtype=dtype, seed=4)
+    ref.backward(dyr)
+    cu = lambda t: t.detach().cuda()
+    y, mean, rstd = ops.sinc_fused_fwd(cu(x), cu(filt), cu(lw), cu(lb), cu(pa), cu(pb), C_=C_, k=k, dtype=dtype)
+    assert rel_err(y[..., :C_].float().transpose(1, 2), ref) < tol(dtype)
+    assert float(y[..., C_:].float().abs().max()) == 0.0
+    dycl = torch.zeros(B, L, 128)
+    dycl[..., :C_] = dyr.transpose(1, 2)
+    dfilt = torch.zeros(C_, k, device="cuda")
+    dpar = torch.zeros(4, 128, device="cuda")
+    ops.sinc_fused_bwd(cu(x), cu(filt), cu(lw), cu(lb), cu(pa), cu(pb), dev(dycl, dtype), mean, rstd, dfilt, dpar, C_=C_, k=k)
+    assert rel_err(dfilt, filt.grad) < 2e-4
+    for i, p in enumerate((lw, lb, pa, pb)):
+        assert rel_err(dpar[i, :C_], p.grad) < 2e-4, i
+
+
+# ------------------------------------------------------------------------------------------ tokens / loss
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_token_plumbing(ops, dtype):
+    B, cb, T, D, K = 2, 3, 50, 64, 7
+    N = B * cb
+    mask = O.seeded_mask(N, T, K, 5)
+    ids_keep, ids_restore = O.make_maskinfo(mask)
+    x = rnd(B, T, D, dtype=dtype, seed=1)
+    xp = rnd(N, T, D, dtype=dtype, seed=2)
+    gi = ids_keep.unsqueeze(-1).expand(-1, -1, D)
+    ref = torch.gather(x.repeat_interleave(cb, 0), 1, gi) + torch.gather(xp, 1, gi)
+    out = ops.gather_tokens(dev(x, dtype), ids_keep.int().cuda(), cb=cb, b=dev(xp, dtype))
+    assert rel_err(out.float(), ref) < tol(dtype)
+    # decoder input
+    tok = rnd(N, K, D, dtype=dtype, seed=3)
+    noise = rnd(N, T - K, D, dtype=torch.float32, seed=4) * 0.01
+    ref = O.decoder_input(tok, ids_restore, noise)
+    out = ops.decoder_input(dev(tok, dtype), noise.cuda(), ids_restore.int().cuda())
+    assert rel_err(out.float(), ref.to(dtype).float()) < 1e-6
+    # scatter + clone reduce == autograd of (repeat_interleave, mask, gather)
+    xr = x.clone().requires_grad_(True)
+    xc = xr.repeat_interleave(cb, 0)
+    xm = xc * (1 - mask.float().unsqueeze(-1))
+    tokens = torch.gather(xc, 1, gi)
+    dxm, dtok = rnd(N, T, D, dtype=dtype, seed=5), rnd(N, K, D, dtype=dtype, seed=6)
+    ((xm * dxm).sum() + (tokens * dtok).sum()).backward()
+    out = ops.clone_reduce(dev(dxm, dtype), dev(dtok, dtype), ids_restore.int().cuda(), cb)
+    assert rel_err(out.float(), xr.grad) < tol(dtype)
+    sc = ops.scatter_tokens(dev(dtok, dtype), ids_restore.int().cuda(), T)
+    ref = torch.zeros(N, T, D).scatter_(1, gi, dtok)
+    assert rel_err(sc.float(), ref) < 1e-6
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_d2v_loss(ops, dtype):
+    B, cb, T, D, K = 2, 3, 40, 64, 6
+    N = B * cb
+    mask = O.seeded_mask(N, T, K, 9)
+    x = rnd(N, T, D, dtype=dtype, seed=1).requires_grad_(True)
+    y = rnd(B, T, D, dtype=torch.float32, seed=2)
+    mb = mask.bool()
+    ysel = y.repeat_interleave(cb, 0)[mb]
+    loss = O.d2v_loss(x[mb], ysel)
+    loss.sum().backward()
+    stats = torch.zeros(4 * D + 2, dtype=torch.float64, device="cuda")
+    rows = torch.empty(N, T, D, dtype=torch.float32, device="cuda")
+    dx = ops.d2v_loss(dev(x.detach(), dtype), y.cuda(), mask.cuda(), cb, stats=stats, loss_rows=rows)
+    st = stats.cpu()
+    assert abs(float(st[4 * D]) - float(loss.sum())) / float(loss.sum()) < 1e-5
+    assert int(st[4 * D + 1]) == int(mask.sum())
+    assert rel_err(rows[mb.cuda()], loss) < 1e-5
+    assert rel_err(dx.float(), x.grad) < tol(dtype)
+    n = float(st[4 * D + 1])
+    for off, ref in ((0, x.detach()[mb]), (2 * D, ysel)):
+        s, ss = st[off:off + D], st[off + D:off + 2 * D]
+        var = (ss - s * s / n) / (n - 1)
+        v = torch.sqrt(var + 1e-6).mean()
+        assert abs(float(v) - float(O.compute_var(ref))) < 1e-5
+
+
+def test_ema_adam_cast(ops):
+    n = 100003
+    g = torch.Generator().manual_seed(0)
+    e, p = torch.randn(n + 1, generator=g)[:n], torch.randn(n + 1, generator=g)[:n]
+    ed = e.cuda().clone()
+    # 16-B alignment of the flat buffers is part of the contract
+    ops.ema_update(ed, p.cuda(), 0.9997)
+    assert rel_err(ed, e * 0.9997 + p * (1 - 0.9997)) < 1e-6
+    pp, gg = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    m, v = torch.zeros(n), torch.zeros(n)
+    pd, md, vd = pp.cuda().clone(), m.cuda(), v.cuda()
+    ref = pp.clone()
+    lr, b1, b2, eps, wd = 1e-3, 0.9, 0.98, 1e-6, 0.01
+    for step in (1, 2):
+        ops.adam_step(pd, gg.cuda(), md, vd, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=step)
+        m = m * b1 + gg * (1 - b1)
+        v = v * b2 + gg * gg * (1 - b2)
+        ss = lr * math.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        ref = ref - wd * lr * ref
+        ref = ref - ss * m / (v.sqrt() + eps)
+    assert rel_err(pd, ref) < 1e-5
+    out = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ops.sumsq(gg.cuda(), out)
+    assert abs(float(out) - float((gg.double() ** 2).sum())) / float(out) < 1e-6
+    a = torch.randn(37, 64, generator=g)
+    b = torch.zeros(37, 96, dtype=torch.bfloat16, device="cuda")
+    ops.cast2d(a.cuda(), b[:, :64])
+    assert torch.equal(b[:, :64].float().cpu(), a.to(torch.bfloat16).float()) and float(b[:, 64:].float().abs().max()) == 0
