@@ -24,7 +24,7 @@ SIGNATURES = {
                        _i, _p],
     "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "a2v_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _f, _i, _p],
+    "a2v_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _f, _i, _p],
     "a2v_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _p],
     "a2v_instnorm_targets": [_i, C.POINTER(_p), _i, _p, _p, _p, _i, _i, _i, _f, _p],
     "a2v_colsum": [_i, _p, _p, _ll, _i, _ll, _p],
@@ -38,11 +38,11 @@ SIGNATURES = {
     "a2v_decoder_input": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "a2v_d2v_loss": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "a2v_ema_update": [_p, _p, _ll, _f, _p],
-    "a2v_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p],
+    "a2v_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p, _p, _p],
     "a2v_sumsq": [_p, _ll, _p, _p],
     "a2v_pack_weight": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "a2v_unpack_wgrad": [_p, _p, _i, _i, _i, _i, _p],
-    "a2v_col2im": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _p],
+    "a2v_col2im": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _p],
     "a2v_cast2d": [_i, _i, _p, _p, _ll, _i, _ll, _ll, _p],
     "a2v_abi_version": [],
 }

@@ -1,0 +1,153 @@
+"""Configuration of the pretraining hot path.  Field names follow the reference's dataclasses
+(nn/data2vec2.py:56-165 Data2VecMultiConfig, nn/modalities/audio.py:29-51 D2vAudioConfig,
+nn/modalities/base.py:30-72 D2vModalityConfig, nn/modalities/modules.py:34-47 D2vDecoderConfig)
+restricted to the switches the shipped recipe (configs/MeerKAT/a2v_large_pretrain_best.yaml) uses.
+"""
+from __future__ import annotations
+
+import ast
+import math
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+LARGE_LAYERS_STR = "[(127, 63, 1)] +[(512, 10, 5)] + [(512, 3, 2)] * 3 + [(512, 3, 1)] + [(512, 2, 1)] * 2"
+
+
+def parse_conv_layers(spec) -> List[Tuple[int, int, int]]:
+    """The reference eval()s this string (audio.py:68); parse the same grammar safely
+    (list literals of int tuples combined with + and *)."""
+    if not isinstance(spec, str):
+        return [tuple(int(v) for v in t) for t in spec]
+
+    def ev(node):
+        if isinstance(node, ast.Expression):
+            return ev(node.body)
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Add):
+            return ev(node.left) + ev(node.right)
+        if isinstance(node, ast.BinOp) and isinstance(node.op, ast.Mult):
+            l, r = ev(node.left), ev(node.right)
+            return l * r
+        if isinstance(node, ast.List):
+            return [ev(e) for e in node.elts]
+        if isinstance(node, ast.Tuple):
+            return tuple(ev(e) for e in node.elts)
+        if isinstance(node, ast.Constant) and isinstance(node.value, int):
+            return node.value
+        raise ValueError(f"unsupported syntax in conv_feature_layers: {ast.dump(node)}")
+
+    out = ev(ast.parse(spec.strip(), mode="eval"))
+    return [tuple(int(v) for v in t) for t in out]
+
+
+@dataclass
+class D2vDecoderConfig:
+    decoder_dim: int = 768
+    decoder_groups: int = 16
+    decoder_kernel: int = 7
+    decoder_layers: int = 4
+    input_dropout: float = 0.1
+    decoder_residual: bool = True
+
+
+@dataclass
+class D2vAudioConfig:
+    conv_feature_layers: str = LARGE_LAYERS_STR
+    sample_rate: int = 8000
+    conv_pos_width: int = 95
+    conv_pos_groups: int = 16
+    conv_pos_depth: int = 5
+    sinc_input: bool = True
+    sinc_norm: str = "layer_norm"
+    use_pswish: bool = True
+    prenet_depth: int = 8
+    prenet_dropout: float = 0.1
+    mask_prob: float = 1.5
+    mask_length: int = 2
+    mask_noise_std: float = 0.01
+    mask_dropout: float = 0.0
+    add_masks: bool = False
+    encoder_zero_mask: bool = True
+    use_alibi_encoder: bool = True
+    alibi_scale: float = 1.0
+    learned_alibi_scale: bool = True
+    learned_alibi_scale_per_head: bool = True
+    local_grad_mult: float = 1.0
+    decoder: D2vDecoderConfig = field(default_factory=D2vDecoderConfig)
+
+
+@dataclass
+class Data2VecMultiConfig:
+    depth: int = 16
+    embed_dim: int = 1024
+    num_heads: int = 16
+    mlp_ratio: float = 4.0
+    norm_eps: float = 1e-5
+    clone_batch: int = 12
+    encoder_dropout: float = 0.1
+    post_mlp_drop: float = 0.1
+    attention_dropout: float = 0.1
+    average_top_k_layers: int = 16
+    instance_norm_target_layer: bool = True
+    ema_decay: float = 0.9997
+    ema_end_decay: float = 1.0
+    ema_anneal_end_step: int = 300000
+    min_target_var: float = 0.1
+    min_pred_var: float = 0.01
+    loss_beta: float = 0.0
+    source_mixup: float = 0.5
+    mixup_prob: float = 1.0
+    same_mixup: bool = True
+    mixing_window_length: float = 0.05
+    gain_mode: str = "A_weighting"
+    seed: int = 1
+    audio: D2vAudioConfig = field(default_factory=D2vAudioConfig)
+
+    # ---- derived
+    @property
+    def conv_layers(self):
+        return parse_conv_layers(self.audio.conv_feature_layers)
+
+    @property
+    def head_dim(self):
+        return self.embed_dim // self.num_heads
+
+    @property
+    def pos_kernel(self):
+        return max(3, self.audio.conv_pos_width // self.audio.conv_pos_depth)    # audio.py:90-91
+
+    @property
+    def mlp_dim(self):
+        return int(self.embed_dim * self.mlp_ratio)
+
+    def frame_counts(self, n_samples: int):
+        """nn/utils.py:1085-1090: Conv1d padding 'same' for stride 1 else ceil(stride/2)."""
+        out, t = [], n_samples
+        for (_, k, s) in self.conv_layers:
+            if s != 1:
+                p = int(math.ceil(s / 2))
+                t = (t + 2 * p - (k - 1) - 1) // s + 1
+            out.append(t)
+        return out
+
+
+def large_config(**kw) -> Data2VecMultiConfig:
+    """configs/MeerKAT/a2v_large_pretrain_best.yaml:84-147"""
+    return Data2VecMultiConfig(**kw)
+
+
+def base_star_config(**kw) -> Data2VecMultiConfig:
+    """Build-defined 'animal2vec-base' (the reference ships only the large YAML)."""
+    a = D2vAudioConfig(prenet_depth=4, decoder=D2vDecoderConfig(decoder_dim=384, decoder_layers=4))
+    d = dict(depth=12, embed_dim=768, num_heads=12, clone_batch=8, average_top_k_layers=12, audio=a)
+    d.update(kw)
+    return Data2VecMultiConfig(**d)
+
+
+def tiny_config(conv_feature_layers=None, **kw) -> Data2VecMultiConfig:
+    """The dims of tests/golden/tiny_pretrain.npz (oracle/gen_golden.py)."""
+    layers = conv_feature_layers or "[(31, 15, 1)] + [(32, 10, 5)] + [(32, 3, 2)] * 3 + [(32, 3, 1)] + [(32, 2, 1)] * 2"
+    a = D2vAudioConfig(conv_feature_layers=layers, conv_pos_groups=4, prenet_depth=1,
+                       decoder=D2vDecoderConfig(decoder_dim=32, decoder_groups=4, decoder_layers=2))
+    d = dict(depth=2, embed_dim=64, num_heads=4, clone_batch=2, average_top_k_layers=2, audio=a)
+    d.update(kw)
+    return Data2VecMultiConfig(**d)

@@ -179,9 +179,12 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const f
 // fairseq Adam (decoupled weight decay applied before the step), flat fp32 buffers
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n, float lr,
-                                                   float b1, float b2, float eps, float wd, float step_size,
-                                                   float gscale) {
+                                                   float b1, float b2, float eps, float wd_, float step_size,
+                                                   float gscale_, const unsigned char* __restrict__ decay_mask,
+                                                   const float* __restrict__ gscale_dev) {
+  const float gscale = gscale_ * (gscale_dev ? *gscale_dev : 1.f);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float wd = (!decay_mask || decay_mask[i >> 6]) ? wd_ : 0.f;
     const float gr = g[i] * gscale;
     const float mi = m[i] * b1 + gr * (1.f - b1);
     const float vi = v[i] * b2 + gr * gr * (1.f - b2);
@@ -249,7 +252,8 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restri
 //   dX[b,u,ci] = sum_{t,j : t*s - p + j = u} dA[(b,t)][j*C + ci]
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dA, T* __restrict__ dX, int B, int T_in,
-                                                     int T_out, int C, int k, int s, int p, long long lda) {
+                                                     int T_out, int C, int k, int s, int p, long long lda,
+                                                     long long ldo) {
   const int vecs = C / 8;
   const long long total = (long long)B * T_in * vecs;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -267,7 +271,7 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dA, T
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] += x[q];
     }
-    Vec8<T>::store(dX + bu * C + v * 8, acc);
+    Vec8<T>::store(dX + bu * ldo + v * 8, acc);
   }
 }
 
@@ -359,13 +363,16 @@ extern "C" int a2v_ema_update(float* ema, const float* p, long long n, float dec
   return A2V_OK;
 }
 
+// decay_mask: one byte per 64 parameters (0 -> weight decay off for that block) or NULL;
+// grad_scale_dev: optional device scalar multiplied into grad_scale (clip / sample-size factor).
 extern "C" int a2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                             float eps, float weight_decay, int step, float grad_scale, hipStream_t st) {
+                             float eps, float weight_decay, int step, float grad_scale,
+                             const unsigned char* decay_mask, const float* grad_scale_dev, hipStream_t st) {
   if (n <= 0 || step <= 0) return A2V_ERR_ARG;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     step_size, grad_scale);
+                     step_size, grad_scale, decay_mask, grad_scale_dev);
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }
@@ -402,12 +409,12 @@ extern "C" int a2v_unpack_wgrad(const float* packed, float* gw, int GN, int Cg, 
 }
 
 extern "C" int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, int C, int k, int s, int p,
-                          long long lda, hipStream_t st) {
-  if (B <= 0 || C % 8 || lda % 8 || s <= 0) return A2V_ERR_ARG;
+                          long long lda, long long ldo, hipStream_t st) {
+  if (B <= 0 || C % 8 || lda % 8 || ldo % 8 || ldo < C || s <= 0) return A2V_ERR_ARG;
   const int g = grid_for((long long)B * T_in * (C / 8));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dA, (bf16*)dX, B, T_in, T_out, C, k, s, p, lda),
-             hipLaunchKernelGGL(col2im_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dA, (float*)dX, B, T_in, T_out, C, k, s, p, lda));
+             hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dA, (bf16*)dX, B, T_in, T_out, C, k, s, p, lda, ldo),
+             hipLaunchKernelGGL(col2im_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dA, (float*)dX, B, T_in, T_out, C, k, s, p, lda, ldo));
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }

@@ -12,8 +12,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             T* __restrict__ sum_out, float* __restrict__ mean_out,
-                                                            float* __restrict__ rstd_out, long long M, int C,
-                                                            long long ldx, long long ldy, float eps, int act) {
+                                                            float* __restrict__ rstd_out, const T* __restrict__ post,
+                                                            long long M, int C, long long ldx, long long ldy, float eps,
+                                                            int act) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -61,6 +62,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         if (gamma) t = t * gamma[col + i] + beta[col + i];
         if (act == 1) t = gelu_f(t);
         o[i] = t;
+      }
+      if (post) {
+        float r[8];
+        Vec8<T>::load(post + row * ldy + col, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] += r[i];
       }
       Vec8<T>::store(y + row * ldy + col, o);
     }
@@ -244,13 +251,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 // =============================================================================================
 template <typename T>
 static int ln_fwd_launch(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out,
-                         float* mean, float* rstd, long long M, int C, long long ldx, long long ldy, float eps, int act,
+                         float* mean, float* rstd, const void* post, long long M, int C, long long ldx, long long ldy, float eps, int act,
                          hipStream_t st) {
   const int nch = (C + 511) / 512;
   dim3 grid((unsigned)((M + 3) / 4)), blk(256);
 #define LN_F(N)                                                                                                      \
   hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
-                     (T*)sum_out, mean, rstd, M, C, ldx, ldy, eps, act)
+                     (T*)sum_out, mean, rstd, (const T*)post, M, C, ldx, ldy, eps, act)
   switch (nch) {
     case 1: LN_F(1); break;
     case 2: LN_F(2); break;
@@ -264,12 +271,12 @@ static int ln_fwd_launch(const void* x, const void* res, const float* gamma, con
 }
 
 extern "C" int a2v_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta,
-                                 void* y, void* sum_out, float* mean, float* rstd, long long M, int C, long long ldx,
-                                 long long ldy, float eps, int act, hipStream_t stream) {
+                                 void* y, void* sum_out, float* mean, float* rstd, const void* post, long long M, int C,
+                                 long long ldx, long long ldy, float eps, int act, hipStream_t stream) {
   if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || C > 512 * LN_MAXCHUNK) return A2V_ERR_ARG;
   if ((gamma == nullptr) != (beta == nullptr)) return A2V_ERR_ARG;
-  if (dtype == A2V_BF16) return ln_fwd_launch<bf16>(x, res, gamma, beta, y, sum_out, mean, rstd, M, C, ldx, ldy, eps, act, stream);
-  if (dtype == A2V_F32) return ln_fwd_launch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, M, C, ldx, ldy, eps, act, stream);
+  if (dtype == A2V_BF16) return ln_fwd_launch<bf16>(x, res, gamma, beta, y, sum_out, mean, rstd, post, M, C, ldx, ldy, eps, act, stream);
+  if (dtype == A2V_F32) return ln_fwd_launch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, post, M, C, ldx, ldy, eps, act, stream);
   return A2V_ERR_DTYPE;
 }
 

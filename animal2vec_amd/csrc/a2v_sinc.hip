@@ -40,7 +40,7 @@ __global__ void sinc_filters_fwd_kernel(const float* __restrict__ low_hz, const 
   f[half] = 2.f * band * inv;                                                      // :207
 }
 
-// dlow[c], dband[c] (written, not accumulated) from dfilt[c][j]
+// dlow[c], dband[c] are ACCUMULATED (+=) from dfilt[c][j]
 __global__ void sinc_filters_bwd_kernel(const float* __restrict__ low_hz, const float* __restrict__ band_hz,
                                         const float* __restrict__ n_, const float* __restrict__ window,
                                         const float* __restrict__ dfilt, float* __restrict__ dlow,
@@ -67,8 +67,8 @@ __global__ void sinc_filters_bwd_kernel(const float* __restrict__ low_hz, const 
   const float gh = inrange ? g_high : 0.f;
   const float sl = lo_p > 0.f ? 1.f : (lo_p < 0.f ? -1.f : 0.f);
   const float sb = ba_p > 0.f ? 1.f : (ba_p < 0.f ? -1.f : 0.f);
-  dlow[c] = sl * (g_low + gh);
-  dband[c] = sb * gh;
+  dlow[c] += sl * (g_low + gh);
+  dband[c] += sb * gh;
 }
 
 __device__ __forceinline__ int reflect_idx(int i, int L) {

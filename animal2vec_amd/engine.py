@@ -1,0 +1,383 @@
+"""Manual forward / backward schedule of the animal2vec pretraining step on one MI355X.
+
+Python only sequences kernel launches on the current HIP stream (static shapes, no host syncs, so a
+whole step is graph-capturable); every FLOP and byte is moved by the kernels behind include/a2v.h.
+The schedule mirrors Data2VecMultiModel.forward (reference nn/data2vec2.py:516-991):
+
+  student : SincConv+LN+PSwish -> conv stack -> project -> clone/mask -> pos-conv -> gather kept tokens
+            -> prenet + blocks (ALiBi from kept positions) -> decoder -> masked MSE vs teacher targets
+  teacher : (no grad, EMA weights) pos-conv -> prenet + blocks on all T frames -> instance-norm targets
+
+and the backward is written out by hand in exactly the reverse order, which is also the order of the
+flat gradient buffer (params.py), so finished gradient slices can be all-reduced while the rest of
+backward still runs (`on_grad_ready` callback).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from . import ops
+from .config import Data2VecMultiConfig
+from .params import P, Packs, ParamStore
+
+
+class Engine:
+    def __init__(self, cfg: Data2VecMultiConfig, store: ParamStore, dtype=torch.bfloat16):
+        self.cfg, self.store, self.dtype = cfg, store, dtype
+        self.sp = Packs(store, dtype, teacher=False, need_grad=True)
+        self.tp = Packs(store, dtype, teacher=True, need_grad=False)
+        self.sp.refresh()
+        self.tp.refresh()
+        self.layers = cfg.conv_layers
+        self.sv: Dict[str, object] = {}
+        self.on_grad_ready: Optional[Callable[[str], None]] = None
+        dev = store.device
+        self.stats = torch.zeros(4 * cfg.embed_dim + 2, dtype=torch.float64, device=dev)
+        c0 = self.layers[0][0]
+        k0 = self.layers[0][1]
+        self.dfilt = torch.zeros(c0, k0, dtype=torch.float32, device=dev)
+        self.dpar = torch.zeros(4, 128, dtype=torch.float32, device=dev)
+
+    # ------------------------------------------------------------------ helpers
+    def refresh_student_packs(self):
+        self.sp.refresh()
+
+    def refresh_teacher_packs(self):
+        self.tp.refresh()
+
+    def _pads(self, i):
+        """(pad_left) of feature-extractor layer i: 'same' (left = (k-1)//2) for stride 1 else ceil(s/2)."""
+        _, k, s = self.layers[i]
+        return (k - 1) // 2 if s == 1 else (s + 1) // 2
+
+    # ------------------------------------------------------------------ front end
+    def frontend_fwd(self, source: torch.Tensor, save: bool):
+        """source (B,L) fp32 -> feats (B,T,D) [project_features output].  reference base.py:194-213"""
+        cfg, st, sp, sv = self.cfg, self.store, self.sp, self.sv
+        p = st.p
+        pre = P + "local_encoder.conv_layers."
+        B, L = source.shape
+        c0, k0, _ = self.layers[0]
+        filt = ops.sinc_filters_fwd(p[pre + "0.0.low_hz_"], p[pre + "0.0.band_hz_"], st.sinc_n, st.sinc_window, C_=c0,
+                                    Cp=128, k=k0, min_low_hz=50.0, min_band_hz=st.sinc_min_band,
+                                    sample_rate=cfg.audio.sample_rate)
+        y, mean, rstd = ops.sinc_fused_fwd(source, filt, p[pre + "0.2.1.weight"], p[pre + "0.2.1.bias"],
+                                           p[pre + "0.3.p_swish_alpha"], p[pre + "0.3.p_swish_beta"], C_=c0, k=k0,
+                                           dtype=self.dtype, save_stats=save)
+        if save:
+            sv["src"], sv["filt"], sv["y0"], sv["st0"] = source, filt, y, (mean, rstd)
+        T_in = L
+        for i in range(1, len(self.layers)):
+            dim, k, s = self.layers[i]
+            pl = self._pads(i)
+            T_out = T_in if s == 1 else (T_in + 2 * pl - k) // s + 1
+            c = ops.conv1d_cl(y, sp.w[pre + f"{i}.0.weight"], None, k=k, stride=s, pad=pl, groups=1, T_out=T_out, n_out=dim)
+            yn, mean, rstd = ops.layernorm_fwd(c, p[pre + f"{i}.2.1.weight"], p[pre + f"{i}.2.1.bias"], 1e-5, act=1,
+                                               save_stats=save)
+            if save:
+                sv[f"c{i}"], sv[f"st{i}"], sv[f"y{i}"] = c, (mean, rstd), yn
+            y, T_in = yn, T_out
+        ln, mean, rstd = ops.layernorm_fwd(y, p[P + "project_features.1.weight"], p[P + "project_features.1.bias"], 1e-5,
+                                           save_stats=save)
+        D = cfg.embed_dim
+        feats = ops.linear(ln.view(B * T_in, -1), sp.w[P + "project_features.2.weight"], p[P + "project_features.2.bias"])
+        if save:
+            sv["pf_ln"], sv["pf_st"] = ln, (mean, rstd)
+        return feats.view(B, T_in, D)
+
+    def frontend_bwd(self, dfeat: torch.Tensor):
+        cfg, st, sp, sv = self.cfg, self.store, self.sp, self.sv
+        p, g = st.p, st.g
+        pre = P + "local_encoder.conv_layers."
+        B, T, D = dfeat.shape
+        ln = sv["pf_ln"]
+        cf = ln.shape[-1]
+        d2 = dfeat.view(B * T, D)
+        ops.linear_wgrad(ln.view(B * T, cf), d2, g[P + "project_features.2.weight"])
+        ops.colsum(d2, g[P + "project_features.2.bias"])
+        dln = ops.linear(d2, sp.wt[P + "project_features.2.weight"])
+        nl = len(self.layers)
+        dy = ops.layernorm_bwd(dln.view(B, T, cf), sv[f"y{nl - 1}"], p[P + "project_features.1.weight"],
+                               p[P + "project_features.1.bias"], *sv["pf_st"], dgamma=g[P + "project_features.1.weight"],
+                               dbeta=g[P + "project_features.1.bias"])
+        self._ready("project")
+        for i in reversed(range(1, nl)):
+            dim, k, s = self.layers[i]
+            pl = self._pads(i)
+            wname = pre + f"{i}.0.weight"
+            m = sp.meta[wname]
+            x_in = sv[f"y{i - 1}"]
+            T_in, T_out = x_in.shape[1], dy.shape[1]
+            dc = ops.layernorm_bwd(dy, sv[f"c{i}"], p[pre + f"{i}.2.1.weight"], p[pre + f"{i}.2.1.bias"], *sv[f"st{i}"],
+                                   act=1, dgamma=g[pre + f"{i}.2.1.weight"], dbeta=g[pre + f"{i}.2.1.bias"])
+            gw = sp.gw[wname]
+            gw.zero_()
+            ops.conv1d_cl_wgrad(x_in, dc, gw, k=k, stride=s, pad=pl, groups=1, T_out=T_out)
+            ops.unpack_wgrad(gw, g[wname], GN=dim, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
+            if s > 1:
+                dA = ops.linear(dc.view(B * T_out, dim), sp.wt[wname])
+                if i == 1:
+                    dy = torch.zeros(B, T_in, 128, dtype=self.dtype, device=dfeat.device) if m["Cgp"] != 128 else \
+                        torch.empty(B, T_in, 128, dtype=self.dtype, device=dfeat.device)
+                    ops.col2im(dA, B=B, T_in=T_in, T_out=T_out, C_=m["Cgp"], k=k, s=s, p=pl, out=dy)
+                else:
+                    dy = ops.col2im(dA, B=B, T_in=T_in, T_out=T_out, C_=m["Cgp"], k=k, s=s, p=pl)
+            else:
+                dy = ops.conv1d_cl(dc, sp.wt[wname], None, k=k, stride=1, pad=k - 1 - pl, groups=1, T_out=T_in,
+                                   n_out=m["Cg"])
+        c0, k0, _ = self.layers[0]
+        self.dfilt.zero_()
+        self.dpar.zero_()
+        ops.sinc_fused_bwd(sv["src"], sv["filt"], p[pre + "0.2.1.weight"], p[pre + "0.2.1.bias"],
+                           p[pre + "0.3.p_swish_alpha"], p[pre + "0.3.p_swish_beta"], dy, *sv["st0"], self.dfilt, self.dpar,
+                           C_=c0, k=k0)
+        g[pre + "0.2.1.weight"].add_(self.dpar[0, :c0])
+        g[pre + "0.2.1.bias"].add_(self.dpar[1, :c0])
+        g[pre + "0.3.p_swish_alpha"].view(-1).add_(self.dpar[2, :c0])
+        g[pre + "0.3.p_swish_beta"].view(-1).add_(self.dpar[3, :c0])
+        ops.sinc_filters_bwd(p[pre + "0.0.low_hz_"], p[pre + "0.0.band_hz_"], st.sinc_n, st.sinc_window, self.dfilt, C_=c0,
+                             k=k0, min_low_hz=50.0, min_band_hz=st.sinc_min_band, sample_rate=cfg.audio.sample_rate,
+                             dlow=g[pre + "0.0.low_hz_"], dband=g[pre + "0.0.band_hz_"])
+        self._ready("frontend")
+
+    # ------------------------------------------------------------------ transformer block
+    def block_fwd(self, x, prefix, pk: Packs, params, pos, alibi_scale, H, save: Optional[str], want_t=False):
+        """AltBlock post-LN with ffn targets (reference modules.py:328-337).  x (N,S,D)."""
+        N, S, D = x.shape
+        eps = self.cfg.norm_eps
+        x2 = x.view(N * S, D)
+        qkv = ops.linear(x2, pk.w[prefix + "attn.qkv.weight"], params[prefix + "attn.qkv.bias"])
+        att, lse = ops.attention_fwd(qkv.view(N, S, 3 * D), pos, self.store.alibi_slopes, alibi_scale, H,
+                                     need_lse=save is not None)
+        s1 = ops.linear(att.view(N * S, D), pk.w[prefix + "attn.proj.weight"], params[prefix + "attn.proj.bias"], res=x2)
+        x1, m1, r1 = ops.layernorm_fwd(s1, params[prefix + "norm1.weight"], params[prefix + "norm1.bias"], eps,
+                                       save_stats=save is not None)
+        hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
+        hpre = torch.empty(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
+        gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre)
+        t = None
+        if want_t:
+            t = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"])
+            x2o, m2, r2 = ops.layernorm_fwd(t, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps, res=x1,
+                                            save_stats=False)
+        else:
+            s2 = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"], res=x1)
+            x2o, m2, r2 = ops.layernorm_fwd(s2, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
+                                            save_stats=save is not None)
+        if save is not None:
+            self.sv[save] = dict(x=x2, qkv=qkv, att=att, lse=lse, s1=s1, st1=(m1, r1), x1=x1, hpre=hpre, g=gact, s2=s2,
+                                 st2=(m2, r2), N=N, S=S)
+        return x2o.view(N, S, D), (t.view(N, S, D) if t is not None else None)
+
+    def block_bwd(self, dx, prefix, pos, alibi_scale, H, key):
+        sv = self.sv.pop(key)
+        st, sp = self.store, self.sp
+        p, g = st.p, st.g
+        N, S = sv["N"], sv["S"]
+        D = dx.shape[-1]
+        dx = dx.reshape(N * S, D)
+        ds2 = ops.layernorm_bwd(dx, sv["s2"], p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], *sv["st2"],
+                                dgamma=g[prefix + "norm2.weight"], dbeta=g[prefix + "norm2.bias"],
+                                dxsum=g[prefix + "mlp.fc2.bias"])
+        ops.linear_wgrad(sv["g"], ds2, g[prefix + "mlp.fc2.weight"])
+        dh = ops.linear(ds2, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"])
+        ops.linear_wgrad(sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
+        dx1 = ops.linear(dh, sp.wt[prefix + "mlp.fc1.weight"], res=ds2)
+        ds1 = ops.layernorm_bwd(dx1, sv["s1"], p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], *sv["st1"],
+                                dgamma=g[prefix + "norm1.weight"], dbeta=g[prefix + "norm1.bias"],
+                                dxsum=g[prefix + "attn.proj.bias"])
+        ops.linear_wgrad(sv["att"].view(N * S, D), ds1, g[prefix + "attn.proj.weight"])
+        datt = ops.linear(ds1, sp.wt[prefix + "attn.proj.weight"])
+        dqkv = ops.attention_bwd(sv["qkv"].view(N, S, 3 * D), sv["att"], datt.view(N, S, D), sv["lse"], pos,
+                                 st.alibi_slopes, alibi_scale, H, g[P + "alibi_scale"].view(-1))
+        dq2 = dqkv.view(N * S, 3 * D)
+        ops.colsum(dq2, g[prefix + "attn.qkv.bias"])
+        ops.linear_wgrad(sv["x"], dq2, g[prefix + "attn.qkv.weight"])
+        dxin = ops.linear(dq2, sp.wt[prefix + "attn.qkv.weight"], res=ds1)
+        return dxin.view(N, S, D)
+
+    # ------------------------------------------------------------------ grouped conv + LN + GELU stacks
+    def posconv_fwd(self, feats, pk: Packs, params, mask_u8, cb, save: bool):
+        """relative_positional_encoder (audio.py:90-113) on x.repeat_interleave(cb)*(1-mask) (student) or
+        on feats (teacher); the clone/mask view is taken by the A-operand loader, never materialised."""
+        cfg = self.cfg
+        a = cfg.audio
+        B, T, D = feats.shape
+        k = cfg.pos_kernel
+        N = B * cb
+        x = feats
+        for i in range(1, a.conv_pos_depth + 1):
+            w = P + f"relative_positional_encoder.{i}.0.weight"
+            first = i == 1 and mask_u8 is not None
+            c = ops.conv1d_cl(x, pk.w[w], params[P + f"relative_positional_encoder.{i}.0.bias"], k=k, stride=1, pad=k // 2,
+                              groups=a.conv_pos_groups, T_out=T, n_out=D, rowmask=mask_u8 if first else None,
+                              bdiv=cb if first else 1, n_batch=N if first else None)
+            y, mean, rstd = ops.layernorm_fwd(c, None, None, 1e-5, act=1, save_stats=save)
+            if save:
+                self.sv[f"pc{i}"] = dict(x=x, c=c, st=(mean, rstd))
+            x = y
+        return x
+
+    def posconv_bwd(self, dy, mask_u8, cb):
+        cfg, st, sp = self.cfg, self.store, self.sp
+        a = cfg.audio
+        g = st.g
+        k = cfg.pos_kernel
+        G = a.conv_pos_groups
+        N, T, D = dy.shape
+        for i in reversed(range(1, a.conv_pos_depth + 1)):
+            sv = self.sv.pop(f"pc{i}")
+            w = P + f"relative_positional_encoder.{i}.0.weight"
+            m = sp.meta[w]
+            first = i == 1
+            dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1,
+                                   dxsum=g[P + f"relative_positional_encoder.{i}.0.bias"])
+            gw = sp.gw[w]
+            gw.zero_()
+            ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T,
+                                rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None)
+            ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
+            dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D)
+        return dy        # gradient wrt the (masked, cloned) pos-conv input (N,T,D)
+
+    def decoder_fwd(self, dec_in, save: bool):
+        """Decoder1d (modules.py:137-192): grouped conv + LN(no affine) + GELU (+ residual) x L, then proj."""
+        cfg, st, sp = self.cfg, self.store, self.sp
+        dec = cfg.audio.decoder
+        p = st.p
+        N, T, D = dec_in.shape
+        x = dec_in
+        k = dec.decoder_kernel
+        for i in range(dec.decoder_layers):
+            w = P + f"decoder.blocks.{i}.0.weight"
+            c = ops.conv1d_cl(x, sp.w[w], p[P + f"decoder.blocks.{i}.0.bias"], k=k, stride=1, pad=k // 2,
+                              groups=dec.decoder_groups, T_out=T, n_out=dec.decoder_dim)
+            resid = x if (dec.decoder_residual and x.shape[-1] == dec.decoder_dim) else None
+            y, mean, rstd = ops.layernorm_fwd(c, None, None, 1e-5, act=1, save_stats=save, post=resid)
+            if save:
+                self.sv[f"dc{i}"] = dict(x=x, c=c, st=(mean, rstd), resid=resid is not None)
+            x = y
+        out = ops.linear(x.view(N * T, dec.decoder_dim), sp.w[P + "decoder.proj.weight"], p[P + "decoder.proj.bias"])
+        if save:
+            self.sv["dec_last"] = x
+        return out.view(N, T, D)
+
+    def decoder_bwd(self, dout):
+        cfg, st, sp = self.cfg, self.store, self.sp
+        dec = cfg.audio.decoder
+        g = st.g
+        N, T, D = dout.shape
+        Dd = dec.decoder_dim
+        k = dec.decoder_kernel
+        G = dec.decoder_groups
+        d2 = dout.view(N * T, D)
+        x_last = self.sv.pop("dec_last")
+        ops.linear_wgrad(x_last.view(N * T, Dd), d2, g[P + "decoder.proj.weight"])
+        ops.colsum(d2, g[P + "decoder.proj.bias"])
+        dy = ops.linear(d2, sp.wt[P + "decoder.proj.weight"]).view(N, T, Dd)
+        for i in reversed(range(dec.decoder_layers)):
+            sv = self.sv.pop(f"dc{i}")
+            w = P + f"decoder.blocks.{i}.0.weight"
+            m = sp.meta[w]
+            dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1, dxsum=g[P + f"decoder.blocks.{i}.0.bias"])
+            gw = sp.gw[w]
+            gw.zero_()
+            ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T)
+            ops.unpack_wgrad(gw, g[w], GN=Dd, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
+            n_in = sv["x"].shape[-1]
+            dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=n_in,
+                               res=dy if sv["resid"] else None)
+        self._ready("decoder")
+        return dy        # (N,T,D) gradient wrt decoder input
+
+    def _ready(self, what: str):
+        if self.on_grad_ready is not None:
+            self.on_grad_ready(what)
+
+    # ------------------------------------------------------------------ teacher
+    @torch.no_grad()
+    def teacher_targets(self, feats):
+        """Teacher section + make_targets (data2vec2.py:779-846,1023-1066): feats (B,T,D) -> y fp32."""
+        cfg, st, tp = self.cfg, self.store, self.tp
+        t = st.t
+        B, T, D = feats.shape
+        H = cfg.num_heads
+        asc = t[P + "alibi_scale"].view(-1)
+        x_pos = self.posconv_fwd(feats, tp, t, None, 1, save=False)
+        x, _, _ = ops.layernorm_fwd(feats, t[P + "context_encoder.norm.weight"], t[P + "context_encoder.norm.bias"],
+                                    cfg.norm_eps, res=x_pos, save_stats=False)
+        for i in range(cfg.audio.prenet_depth):
+            x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", tp, t, None, asc, H, save=None)
+        ts: List[torch.Tensor] = []
+        first_target = cfg.depth - cfg.average_top_k_layers
+        for i in range(cfg.depth):
+            x, tt = self.block_fwd(x, f"blocks.{i}.", tp, t, None, asc, H, save=None, want_t=i >= first_target)
+            if tt is not None:
+                ts.append(tt)
+        return ops.instnorm_targets(ts, eps=1e-5)
+
+    # ------------------------------------------------------------------ whole step
+    def forward_backward(self, source, mask_u8, ids_keep, ids_restore, noise, *, backward=True, gscale=1.0,
+                         keep_debug=False):
+        """One micro-batch.  source (B,L) fp32; mask_u8 (B*cb,T) 1=masked; ids_keep (B*cb,K) int32 (ascending
+        kept frames); ids_restore (B*cb,T) int32; noise (B*cb,T-K,D) fp32 (row j <-> j-th masked frame).
+        Accumulates parameter gradients into store.grad and loss/variance sums into self.stats."""
+        cfg, st, sp = self.cfg, self.store, self.sp
+        p = st.p
+        cb, H, D = cfg.clone_batch, cfg.num_heads, cfg.embed_dim
+        a = cfg.audio
+        dbg = {}
+        feats = self.frontend_fwd(source, save=backward)                       # (B,T,D)
+        B, T, _ = feats.shape
+        N, K = ids_keep.shape
+        asc = p[P + "alibi_scale"].view(-1)
+        # ---- teacher targets from the student's local features (data2vec2.py:811-818)
+        y = self.teacher_targets(feats)
+        # ---- student context encoder (base.py:215-344)
+        x_pos = self.posconv_fwd(feats, sp, p, mask_u8, cb, save=backward)     # (N,T,D)
+        tok = ops.gather_tokens(feats, ids_keep, cb=cb, b=x_pos)               # (N,K,D)
+        x, m0, r0 = ops.layernorm_fwd(tok, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
+                                      cfg.norm_eps, save_stats=backward)
+        if backward:
+            self.sv["tok"], self.sv["tok_st"] = tok, (m0, r0)
+        for i in range(a.prenet_depth):
+            x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, ids_keep, asc, H,
+                                  save=f"pb{i}" if backward else None)
+        if keep_debug:
+            dbg["prenet_out"] = x
+        for i in range(cfg.depth):
+            x, _ = self.block_fwd(x, f"blocks.{i}.", sp, p, ids_keep, asc, H, save=f"mb{i}" if backward else None)
+        if keep_debug:
+            dbg["encoder_out"] = x
+        # ---- decoder + loss
+        dec_in = ops.decoder_input(x, noise, ids_restore)                      # (N,T,D)
+        dec_out = self.decoder_fwd(dec_in, save=backward)
+        loss_rows = torch.empty(N, T, D, dtype=torch.float32, device=x.device) if keep_debug else None
+        dx = ops.d2v_loss(dec_out, y, mask_u8, cb, stats=self.stats, want_dx=backward, gscale=gscale, loss_rows=loss_rows)
+        if keep_debug:
+            dbg.update(local_features=feats, targets=y, x_pos=x_pos, decoder_in=dec_in, decoder_out=dec_out,
+                       loss_rows=loss_rows)
+        if not backward:
+            return dbg
+        # ================================= backward =================================
+        ddec_in = self.decoder_bwd(dx)                                         # (N,T,D)
+        dxe = ops.gather_tokens(ddec_in, ids_keep, cb=1)                       # (N,K,D)
+        for i in reversed(range(cfg.depth)):
+            dxe = self.block_bwd(dxe, f"blocks.{i}.", ids_keep, asc, H, f"mb{i}")
+            self._ready(f"block{i}")
+        for i in reversed(range(a.prenet_depth)):
+            dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", ids_keep, asc, H, f"pb{i}")
+            self._ready(f"prenet{i}")
+        g = st.g
+        dtok = ops.layernorm_bwd(dxe, self.sv.pop("tok"), p[P + "context_encoder.norm.weight"],
+                                 p[P + "context_encoder.norm.bias"], *self.sv.pop("tok_st"),
+                                 dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"])
+        dxpos = ops.scatter_tokens(dtok, ids_restore, T)                       # (N,T,D)
+        dxm = self.posconv_bwd(dxpos, mask_u8, cb)                             # (N,T,D)
+        self._ready("posconv")
+        dfeat = ops.clone_reduce(dxm, dtok, ids_restore, cb)                   # (B,T,D)
+        self.frontend_bwd(dfeat)
+        self.sv.clear()
+        return dbg

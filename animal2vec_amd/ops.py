@@ -161,7 +161,7 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi):
 # ----------------------------------------------------------------------------------------------
 #                                         normalisation
 # ----------------------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=None, sum_out=None):
+def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=None, sum_out=None, post=None):
     """x (..., C) contiguous rows.  Returns y, mean, rstd."""
     C_ = x.shape[-1]
     M = x.numel() // C_
@@ -169,7 +169,7 @@ def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rc = _L().a2v_layernorm_fwd(dt(x), ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(y), ptr(sum_out), ptr(mean),
-                                ptr(rstd), M, C_, C_, C_, eps, act, stream())
+                                ptr(rstd), ptr(post), M, C_, C_, C_, eps, act, stream())
     check(rc, "a2v_layernorm_fwd")
     return y, mean, rstd
 
@@ -216,9 +216,10 @@ def sinc_filters_fwd(low_hz, band_hz, n_, window, *, C_, Cp, k, min_low_hz, min_
     return filt
 
 
-def sinc_filters_bwd(low_hz, band_hz, n_, window, dfilt, *, C_, k, min_low_hz, min_band_hz, sample_rate):
-    dlow = torch.empty(C_, dtype=torch.float32, device=low_hz.device)
-    dband = torch.empty(C_, dtype=torch.float32, device=low_hz.device)
+def sinc_filters_bwd(low_hz, band_hz, n_, window, dfilt, *, C_, k, min_low_hz, min_band_hz, sample_rate, dlow=None,
+                     dband=None):
+    dlow = dlow if dlow is not None else torch.zeros(C_, dtype=torch.float32, device=low_hz.device)
+    dband = dband if dband is not None else torch.zeros(C_, dtype=torch.float32, device=low_hz.device)
     rc = _L().a2v_sinc_filters_bwd(ptr(low_hz), ptr(band_hz), ptr(n_), ptr(window), ptr(dfilt), ptr(dlow), ptr(dband),
                                    C_, k, float(min_low_hz), float(min_band_hz), float(sample_rate), stream())
     check(rc, "a2v_sinc_filters_bwd")
@@ -297,9 +298,10 @@ def ema_update(ema, p, decay):
     check(rc, "a2v_ema_update")
 
 
-def adam_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+def adam_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, decay_mask=None,
+              grad_scale_dev=None):
     rc = _L().a2v_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                            grad_scale, stream())
+                            grad_scale, ptr(decay_mask), ptr(grad_scale_dev), stream())
     check(rc, "a2v_adam_step")
 
 
@@ -322,9 +324,10 @@ def unpack_wgrad(packed, gw, *, GN, Cg, k, Cgp):
     check(rc, "a2v_unpack_wgrad")
 
 
-def col2im(dA, *, B, T_in, T_out, C_, k, s, p):
-    dX = torch.empty(B, T_in, C_, dtype=dA.dtype, device=dA.device)
-    rc = _L().a2v_col2im(dt(dA), ptr(dA), ptr(dX), B, T_in, T_out, C_, k, s, p, dA.stride(-2), stream())
+def col2im(dA, *, B, T_in, T_out, C_, k, s, p, out=None):
+    """out (B,T_in,>=C_) may be wider than C_ (extra channels untouched)."""
+    dX = out if out is not None else torch.empty(B, T_in, C_, dtype=dA.dtype, device=dA.device)
+    rc = _L().a2v_col2im(dt(dA), ptr(dA), ptr(dX), B, T_in, T_out, C_, k, s, p, dA.stride(-2), dX.stride(-2), stream())
     check(rc, "a2v_col2im")
     return dX
 

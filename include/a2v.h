@@ -80,8 +80,8 @@ int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d
  * Replaces Fp32LayerNorm / nn.LayerNorm call sites: nn/utils.py:1105-1115, audio.py:86,106,
  * modules.py:85,152,330,333. */
 int a2v_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
-                      void* sum_out, float* mean, float* rstd, long long M, int C, long long ldx, long long ldy,
-                      float eps, int act, a2v_stream_t stream);
+                      void* sum_out, float* mean, float* rstd, const void* post, long long M, int C, long long ldx,
+                      long long ldy, float eps, int act, a2v_stream_t stream);
 /* dx [+ dres]; dgamma/dbeta (C) and dxsum (C, column sums of dx) are accumulated with atomics. */
 int a2v_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, void* dx, const void* dres, float* dgamma, float* dbeta,
@@ -99,7 +99,7 @@ int a2v_sinc_filters_fwd(const float* low_hz, const float* band_hz, const float*
                          int C, int Cp, int k, float min_low_hz, float min_band_hz, float sample_rate,
                          a2v_stream_t stream);
 int a2v_sinc_filters_bwd(const float* low_hz, const float* band_hz, const float* n_, const float* window,
-                         const float* dfilt, float* dlow, float* dband, int C, int k, float min_low_hz,
+                         const float* dfilt, float* dlow /* += */, float* dband /* += */, int C, int k, float min_low_hz,
                          float min_band_hz, float sample_rate, a2v_stream_t stream);
 /* x (B,L) fp32 -> y (B,L,128) channels-last: reflect pad + conv1d + LayerNorm(C) + PSwish in one
  * pass -- SincConv.forward (sinc.py:107-159) + ConvFeatureExtractionModel block 0 tail
@@ -137,7 +137,8 @@ int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsigned char* 
 int a2v_ema_update(float* ema, const float* p, long long n, float decay, a2v_stream_t stream);
 /* fairseq Adam (configs/MeerKAT/a2v_large_pretrain_best.yaml:64-79). */
 int a2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, float grad_scale, a2v_stream_t stream);
+                  float eps, float weight_decay, int step, float grad_scale, const unsigned char* decay_mask,
+                  const float* grad_scale_dev, a2v_stream_t stream);
 int a2v_sumsq(const float* x, long long n, double* out, a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- layout helpers
@@ -148,7 +149,7 @@ int a2v_pack_weight(int dtype, const float* w, void* out, int G, int N, int Cg, 
                     a2v_stream_t stream);
 int a2v_unpack_wgrad(const float* packed, float* gw, int GN, int Cg, int k, int Cgp, a2v_stream_t stream);
 int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, int C, int k, int s, int p,
-               long long lda, a2v_stream_t stream);
+               long long lda, long long ldo, a2v_stream_t stream);
 int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out, long long M, int C, long long ldi,
                long long ldo, a2v_stream_t stream);
 
