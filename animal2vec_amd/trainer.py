@@ -1,0 +1,168 @@
+"""Native data-parallel pretraining step: micro-batch fwd/bwd (engine.py) -> bucketed RCCL all-reduce of
+the flat gradient buffer overlapped with backward -> clip + Adam (one launch) -> EMA teacher (one
+launch) -> operand re-pack.  Replaces, for the hot path only, what fairseq's Trainer.train_step +
+LegacyDDP + EMAModule do around the reference model (nn/audio_train_routine.py:330-334,
+nn/data2vec2.py:386-410); no control plane (checkpoint policy, logging, LR schedules beyond
+warm-up/cosine) is rebuilt here.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+from .config import Data2VecMultiConfig
+from .engine import Engine
+from .params import P, ParamStore
+
+
+@dataclass
+class OptimConfig:
+    """configs/MeerKAT/a2v_large_pretrain_best.yaml:61-81"""
+    lr: float = 1e-4
+    adam_betas: Tuple[float, float] = (0.9, 0.98)
+    adam_eps: float = 1e-6
+    weight_decay: float = 0.01
+    clip_norm: float = 1.0
+    warmup_updates: int = 10000
+    max_update: int = 384230
+
+
+def get_annealed_rate(start, end, curr_step, total_steps):
+    """reference nn/modalities/base.py:492-497"""
+    if curr_step >= total_steps:
+        return end
+    r = end - start
+    return end - r * (1 - curr_step / total_steps)
+
+
+class PretrainTrainer:
+    def __init__(self, cfg: Data2VecMultiConfig, optim: Optional[OptimConfig] = None, dtype=torch.bfloat16,
+                 device="cuda", seed: int = 0, process_group=None):
+        self.cfg, self.optim = cfg, optim or OptimConfig()
+        self.store = ParamStore(cfg, device=device)
+        self.store.init_reference(seed)
+        self.engine = Engine(cfg, self.store, dtype=dtype)
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.num_updates = 0
+        self.ema_decay = cfg.ema_decay
+        self._buckets = self._make_buckets()
+        self._handles = []
+        self._overlap = False
+        self.engine.on_grad_ready = self._grad_ready
+        dev = self.store.device
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._gscale = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.last = {}
+
+    # ------------------------------------------------------------------ gradient buckets
+    def _make_buckets(self) -> Dict[str, Tuple[int, int]]:
+        """Contiguous slices of the flat gradient buffer, keyed by the engine's grad-ready events."""
+        cfg = self.cfg
+        bounds: List[Tuple[str, int]] = []       # (event, start offset)
+
+        def start_of(name):
+            return self.store.by_name[name].offset
+
+        bounds.append(("decoder", 0))
+        for i in reversed(range(cfg.depth)):
+            bounds.append((f"block{i}", start_of(f"blocks.{i}.norm2.weight")))
+        for i in reversed(range(cfg.audio.prenet_depth)):
+            bounds.append((f"prenet{i}", start_of(P + f"context_encoder.blocks.{i}.norm2.weight")))
+        bounds.append(("posconv", start_of(P + "context_encoder.norm.weight")))
+        bounds.append(("project", start_of(P + "project_features.2.weight")))
+        nl = len(cfg.conv_layers)
+        bounds.append(("frontend", start_of(P + f"local_encoder.conv_layers.{nl - 1}.2.1.weight")))
+        out = {}
+        for j, (ev, lo) in enumerate(bounds):
+            hi = bounds[j + 1][1] if j + 1 < len(bounds) else self.store.total
+            out[ev] = (lo, hi)
+        return out
+
+    def _grad_ready(self, event: str):
+        if not self._overlap or self.world == 1:
+            return
+        lo, hi = self._buckets[event]
+        # ProcessGroupNCCL (= RCCL on ROCm) runs the collective on its own stream after the compute
+        # stream's work so far; the rest of backward keeps issuing on the compute stream meanwhile.
+        self._handles.append(dist.all_reduce(self.store.grad[lo:hi], group=self.pg, async_op=True))
+
+    # ------------------------------------------------------------------ schedules
+    def lr_at(self, step: int) -> float:
+        o = self.optim
+        if step < o.warmup_updates:
+            return o.lr * step / max(1, o.warmup_updates)
+        t = (step - o.warmup_updates) / max(1, o.max_update - o.warmup_updates)
+        return 0.5 * o.lr * (1 + math.cos(math.pi * min(1.0, t)))
+
+    def ema_decay_at(self, num_updates: int) -> float:
+        """data2vec2.py:395-406"""
+        c = self.cfg
+        if c.ema_decay == c.ema_end_decay:
+            return c.ema_decay
+        if num_updates >= c.ema_anneal_end_step:
+            return c.ema_end_decay
+        return get_annealed_rate(c.ema_decay, c.ema_end_decay, num_updates, c.ema_anneal_end_step)
+
+    # ------------------------------------------------------------------ one optimizer step
+    def train_step(self, micro_batches: Sequence[dict]) -> None:
+        """micro_batches: dicts with source (B,L) fp32, mask_u8, ids_keep, ids_restore, and either
+        `noise` (N,T-K,D) fp32 or None (then N(0, mask_noise_std) is drawn on device)."""
+        st, eng, o = self.store, self.engine, self.optim
+        st.grad.zero_()
+        eng.stats.zero_()
+        self._handles = []
+        nmb = len(micro_batches)
+        for j, mb in enumerate(micro_batches):
+            self._overlap = j == nmb - 1
+            noise = mb.get("noise")
+            if noise is None:
+                N, K = mb["ids_keep"].shape
+                T = mb["ids_restore"].shape[1]
+                noise = torch.empty(N, T - K, self.cfg.embed_dim, dtype=torch.float32, device=st.device).normal_(
+                    0, self.cfg.audio.mask_noise_std)
+            eng.forward_backward(mb["source"], mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise)
+        self._overlap = False
+        D = self.cfg.embed_dim
+        if self.world > 1:
+            for h in self._handles:
+                h.wait()
+            dist.all_reduce(eng.stats, group=self.pg)          # loss / count / variance sums, one packed call
+        # grads <- sum over ranks; scale by 1/sample_size, clip to clip_norm (fairseq Trainer semantics)
+        self._sumsq.zero_()
+        ops.sumsq(st.grad, self._sumsq)
+        ss = eng.stats[4 * D + 1]
+        inv = (1.0 / ss).to(torch.float32)
+        gnorm = torch.sqrt(self._sumsq[0]).to(torch.float32) * inv
+        clip = torch.clamp(o.clip_norm / (gnorm + 1e-6), max=1.0) if o.clip_norm > 0 else torch.ones_like(gnorm)
+        self._gscale.copy_((inv * clip).reshape(1))
+        self.num_updates += 1
+        ops.adam_step(st.flat, st.grad, st.adam_m, st.adam_v, lr=self.lr_at(self.num_updates), beta1=o.adam_betas[0],
+                      beta2=o.adam_betas[1], eps=o.adam_eps, weight_decay=o.weight_decay, step=self.num_updates,
+                      decay_mask=st.decay_mask, grad_scale_dev=self._gscale)
+        eng.refresh_student_packs()
+        # EMA teacher (set_num_updates, data2vec2.py:386-410)
+        self.ema_decay = self.ema_decay_at(self.num_updates)
+        if self.ema_decay < 1:
+            ops.ema_update(st.teacher, st.flat[st.sh_lo:st.sh_hi], self.ema_decay)
+            eng.refresh_teacher_packs()
+        self.last = dict(stats=eng.stats, gnorm=gnorm)
+
+    # ------------------------------------------------------------------ logging-side scalars (sync)
+    def metrics(self) -> Dict[str, float]:
+        """loss / sample_size, pred_var, target_var (data2vec2.py:956-970,1095-1110) -- host sync."""
+        D = self.cfg.embed_dim
+        s = self.last["stats"].cpu()
+        n = float(s[4 * D + 1])
+
+        def var(off):
+            a, b = s[off:off + D], s[off + D:off + 2 * D]
+            return float(torch.sqrt((b - a * a / n) / (n - 1) + 1e-6).mean())
+
+        return dict(loss=float(s[4 * D]) / n, sample_size=n, pred_var=var(0), target_var=var(2 * D),
+                    gnorm=float(self.last["gnorm"]), ema_decay=self.ema_decay * 1000)

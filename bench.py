@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Headline benchmark: audio-seconds/s of animal2vec pretraining (10 s @ 8 kHz clips) on N MI355X.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one optimizer step on a FIXED global batch (strong scaling): micro-batches of fwd+bwd through
+the hand-written HIP path, bucketed RCCL gradient all-reduce overlapped with backward, clip + Adam, EMA
+teacher update, operand re-pack.  Rank 0 prints ONE JSON line (contract in the task brief) carrying the
+roofline of the dominant kernel and the CPU baseline (the oracle timed on this box's host cores).
+Synthetic data: randn waveforms, per-clip normalised; seeded masks keeping K of T frames.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+
+
+def flops_model(cfg, L):
+    import math
+    D, cb = cfg.embed_dim, cfg.clone_batch
+    a, dec = cfg.audio, cfg.audio.decoder
+    nb = a.prenet_depth + cfg.depth
+    Ts = cfg.frame_counts(L)
+    T = Ts[-1]
+    fe, cin = 0.0, 1
+    for (dim, k, s), t in zip(cfg.conv_layers, Ts):
+        fe += t * dim * cin * k
+        cin = dim
+    proj = T * cin * D
+
+    def tr(S, rows):     # MACs of nb blocks on `rows` sequences of S tokens
+        return rows * nb * (S * 12 * D * D + 2 * S * S * D)
+
+    pos = a.conv_pos_depth * D * (D // a.conv_pos_groups) * cfg.pos_kernel
+    dd = dec.decoder_dim
+    decm = dd * (D // dec.decoder_groups) * dec.decoder_kernel + (dec.decoder_layers - 1) * dd * (dd // dec.decoder_groups) * dec.decoder_kernel + dd * D
+    return dict(T=T, front=fe + proj, teacher=tr(T, 1) + pos * T, pos_student=pos * cb * T, decoder=decm * cb * T,
+                student=lambda K: tr(K, cb))
+
+
+def gflop_per_clip(cfg, L, K):
+    m = flops_model(cfg, L)
+    fwd = m["front"] + m["teacher"] + m["pos_student"] + m["decoder"] + m["student"](K)
+    fb = 3 * (m["front"] + m["pos_student"] + m["decoder"] + m["student"](K)) + m["teacher"]
+    return 2 * fwd / 1e9, 2 * fb / 1e9
+
+
+class GemmRecorder:
+    """Brackets every conv_gemm / wgrad launch with HIP events on the launch stream (torch's current
+    stream) and accumulates algorithmic FLOPs = 2*M*N*K*G per launch."""
+
+    def __init__(self):
+        self.recs = []
+
+    def wrap(self, ops):
+        self._cg, self._wg = ops.conv_gemm, ops.conv_wgrad
+        rec = self
+
+        def cg(x, w, out, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = rec._cg(x, w, out, **kw)
+            e1.record()
+            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1))
+            return r
+
+        def wg(x, dy, gw, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = rec._wg(x, dy, gw, **kw)
+            e1.record()
+            rec.recs.append(("tn", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1))
+            return r
+
+        ops.conv_gemm, ops.conv_wgrad = cg, wg
+
+    def unwrap(self, ops):
+        ops.conv_gemm, ops.conv_wgrad = self._cg, self._wg
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for kind in ("nt", "tn"):
+            rs = [(f, e0.elapsed_time(e1)) for k, f, e0, e1 in self.recs if k == kind]
+            if rs:
+                fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
+                out[kind] = dict(launches=len(rs), flops=fl, ms=ms, avg_us=1e3 * ms / len(rs), tflops=fl / ms / 1e9)
+        return out
+
+
+def make_microbatch(cfg, B, L, K, seed, device):
+    from animal2vec_amd.masking import make_maskinfo, seeded_keep_mask
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randn(B, L, generator=g)
+    src = torch.nn.functional.layer_norm(src, (L,)).to(device)
+    T = cfg.frame_counts(L)[-1]
+    mask = seeded_keep_mask(B * cfg.clone_batch, T, K, seed + 1, device=device)
+    m, keep, restore = make_maskinfo(mask)
+    return dict(source=src, mask_u8=m, ids_keep=keep, ids_restore=restore, noise=None)
+
+
+def cpu_baseline(model_name, L, K):
+    """The oracle (CPU restatement pinned to the reference) timed on this host: one clip, fwd+bwd."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import a2v_oracle as O
+    dims = O.LARGE if model_name == "large" else O.BASE_STAR
+    cfg = O.OracleConfig(**dims)
+    ncores = os.cpu_count()
+    torch.set_num_threads(ncores)
+    p = O.init_params(cfg, seed=0)
+    ema = O.make_teacher(p)
+    for v in p.values():
+        v.requires_grad_(True)
+    T = O.frame_counts(L, cfg.conv_feature_layers)[-1]
+    g = torch.Generator().manual_seed(1234)
+    src = torch.nn.functional.layer_norm(torch.randn(1, L, generator=g), (L,))
+    mask = O.seeded_mask(cfg.clone_batch, T, K, 7)
+    noise = torch.randn(cfg.clone_batch, T - K, cfg.embed_dim, generator=g) * 0.01
+    t0 = time.perf_counter()
+    res = O.pretrain_forward(p, ema, src, mask, noise, cfg)
+    res["losses"]["AUDIO_regression"].sum().backward()
+    dt = time.perf_counter() - t0
+    return dict(value=round(L / 8000.0 / dt, 4), unit="audio-s/s", cores=ncores, kind="port",
+                sample=f"1 clip x {L / 8000:.0f}s, {model_name} model, fwd+bwd (teacher targets + student grads), fp32, "
+                       f"torch CPU {ncores} threads, single untimed-warm-up-free run: {dt:.1f}s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="large", choices=["large", "base"])
+    ap.add_argument("--global-batch", type=int, default=64, help="clips per optimizer step over all GPUs")
+    ap.add_argument("--micro-batch", type=int, default=8, help="clips per fwd/bwd launch sequence per GPU")
+    ap.add_argument("--samples", type=int, default=80000)
+    ap.add_argument("--keep", type=int, default=140)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from animal2vec_amd import ops
+    from animal2vec_amd.config import base_star_config, large_config
+    from animal2vec_amd.trainer import PretrainTrainer
+
+    cfg = large_config() if args.model == "large" else base_star_config()
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    assert args.global_batch % (world * args.micro_batch) == 0, "global batch must split into micro-batches per rank"
+    n_mb = args.global_batch // (world * args.micro_batch)
+    tr = PretrainTrainer(cfg, dtype=dtype, device=dev, seed=0)
+    L, K = args.samples, args.keep
+    mbs = [make_microbatch(cfg, args.micro_batch, L, K, 1234 + 1000 * rank + 10 * j, dev) for j in range(n_mb)]
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(mbs)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.train_step(mbs)
+    sync()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    met = tr.metrics()
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        rec = GemmRecorder()
+        rec.wrap(ops)
+        try:
+            tr.engine.stats.zero_()
+            tr.engine.forward_backward(mbs[0]["source"], mbs[0]["mask_u8"], mbs[0]["ids_keep"], mbs[0]["ids_restore"],
+                                       torch.zeros(args.micro_batch * cfg.clone_batch, cfg.frame_counts(L)[-1] - K,
+                                                   cfg.embed_dim, device=dev))
+            s = rec.summary()
+        finally:
+            rec.unwrap(ops)
+        nt = s["nt"]
+        roof = dict(bound="mfma", kernel="gemm_nt_bf16_kernel" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
+                    achieved=round(nt["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                    frac=round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    launches_per_microbatch=nt["launches"], avg_launch_us=round(nt["avg_us"], 2),
+                    wgrad_kernel=dict(tflops=round(s["tn"]["tflops"], 2), launches=s["tn"]["launches"],
+                                      avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        audio_s = args.global_batch * L / cfg.audio.sample_rate
+        value = audio_s * args.steps / dt
+        gf_fwd, gf_fb = gflop_per_clip(cfg, L, K)
+        line = {
+            "metric": "audio-seconds/s pretrain (10s@8kHz, large model)" if args.model == "large" else
+                      "audio-seconds/s pretrain (10s@8kHz, base* model)",
+            "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"animal2vec-{args.model} pretrain step (student fwd+bwd, EMA-teacher targets, grad "
+                                   f"all-reduce, clip+Adam, EMA) on {L}-sample clips @ {cfg.audio.sample_rate} Hz, "
+                                   f"{K}/{cfg.frame_counts(L)[-1]} frames kept, clone_batch {cfg.clone_batch}",
+                       "global_batch": args.global_batch, "micro_batch": args.micro_batch, "micro_batches_per_rank": n_mb,
+                       "parallelism": f"dp{world}", "dropout": "off", "mixup": "off"},
+            "model_tflops_per_s": round(gf_fb * args.global_batch * args.steps / dt / 1e3, 2),
+            "mfu_vs_bf16_dense_peak": round(gf_fb * args.global_batch * args.steps / dt / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            "loss_per_sample": round(met["loss"], 5), "pred_var": round(met["pred_var"], 5),
+            "target_var": round(met["target_var"], 5),
+            "roofline": roof,
+        }
+        if args.cpu_baseline == "auto" and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.model, L, K)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
