@@ -73,7 +73,8 @@ class GemmRecorder:
             e0.record()
             r = rec._cg(x, w, out, **kw)
             e1.record()
-            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1))
+            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1,
+                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1))))
             return r
 
         def wg(x, dy, gw, **kw):
@@ -81,7 +82,8 @@ class GemmRecorder:
             e0.record()
             r = rec._wg(x, dy, gw, **kw)
             e1.record()
-            rec.recs.append(("tn", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1))
+            rec.recs.append(("tn", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1,
+                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1))))
             return r
 
         ops.conv_gemm, ops.conv_wgrad = cg, wg
@@ -89,11 +91,21 @@ class GemmRecorder:
     def unwrap(self, ops):
         ops.conv_gemm, ops.conv_wgrad = self._cg, self._wg
 
+    def table(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for k, f, e0, e1, shape in self.recs:
+            a = agg.setdefault((k,) + shape, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += f; a[2] += e0.elapsed_time(e1)
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
+        return [dict(kind=k[0], M=k[1], N=k[2], K=k[3], G=k[4], launches=v[0], ms=round(v[2], 3),
+                     tflops=round(v[1] / v[2] / 1e9, 1)) for k, v in rows]
+
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for kind in ("nt", "tn"):
-            rs = [(f, e0.elapsed_time(e1)) for k, f, e0, e1 in self.recs if k == kind]
+            rs = [(f, e0.elapsed_time(e1)) for k, f, e0, e1, _ in self.recs if k == kind]
             if rs:
                 fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
                 out[kind] = dict(launches=len(rs), flops=fl, ms=ms, avg_us=1e3 * ms / len(rs), tflops=fl / ms / 1e9)
@@ -150,6 +162,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--gemm-table", default=None, help="dump per-shape GEMM timings (json) from the roofline leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -204,6 +217,9 @@ def main():
                                        torch.zeros(args.micro_batch * cfg.clone_batch, cfg.frame_counts(L)[-1] - K,
                                                    cfg.embed_dim, device=dev))
             s = rec.summary()
+            if args.gemm_table:
+                with open(args.gemm_table, "w") as f:
+                    json.dump(rec.table(), f, indent=0)
         finally:
             rec.unwrap(ops)
         nt = s["nt"]
