@@ -18,9 +18,9 @@ _p, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
 
 # name -> argtypes (mirrors include/a2v.h one to one; tests/test_abi.py cross-checks both)
 SIGNATURES = {
-    "a2v_conv_gemm": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _ll, _p, _ll, _i, _p, _p, _ll,
+    "a2v_conv_gemm": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _ll, _p, _ll, _i, _p, _p, _ll,
                       _p, _p, _i, _i, _i, _i, _i, _p],
-    "a2v_conv_wgrad": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
+    "a2v_conv_wgrad": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                        _i, _p],
     "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "liba2v_hip.so")
-SOURCES = ["a2v_gemm.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip"]
+SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 
@@ -31,11 +31,11 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    hdr = os.path.join(CSRC, "a2v_common.h")
+    hdrs = [os.path.join(CSRC, "a2v_common.h"), os.path.join(CSRC, "a2v_gemm.h")]
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src, hdr]):
+        if force or _stale(obj, [src, *hdrs]):
             jobs.append((src, obj))
 
     def cc(job):

@@ -1,0 +1,350 @@
+// bf16 throughput kernels of the implicit-GEMM family (see a2v_gemm.hip for the contract).
+//
+// What differs from the general kernels: the operand loaders are branch-free and almost VALU-free.
+//   * eligible shapes have Cg % 64 == 0, so a 64-wide K tile never straddles two conv taps: the tap
+//     index and the byte offset inside the source row are wave-uniform scalars that advance with a
+//     couple of SALU ops per K tile; each thread keeps one 64-bit base pointer per staged row.
+//   * out-of-range rows (conv padding, masked clone rows) read a safe address and are zeroed with
+//     v_cndmask instead of being branched around; M/N tails read a clamped valid row (the epilogue
+//     drops them), so plain Linear layers run with no predicate at all.
+//   * tile shapes: 128x128 (2x2 waves) for wide N, 256x64 (4x1 waves) for the grouped convolutions whose
+//     per-group N is 64 / 48 -- no half-empty MFMA tiles.
+#include "a2v_gemm.h"
+
+// component-wise select (a vector ?: on uint4 is lowered through scratch memory by hipcc)
+__device__ __forceinline__ uint4 sel4(bool ok, uint4 v) {
+  uint4 r;
+  r.x = ok ? v.x : 0u; r.y = ok ? v.y : 0u; r.z = ok ? v.z : 0u; r.w = ok ? v.w : 0u;
+  return r;
+}
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
+  constexpr int WN = BN / 64, WM = 4 / WN;
+  static_assert(BM == 64 * WM, "wave tile is 64x64");
+  constexpr int A_CH = BM / 32, B_CH = BN / 32;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  const int grp = blockIdx.y;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int crow = tid >> 3, cchunk = tid & 7;
+  const ConvA& a = g.a;
+  const char* const safe = (const char*)a.ptr;
+
+  // Staging state lives in NAMED scalars (not arrays): arrays here end up in scratch memory once the
+  // schedule barriers below are present.
+#define A2V_REP4(X) X(0) X(1) X(2) X(3)
+#define A2V_REP48(X) X(4) X(5) X(6) X(7)
+#define DECL_A(i) const char* pa##i = safe; int ta##i = 0; const unsigned char* ma##i = nullptr; uint4 ra##i = {0u, 0u, 0u, 0u};
+#define DECL_B(i) const char* pb##i = safe; uint4 rb##i = {0u, 0u, 0u, 0u};
+  A2V_REP4(DECL_A) A2V_REP48(DECL_A) A2V_REP4(DECL_B)
+#define INIT_A(i)                                                                                             \
+  if (i < A_CH) {                                                                                             \
+    int m = m0 + crow + 32 * i;                                                                               \
+    m = m < g.M ? m : g.M - 1;                                                                                \
+    const int b = m / a.T_out, t = m - b * a.T_out;                                                           \
+    ta##i = t * a.stride - a.pad;                                                                             \
+    pa##i = (const char*)a.ptr + ((long long)(b / a.bdiv) * a.bstride + (long long)grp * a.goff + cchunk * 8 + \
+                                  (long long)ta##i * a.pitch) * 2;                                            \
+    ma##i = a.rowmask ? a.rowmask + (long long)b * a.T_in : nullptr;                                          \
+  }
+#define INIT_B(i)                                                                                             \
+  if (i < B_CH) {                                                                                             \
+    int n = n0 + crow + 32 * i;                                                                               \
+    n = n < g.N ? n : g.N - 1;                                                                                \
+    pb##i = (const char*)g.B + ((long long)grp * g.b_gstride + (long long)n * g.ldb + cchunk * 8) * 2;        \
+  }
+  A2V_REP4(INIT_A) A2V_REP48(INIT_A) A2V_REP4(INIT_B)
+  long long soffA = 0, soffB = 0;     // wave-uniform byte offsets of the current K tile
+  int tap = 0, ci0 = 0;
+  const long long tap_step = (a.pitch - (a.Cg - 64)) * 2;
+
+#define LOAD_A(i)                                                              \
+  if (i < A_CH) {                                                              \
+    if constexpr (CONV) {                                                      \
+      const int row = ta##i + tap;                                             \
+      bool ok = (unsigned)row < (unsigned)a.T_in && (ci0 + cchunk * 8 < a.Cv); \
+      if (a.rowmask) ok = ok && (ma##i[ok ? row : 0] == 0);                    \
+      const char* p = ok ? pa##i + soffA : safe;                               \
+      ra##i = sel4(ok, *(const uint4*)p);                                      \
+    } else {                                                                   \
+      ra##i = *(const uint4*)(pa##i + soffA);                                  \
+    }                                                                          \
+  }
+#define LOAD_B(i) if (i < B_CH) rb##i = *(const uint4*)(pb##i + soffB);
+#define LOAD_TILE()                                                            \
+  {                                                                            \
+    A2V_REP4(LOAD_A) A2V_REP48(LOAD_A) A2V_REP4(LOAD_B)                        \
+    if (kt_next + 1 < nk) {      /* wave-uniform: stay on the last tile instead of running past K */ \
+      soffB += 128;                                                            \
+      ci0 += 64;                                                               \
+      if (ci0 == a.Cg) { ci0 = 0; ++tap; soffA += tap_step; } else { soffA += 128; } \
+    }                                                                          \
+    ++kt_next;                                                                 \
+  }
+#define STORE_A(i) if (i < A_CH) *(uint4*)(sa_ + swz128(crow + 32 * i, cchunk)) = ra##i;
+#define STORE_B(i) if (i < B_CH) *(uint4*)(sa_ + A_BYTES + swz128(crow + 32 * i, cchunk)) = rb##i;
+#define STORE_TILE(buf_)                                                       \
+  {                                                                            \
+    char* sa_ = smem + (buf_) * STAGE;                                         \
+    A2V_REP4(STORE_A) A2V_REP48(STORE_A) A2V_REP4(STORE_B)                     \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / 64;
+  int kt_next = 0;               // index of the tile the next LOAD_TILE() fetches
+  LOAD_TILE();
+  STORE_TILE(0);
+  __syncthreads();
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    LOAD_TILE();                 // tile kt+1 (the last iteration re-reads tile nk-1; never consumed)
+    // keep the global loads ahead of the MFMA block: hipcc otherwise sinks them next to the ds_write
+    // that consumes them and the HBM/L2 latency is no longer hidden behind the matrix work
+    __builtin_amdgcn_sched_barrier(0);
+    const char* sa_ = smem + buf * STAGE;
+    const char* sb_ = sa_ + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(sa_ + swz128(wm * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb_ + swz128(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+#undef LOAD_A
+#undef LOAD_B
+#undef STORE_A
+#undef STORE_B
+#undef INIT_A
+#undef INIT_B
+#undef DECL_A
+#undef DECL_B
+
+  float* stage = (float*)smem + wid * (64 * 68);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(i * 16 + fq * 4 + r) * 68 + j * 16 + fr] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_epilogue<bf16>(g, stage, lane, m0 + wm * 64, n0 + wn * 64, grp);
+}
+
+template <int BM, int BN, bool CONV>
+static void launch_nt(const GemmArgs& g, hipStream_t stream) {
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LDS = 2 * STAGE > NT_LDS_BYTES ? 2 * STAGE : NT_LDS_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_fast_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  dim3 grid(cdiv(g.M, BM) * cdiv(g.N, BN), g.G, 1);
+  hipLaunchKernelGGL((gemm_nt_bf16_fast_kernel<BM, BN, CONV>), grid, dim3(256), LDS, stream, g);
+}
+
+bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream) {
+  if (g.a.Cg % 64 != 0 || g.K % 64 != 0) return false;
+  const bool conv = g.a.taps > 1 || g.a.pad != 0 || g.a.rowmask != nullptr || g.a.stride != 1 || g.a.T_in != g.a.T_out ||
+                    g.a.Cv != g.a.Cg;
+  if (g.N <= 64) {
+    if (conv) launch_nt<256, 64, true>(g, stream); else launch_nt<256, 64, false>(g, stream);
+  } else {
+    if (conv) launch_nt<128, 128, true>(g, stream); else launch_nt<128, 128, false>(g, stream);
+  }
+  return true;
+}
+
+// =============================================================================================
+//      bf16 TN (weight gradient) with incremental row bookkeeping and branch-free loads
+// =============================================================================================
+__global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int tiles_k = (g.K + 127) / 128;
+  const int tn_ = blockIdx.x / tiles_k, tk = blockIdx.x - tn_ * tiles_k;
+  const int grp = blockIdx.y;
+  const int n0 = tn_ * 128, k0 = tk * 128;
+  const int mbeg = blockIdx.z * g.m_chunk;
+  const int mend = min(g.M, mbeg + g.m_chunk);
+  const int nsteps = (mend - mbeg + 63) / 64;
+  if (nsteps <= 0) return;
+  const ConvA& a = g.a;
+  const char* const safe = (const char*)a.ptr;
+
+  const int crow = tid >> 4, cchunk = tid & 15;       // rows crow + 16 i, 16-B chunk cchunk (8 columns)
+  // P operand (dY): fixed column chunk, rows advance by 64 per step
+  const int pn = n0 + cchunk * 8;
+  const bool pn_ok = pn < g.N;
+  const char* pp[4];
+  // Q operand (implicit im2col): fixed (tap, channel) per thread, rows advance
+  const int kk0 = k0 + cchunk * 8;
+  const int tapq = kk0 < g.K ? kk0 / a.Cg : 0;
+  const int ciq = kk0 < g.K ? kk0 - tapq * a.Cg : 0;
+  const bool kk_ok = kk0 < g.K && ciq < a.Cv;
+  int tq[4], rowq[4], mrow[4];
+  const char* qp[4];
+  const unsigned char* mk[4];
+  // (re)derive the implicit-A state of staged row i from its GEMM row index
+#define TN_SETUP_ROW(i)                                                                                \
+  {                                                                                                    \
+    const int mm = mrow[i] < g.M ? mrow[i] : g.M - 1;                                                  \
+    const int b = mm / a.T_out;                                                                        \
+    tq[i] = mm - b * a.T_out;                                                                          \
+    rowq[i] = tq[i] * a.stride - a.pad + tapq;                                                         \
+    qp[i] = (const char*)a.ptr +                                                                       \
+            ((long long)(b / a.bdiv) * a.bstride + (long long)rowq[i] * a.pitch + (long long)grp * a.goff + ciq) * 2; \
+    mk[i] = a.rowmask ? a.rowmask + (long long)b * a.T_in : nullptr;                                   \
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    mrow[i] = mbeg + crow + 16 * i;
+    pp[i] = (const char*)g.P + ((long long)mrow[i] * g.ldp + (long long)grp * g.p_goff + (pn_ok ? pn : 0)) * 2;
+    TN_SETUP_ROW(i);
+  }
+  const long long p_step = 64LL * g.ldp * 2;
+  const long long q_step = 64LL * a.stride * a.pitch * 2;
+  uint4 rp[4], rq[4];
+
+#define LOAD_TILE()                                                                                   \
+  {                                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+      const bool inm = mrow[i] < mend;                                                                \
+      const bool okp = pn_ok && inm;                                                                  \
+      const uint4 v = *(const uint4*)(okp ? pp[i] : safe);                                            \
+      rp[i] = sel4(okp, v);                                                                           \
+      bool okq = kk_ok && inm && (unsigned)rowq[i] < (unsigned)a.T_in;                                \
+      if (a.rowmask) okq = okq && (mk[i][okq ? rowq[i] : 0] == 0);                                    \
+      const uint4 w = *(const uint4*)(okq ? qp[i] : safe);                                            \
+      rq[i] = sel4(okq, w);                                                                           \
+      /* advance this staged row by 64 GEMM rows */                                                   \
+      pp[i] += p_step;                                                                                \
+      mrow[i] += 64;                                                                                  \
+      tq[i] += 64;                                                                                    \
+      rowq[i] += 64 * a.stride;                                                                       \
+      qp[i] += q_step;                                                                                \
+      if (tq[i] >= a.T_out) TN_SETUP_ROW(i);      /* crossed into the next batch item (rare) */       \
+    }                                                                                                 \
+  }
+#define TN_OFF(r) ((r) * 256 + ((((cchunk >> 1) ^ tn_f(r)) & 7) << 5) + ((cchunk & 1) << 4))
+#define STORE_TILE(buf_)                                                                              \
+  {                                                                                                   \
+    char* sp_ = smem + (buf_) * 16384;                                                                \
+    char* sq_ = smem + 32768 + (buf_) * 16384;                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
+      *(uint4*)(sp_ + TN_OFF(crow + 16 * i)) = rp[i];                                                 \
+      *(uint4*)(sq_ + TN_OFF(crow + 16 * i)) = rq[i];                                                 \
+    }                                                                                                 \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  LOAD_TILE();
+  STORE_TILE(0);
+  __syncthreads();
+
+  const int gq = lane >> 4;
+  const int q = (lane & 15) >> 2, p = lane & 3;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) LOAD_TILE();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* sp_ = smem + buf * 16384;
+    const char* sq_ = smem + 32768 + buf * 16384;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+      const int r_lo = ks * 32 + 8 * gq + q;
+      const int r_hi = r_lo + 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int col = wm * 64 + i * 16 + 4 * p;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tn_off(r_lo, col)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tn_off(r_hi, col)));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        fa[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = wn * 64 + j * 16 + 4 * p;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq_ + tn_off(r_lo, col)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq_ + tn_off(r_hi, col)));
+        union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+        u.s.a = lo; u.s.b = hi;
+        fb[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (st + 1 < nsteps) STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+#undef TN_OFF
+#undef TN_SETUP_ROW
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + wm * 64 + i * 16 + fq * 4 + r;
+      if (n >= g.N) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k0 + wn * 64 + j * 16 + fr;
+        if (kk < g.K) atomicAdd(g.W + (long long)grp * g.w_gstride + (long long)n * g.ldw + kk, acc[i][j][r]);
+      }
+    }
+}
+
+bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    attr = true;
+  }
+  dim3 grid(cdiv(g.N, 128) * cdiv(g.K, 128), g.G, splits);
+  hipLaunchKernelGGL(gemm_tn_bf16_fast_kernel, grid, dim3(256), 65536, stream, g);
+  return true;
+}

@@ -114,7 +114,7 @@ class Engine:
                                    act=1, dgamma=g[pre + f"{i}.2.1.weight"], dbeta=g[pre + f"{i}.2.1.bias"])
             gw = sp.gw[wname]
             gw.zero_()
-            ops.conv1d_cl_wgrad(x_in, dc, gw, k=k, stride=s, pad=pl, groups=1, T_out=T_out)
+            ops.conv1d_cl_wgrad(x_in, dc, gw, k=k, stride=s, pad=pl, groups=1, T_out=T_out, cv=m["Cgp"] if i == 1 else m["Cg"])
             ops.unpack_wgrad(gw, g[wname], GN=dim, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
             if s > 1:
                 dA = ops.linear(dc.view(B * T_out, dim), sp.wt[wname])
@@ -126,7 +126,7 @@ class Engine:
                     dy = ops.col2im(dA, B=B, T_in=T_in, T_out=T_out, C_=m["Cgp"], k=k, s=s, p=pl)
             else:
                 dy = ops.conv1d_cl(dc, sp.wt[wname], None, k=k, stride=1, pad=k - 1 - pl, groups=1, T_out=T_in,
-                                   n_out=m["Cg"])
+                                   n_out=m["Cg"], cv=m["N"])
         c0, k0, _ = self.layers[0]
         self.dfilt.zero_()
         self.dpar.zero_()
@@ -213,7 +213,7 @@ class Engine:
             first = i == 1 and mask_u8 is not None
             c = ops.conv1d_cl(x, pk.w[w], params[P + f"relative_positional_encoder.{i}.0.bias"], k=k, stride=1, pad=k // 2,
                               groups=a.conv_pos_groups, T_out=T, n_out=D, rowmask=mask_u8 if first else None,
-                              bdiv=cb if first else 1, n_batch=N if first else None)
+                              bdiv=cb if first else 1, n_batch=N if first else None, cv=pk.meta[w]["Cg"])
             y, mean, rstd = ops.layernorm_fwd(c, None, None, 1e-5, act=1, save_stats=save)
             if save:
                 self.sv[f"pc{i}"] = dict(x=x, c=c, st=(mean, rstd))
@@ -237,9 +237,11 @@ class Engine:
             gw = sp.gw[w]
             gw.zero_()
             ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T,
-                                rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None)
+                                rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None,
+                                cv=m["Cg"])
             ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
-            dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D)
+            dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D,
+                               cv=m["N"])
         return dy        # gradient wrt the (masked, cloned) pos-conv input (N,T,D)
 
     def decoder_fwd(self, dec_in, save: bool):
@@ -253,7 +255,7 @@ class Engine:
         for i in range(dec.decoder_layers):
             w = P + f"decoder.blocks.{i}.0.weight"
             c = ops.conv1d_cl(x, sp.w[w], p[P + f"decoder.blocks.{i}.0.bias"], k=k, stride=1, pad=k // 2,
-                              groups=dec.decoder_groups, T_out=T, n_out=dec.decoder_dim)
+                              groups=dec.decoder_groups, T_out=T, n_out=dec.decoder_dim, cv=sp.meta[w]["Cg"])
             resid = x if (dec.decoder_residual and x.shape[-1] == dec.decoder_dim) else None
             y, mean, rstd = ops.layernorm_fwd(c, None, None, 1e-5, act=1, save_stats=save, post=resid)
             if save:
@@ -284,11 +286,11 @@ class Engine:
             dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1, dxsum=g[P + f"decoder.blocks.{i}.0.bias"])
             gw = sp.gw[w]
             gw.zero_()
-            ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T)
+            ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, cv=m["Cg"])
             ops.unpack_wgrad(gw, g[w], GN=Dd, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
             n_in = sv["x"].shape[-1]
             dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=n_in,
-                               res=dy if sv["resid"] else None)
+                               res=dy if sv["resid"] else None, cv=m["N"])
         self._ready("decoder")
         return dy        # (N,T,D) gradient wrt decoder input
 

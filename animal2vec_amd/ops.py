@@ -44,7 +44,7 @@ def per16(t: torch.Tensor) -> int:
 # ----------------------------------------------------------------------------------------------
 #                                         GEMM family
 # ----------------------------------------------------------------------------------------------
-def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, a_pitch, a_bstride,
+def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride,
               a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
               gelu=False, gelu_bwd=False, pre_out=None, colsum=None):
     flags = 0
@@ -60,7 +60,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
         flags |= EPI_STORE_PRE
     if colsum is not None:
         flags |= EPI_COLSUM
-    rc = _L().a2v_conv_gemm(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg,
+    rc = _L().a2v_conv_gemm(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
                             ptr(rowmask), bdiv, ptr(w), ldb, b_gstride, ptr(out), ldc, c_goff, ptr(pre_out),
                             ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
                             stream())
@@ -82,25 +82,27 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
 
 
 def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=None, rowmask=None, bdiv=1,
-              n_batch=None, res=None, colsum=None):
-    """Channels-last Conv1d as implicit GEMM.  x (Bsrc,T_in,Cp); w_packed (G, n_out/G, k*Cg);
+              n_batch=None, res=None, colsum=None, cv=None):
+    """Channels-last Conv1d as implicit GEMM.  x (Bsrc,T_in,Cp); w_packed (G, n_out/G, k*Cg) where Cg is
+    the (possibly zero-padded) tap width; cv = real input channels per group (default Cg);
     out (B,T_out,n_out) with B = n_batch or Bsrc."""
     Bsrc, T_in, Cp = x.shape
     B = n_batch if n_batch is not None else Bsrc
     G = groups
     Cg = w_packed.shape[-1] // k
+    cv = Cg if cv is None else cv
     N = n_out // G
     if out is None:
         out = torch.empty(B, T_out, n_out, dtype=x.dtype, device=x.device)
     return conv_gemm(x, w_packed, out, M=B * T_out, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride,
-                     pad=pad, taps=k, Cg=Cg, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=Cg if G > 1 else 0,
+                     pad=pad, taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=cv if G > 1 else 0,
                      rowmask=rowmask, bdiv=bdiv, ldb=w_packed.stride(-2), b_gstride=w_packed.stride(0) if G > 1 else 0,
                      ldc=n_out, c_goff=N, bias=bias, res=res, ldr=n_out if res is not None else 0, colsum=colsum)
 
 
-def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, a_pitch, a_bstride, a_goff=0,
+def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride, a_goff=0,
                rowmask=None, bdiv=1, ldp, p_goff=0, ldw, w_gstride=0):
-    rc = _L().a2v_conv_wgrad(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg,
+    rc = _L().a2v_conv_wgrad(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
                              ptr(rowmask), bdiv, ptr(dy), ldp, p_goff, ptr(gw), ldw, w_gstride, M, N, K, G, stream())
     check(rc, "a2v_conv_wgrad")
     return gw
@@ -115,7 +117,7 @@ def linear_wgrad(x, dy, gw):
                       ldp=dy.stride(0), ldw=gw.stride(0))
 
 
-def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=None, bdiv=1, n_batch=None):
+def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=None, bdiv=1, n_batch=None, cv=None):
     """gw_packed (G, N, k*Cg) fp32 += implicit-im2col(x)^T dy."""
     Bsrc, T_in, Cp = x.shape
     B = n_batch if n_batch is not None else Bsrc
@@ -123,8 +125,9 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
     Cg = gw_packed.shape[-1] // k
     N = gw_packed.shape[-2]
     n_out = dy.shape[-1]
+    cv = Cg if cv is None else cv
     return conv_wgrad(x, dy, gw_packed, M=B * T_out, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride, pad=pad,
-                      taps=k, Cg=Cg, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=Cg if G > 1 else 0,
+                      taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=cv if G > 1 else 0,
                       rowmask=rowmask, bdiv=bdiv, ldp=n_out, p_goff=N, ldw=gw_packed.stride(-2),
                       w_gstride=gw_packed.stride(0) if G > 1 else 0)
 

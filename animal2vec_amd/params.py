@@ -243,6 +243,14 @@ def _pad8(c: int) -> int:
     return (c + 7) // 8 * 8
 
 
+def _padk(c: int, dtype) -> int:
+    """Tap width in the packed operand: bf16 pads >=32-wide taps up to a multiple of 64 so that a 64-wide
+    K tile never straddles two taps (the fast implicit-GEMM path); the padding reads as zero."""
+    if dtype == torch.bfloat16 and c >= 32 and c % 64:
+        return (c + 63) // 64 * 64
+    return _pad8(c)
+
+
 class Packs:
     """MFMA operand images of the weights in the activation dtype: K-contiguous forward operands,
     transposed / tap-flipped operands for the input gradients.  Rebuilt by a few pack kernels after
@@ -281,10 +289,12 @@ class Packs:
                 else:
                     G = cfg.audio.decoder.decoder_groups
                 N = Cout // G
-                Cgp = _pad8(Cg)
+                # tap padding to 64 only for the grouped convs (dense feature-extractor convs are 128/512 wide)
+                Cgp = _padk(Cg, dtype) if G > 1 else _pad8(Cg)
+                Np = _padk(N, dtype) if G > 1 else N
                 li = int(name.split("conv_layers.")[1].split(".")[0]) if "local_encoder" in name else None
                 stride = cfg.conv_layers[li][2] if li is not None else 1
-                m = dict(kind="conv", G=G, N=N, Cg=Cg, Cgp=Cgp, k=k, stride=stride)
+                m = dict(kind="conv", G=G, N=N, Cg=Cg, Cgp=Cgp, Np=Np, k=k, stride=stride)
                 self.meta[name] = m
                 self.w[name] = torch.empty(G, N, k * Cgp, dtype=dtype, device=dev)
                 if need_grad:
@@ -292,8 +302,8 @@ class Packs:
                     if G == 1 and stride > 1:
                         self.wt[name] = torch.empty(k * Cgp, Cout, dtype=dtype, device=dev)     # mode 2
                     else:
-                        assert Cgp == Cg, "grouped / stride-1 convs need Cg % 8 == 0"
-                        self.wt[name] = torch.empty(G, Cg, k * N, dtype=dtype, device=dev)     # mode 1
+                        assert Cg % 8 == 0, "grouped / stride-1 convs need Cg % 8 == 0"
+                        self.wt[name] = torch.empty(G, Cg, k * Np, dtype=dtype, device=dev)    # mode 1
 
     @torch.no_grad()
     def refresh(self):
@@ -310,4 +320,4 @@ class Packs:
                     if m["G"] == 1 and m["stride"] > 1:
                         ops.pack_weight(src, self.wt[name], G=1, N=m["N"], Cg=m["Cg"], k=m["k"], Cgp=m["Cgp"], mode=2)
                     else:
-                        ops.pack_weight(src, self.wt[name], G=m["G"], N=m["N"], Cg=m["Cg"], k=m["k"], mode=1)
+                        ops.pack_weight(src, self.wt[name], G=m["G"], N=m["N"], Cg=m["Cg"], k=m["k"], Np=m["Np"], mode=1)

@@ -41,15 +41,15 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 
 /* ---------------------------------------------------------------- implicit-GEMM (MFMA) family
  * C[m][g*c_goff + n] = epi( sum_kk A_g[m][kk] * Bw[g][n][kk] ),  kk = tap*Cg + ci,
- * A_g[m=(b,t)][kk] = X[b / bdiv][t*stride - pad + tap][g*a_goff + ci]   (0 outside [0,T_in), and 0
- * where rowmask[b*T_in + row] != 0).
+ * A_g[m=(b,t)][kk] = X[b / bdiv][t*stride - pad + tap][g*a_goff + ci]   (0 outside [0,T_in), 0 for
+ * ci >= Cv (tap padding of the packed weights), and 0 where rowmask[b*T_in + row] != 0).
  * Replaces: F.linear in AltAttention/Mlp/project_features/decoder.proj (nn/modalities/modules.py:371,
  * 408; timm Mlp; nn/modalities/audio.py:87; modules.py:191), nn.Conv1d of the feature extractor
  * (nn/utils.py:1085-1090), the grouped positional/decoder convs (audio.py:97-103, modules.py:143-149)
  * and their autograd input gradients; with rowmask/bdiv also x.repeat_interleave(cb)*(1-mask)
  * (nn/modalities/base.py:244,464). */
 int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in, int T_out,
-                  int stride, int pad, int taps, int Cg, const unsigned char* rowmask, int bdiv, const void* Bw,
+                  int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv, const void* Bw,
                   long long ldb, long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
                   long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
                   a2v_stream_t stream);
@@ -57,7 +57,7 @@ int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long long a_bstri
 /* W[g][n][kk] += sum_m P[m][g*p_goff + n] * A_g[m][kk]   (fp32 atomics; zero W first)
  * Replaces autograd's weight gradients of the ops above. */
 int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in, int T_out,
-                   int stride, int pad, int taps, int Cg, const unsigned char* rowmask, int bdiv, const void* P,
+                   int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv, const void* P,
                    long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
                    a2v_stream_t stream);
 

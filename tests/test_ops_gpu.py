@@ -143,6 +143,33 @@ def test_conv_fwd_and_wgrad(ops, dtype, cfg):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_conv_padded_taps(ops, dtype):
+    """Cg = 48 real channels per group, taps zero-padded to 64 in the packed operand (fast bf16 path)."""
+    B, T, G, k, Cg, N = 2, 300, 4, 7, 48, 48
+    x = rnd(B, G * Cg, T, dtype=dtype, seed=1)
+    w = rnd(G * N, Cg, k, dtype=dtype, seed=2, scale=0.05)
+    ref = F.conv1d(x, w, padding=k // 2, groups=G)
+    xcl = to_cl(x, G * Cg, dtype)
+    wp = dev(pack_ref(w, G, 64), dtype)
+    y = ops.conv1d_cl(xcl, wp, None, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=G * N, cv=Cg)
+    assert rel_err(y.float().transpose(1, 2), ref) < tol(dtype)
+    dy = rnd(B, G * N, T, dtype=dtype, seed=3)
+    wr = w.clone().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    F.conv1d(xr, wr, padding=k // 2, groups=G).backward(dy)
+    gw = torch.zeros(G, N, k * 64, dtype=torch.float32, device="cuda")
+    dycl = to_cl(dy, G * N, dtype)
+    ops.conv1d_cl_wgrad(xcl, dycl, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, cv=Cg)
+    gw_un = torch.zeros(G * N, Cg, k, dtype=torch.float32, device="cuda")
+    ops.unpack_wgrad(gw, gw_un, GN=G * N, Cg=Cg, k=k, Cgp=64)
+    assert rel_err(gw_un, wr.grad) < tol(dtype, 2)
+    wt = torch.empty(G, Cg, k * 64, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(w, torch.float32), wt, G=G, N=N, Cg=Cg, k=k, Np=64, mode=1)
+    dx = ops.conv1d_cl(dycl, wt, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=G * Cg, cv=N)
+    assert rel_err(dx.float().transpose(1, 2), xr.grad) < tol(dtype, 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_clone_mask_view(ops, dtype):
     """x.repeat_interleave(cb) * (1 - mask) -> grouped conv, without materialising the clones"""
     B, cb, T, D, G, k = 2, 3, 96, 64, 4, 19
