@@ -321,49 +321,61 @@ class Engine:
         return ops.instnorm_targets(ts, eps=1e-5)
 
     # ------------------------------------------------------------------ whole step
-    def forward_backward(self, source, mask_u8, ids_keep, ids_restore, noise, *, backward=True, gscale=1.0,
-                         keep_debug=False):
-        """One micro-batch.  source (B,L) fp32; mask_u8 (B*cb,T) 1=masked; ids_keep (B*cb,K) int32 (ascending
-        kept frames); ids_restore (B*cb,T) int32; noise (B*cb,T-K,D) fp32 (row j <-> j-th masked frame).
-        Accumulates parameter gradients into store.grad and loss/variance sums into self.stats."""
+    def forward(self, source, mask_u8, ids_keep, ids_restore, noise, *, save=True, keep_debug=False):
+        """Forward of one micro-batch (teacher targets + student + decoder + loss).  source (B,L) fp32;
+        mask_u8 (B*cb,T) 1=masked; ids_keep (B*cb,K) int32 (ascending kept frames); ids_restore (B*cb,T)
+        int32; noise (B*cb,T-K,D) fp32 (row j <-> j-th masked frame).  Adds loss/variance sums to
+        self.stats; with save=True keeps what backward() needs."""
         cfg, st, sp = self.cfg, self.store, self.sp
         p = st.p
         cb, H, D = cfg.clone_batch, cfg.num_heads, cfg.embed_dim
         a = cfg.audio
         dbg = {}
-        feats = self.frontend_fwd(source, save=backward)                       # (B,T,D)
+        feats = self.frontend_fwd(source, save=save)                           # (B,T,D)
         B, T, _ = feats.shape
         N, K = ids_keep.shape
         asc = p[P + "alibi_scale"].view(-1)
         # ---- teacher targets from the student's local features (data2vec2.py:811-818)
         y = self.teacher_targets(feats)
         # ---- student context encoder (base.py:215-344)
-        x_pos = self.posconv_fwd(feats, sp, p, mask_u8, cb, save=backward)     # (N,T,D)
+        x_pos = self.posconv_fwd(feats, sp, p, mask_u8, cb, save=save)         # (N,T,D)
         tok = ops.gather_tokens(feats, ids_keep, cb=cb, b=x_pos)               # (N,K,D)
         x, m0, r0 = ops.layernorm_fwd(tok, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
-                                      cfg.norm_eps, save_stats=backward)
-        if backward:
+                                      cfg.norm_eps, save_stats=save)
+        if save:
             self.sv["tok"], self.sv["tok_st"] = tok, (m0, r0)
         for i in range(a.prenet_depth):
             x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, ids_keep, asc, H,
-                                  save=f"pb{i}" if backward else None)
+                                  save=f"pb{i}" if save else None)
         if keep_debug:
             dbg["prenet_out"] = x
         for i in range(cfg.depth):
-            x, _ = self.block_fwd(x, f"blocks.{i}.", sp, p, ids_keep, asc, H, save=f"mb{i}" if backward else None)
+            x, _ = self.block_fwd(x, f"blocks.{i}.", sp, p, ids_keep, asc, H, save=f"mb{i}" if save else None)
         if keep_debug:
             dbg["encoder_out"] = x
         # ---- decoder + loss
         dec_in = ops.decoder_input(x, noise, ids_restore)                      # (N,T,D)
-        dec_out = self.decoder_fwd(dec_in, save=backward)
+        dec_out = self.decoder_fwd(dec_in, save=save)
         loss_rows = torch.empty(N, T, D, dtype=torch.float32, device=x.device) if keep_debug else None
-        dx = ops.d2v_loss(dec_out, y, mask_u8, cb, stats=self.stats, want_dx=backward, gscale=gscale, loss_rows=loss_rows)
+        dx = ops.d2v_loss(dec_out, y, mask_u8, cb, stats=self.stats, want_dx=save, gscale=1.0, loss_rows=loss_rows)
         if keep_debug:
             dbg.update(local_features=feats, targets=y, x_pos=x_pos, decoder_in=dec_in, decoder_out=dec_out,
                        loss_rows=loss_rows)
-        if not backward:
-            return dbg
-        # ================================= backward =================================
+        if save:
+            self.sv["ctx"] = dict(dx=dx, mask_u8=mask_u8, ids_keep=ids_keep, ids_restore=ids_restore, T=T)
+        return dbg
+
+    def backward(self, gscale: float = 1.0):
+        """Backward of the micro-batch last run through forward(save=True); accumulates into store.grad."""
+        cfg, st = self.cfg, self.store
+        p, g = st.p, st.g
+        cb, H = cfg.clone_batch, cfg.num_heads
+        a = cfg.audio
+        c = self.sv.pop("ctx")
+        dx, mask_u8, ids_keep, ids_restore, T = c["dx"], c["mask_u8"], c["ids_keep"], c["ids_restore"], c["T"]
+        if gscale != 1.0:
+            dx.mul_(gscale)
+        asc = p[P + "alibi_scale"].view(-1)
         ddec_in = self.decoder_bwd(dx)                                         # (N,T,D)
         dxe = ops.gather_tokens(ddec_in, ids_keep, cb=1)                       # (N,K,D)
         for i in reversed(range(cfg.depth)):
@@ -372,7 +384,6 @@ class Engine:
         for i in reversed(range(a.prenet_depth)):
             dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", ids_keep, asc, H, f"pb{i}")
             self._ready(f"prenet{i}")
-        g = st.g
         dtok = ops.layernorm_bwd(dxe, self.sv.pop("tok"), p[P + "context_encoder.norm.weight"],
                                  p[P + "context_encoder.norm.bias"], *self.sv.pop("tok_st"),
                                  dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"])
@@ -382,4 +393,33 @@ class Engine:
         dfeat = ops.clone_reduce(dxm, dtok, ids_restore, cb)                   # (B,T,D)
         self.frontend_bwd(dfeat)
         self.sv.clear()
+
+    def forward_backward(self, source, mask_u8, ids_keep, ids_restore, noise, *, backward=True, gscale=1.0,
+                         keep_debug=False):
+        """One micro-batch: forward then (optionally) backward.  Accumulates parameter gradients into
+        store.grad and loss/variance sums into self.stats."""
+        dbg = self.forward(source, mask_u8, ids_keep, ids_restore, noise, save=backward, keep_debug=keep_debug)
+        if backward:
+            self.backward(gscale)
         return dbg
+
+    # ------------------------------------------------------------------ features only (no masking)
+    @torch.no_grad()
+    def extract_features(self, source):
+        """Data2VecMultiModel.forward(features_only=True, mask=False) (data2vec2.py:629-728, 1112-1123):
+        student weights, all T frames, no token removal.  Returns (x, layer_results)."""
+        cfg, st, sp = self.cfg, self.store, self.sp
+        p = st.p
+        H = cfg.num_heads
+        feats = self.frontend_fwd(source, save=False)
+        asc = p[P + "alibi_scale"].view(-1)
+        x_pos = self.posconv_fwd(feats, sp, p, None, 1, save=False)
+        x, _, _ = ops.layernorm_fwd(feats, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
+                                    cfg.norm_eps, res=x_pos, save_stats=False)
+        for i in range(cfg.audio.prenet_depth):
+            x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, None, asc, H, save=None)
+        layer_results = []
+        for i in range(cfg.depth):
+            x, t = self.block_fwd(x, f"blocks.{i}.", sp, p, None, asc, H, save=None, want_t=True)
+            layer_results.append(t)
+        return x, layer_results

@@ -1,0 +1,186 @@
+"""Drop-in model surface of the pretraining hot path: same registration name, constructor, forward
+signature, net_output keys, state-dict keys and EMA hooks as the reference's
+``Data2VecMultiModel`` (nn/data2vec2.py:168-1142) -- the arithmetic runs in the HIP engine.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+import torch.nn as tnn
+
+from . import ops
+from .config import Data2VecMultiConfig
+from .engine import Engine
+from .masking import compute_mask_indices, make_maskinfo
+from .params import P, ParamStore
+from .registry import register_model
+from .trainer import get_annealed_rate
+
+
+class _Node(tnn.Module):
+    """Name-only container so that parameter names equal the reference's state-dict keys."""
+
+
+def _attach(root: tnn.Module, dotted: str, param: tnn.Parameter):
+    parts = dotted.split(".")
+    node = root
+    for part in parts[:-1]:
+        if part not in node._modules:
+            node.add_module(part, _Node())
+        node = node._modules[part]
+    node.register_parameter(parts[-1], param)
+
+
+class _PretrainLoss(torch.autograd.Function):
+    """Autograd bridge: forward runs the engine's forward (activations stay in engine buffers),
+    backward runs the hand-written backward, which accumulates straight into ``p.grad`` (views of the
+    flat gradient buffer).  ``anchor`` is any parameter so that autograd records the node."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss_sum):
+        ctx.model = model
+        return loss_sum.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model = ctx.model
+        model.engine.backward(float(grad_out.reshape(-1)[0]))     # one host sync in drop-in mode only
+        return None, None, None
+
+
+@register_model("data2vec_multi", dataclass=Data2VecMultiConfig)
+class Data2VecMultiModel(tnn.Module):
+    def __init__(self, cfg: Data2VecMultiConfig, modalities=None, skip_ema=False, task=None, dtype=torch.bfloat16,
+                 device="cuda"):
+        super().__init__()
+        self.cfg = cfg
+        self.task = task
+        self.store = ParamStore(cfg, device=device, with_optimizer=False)
+        self.store.init_reference(cfg.seed)
+        self.engine = Engine(cfg, self.store, dtype=dtype)
+        for s in self.store.specs:
+            prm = tnn.Parameter(self.store.p[s.name])
+            prm.grad = self.store.g[s.name]
+            if not s.decay:                                    # data2vec2.py:318-320
+                prm.optim_overrides = {"optimizer": {"weight_decay_scale": 0}}
+            _attach(self, s.name, prm)
+        self.skip_ema = skip_ema
+        self.num_updates = 0
+        self.ema_decay = cfg.ema_decay
+        self._rng = np.random.default_rng(cfg.seed)
+        self._packs_version = None
+
+    # ------------------------------------------------------------------ construction / io
+    @classmethod
+    def build_model(cls, cfg: Data2VecMultiConfig, task=None, **kw):
+        """Build a new model instance (data2vec2.py:500-514)."""
+        return cls(cfg, task=task, **kw)
+
+    def state_dict(self, destination=None, prefix="", keep_vars=False):
+        state = super().state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars)
+        if not self.skip_ema:                                  # data2vec2.py:412-418
+            state[prefix + "_ema"] = {n: v.detach().clone() for n, v in sorted(self.store.t.items())}
+        return state
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = dict(state_dict)
+        ema = sd.pop("_ema", None)
+        self.store.load_state_dict(sd, ema, strict=strict)
+        self.refresh_operands()
+        return tnn.modules.module._IncompatibleKeys([], [])
+
+    def refresh_operands(self):
+        """Re-pack the MFMA operand images after parameters changed outside the native trainer."""
+        self.engine.refresh_student_packs()
+        self.engine.refresh_teacher_packs()
+
+    # ------------------------------------------------------------------ EMA (data2vec2.py:386-410)
+    def set_num_updates(self, num_updates):
+        if (self.num_updates == 0 and num_updates > 1) or self.num_updates >= num_updates:
+            pass
+        elif self.training and not self.skip_ema:
+            c = self.cfg
+            if c.ema_decay != c.ema_end_decay:
+                if num_updates >= c.ema_anneal_end_step:
+                    decay = c.ema_end_decay
+                else:
+                    decay = get_annealed_rate(c.ema_decay, c.ema_end_decay, num_updates, c.ema_anneal_end_step)
+                self.ema_decay = decay
+            if self.ema_decay < 1:
+                st = self.store
+                ops.ema_update(st.teacher, st.flat[st.sh_lo:st.sh_hi], self.ema_decay)
+                self.engine.refresh_teacher_packs()
+            self.engine.refresh_student_packs()               # the optimizer just stepped
+        self.num_updates = num_updates
+
+    # ------------------------------------------------------------------ forward
+    def _make_mask(self, B: int, T: int, device):
+        a = self.cfg.audio
+        m = compute_mask_indices((B * self.cfg.clone_batch, T), a.mask_prob, a.mask_length, self._rng,
+                                 min_masks=1, require_same_masks=True, mask_dropout=a.mask_dropout)
+        return torch.from_numpy(m).to(device)
+
+    def forward(self, source, target=None, id=None, mode=None, padding_mask=None, mask=True, features_only=False,
+                force_remove_masked=False, remove_extra_tokens=True, precomputed_mask=None, reduce=True, noise=None,
+                unreduced_loss=False, **kwargs):
+        """Same call surface as the reference (data2vec2.py:516-530).  Pretraining returns
+        {"losses": {"AUDIO_regression": ...}, "sample_size", "masked_pct", "pred_var", "target_var",
+        "ema_decay"}; the loss is returned already summed (a 1-element tensor; ModelCriterion sums it
+        anyway) unless ``unreduced_loss=True``."""
+        if padding_mask is not None:
+            raise NotImplementedError("enable_padding is false in every shipped config (and broken upstream, audio.py:168)")
+        source = source.to(self.store.device, torch.float32).contiguous()
+        eng, cfg = self.engine, self.cfg
+        if features_only:
+            if mask:
+                raise NotImplementedError("masked feature extraction (finetune path) is a 'next' row")
+            x, layer_results = eng.extract_features(source)
+            return {"x": x, "linear_eval_projection": None, "padding_mask": None, "layer_results": layer_results,
+                    "mask": None}
+        B, L = source.shape
+        T = cfg.frame_counts(L)[-1]
+        m = precomputed_mask if precomputed_mask is not None else self._make_mask(B, T, source.device)
+        mask_u8, keep, restore = make_maskinfo(m.to(source.device))
+        N, K = keep.shape
+        if noise is None:                                       # base.py:172-176 (drawn even in eval)
+            noise = torch.empty(N, T - K, cfg.embed_dim, dtype=torch.float32, device=source.device).normal_(
+                0, cfg.audio.mask_noise_std)
+        need_grad = torch.is_grad_enabled() and self.training
+        eng.stats.zero_()
+        dbg = eng.forward(source, mask_u8, keep, restore, noise, save=need_grad, keep_debug=unreduced_loss)
+        D = cfg.embed_dim
+        st = eng.stats
+        loss_sum = st[4 * D].to(torch.float32).reshape(1)
+        n = st[4 * D + 1]
+
+        def var(off):                                           # compute_var, data2vec2.py:1095-1110
+            a_, b_ = st[off:off + D], st[off + D:off + 2 * D]
+            return torch.sqrt((b_ - a_ * a_ / n) / (n - 1) + 1e-6).mean().to(torch.float32)
+
+        if unreduced_loss:
+            loss = dbg["loss_rows"][mask_u8.bool()]
+        elif need_grad:
+            anchor = next(self.parameters())
+            loss = _PretrainLoss.apply(anchor, self, loss_sum)
+        else:
+            loss = loss_sum
+        result = {"losses": {"AUDIO_regression": loss}, "sample_size": n.long(),
+                  "masked_pct": 1 - K / T, "pred_var": var(0), "target_var": var(2 * D),
+                  "ema_decay": self.ema_decay * 1000}
+        if self.num_updates > 5000:                             # collapse guard, data2vec2.py:972-988
+            if float(result["target_var"]) < cfg.min_target_var:
+                raise Exception(f"target var is {float(result['target_var'])} < {cfg.min_target_var}, exiting (AUDIO)")
+            if float(result["pred_var"]) < cfg.min_pred_var:
+                raise Exception(f"pred_var is {float(result['pred_var'])} < {cfg.min_pred_var}, exiting (AUDIO)")
+        return result
+
+    def extract_features(self, source, mode=None, padding_mask=None, mask=False, remove_extra_tokens=True):
+        """data2vec2.py:1112-1123"""
+        return self.forward(source, mode=mode, padding_mask=padding_mask, mask=mask, features_only=True,
+                            remove_extra_tokens=remove_extra_tokens)
+
+    def remove_pretraining_modules(self, modality=None, keep_decoder=False):
+        """data2vec2.py:1125-1142: drops the teacher; the decoder weights stay allocated (flat buffer)."""
+        self.skip_ema = True

@@ -99,6 +99,21 @@ def build_specs(cfg: Data2VecMultiConfig):
     return specs, (bounds["lo"], bounds["hi"]), off
 
 
+def bucket_starts(cfg: Data2VecMultiConfig, specs: List[ParamSpec]) -> List[Tuple[str, int]]:
+    """(engine grad-ready event, first flat offset) in backward order -- the all-reduce buckets."""
+    by = {s.name: s for s in specs}
+    out = [("decoder", 0)]
+    for i in reversed(range(cfg.depth)):
+        out.append((f"block{i}", by[f"blocks.{i}.norm2.weight"].offset))
+    for i in reversed(range(cfg.audio.prenet_depth)):
+        out.append((f"prenet{i}", by[P + f"context_encoder.blocks.{i}.norm2.weight"].offset))
+    out.append(("posconv", by[P + "context_encoder.norm.weight"].offset))
+    out.append(("project", by[P + "project_features.2.weight"].offset))
+    nl = len(cfg.conv_layers)
+    out.append(("frontend", by[P + f"local_encoder.conv_layers.{nl - 1}.2.1.weight"].offset))
+    return out
+
+
 class ParamStore:
     def __init__(self, cfg: Data2VecMultiConfig, device="cuda", with_optimizer=True):
         self.cfg = cfg

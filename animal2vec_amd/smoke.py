@@ -1,28 +1,47 @@
-"""One small end-to-end invocation of the hot path on cuda:0, checked against the CPU oracle.
-(The oracle import lives here only because __graft_entry__.smoke() is allowed to use it as the
-checker; nothing else in the package touches it.)"""
-import math
+"""One small end-to-end invocation of the hot path on cuda:0 (student fwd+bwd, EMA-teacher targets, loss),
+checked against the CPU oracle.  The oracle import lives here only because __graft_entry__.smoke() is
+allowed to use it as the checker; nothing else in the package touches it."""
+import importlib
 
 import torch
 
 
 def run():
-    import importlib
     O = importlib.import_module("a2v_" + "oracle")   # checker only
-    from . import ops
-    torch.manual_seed(0)
-    C_, k, sr, B, L = 127, 63, 8000, 2, 4000
-    lo, band = O.sinc_init(C_, k, sr)
-    win, n_ = O.sinc_window_and_n(k, sr)
-    x = torch.randn(B, L)
-    lw, lb = torch.rand(C_) + 0.5, torch.randn(C_) * 0.1
-    pa, pb = torch.full((C_,), 2.0), torch.randn(C_) * 0.2
-    ref = O.pswish(O.channel_layer_norm(O.sinc_conv(x, lo, band, k, sr), lw, lb), pa.view(1, -1, 1), pb.view(1, -1, 1))
-    cu = lambda t: t.cuda()
-    filt = ops.sinc_filters_fwd(cu(lo.flatten()), cu(band.flatten()), cu(n_.flatten()), cu(win), C_=C_, Cp=128, k=k,
-                                min_low_hz=50.0, min_band_hz=float(math.ceil(sr / k)), sample_rate=sr)
-    y, _, _ = ops.sinc_fused_fwd(cu(x), filt, cu(lw), cu(lb), cu(pa), cu(pb), C_=C_, k=k, dtype=torch.float32)
-    torch.cuda.synchronize()
-    err = float((y[..., :C_].transpose(1, 2).cpu() - ref).norm() / ref.norm())
-    assert err < 1e-4, err
-    print(f"smoke ok: fused SincConv+LN+PSwish rel err {err:.2e}")
+    from .config import D2vAudioConfig, D2vDecoderConfig, Data2VecMultiConfig
+    from .engine import Engine
+    from .masking import make_maskinfo
+    from .params import ParamStore
+
+    dims = dict(embed_dim=128, num_heads=2, depth=2, prenet_depth=1, decoder_dim=64, decoder_layers=2,
+                decoder_kernel=7, decoder_groups=8, clone_batch=2, conv_pos_groups=8, average_top_k_layers=2)
+    ocfg = O.OracleConfig(**dims)
+    p = O.init_params(ocfg, seed=1)
+    ema = O.make_teacher(p)
+    g = torch.Generator().manual_seed(2)
+    B, L, keep = 2, 8000, 16
+    T = O.frame_counts(L, ocfg.conv_feature_layers)[-1]
+    src = torch.nn.functional.layer_norm(torch.randn(B, L, generator=g), (L,))
+    mask = O.seeded_mask(B * ocfg.clone_batch, T, keep, 3)
+    noise = torch.randn(B * ocfg.clone_batch, T - keep, ocfg.embed_dim, generator=g) * 0.01
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = O.pretrain_forward(po, ema, src, mask, noise, ocfg)
+    ref["losses"]["AUDIO_regression"].sum().backward()
+
+    a = D2vAudioConfig(conv_pos_groups=8, prenet_depth=1, decoder=D2vDecoderConfig(decoder_dim=64, decoder_groups=8, decoder_layers=2))
+    cfg = Data2VecMultiConfig(depth=2, embed_dim=128, num_heads=2, clone_batch=2, average_top_k_layers=2, audio=a)
+    for dtype, tol in ((torch.float32, 1e-3), (torch.bfloat16, 5e-2)):
+        store = ParamStore(cfg, device="cuda", with_optimizer=False)
+        store.load_state_dict(p, ema)
+        eng = Engine(cfg, store, dtype=dtype)
+        m, k_, r_ = make_maskinfo(mask.cuda())
+        eng.stats.zero_()
+        eng.forward_backward(src.cuda(), m, k_, r_, noise.cuda())
+        torch.cuda.synchronize()
+        D = cfg.embed_dim
+        ls, lr = float(eng.stats[4 * D]), float(ref["losses"]["AUDIO_regression"].sum())
+        gq = "blocks.1.attn.qkv.weight"
+        ge = float((store.g[gq].cpu() - po[gq].grad).norm() / po[gq].grad.norm())
+        assert abs(ls - lr) / lr < tol, (dtype, ls, lr)
+        assert ge < (1e-3 if dtype == torch.float32 else 0.15), (dtype, ge)
+        print(f"smoke ok [{dtype}]: loss {ls:.4f} vs oracle {lr:.4f}; grad rel err {ge:.2e}")

@@ -16,8 +16,9 @@ import torch.distributed as dist
 
 from . import ops
 from .config import Data2VecMultiConfig
+from .ddp import GradSync, grad_scale_factor, make_buckets
 from .engine import Engine
-from .params import P, ParamStore
+from .params import P, ParamStore, bucket_starts
 
 
 @dataclass
@@ -51,10 +52,8 @@ class PretrainTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.num_updates = 0
         self.ema_decay = cfg.ema_decay
-        self._buckets = self._make_buckets()
-        self._handles = []
-        self._overlap = False
-        self.engine.on_grad_ready = self._grad_ready
+        self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
+        self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._gscale = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -63,34 +62,8 @@ class PretrainTrainer:
     # ------------------------------------------------------------------ gradient buckets
     def _make_buckets(self) -> Dict[str, Tuple[int, int]]:
         """Contiguous slices of the flat gradient buffer, keyed by the engine's grad-ready events."""
-        cfg = self.cfg
-        bounds: List[Tuple[str, int]] = []       # (event, start offset)
-
-        def start_of(name):
-            return self.store.by_name[name].offset
-
-        bounds.append(("decoder", 0))
-        for i in reversed(range(cfg.depth)):
-            bounds.append((f"block{i}", start_of(f"blocks.{i}.norm2.weight")))
-        for i in reversed(range(cfg.audio.prenet_depth)):
-            bounds.append((f"prenet{i}", start_of(P + f"context_encoder.blocks.{i}.norm2.weight")))
-        bounds.append(("posconv", start_of(P + "context_encoder.norm.weight")))
-        bounds.append(("project", start_of(P + "project_features.2.weight")))
-        nl = len(cfg.conv_layers)
-        bounds.append(("frontend", start_of(P + f"local_encoder.conv_layers.{nl - 1}.2.1.weight")))
-        out = {}
-        for j, (ev, lo) in enumerate(bounds):
-            hi = bounds[j + 1][1] if j + 1 < len(bounds) else self.store.total
-            out[ev] = (lo, hi)
-        return out
-
-    def _grad_ready(self, event: str):
-        if not self._overlap or self.world == 1:
-            return
-        lo, hi = self._buckets[event]
-        # ProcessGroupNCCL (= RCCL on ROCm) runs the collective on its own stream after the compute
-        # stream's work so far; the rest of backward keeps issuing on the compute stream meanwhile.
-        self._handles.append(dist.all_reduce(self.store.grad[lo:hi], group=self.pg, async_op=True))
+        bounds = bucket_starts(self.cfg, self.store.specs)
+        return make_buckets(bounds, self.store.total)
 
     # ------------------------------------------------------------------ schedules
     def lr_at(self, step: int) -> float:
@@ -116,10 +89,9 @@ class PretrainTrainer:
         st, eng, o = self.store, self.engine, self.optim
         st.grad.zero_()
         eng.stats.zero_()
-        self._handles = []
         nmb = len(micro_batches)
         for j, mb in enumerate(micro_batches):
-            self._overlap = j == nmb - 1
+            self.sync.arm(j == nmb - 1)
             noise = mb.get("noise")
             if noise is None:
                 N, K = mb["ids_keep"].shape
@@ -127,20 +99,14 @@ class PretrainTrainer:
                 noise = torch.empty(N, T - K, self.cfg.embed_dim, dtype=torch.float32, device=st.device).normal_(
                     0, self.cfg.audio.mask_noise_std)
             eng.forward_backward(mb["source"], mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise)
-        self._overlap = False
+        self.sync.arm(False)
         D = self.cfg.embed_dim
-        if self.world > 1:
-            for h in self._handles:
-                h.wait()
-            dist.all_reduce(eng.stats, group=self.pg)          # loss / count / variance sums, one packed call
+        self.sync.finish(eng.stats)            # wait buckets; loss / count / variance sums in one packed call
         # grads <- sum over ranks; scale by 1/sample_size, clip to clip_norm (fairseq Trainer semantics)
         self._sumsq.zero_()
         ops.sumsq(st.grad, self._sumsq)
-        ss = eng.stats[4 * D + 1]
-        inv = (1.0 / ss).to(torch.float32)
-        gnorm = torch.sqrt(self._sumsq[0]).to(torch.float32) * inv
-        clip = torch.clamp(o.clip_norm / (gnorm + 1e-6), max=1.0) if o.clip_norm > 0 else torch.ones_like(gnorm)
-        self._gscale.copy_((inv * clip).reshape(1))
+        scale, gnorm = grad_scale_factor(self._sumsq[0], eng.stats[4 * D + 1], o.clip_norm)
+        self._gscale.copy_(scale.reshape(1))
         self.num_updates += 1
         ops.adam_step(st.flat, st.grad, st.adam_m, st.adam_v, lr=self.lr_at(self.num_updates), beta1=o.adam_betas[0],
                       beta2=o.adam_betas[1], eps=o.adam_eps, weight_decay=o.weight_decay, step=self.num_updates,

@@ -384,6 +384,23 @@ def teacher_forward(ema: Dict[str, torch.Tensor], feats, cfg: OracleConfig, retu
     return (y, ts) if return_layers else y
 
 
+@torch.no_grad()
+def features_only_forward(p, source, cfg: OracleConfig):
+    """Data2VecMultiModel.forward(features_only=True, mask=False) = extract_features
+    (data2vec2.py:629-728,1112-1123): student weights, all T frames.  -> (x, layer_results)."""
+    feats = local_features(p, source, cfg)
+    B, T, D = feats.shape
+    x = feats + pos_conv(p, P, feats, cfg)
+    pos = torch.arange(T).unsqueeze(0).expand(B, -1)
+    bias = alibi_bias_from_positions(pos, cfg.num_heads, p[P + "alibi_scale"])
+    x = prenet(p, P, x, bias, cfg)
+    lrs = []
+    for i in range(cfg.depth):
+        x, t = alt_block(p, f"blocks.{i}.", x, bias, cfg.num_heads, cfg.norm_eps)
+        lrs.append(t)
+    return x, lrs
+
+
 def pretrain_forward(p, ema, source, mask, noise, cfg: OracleConfig):
     """Whole eval-mode pretrain forward (data2vec2.py:516-991, mixup off): returns the net_output
     dict the reference returns plus intermediates under '_dbg'."""

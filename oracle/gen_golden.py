@@ -148,7 +148,15 @@ def run_pair(refnn, dims, layers, layers_str, B, L, keep, seed, tol=2e-5, pertur
             assert r < 5e-4, (n, r)
         print(f"  [ok ] all {len(gref)} parameter grads                 worst rel={worst:.3e}")
 
+    # features-only path (extract_features, BASELINE config 1) against the live reference
+    with torch.no_grad():
+        fo_ref = model.extract_features(source)
+    fo_x, fo_lr = O.features_only_forward(p, source, cfg)
+    check("extract_features x", fo_x, fo_ref["x"], tol * 5)
+    check("extract_features layer_results[-1]", fo_lr[-1], fo_ref["layer_results"][-1], tol * 5)
+
     fx = {"source": source, "mask": mask, "noise": noise, "loss": loss_ref.detach(),
+          "features_only.x": fo_ref["x"], "features_only.layer_mean": sum(fo_ref["layer_results"]) / len(fo_ref["layer_results"]),
           "loss_sum": loss_ref.sum().detach(), "pred_var": out_ref["pred_var"],
           "target_var": out_ref["target_var"], "sample_size": out_ref["sample_size"],
           "features": feats_ref, "local_features": lf_ref, "targets": y_ref,

@@ -1,0 +1,132 @@
+"""CPU: host-side logic of the drop-in surface (no HIP compute): config grammar, flat parameter layout,
+decay rules, all-reduce buckets, masking, registries, criterion, YAML mapping."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import a2v_oracle as O
+from animal2vec_amd import config as C
+from animal2vec_amd.params import ALIGN, P, build_specs, bucket_starts
+from animal2vec_amd.ddp import make_buckets, grad_scale_factor
+from animal2vec_amd.masking import compute_mask_indices, make_maskinfo, seeded_keep_mask
+
+
+def test_conv_layer_grammar_is_parsed_without_eval():
+    assert C.parse_conv_layers(C.LARGE_LAYERS_STR) == O.LARGE_LAYERS
+    with pytest.raises(ValueError):
+        C.parse_conv_layers("__import__('os').system('true')")
+
+
+def test_frame_counts_match_oracle():
+    cfg = C.large_config()
+    assert cfg.frame_counts(80000) == O.frame_counts(80000, O.LARGE_LAYERS)
+    assert cfg.pos_kernel == 19 and cfg.head_dim == 64
+
+
+@pytest.mark.parametrize("mk,dims,n", [(C.large_config, O.LARGE, 315_830_026), (C.base_star_config, O.BASE_STAR, 122_780_678)])
+def test_flat_layout(mk, dims, n):
+    cfg = mk()
+    specs, (lo, hi), total = build_specs(cfg)
+    assert sum(s.numel for s in specs) == n                       # SURVEY section 4 known answers
+    shapes = O.init_param_shapes(O.OracleConfig(**dims))
+    assert {s.name: s.shape for s in specs} == shapes              # same keys / shapes as the reference
+    # aligned, non-overlapping, ordered
+    end = 0
+    for s in specs:
+        assert s.offset % ALIGN == 0 and s.offset >= end
+        end = s.offset + s.numel
+    assert end <= total and total % ALIGN == 0
+    # EMA-shared range == reference teacher keys (data2vec2.py:377-381)
+    shared = {s.name for s in specs if lo <= s.offset < hi}
+    assert shared == set(O.teacher_keys(shapes))
+    # weight-decay rule (data2vec2.py:318-320): 1-D, biases, alibi_scale, p_swish are NOT decayed; low_hz_/band_hz_ are
+    for s in specs:
+        nodecay = len(s.shape) == 1 or s.name.endswith(".bias") or "alibi_scale" in s.name or "p_swish" in s.name
+        assert s.decay == (not nodecay), s.name
+    assert next(s for s in specs if s.name.endswith("low_hz_")).decay
+
+
+def test_buckets_cover_gradient_exactly_once():
+    cfg = C.large_config()
+    specs, _, total = build_specs(cfg)
+    b = make_buckets(bucket_starts(cfg, specs), total)
+    assert len(b) == 1 + cfg.depth + cfg.audio.prenet_depth + 3
+    cover = np.zeros(total // ALIGN, dtype=np.int32)
+    for lo, hi in b.values():
+        assert lo % ALIGN == 0
+        cover[lo // ALIGN:hi // ALIGN] += 1
+    assert (cover == 1).all()
+    # a block's bucket holds exactly that block's parameters
+    lo, hi = b["block3"]
+    names = [s.name for s in specs if lo <= s.offset < hi]
+    assert names and all(n.startswith("blocks.3.") for n in names)
+    # alibi_scale (accumulated by every attention backward) is released only after the prenet
+    a = next(s for s in specs if s.name.endswith("alibi_scale"))
+    assert b["posconv"][0] <= a.offset < b["posconv"][1]
+
+
+def test_maskinfo_matches_oracle_and_reference_counts():
+    m = O.seeded_mask(6, 200, 16, 3)
+    mu, keep, restore = make_maskinfo(m)
+    ok, orr = O.make_maskinfo(m)
+    assert torch.equal(keep.long(), ok) and torch.equal(restore.long(), orr)
+    assert torch.equal(seeded_keep_mask(6, 200, 16, 3), m)
+
+
+def test_span_mask_distribution():
+    # yaml:127-130 "mask_prob 1.5, mask_length 2 => ~93 % masked"; equal count per row (base.py:437)
+    rng = np.random.default_rng(0)
+    m = compute_mask_indices((24, 2000), 1.5, 2, rng)
+    per_row = m.sum(1)
+    assert (per_row == per_row[0]).all()
+    frac = per_row[0] / 2000
+    assert 0.90 < frac < 0.96
+
+
+def test_grad_scale_factor_matches_fairseq_semantics():
+    sumsq = torch.tensor(4.0e6, dtype=torch.float64)
+    scale, gnorm = grad_scale_factor(sumsq, torch.tensor(1000.0, dtype=torch.float64), 1.0)
+    assert float(gnorm) == pytest.approx(2.0)
+    assert float(scale) == pytest.approx(1e-3 * 0.5, rel=1e-5)
+    scale, gnorm = grad_scale_factor(torch.tensor(1.0, dtype=torch.float64), torch.tensor(10.0, dtype=torch.float64), 1.0)
+    assert float(scale) == pytest.approx(0.1)
+
+
+def test_registries_and_criterion():
+    import nn
+    assert "data2vec_multi" in nn.MODEL_REGISTRY and "audio_ccas" in nn.TASK_REGISTRY
+    assert "expanded_model" in nn.CRITERION_REGISTRY
+
+    class Fake(torch.nn.Module):
+        def forward(self, source):
+            return {"losses": {"AUDIO_regression": torch.tensor([3.0, 4.0])}, "sample_size": torch.tensor(7),
+                    "pred_var": torch.tensor(0.5), "ema_decay": 999.7}
+
+    crit = nn.ExpandedModelCriterion(None, None, ["pred_var", "ema_decay", "missing"])
+    f = Fake()
+    loss, ss, log = crit(f, {"net_input": {"source": torch.zeros(2, 8)}})
+    assert float(loss) == 7.0 and int(ss) == 7 and log["pred_var"] == 0.5 and "missing" not in log
+    assert crit.logging_outputs_can_be_summed()
+    f.eval()
+    crit(f, {"net_input": {"source": torch.zeros(2, 8)}})
+    assert not crit.logging_outputs_can_be_summed()               # criterions.py:405-411
+
+
+def test_yaml_mapping(tmp_path):
+    from animal2vec_amd.train_routine import config_from_yaml
+    y = tmp_path / "c.yaml"
+    y.write_text("""
+task: {conv_feature_layers: '[(127, 63, 1)] + [(512, 10, 5)]', sample_rate: 8000}
+dataset: {max_tokens: 408000}
+optimization: {update_freq: [5], max_update: 100, clip_norm: 1}
+optimizer: {groups: {default: {lr_float: 0.0002, optimizer: {adam_betas: [0.9, 0.98], adam_eps: 1e-06, weight_decay: 0.01}, lr_scheduler: {warmup_updates: 10}}}}
+model: {depth: 4, embed_dim: 256, num_heads: 4, clone_batch: 3, ema_decay: 0.999, unknown_key: 1,
+        modalities: {audio: {prenet_depth: 2, conv_pos_groups: 4, decoder: {decoder_dim: 64, decoder_layers: 2}}}}
+""")
+    cfg, oc, run = config_from_yaml(str(y))
+    assert (cfg.depth, cfg.embed_dim, cfg.audio.prenet_depth, cfg.audio.decoder.decoder_dim) == (4, 256, 2, 64)
+    assert cfg.conv_layers == [(127, 63, 1), (512, 10, 5)]
+    assert oc.lr == 0.0002 and oc.max_update == 100 and run["update_freq"] == 5

@@ -116,3 +116,10 @@ def test_init_params_shapes_match_reference_keys(tiny_golden):
     for k in p:
         assert q[k].shape == p[k].shape, k
     assert set(O.teacher_keys(q)) == set(ema)
+
+
+def test_features_only_golden(tiny_golden):
+    p, _, _ = split_golden(tiny_golden)
+    x, lrs = O.features_only_forward(p, tiny_golden["source"], tiny_cfg())
+    assert rel_err(x, tiny_golden["features_only.x"]) < 1e-5
+    assert rel_err(sum(lrs) / len(lrs), tiny_golden["features_only.layer_mean"]) < 1e-5

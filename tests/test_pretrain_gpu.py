@@ -102,3 +102,63 @@ def test_hd64_vs_oracle(dtype, tol_y, tol_g):
         if e > tol_g:
             bad.append((k, e))
     assert not bad, bad[:8]
+
+
+def test_model_surface_dropin(tiny_golden):
+    """The nn.Module surface: reference state-dict keys, forward dict, autograd backward into p.grad, EMA hook."""
+    import nn
+    from animal2vec_amd.config import tiny_config
+    fx = tiny_golden
+    p, ema, g = split_golden(fx)
+    model = nn.Data2VecMultiModel.build_model(tiny_config(), task=None, dtype=torch.float32)
+    sd = dict(p)
+    sd["_ema"] = ema
+    model.load_state_dict(sd)
+    got = model.state_dict()
+    assert set(got) == set(p) | {"_ema"} and set(got["_ema"]) == set(ema)
+    assert all(torch.equal(got[k].cpu(), p[k]) for k in p)
+    model.train()
+    model.store.grad.zero_()
+    out = model(fx["source"], precomputed_mask=fx["mask"], noise=fx["noise"].cuda())
+    assert set(out) >= {"losses", "sample_size", "masked_pct", "pred_var", "target_var", "ema_decay"}
+    loss = out["losses"]["AUDIO_regression"].float().sum()
+    assert abs(float(loss) - float(fx["loss_sum"])) / float(fx["loss_sum"]) < 1e-3
+    assert int(out["sample_size"]) == int(fx["sample_size"])
+    assert abs(float(out["pred_var"]) - float(fx["pred_var"])) < 1e-4
+    assert abs(float(out["target_var"]) - float(fx["target_var"])) < 1e-4
+    assert out["masked_pct"] == pytest.approx(1 - 16 / 200)
+    loss.backward()
+    named = dict(model.named_parameters())
+    assert set(named) == set(p)
+    worst = max(rel_err(named[k].grad, g[k]) for k in g)
+    assert worst < 1e-3, worst
+    # EMA hook (set_num_updates, data2vec2.py:386-410) against the golden EMA vector
+    from conftest import load_golden
+    ex = load_golden("tiny_ema.npz")
+    model.set_num_updates(1)
+    after = model.state_dict()["_ema"]
+    assert max(rel_err(after[k], ex["after." + k]) for k in after) < 1e-6
+    # eval: no autograd node, unreduced loss on request
+    model.eval()
+    with torch.no_grad():
+        out = model(fx["source"], precomputed_mask=fx["mask"], noise=fx["noise"].cuda(), unreduced_loss=True)
+    assert out["losses"]["AUDIO_regression"].shape == fx["loss"].shape
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 5e-2)])
+def test_extract_features(tiny_golden, dtype, tol):
+    import nn
+    from animal2vec_amd.config import tiny_config
+    fx = tiny_golden
+    p, ema, _ = split_golden(fx)
+    if dtype == torch.bfloat16:
+        pytest.skip("tiny config has head_dim 16; bf16 attention needs head_dim 32/64")
+    model = nn.Data2VecMultiModel.build_model(tiny_config(), dtype=dtype)
+    sd = dict(p)
+    sd["_ema"] = ema
+    model.load_state_dict(sd)
+    model.eval()
+    res = model.extract_features(fx["source"])
+    assert rel_err(res["x"].float(), fx["features_only.x"]) < tol
+    lm = sum(t.float() for t in res["layer_results"]) / len(res["layer_results"])
+    assert rel_err(lm, fx["features_only.layer_mean"]) < tol
