@@ -12,30 +12,30 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liba2v_hip.so")
 
 F32, BF16 = 0, 1
-EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT = 1, 2, 4, 8, 16, 32, 64
 
-_p, _i, _ll, _f = C.c_void_p, C.c_int, C.c_longlong, C.c_float
+_p, _i, _ll, _f, _u = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint
 
 # name -> argtypes (mirrors include/a2v.h one to one; tests/test_abi.py cross-checks both)
 SIGNATURES = {
     "a2v_conv_gemm": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _ll, _p, _ll, _i, _p, _p, _ll,
-                      _p, _p, _i, _i, _i, _i, _i, _p],
+                      _p, _p, _i, _i, _i, _i, _i, _f, _u, _p],
     "a2v_conv_wgrad": [_i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                        _i, _p],
-    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "a2v_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _f, _i, _p],
-    "a2v_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _p],
+    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _f, _i, _f, _u, _p],
+    "a2v_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _f, _u, _i, _p, _p],
     "a2v_instnorm_targets": [_i, C.POINTER(_p), _i, _p, _p, _p, _i, _i, _i, _f, _p],
     "a2v_colsum": [_i, _p, _p, _ll, _i, _ll, _p],
     "a2v_sinc_filters_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _p],
     "a2v_sinc_filters_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _p],
     "a2v_sinc_fused_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "a2v_sinc_fused_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
-    "a2v_gather_tokens": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
+    "a2v_gather_tokens": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u, _p],
     "a2v_scatter_tokens": [_i, _p, _p, _p, _i, _i, _i, _i, _p],
     "a2v_clone_reduce": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
-    "a2v_decoder_input": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "a2v_decoder_input": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u, _p],
     "a2v_d2v_loss": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "a2v_ema_update": [_p, _p, _ll, _f, _p],
     "a2v_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p, _p, _p],
@@ -44,6 +44,7 @@ SIGNATURES = {
     "a2v_unpack_wgrad": [_p, _p, _i, _i, _i, _i, _p],
     "a2v_col2im": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _p],
     "a2v_cast2d": [_i, _i, _p, _p, _ll, _i, _ll, _ll, _p],
+    "a2v_dropout_mask": [_p, _ll, _f, _u, _p],
     "a2v_abi_version": [],
 }
 

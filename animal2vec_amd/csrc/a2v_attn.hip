@@ -46,6 +46,7 @@ struct AttnArgs {
   const float* alibi_scale;       // (H) learned, clamped at 0 here
   int N, S, H;
   float scale;
+  Drop drop;                      // attention dropout on the softmax probabilities (modules.py:405)
 };
 
 #define FP32_PITCH(HD) ((HD) + 4)
@@ -169,9 +170,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __expf(s[j][r] - m_new);
+        float p = __expf(s[j][r] - m_new);
+        ps += p;                                  // the normaliser is dropout-free
+        if (a.drop.thresh) {
+          const unsigned long long idx =
+              (((unsigned long long)n * H + h) * S + qc) * (unsigned long long)S + (kv0 + 16 * j + 4 * g + r);
+          p = drop_apply(a.drop, idx, p);
+        }
         s[j][r] = p;
-        ps += p;
       }
     l_run = l_run * alpha + ps;
 #pragma unroll
@@ -254,6 +260,7 @@ struct AttnBwdArgs {
   const int* pos; const float* slopes; const float* alibi_scale;
   int N, S, H;
   float scale;
+  Drop drop;
 };
 
 template <typename T, int HD>
@@ -401,8 +408,15 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
         const float dist = fabsf(sPosQ[ql] - pos_kv);
         const float sc = sacc[r] * a.scale + coef * dist;
         const float pv = kv_ok ? __expf(sc - sLse[ql]) : 0.f;
-        const float dsv = pv * (pacc[r] - sDelta[ql]);
-        p[i][r] = pv;
+        float pdrop = pv, dpe = pacc[r];
+        if (a.drop.thresh) {                       // same mask as the forward: P_drop = P*m/(1-p), dP = (dO V^T)*m/(1-p)
+          const int qg = q0 + ql < S ? q0 + ql : S - 1;
+          const unsigned long long idx = (((unsigned long long)n * H + h) * S + qg) * (unsigned long long)S + kvc;
+          pdrop = drop_apply(a.drop, idx, pv);
+          dpe = drop_apply(a.drop, idx, pacc[r]);
+        }
+        const float dsv = pv * (dpe - sDelta[ql]);
+        p[i][r] = pdrop;
         ds[i][r] = dsv;
         dal -= dsv * dist;
       }
@@ -526,9 +540,10 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
 }
 
 extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const int* pos, const float* slopes,
-                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, hipStream_t stream) {
-  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale) return A2V_ERR_ARG;
-  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale};
+                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
+                                 unsigned drop_seed, hipStream_t stream) {
+  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
+  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed)};
   if (dtype == A2V_BF16) {
     if (HD == 64) return attn_fwd_launch<bf16, 64>(a, stream);
     if (HD == 32) return attn_fwd_launch<bf16, 32>(a, stream);
@@ -563,9 +578,12 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
 // the caller casts it into the q slot of dqkv (a2v_cast2d).
 extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse,
                                  float* delta, void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
-                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, hipStream_t stream) {
-  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || !dq32) return A2V_ERR_ARG;
-  AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale};
+                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
+                                 unsigned drop_seed, hipStream_t stream) {
+  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || !dq32 || drop_p < 0.f || drop_p >= 1.f)
+    return A2V_ERR_ARG;
+  AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale,
+                make_drop(drop_p, drop_seed)};
   if (dtype == A2V_BF16) {
     if (HD == 64) return attn_bwd_launch<bf16, 64>(a, out, delta, stream);
     if (HD == 32) return attn_bwd_launch<bf16, 32>(a, out, delta, stream);

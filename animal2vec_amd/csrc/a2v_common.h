@@ -118,6 +118,29 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
   return cdf + x * pdf;
 }
 
+// Counter-based dropout (no mask tensor is ever stored): keep(seed, idx) is a pure function of a per-site
+// seed and the element's linear index, so the backward kernels regenerate exactly the forward mask.
+struct Drop {
+  unsigned seed;      // per call site / micro-batch
+  unsigned thresh;    // drop when hash < thresh  (thresh = p * 2^32)
+  float scale;        // 1 / (1 - p); 0 threshold disables
+};
+__device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned long long idx) {
+  unsigned u = (unsigned)idx * 0x9E3779B1u + seed + (unsigned)(idx >> 32) * 0x7F4A7C15u;
+  u ^= u >> 16; u *= 0x85EBCA6Bu; u ^= u >> 13; u *= 0xC2B2AE35u; u ^= u >> 16;
+  return u;
+}
+__device__ __forceinline__ float drop_apply(const Drop& d, unsigned long long idx, float v) {
+  return drop_hash(d.seed, idx) < d.thresh ? 0.f : v * d.scale;
+}
+static inline Drop make_drop(float p, unsigned seed) {
+  Drop d;
+  d.seed = seed;
+  d.thresh = p > 0.f ? (unsigned)((double)p * 4294967296.0) : 0u;
+  d.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  return d;
+}
+
 // Bijective XCD-aware remap of a linear workgroup id: ids that share (id % 8) run on one XCD
 // (round-robin dispatch), so give each XCD a contiguous chunk of the tile space.
 __device__ __forceinline__ int xcd_remap(int id, int n) {

@@ -9,7 +9,7 @@
 template <typename T>
 __global__ __launch_bounds__(256) void gather_tokens_kernel(const T* __restrict__ a, const T* __restrict__ b,
                                                             const int* __restrict__ ids, T* __restrict__ out, int N,
-                                                            int K, int D, int Ta, int cb) {
+                                                            int K, int D, int Ta, int cb, Drop drop) {
   const int vecs = D / 8;
   const long long total = (long long)N * K * vecs;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -24,6 +24,10 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const T* __restrict_
       Vec8<T>::load(b + ((long long)n * Ta + t) * D + v * 8, y);
 #pragma unroll
       for (int j = 0; j < 8; ++j) x[j] += y[j];
+    }
+    if (drop.thresh) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = drop_apply(drop, (unsigned long long)nk * D + v * 8 + j, x[j]);
     }
     Vec8<T>::store(out + nk * D + v * 8, x);
   }
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void clone_reduce_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict__ x, const float* __restrict__ noise,
                                                             const int* __restrict__ restore, T* __restrict__ out, int N,
-                                                            int K, int D, int Tn) {
+                                                            int K, int D, int Tn, Drop drop) {
   const int vecs = D / 8;
   const long long total = (long long)N * Tn * vecs;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -87,9 +91,13 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict_
     const int n = (int)(nt / Tn);
     const int r = restore[nt];
     float o[8];
-    if (r < K)
+    if (r < K) {
       Vec8<T>::load(x + ((long long)n * K + r) * D + v * 8, o);
-    else
+      if (drop.thresh) {           // decoder input_dropout on the encoder tokens (base.py:163-165)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = drop_apply(drop, ((unsigned long long)n * K + r) * D + v * 8 + j, o[j]);
+      }
+    } else
       Vec8<float>::load(noise + ((long long)n * (Tn - K) + (r - K)) * D + v * 8, o);
     Vec8<T>::store(out + nt * D + v * 8, o);
   }
@@ -300,12 +308,13 @@ static inline int grid_for(long long total, int cap = 8192) {
   if (dtype == A2V_BF16) { CALL_BF16; } else if (dtype == A2V_F32) { CALL_F32; } else return A2V_ERR_DTYPE;
 
 extern "C" int a2v_gather_tokens(int dtype, const void* a, const void* b, const int* ids, void* out, int N, int K, int D,
-                                 int Ta, int cb, hipStream_t st) {
-  if (N <= 0 || K <= 0 || D % 8 || cb <= 0) return A2V_ERR_ARG;
+                                 int Ta, int cb, float drop_p, unsigned drop_seed, hipStream_t st) {
+  if (N <= 0 || K <= 0 || D % 8 || cb <= 0 || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
+  const Drop drop = make_drop(drop_p, drop_seed);
   const int g = grid_for((long long)N * K * (D / 8));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(gather_tokens_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, ids, (bf16*)out, N, K, D, Ta, cb),
-             hipLaunchKernelGGL(gather_tokens_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, ids, (float*)out, N, K, D, Ta, cb));
+             hipLaunchKernelGGL(gather_tokens_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, ids, (bf16*)out, N, K, D, Ta, cb, drop),
+             hipLaunchKernelGGL(gather_tokens_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, ids, (float*)out, N, K, D, Ta, cb, drop));
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }
@@ -333,12 +342,13 @@ extern "C" int a2v_clone_reduce(int dtype, const void* dxm, const void* dtok, co
 }
 
 extern "C" int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K,
-                                 int D, int Tn, hipStream_t st) {
-  if (N <= 0 || K <= 0 || K > Tn || D % 8) return A2V_ERR_ARG;
+                                 int D, int Tn, float drop_p, unsigned drop_seed, hipStream_t st) {
+  if (N <= 0 || K <= 0 || K > Tn || D % 8 || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
+  const Drop drop = make_drop(drop_p, drop_seed);
   const int g = grid_for((long long)N * Tn * (D / 8));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(decoder_input_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, noise, restore, (bf16*)out, N, K, D, Tn),
-             hipLaunchKernelGGL(decoder_input_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, noise, restore, (float*)out, N, K, D, Tn));
+             hipLaunchKernelGGL(decoder_input_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, noise, restore, (bf16*)out, N, K, D, Tn, drop),
+             hipLaunchKernelGGL(decoder_input_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, noise, restore, (float*)out, N, K, D, Tn, drop));
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }
@@ -438,4 +448,16 @@ extern "C" int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out
   return A2V_OK;
 }
 
-extern "C" int a2v_abi_version(void) { return 1; }
+// materialise the dropout keep-mask of linear indices [0, n) for a (p, seed) site: test / debugging aid
+__global__ void dropout_mask_kernel(unsigned char* out, long long n, Drop d) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = drop_hash(d.seed, (unsigned long long)i) < d.thresh ? 0 : 1;
+}
+extern "C" int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, unsigned drop_seed, hipStream_t st) {
+  if (n <= 0 || !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, st, keep, n, make_drop(drop_p, drop_seed));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_abi_version(void) { return 2; }

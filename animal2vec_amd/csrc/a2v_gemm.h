@@ -28,9 +28,10 @@ struct GemmArgs {
   float* colsum;                 // [G*N] fp32, atomically accumulated column sums of the output
   int M, N, K, G;
   int flags;
+  Drop drop;                     // F_DROPOUT: applied to (acc + bias [gelu]) before the residual add
 };
 
-enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32 };
+enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64 };
 
 struct WgradArgs {
   ConvA a;                       // implicit A (M x K per group)
@@ -101,6 +102,10 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, i
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
       }
+      if (g.flags & F_DROPOUT) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);
+      }
       if (g.flags & F_RES) v += Vec4<T>::load(R + (long long)m * g.ldr + ccol);
       if (g.flags & F_GELU_BWD) {
         f32x4 h = Vec4<T>::load(R + (long long)m * g.ldr + ccol);
@@ -147,3 +152,4 @@ __device__ __forceinline__ int tn_off(int r, int col) {   // byte offset of elem
 // launchers implemented in a2v_gemm_fast.hip; return false when the shape is not eligible
 bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream);
 bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream);
+int a2v_tn_bf16_tiles(int N, int K);

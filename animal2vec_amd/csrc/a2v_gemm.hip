@@ -426,7 +426,7 @@ extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long l
                              const void* Bw, long long ldb,
                              long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
                              long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
-                             hipStream_t stream) {
+                             float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || G <= 0) return A2V_ERR_ARG;
   if (dtype != A2V_F32 && dtype != A2V_BF16) return A2V_ERR_DTYPE;
   const int esz = dtype == A2V_F32 ? 4 : 2;
@@ -443,6 +443,8 @@ extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long l
   g.B = Bw; g.ldb = ldb; g.b_gstride = b_gstride;
   g.C = C; g.ldc = ldc; g.c_goff = c_goff; g.C2 = C2; g.R = R; g.ldr = ldr;
   g.bias = bias; g.colsum = colsum; g.M = M; g.N = N; g.K = K; g.G = G; g.flags = flags;
+  g.drop = make_drop((flags & F_DROPOUT) ? drop_p : 0.f, drop_seed);
+  if ((flags & F_DROPOUT) && !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
   const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
   dim3 grid(tiles, G, 1);
   if (dtype == A2V_BF16 && a2v_launch_nt_bf16_fast(g, stream)) {
@@ -486,7 +488,7 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
   if (N % per16 || ldp % per16 || p_goff % per16 || (((uintptr_t)P) & 15)) return A2V_ERR_ARG;
   g.P = P; g.ldp = ldp; g.p_goff = p_goff; g.W = W; g.ldw = ldw; g.w_gstride = w_gstride;
   g.M = M; g.N = N; g.K = K; g.G = G;
-  const int tiles = cdiv(N, 128) * cdiv(K, 128);
+  const int tiles = dtype == A2V_BF16 ? a2v_tn_bf16_tiles(N, K) : cdiv(N, 128) * cdiv(K, 128);
   const int step = dtype == A2V_BF16 ? TN_MSTEP : 16;
   // split M so that the grid has ~>= 1024 workgroups, each split a multiple of the M step
   int splits = 1024 / (tiles * G);

@@ -185,16 +185,29 @@ bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream) {
 }
 
 // =============================================================================================
-//      bf16 TN (weight gradient) with incremental row bookkeeping and branch-free loads
+//      bf16 TN (weight gradient): incremental row bookkeeping, branch-free loads,
+//      tiles 128(n) x 128(kk)  or  64(n) x 256(kk) (grouped convs with <= 64 outputs per group)
 // =============================================================================================
+template <int ROWB> __device__ __forceinline__ int tr_off(int r, int col) {   // byte offset of element (r, col)
+  const int blk = col >> 4;
+  const int f = ROWB == 128 ? (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) : tn_f(r);
+  return r * ROWB + ((blk ^ f) << 5) + ((col & 15) << 1);
+}
+
+template <int TNN, int TNK>
 __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
+  constexpr int PCH = TNN / 8, QCH = TNK / 8;          // 16-B chunks per tile row
+  constexpr int NP = PCH / 4, NQ = QCH / 4;            // staged rows per thread
+  constexpr int PROWS = 256 / PCH, QROWS = 256 / QCH;  // rows covered per pass
+  constexpr int P_BYTES = 64 * TNN * 2, Q_BYTES = 64 * TNK * 2, STAGE = P_BYTES + Q_BYTES;
+  constexpr int WK = TNK / 64;                         // waves along kk
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
-  const int tiles_k = (g.K + 127) / 128;
+  const int wm = wid / WK, wn = wid % WK;
+  const int tiles_k = (g.K + TNK - 1) / TNK;
   const int tn_ = blockIdx.x / tiles_k, tk = blockIdx.x - tn_ * tiles_k;
   const int grp = blockIdx.y;
-  const int n0 = tn_ * 128, k0 = tk * 128;
+  const int n0 = tn_ * TNN, k0 = tk * TNK;
   const int mbeg = blockIdx.z * g.m_chunk;
   const int mend = min(g.M, mbeg + g.m_chunk);
   const int nsteps = (mend - mbeg + 63) / 64;
@@ -202,23 +215,29 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
   const ConvA& a = g.a;
   const char* const safe = (const char*)a.ptr;
 
-  const int crow = tid >> 4, cchunk = tid & 15;       // rows crow + 16 i, 16-B chunk cchunk (8 columns)
-  // P operand (dY): fixed column chunk, rows advance by 64 per step
-  const int pn = n0 + cchunk * 8;
+  // P operand (dY): fixed column chunk per thread, rows advance by 64 per step
+  const int prow = tid / PCH, pchunk = tid % PCH;
+  const int pn = n0 + pchunk * 8;
   const bool pn_ok = pn < g.N;
-  const char* pp[4];
+  const char* pp[NP];
+  int mp[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    mp[i] = mbeg + prow + PROWS * i;
+    pp[i] = (const char*)g.P + ((long long)mp[i] * g.ldp + (long long)grp * g.p_goff + (pn_ok ? pn : 0)) * 2;
+  }
   // Q operand (implicit im2col): fixed (tap, channel) per thread, rows advance
-  const int kk0 = k0 + cchunk * 8;
+  const int qrow = tid / QCH, qchunk = tid % QCH;
+  const int kk0 = k0 + qchunk * 8;
   const int tapq = kk0 < g.K ? kk0 / a.Cg : 0;
   const int ciq = kk0 < g.K ? kk0 - tapq * a.Cg : 0;
   const bool kk_ok = kk0 < g.K && ciq < a.Cv;
-  int tq[4], rowq[4], mrow[4];
-  const char* qp[4];
-  const unsigned char* mk[4];
-  // (re)derive the implicit-A state of staged row i from its GEMM row index
+  int tq[NQ], rowq[NQ], mq[NQ];
+  const char* qp[NQ];
+  const unsigned char* mk[NQ];
 #define TN_SETUP_ROW(i)                                                                                \
   {                                                                                                    \
-    const int mm = mrow[i] < g.M ? mrow[i] : g.M - 1;                                                  \
+    const int mm = mq[i] < g.M ? mq[i] : g.M - 1;                                                      \
     const int b = mm / a.T_out;                                                                        \
     tq[i] = mm - b * a.T_out;                                                                          \
     rowq[i] = tq[i] * a.stride - a.pad + tapq;                                                         \
@@ -227,44 +246,43 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
     mk[i] = a.rowmask ? a.rowmask + (long long)b * a.T_in : nullptr;                                   \
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    mrow[i] = mbeg + crow + 16 * i;
-    pp[i] = (const char*)g.P + ((long long)mrow[i] * g.ldp + (long long)grp * g.p_goff + (pn_ok ? pn : 0)) * 2;
+  for (int i = 0; i < NQ; ++i) {
+    mq[i] = mbeg + qrow + QROWS * i;
     TN_SETUP_ROW(i);
   }
   const long long p_step = 64LL * g.ldp * 2;
   const long long q_step = 64LL * a.stride * a.pitch * 2;
-  uint4 rp[4], rq[4];
+  uint4 rp[NP], rq[NQ];
 
 #define LOAD_TILE()                                                                                   \
   {                                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-      const bool inm = mrow[i] < mend;                                                                \
-      const bool okp = pn_ok && inm;                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                  \
+      const bool okp = pn_ok && mp[i] < mend;                                                         \
       const uint4 v = *(const uint4*)(okp ? pp[i] : safe);                                            \
       rp[i] = sel4(okp, v);                                                                           \
-      bool okq = kk_ok && inm && (unsigned)rowq[i] < (unsigned)a.T_in;                                \
+      pp[i] += p_step;                                                                                \
+      mp[i] += 64;                                                                                    \
+    }                                                                                                 \
+    _Pragma("unroll") for (int i = 0; i < NQ; ++i) {                                                  \
+      bool okq = kk_ok && mq[i] < mend && (unsigned)rowq[i] < (unsigned)a.T_in;                       \
       if (a.rowmask) okq = okq && (mk[i][okq ? rowq[i] : 0] == 0);                                    \
       const uint4 w = *(const uint4*)(okq ? qp[i] : safe);                                            \
       rq[i] = sel4(okq, w);                                                                           \
-      /* advance this staged row by 64 GEMM rows */                                                   \
-      pp[i] += p_step;                                                                                \
-      mrow[i] += 64;                                                                                  \
+      mq[i] += 64;                                                                                    \
       tq[i] += 64;                                                                                    \
       rowq[i] += 64 * a.stride;                                                                       \
       qp[i] += q_step;                                                                                \
       if (tq[i] >= a.T_out) TN_SETUP_ROW(i);      /* crossed into the next batch item (rare) */       \
     }                                                                                                 \
   }
-#define TN_OFF(r) ((r) * 256 + ((((cchunk >> 1) ^ tn_f(r)) & 7) << 5) + ((cchunk & 1) << 4))
 #define STORE_TILE(buf_)                                                                              \
   {                                                                                                   \
-    char* sp_ = smem + (buf_) * 16384;                                                                \
-    char* sq_ = smem + 32768 + (buf_) * 16384;                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                   \
-      *(uint4*)(sp_ + TN_OFF(crow + 16 * i)) = rp[i];                                                 \
-      *(uint4*)(sq_ + TN_OFF(crow + 16 * i)) = rq[i];                                                 \
-    }                                                                                                 \
+    char* sp_ = smem + (buf_) * STAGE;                                                                \
+    char* sq_ = sp_ + P_BYTES;                                                                        \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i)                                                    \
+        *(uint4*)(sp_ + tr_off<TNN * 2>(prow + PROWS * i, pchunk * 8)) = rp[i];                       \
+    _Pragma("unroll") for (int i = 0; i < NQ; ++i)                                                    \
+        *(uint4*)(sq_ + tr_off<TNK * 2>(qrow + QROWS * i, qchunk * 8)) = rq[i];                       \
   }
 
   f32x4 acc[4][4];
@@ -284,8 +302,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
     const int buf = st & 1;
     if (st + 1 < nsteps) LOAD_TILE();
     __builtin_amdgcn_sched_barrier(0);
-    const char* sp_ = smem + buf * 16384;
-    const char* sq_ = smem + 32768 + buf * 16384;
+    const char* sp_ = smem + buf * STAGE;
+    const char* sq_ = sp_ + P_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 fa[4], fb[4];
@@ -294,8 +312,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int col = wm * 64 + i * 16 + 4 * p;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tn_off(r_lo, col)));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tn_off(r_hi, col)));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tr_off<TNN * 2>(r_lo, col)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tr_off<TNN * 2>(r_hi, col)));
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = lo; u.s.b = hi;
         fa[i] = u.v;
@@ -303,8 +321,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = wn * 64 + j * 16 + 4 * p;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq_ + tn_off(r_lo, col)));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq_ + tn_off(r_hi, col)));
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq_ + tr_off<TNK * 2>(r_lo, col)));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sq_ + tr_off<TNK * 2>(r_hi, col)));
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
         u.s.a = lo; u.s.b = hi;
         fb[j] = u.v;
@@ -321,7 +339,6 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
   }
 #undef LOAD_TILE
 #undef STORE_TILE
-#undef TN_OFF
 #undef TN_SETUP_ROW
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -338,13 +355,25 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
     }
 }
 
-bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream) {
+template <int TNN, int TNK>
+static void launch_tn(const WgradArgs& g, int splits, hipStream_t stream) {
+  constexpr int LDS = 2 * (64 * TNN * 2 + 64 * TNK * 2);
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_fast_kernel<TNN, TNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
-  dim3 grid(cdiv(g.N, 128) * cdiv(g.K, 128), g.G, splits);
-  hipLaunchKernelGGL(gemm_tn_bf16_fast_kernel, grid, dim3(256), 65536, stream, g);
+  dim3 grid(cdiv(g.N, TNN) * cdiv(g.K, TNK), g.G, splits);
+  hipLaunchKernelGGL((gemm_tn_bf16_fast_kernel<TNN, TNK>), grid, dim3(256), LDS, stream, g);
+}
+
+// returns the number of (n, kk) tiles per group so that the caller can size the M split
+int a2v_tn_bf16_tiles(int N, int K) { return N <= 64 ? cdiv(N, 64) * cdiv(K, 256) : cdiv(N, 128) * cdiv(K, 128); }
+
+bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream) {
+  if (g.N <= 64)
+    launch_tn<64, 256>(g, splits, stream);
+  else
+    launch_tn<128, 128>(g, splits, stream);
   return true;
 }

@@ -14,7 +14,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                                                             T* __restrict__ sum_out, float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, const T* __restrict__ post,
                                                             long long M, int C, long long ldx, long long ldy, float eps,
-                                                            int act) {
+                                                            int act, Drop drop) {
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
         float t = (v[c][i] - mean) * rstd;
         if (gamma) t = t * gamma[col + i] + beta[col + i];
         if (act == 1) t = gelu_f(t);
+        if (drop.thresh) t = drop_apply(drop, (unsigned long long)row * C + col + i, t);
         o[i] = t;
       }
       if (post) {
@@ -85,7 +86,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const T* __restrict__ dres, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dxsum,
                                                             long long M, int C, long long ldx, long long lddy,
-                                                            int act) {
+                                                            int act, Drop drop, int drop_mode, T* __restrict__ dx_drop) {
+  // drop_mode 1: the forward applied dropout AFTER this LN (y = drop(act(LN x))): mask the incoming dy.
+  // drop_mode 2: also emit dx_drop = dropout-masked dx (gradient of a branch x -> drop(f(x)) summed into this
+  //              LN's input); dxsum then sums dx_drop (the branch's bias gradient).
   __shared__ float red[4][64 * 8];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   float ag[NCH][8], ab[NCH][8], as_[NCH][8];
@@ -113,6 +117,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
           const float h = (xv[i] - mean) * rstd;
           const float ga = gamma ? gamma[col + i] : 1.f;
           float d = dv[i];
+          if (drop_mode == 1) d = drop_apply(drop, (unsigned long long)row * C + col + i, d);
           if (act == 1) d *= gelu_grad_f(gamma ? h * ga + beta[col + i] : h);
           ag[c][i] += d * h;
           ab[c][i] += d;
@@ -143,6 +148,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
           for (int i = 0; i < 8; ++i) o[i] += r[i];
         }
         Vec8<T>::store(dx + row * ldx + col, o);
+        if (drop_mode == 2) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] = drop_apply(drop, (unsigned long long)row * C + col + i, o[i]);
+          Vec8<T>::store(dx_drop + row * ldx + col, o);
+        }
         if (dxsum) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) as_[c][i] += Cvt<T>::to(Cvt<T>::from(o[i]));
@@ -252,12 +262,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 template <typename T>
 static int ln_fwd_launch(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out,
                          float* mean, float* rstd, const void* post, long long M, int C, long long ldx, long long ldy, float eps, int act,
-                         hipStream_t st) {
+                         Drop drop, hipStream_t st) {
   const int nch = (C + 511) / 512;
   dim3 grid((unsigned)((M + 3) / 4)), blk(256);
 #define LN_F(N)                                                                                                      \
   hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
-                     (T*)sum_out, mean, rstd, (const T*)post, M, C, ldx, ldy, eps, act)
+                     (T*)sum_out, mean, rstd, (const T*)post, M, C, ldx, ldy, eps, act, drop)
   switch (nch) {
     case 1: LN_F(1); break;
     case 2: LN_F(2); break;
@@ -272,23 +282,27 @@ static int ln_fwd_launch(const void* x, const void* res, const float* gamma, con
 
 extern "C" int a2v_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta,
                                  void* y, void* sum_out, float* mean, float* rstd, const void* post, long long M, int C,
-                                 long long ldx, long long ldy, float eps, int act, hipStream_t stream) {
+                                 long long ldx, long long ldy, float eps, int act, float drop_p, unsigned drop_seed,
+                                 hipStream_t stream) {
   if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || C > 512 * LN_MAXCHUNK) return A2V_ERR_ARG;
   if ((gamma == nullptr) != (beta == nullptr)) return A2V_ERR_ARG;
-  if (dtype == A2V_BF16) return ln_fwd_launch<bf16>(x, res, gamma, beta, y, sum_out, mean, rstd, post, M, C, ldx, ldy, eps, act, stream);
-  if (dtype == A2V_F32) return ln_fwd_launch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, post, M, C, ldx, ldy, eps, act, stream);
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && ldy != C)) return A2V_ERR_ARG;
+  const Drop drop = make_drop(drop_p, drop_seed);
+  if (dtype == A2V_BF16) return ln_fwd_launch<bf16>(x, res, gamma, beta, y, sum_out, mean, rstd, post, M, C, ldx, ldy, eps, act, drop, stream);
+  if (dtype == A2V_F32) return ln_fwd_launch<float>(x, res, gamma, beta, y, sum_out, mean, rstd, post, M, C, ldx, ldy, eps, act, drop, stream);
   return A2V_ERR_DTYPE;
 }
 
 template <typename T>
 static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                          const float* rstd, void* dx, const void* dres, float* dgamma, float* dbeta, float* dxsum,
-                         long long M, int C, long long ldx, long long lddy, int act, hipStream_t st) {
+                         long long M, int C, long long ldx, long long lddy, int act, Drop drop, int drop_mode,
+                         void* dx_drop, hipStream_t st) {
   const int nch = (C + 511) / 512;
   dim3 grid((unsigned)((M + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE))), blk(256);
 #define LN_B(N)                                                                                                  \
   hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), grid, blk, 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, \
-                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act)
+                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, (T*)dx_drop)
   switch (nch) {
     case 1: LN_B(1); break;
     case 2: LN_B(2); break;
@@ -304,12 +318,16 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
 extern "C" int a2v_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* beta,
                                  const float* mean, const float* rstd, void* dx, const void* dres, float* dgamma,
                                  float* dbeta, float* dxsum, long long M, int C, long long ldx, long long lddy, int act,
-                                 hipStream_t stream) {
+                                 float drop_p, unsigned drop_seed, int drop_mode, void* dx_drop, hipStream_t stream) {
   if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || lddy % 8 || C > 512 * LN_MAXCHUNK) return A2V_ERR_ARG;
   if ((gamma == nullptr) != (beta == nullptr)) return A2V_ERR_ARG;
   if ((dgamma == nullptr) != (dbeta == nullptr)) return A2V_ERR_ARG;
-  if (dtype == A2V_BF16) return ln_bwd_launch<bf16>(dy, x, gamma, beta, mean, rstd, dx, dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, stream);
-  if (dtype == A2V_F32) return ln_bwd_launch<float>(dy, x, gamma, beta, mean, rstd, dx, dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, stream);
+  if (drop_mode < 0 || drop_mode > 2 || (drop_mode && !(drop_p > 0.f && drop_p < 1.f)) || (drop_mode == 2 && !dx_drop) ||
+      (drop_mode && (ldx != C || lddy != C)))
+    return A2V_ERR_ARG;
+  const Drop drop = make_drop(drop_mode ? drop_p : 0.f, drop_seed);
+  if (dtype == A2V_BF16) return ln_bwd_launch<bf16>(dy, x, gamma, beta, mean, rstd, dx, dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, dx_drop, stream);
+  if (dtype == A2V_F32) return ln_bwd_launch<float>(dy, x, gamma, beta, mean, rstd, dx, dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, dx_drop, stream);
   return A2V_ERR_DTYPE;
 }
 

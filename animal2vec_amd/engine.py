@@ -143,15 +143,25 @@ class Engine:
         self._ready("frontend")
 
     # ------------------------------------------------------------------ transformer block
-    def block_fwd(self, x, prefix, pk: Packs, params, pos, alibi_scale, H, save: Optional[str], want_t=False):
+    def _site(self, base, site):
+        """per-site dropout seed (None when dropout is off)"""
+        return None if base is None else (base * 1000003 + site * 7919 + 12345) & 0xFFFFFFFF
+
+    def block_fwd(self, x, prefix, pk: Packs, params, pos, alibi_scale, H, save: Optional[str], want_t=False,
+                  drop_base=None, site=0):
         """AltBlock post-LN with ffn targets (reference modules.py:328-337).  x (N,S,D)."""
         N, S, D = x.shape
         eps = self.cfg.norm_eps
         x2 = x.view(N * S, D)
         qkv = ops.linear(x2, pk.w[prefix + "attn.qkv.weight"], params[prefix + "attn.qkv.bias"])
+        c = self.cfg
+        d_att = (c.attention_dropout, self._site(drop_base, 4 * site)) if drop_base is not None else None
+        d_proj = (c.encoder_dropout, self._site(drop_base, 4 * site + 1)) if drop_base is not None else None
+        d_mlp = (c.post_mlp_drop, self._site(drop_base, 4 * site + 2)) if drop_base is not None else None
         att, lse = ops.attention_fwd(qkv.view(N, S, 3 * D), pos, self.store.alibi_slopes, alibi_scale, H,
-                                     need_lse=save is not None)
-        s1 = ops.linear(att.view(N * S, D), pk.w[prefix + "attn.proj.weight"], params[prefix + "attn.proj.bias"], res=x2)
+                                     need_lse=save is not None, drop=d_att)
+        s1 = ops.linear(att.view(N * S, D), pk.w[prefix + "attn.proj.weight"], params[prefix + "attn.proj.bias"], res=x2,
+                        drop=d_proj)
         x1, m1, r1 = ops.layernorm_fwd(s1, params[prefix + "norm1.weight"], params[prefix + "norm1.bias"], eps,
                                        save_stats=save is not None)
         hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
@@ -163,12 +173,12 @@ class Engine:
             x2o, m2, r2 = ops.layernorm_fwd(t, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps, res=x1,
                                             save_stats=False)
         else:
-            s2 = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"], res=x1)
+            s2 = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"], res=x1, drop=d_mlp)
             x2o, m2, r2 = ops.layernorm_fwd(s2, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
                                             save_stats=save is not None)
         if save is not None:
             self.sv[save] = dict(x=x2, qkv=qkv, att=att, lse=lse, s1=s1, st1=(m1, r1), x1=x1, hpre=hpre, g=gact, s2=s2,
-                                 st2=(m2, r2), N=N, S=S)
+                                 st2=(m2, r2), N=N, S=S, drops=(d_att, d_proj, d_mlp))
         return x2o.view(N, S, D), (t.view(N, S, D) if t is not None else None)
 
     def block_bwd(self, dx, prefix, pos, alibi_scale, H, key):
@@ -178,20 +188,22 @@ class Engine:
         N, S = sv["N"], sv["S"]
         D = dx.shape[-1]
         dx = dx.reshape(N * S, D)
-        ds2 = ops.layernorm_bwd(dx, sv["s2"], p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], *sv["st2"],
-                                dgamma=g[prefix + "norm2.weight"], dbeta=g[prefix + "norm2.bias"],
-                                dxsum=g[prefix + "mlp.fc2.bias"])
-        ops.linear_wgrad(sv["g"], ds2, g[prefix + "mlp.fc2.weight"])
-        dh = ops.linear(ds2, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"])
+        d_att, d_proj, d_mlp = sv["drops"]
+        # ds2: gradient of (x1 + drop(mlp)) -> residual path; ds2d: the same through the dropout mask -> mlp branch
+        ds2, ds2d = ops.layernorm_bwd(dx, sv["s2"], p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], *sv["st2"],
+                                      dgamma=g[prefix + "norm2.weight"], dbeta=g[prefix + "norm2.bias"],
+                                      dxsum=g[prefix + "mlp.fc2.bias"], drop=d_mlp, drop_mode=2)
+        ops.linear_wgrad(sv["g"], ds2d, g[prefix + "mlp.fc2.weight"])
+        dh = ops.linear(ds2d, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"])
         ops.linear_wgrad(sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
         dx1 = ops.linear(dh, sp.wt[prefix + "mlp.fc1.weight"], res=ds2)
-        ds1 = ops.layernorm_bwd(dx1, sv["s1"], p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], *sv["st1"],
-                                dgamma=g[prefix + "norm1.weight"], dbeta=g[prefix + "norm1.bias"],
-                                dxsum=g[prefix + "attn.proj.bias"])
-        ops.linear_wgrad(sv["att"].view(N * S, D), ds1, g[prefix + "attn.proj.weight"])
-        datt = ops.linear(ds1, sp.wt[prefix + "attn.proj.weight"])
+        ds1, ds1d = ops.layernorm_bwd(dx1, sv["s1"], p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], *sv["st1"],
+                                      dgamma=g[prefix + "norm1.weight"], dbeta=g[prefix + "norm1.bias"],
+                                      dxsum=g[prefix + "attn.proj.bias"], drop=d_proj, drop_mode=2)
+        ops.linear_wgrad(sv["att"].view(N * S, D), ds1d, g[prefix + "attn.proj.weight"])
+        datt = ops.linear(ds1d, sp.wt[prefix + "attn.proj.weight"])
         dqkv = ops.attention_bwd(sv["qkv"].view(N, S, 3 * D), sv["att"], datt.view(N, S, D), sv["lse"], pos,
-                                 st.alibi_slopes, alibi_scale, H, g[P + "alibi_scale"].view(-1))
+                                 st.alibi_slopes, alibi_scale, H, g[P + "alibi_scale"].view(-1), drop=d_att)
         dq2 = dqkv.view(N * S, 3 * D)
         ops.colsum(dq2, g[prefix + "attn.qkv.bias"])
         ops.linear_wgrad(sv["x"], dq2, g[prefix + "attn.qkv.weight"])
@@ -321,11 +333,13 @@ class Engine:
         return ops.instnorm_targets(ts, eps=1e-5)
 
     # ------------------------------------------------------------------ whole step
-    def forward(self, source, mask_u8, ids_keep, ids_restore, noise, *, save=True, keep_debug=False):
+    def forward(self, source, mask_u8, ids_keep, ids_restore, noise, *, save=True, keep_debug=False, dropout_seed=None):
         """Forward of one micro-batch (teacher targets + student + decoder + loss).  source (B,L) fp32;
         mask_u8 (B*cb,T) 1=masked; ids_keep (B*cb,K) int32 (ascending kept frames); ids_restore (B*cb,T)
         int32; noise (B*cb,T-K,D) fp32 (row j <-> j-th masked frame).  Adds loss/variance sums to
-        self.stats; with save=True keeps what backward() needs."""
+        self.stats; with save=True keeps what backward() needs.  dropout_seed (int) switches the student's
+        train-mode dropouts on (prenet 0.1, attention 0.1, proj 0.1, post-mlp 0.1, decoder input 0.1: yaml:139-147,
+        data2vec2.py:74-77); the teacher always runs in eval mode (data2vec2.py:779-780)."""
         cfg, st, sp = self.cfg, self.store, self.sp
         p = st.p
         cb, H, D = cfg.clone_batch, cfg.num_heads, cfg.embed_dim
@@ -340,21 +354,25 @@ class Engine:
         # ---- student context encoder (base.py:215-344)
         x_pos = self.posconv_fwd(feats, sp, p, mask_u8, cb, save=save)         # (N,T,D)
         tok = ops.gather_tokens(feats, ids_keep, cb=cb, b=x_pos)               # (N,K,D)
+        db = dropout_seed
+        d_pre = (a.prenet_dropout, self._site(db, 9000)) if db is not None and a.prenet_dropout > 0 else None
+        d_dec = (a.decoder.input_dropout, self._site(db, 9001)) if db is not None and a.decoder.input_dropout > 0 else None
         x, m0, r0 = ops.layernorm_fwd(tok, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
-                                      cfg.norm_eps, save_stats=save)
+                                      cfg.norm_eps, save_stats=save, drop=d_pre)
         if save:
             self.sv["tok"], self.sv["tok_st"] = tok, (m0, r0)
         for i in range(a.prenet_depth):
             x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, ids_keep, asc, H,
-                                  save=f"pb{i}" if save else None)
+                                  save=f"pb{i}" if save else None, drop_base=db, site=i)
         if keep_debug:
             dbg["prenet_out"] = x
         for i in range(cfg.depth):
-            x, _ = self.block_fwd(x, f"blocks.{i}.", sp, p, ids_keep, asc, H, save=f"mb{i}" if save else None)
+            x, _ = self.block_fwd(x, f"blocks.{i}.", sp, p, ids_keep, asc, H, save=f"mb{i}" if save else None,
+                                  drop_base=db, site=a.prenet_depth + i)
         if keep_debug:
             dbg["encoder_out"] = x
         # ---- decoder + loss
-        dec_in = ops.decoder_input(x, noise, ids_restore)                      # (N,T,D)
+        dec_in = ops.decoder_input(x, noise, ids_restore, drop=d_dec)          # (N,T,D)
         dec_out = self.decoder_fwd(dec_in, save=save)
         loss_rows = torch.empty(N, T, D, dtype=torch.float32, device=x.device) if keep_debug else None
         dx = ops.d2v_loss(dec_out, y, mask_u8, cb, stats=self.stats, want_dx=save, gscale=1.0, loss_rows=loss_rows)
@@ -362,7 +380,8 @@ class Engine:
             dbg.update(local_features=feats, targets=y, x_pos=x_pos, decoder_in=dec_in, decoder_out=dec_out,
                        loss_rows=loss_rows)
         if save:
-            self.sv["ctx"] = dict(dx=dx, mask_u8=mask_u8, ids_keep=ids_keep, ids_restore=ids_restore, T=T)
+            self.sv["ctx"] = dict(dx=dx, mask_u8=mask_u8, ids_keep=ids_keep, ids_restore=ids_restore, T=T, d_pre=d_pre,
+                                  d_dec=d_dec)
         return dbg
 
     def backward(self, gscale: float = 1.0):
@@ -377,7 +396,7 @@ class Engine:
             dx.mul_(gscale)
         asc = p[P + "alibi_scale"].view(-1)
         ddec_in = self.decoder_bwd(dx)                                         # (N,T,D)
-        dxe = ops.gather_tokens(ddec_in, ids_keep, cb=1)                       # (N,K,D)
+        dxe = ops.gather_tokens(ddec_in, ids_keep, cb=1, drop=c["d_dec"])      # (N,K,D)
         for i in reversed(range(cfg.depth)):
             dxe = self.block_bwd(dxe, f"blocks.{i}.", ids_keep, asc, H, f"mb{i}")
             self._ready(f"block{i}")
@@ -386,7 +405,8 @@ class Engine:
             self._ready(f"prenet{i}")
         dtok = ops.layernorm_bwd(dxe, self.sv.pop("tok"), p[P + "context_encoder.norm.weight"],
                                  p[P + "context_encoder.norm.bias"], *self.sv.pop("tok_st"),
-                                 dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"])
+                                 dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"],
+                                 drop=c["d_pre"], drop_mode=1)
         dxpos = ops.scatter_tokens(dtok, ids_restore, T)                       # (N,T,D)
         dxm = self.posconv_bwd(dxpos, mask_u8, cb)                             # (N,T,D)
         self._ready("posconv")
@@ -395,10 +415,11 @@ class Engine:
         self.sv.clear()
 
     def forward_backward(self, source, mask_u8, ids_keep, ids_restore, noise, *, backward=True, gscale=1.0,
-                         keep_debug=False):
+                         keep_debug=False, dropout_seed=None):
         """One micro-batch: forward then (optionally) backward.  Accumulates parameter gradients into
         store.grad and loss/variance sums into self.stats."""
-        dbg = self.forward(source, mask_u8, ids_keep, ids_restore, noise, save=backward, keep_debug=keep_debug)
+        dbg = self.forward(source, mask_u8, ids_keep, ids_restore, noise, save=backward, keep_debug=keep_debug,
+                           dropout_seed=dropout_seed)
         if backward:
             self.backward(gscale)
         return dbg

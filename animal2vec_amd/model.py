@@ -67,6 +67,7 @@ class Data2VecMultiModel(tnn.Module):
                 prm.optim_overrides = {"optimizer": {"weight_decay_scale": 0}}
             _attach(self, s.name, prm)
         self.skip_ema = skip_ema
+        self.dropout = True          # train-mode dropout (set False for deterministic training-mode checks)
         self.num_updates = 0
         self.ema_decay = cfg.ema_decay
         self._rng = np.random.default_rng(cfg.seed)
@@ -149,7 +150,10 @@ class Data2VecMultiModel(tnn.Module):
                 0, cfg.audio.mask_noise_std)
         need_grad = torch.is_grad_enabled() and self.training
         eng.stats.zero_()
-        dbg = eng.forward(source, mask_u8, keep, restore, noise, save=need_grad, keep_debug=unreduced_loss)
+        self._fwd_count = getattr(self, "_fwd_count", 0) + 1
+        dseed = (self.cfg.seed * 7919 + self._fwd_count) if (self.training and self.dropout) else None
+        dbg = eng.forward(source, mask_u8, keep, restore, noise, save=need_grad, keep_debug=unreduced_loss,
+                          dropout_seed=dseed)
         D = cfg.embed_dim
         st = eng.stats
         loss_sum = st[4 * D].to(torch.float32).reshape(1)

@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, check
+from ._lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, check
 
 
 def _L():
@@ -41,12 +41,20 @@ def per16(t: torch.Tensor) -> int:
     return 16 // t.element_size()
 
 
+def _drop(drop):
+    """(p, seed) or None -> C arguments"""
+    if drop is None or drop[0] <= 0:
+        return 0.0, 0
+    return float(drop[0]), int(drop[1]) & 0xFFFFFFFF
+
+
 # ----------------------------------------------------------------------------------------------
 #                                         GEMM family
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride,
               a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
-              gelu=False, gelu_bwd=False, pre_out=None, colsum=None):
+              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None):
+    """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add."""
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS
@@ -60,15 +68,18 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
         flags |= EPI_STORE_PRE
     if colsum is not None:
         flags |= EPI_COLSUM
+    if drop is not None and drop[0] > 0:
+        flags |= EPI_DROPOUT
+    dp, ds = (drop if drop is not None and drop[0] > 0 else (0.0, 0))
     rc = _L().a2v_conv_gemm(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
                             ptr(rowmask), bdiv, ptr(w), ldb, b_gstride, ptr(out), ldc, c_goff, ptr(pre_out),
                             ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
-                            stream())
+                            dp, ds & 0xFFFFFFFF, stream())
     check(rc, "a2v_conv_gemm")
     return out
 
 
-def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None):
+def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None, drop=None):
     """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w/out/res row-major 2-D (leading dims from strides)."""
     M, K = x.shape
     N = w.shape[0]
@@ -78,7 +89,7 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
     r = gelu_bwd_aux if gelu_bwd_aux is not None else res
     return conv_gemm(x, w, out, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
                      ldb=w.stride(0), ldc=out.stride(0), bias=bias, res=r, ldr=r.stride(0) if r is not None else 0,
-                     gelu=gelu, gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum)
+                     gelu=gelu, gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum, drop=drop)
 
 
 def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=None, rowmask=None, bdiv=1,
@@ -135,19 +146,19 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
 # ----------------------------------------------------------------------------------------------
 #                                         attention
 # ----------------------------------------------------------------------------------------------
-def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True):
+def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None):
     """qkv (N,S,3*H*HD) -> out (N,S,H*HD), lse (N,H,S)"""
     N, S, W = qkv.shape
     HD = W // (3 * H)
     out = torch.empty(N, S, H * HD, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
     rc = _L().a2v_attention_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
-                                HD, HD ** -0.5, stream())
+                                HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_fwd")
     return out, lse
 
 
-def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi):
+def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, drop=None):
     """-> dqkv (N,S,3*H*HD).  dalibi (H) fp32 is accumulated."""
     N, S, W = qkv.shape
     HD = W // (3 * H)
@@ -155,7 +166,8 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi):
     dq32 = torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
     delta = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
     rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(delta), ptr(dqkv), ptr(dq32),
-                                ptr(dalibi), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, stream())
+                                ptr(dalibi), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)),
+                                stream())
     check(rc, "a2v_attention_bwd")
     cast2d(dq32, dqkv.view(N * S, W)[:, : H * HD])
     return dqkv
@@ -164,7 +176,7 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi):
 # ----------------------------------------------------------------------------------------------
 #                                         normalisation
 # ----------------------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=None, sum_out=None, post=None):
+def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=None, sum_out=None, post=None, drop=None):
     """x (..., C) contiguous rows.  Returns y, mean, rstd."""
     C_ = x.shape[-1]
     M = x.numel() // C_
@@ -172,18 +184,25 @@ def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=
     mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
     rc = _L().a2v_layernorm_fwd(dt(x), ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(y), ptr(sum_out), ptr(mean),
-                                ptr(rstd), ptr(post), M, C_, C_, C_, eps, act, stream())
+                                ptr(rstd), ptr(post), M, C_, C_, C_, eps, act, *(_drop(drop)), stream())
     check(rc, "a2v_layernorm_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, beta, mean, rstd, *, act=0, dgamma=None, dbeta=None, dxsum=None, dres=None, out=None):
+def layernorm_bwd(dy, x, gamma, beta, mean, rstd, *, act=0, dgamma=None, dbeta=None, dxsum=None, dres=None, out=None,
+                  drop=None, drop_mode=0):
+    """drop_mode 1: mask incoming dy (dropout followed this LN); drop_mode 2: also return dropout(dx) (second result)."""
     C_ = x.shape[-1]
     M = x.numel() // C_
     dx = out if out is not None else torch.empty_like(x)
+    mode = drop_mode if (drop is not None and drop[0] > 0) else 0
+    dx_drop = torch.empty_like(x) if mode == 2 else None
     rc = _L().a2v_layernorm_bwd(dt(x), ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dres),
-                                ptr(dgamma), ptr(dbeta), ptr(dxsum), M, C_, C_, C_, act, stream())
+                                ptr(dgamma), ptr(dbeta), ptr(dxsum), M, C_, C_, C_, act, *(_drop(drop)), mode, ptr(dx_drop),
+                                stream())
     check(rc, "a2v_layernorm_bwd")
+    if drop_mode == 2:
+        return dx, (dx_drop if dx_drop is not None else dx)
     return dx
 
 
@@ -250,12 +269,12 @@ def sinc_fused_bwd(x, filt, ln_w, ln_b, ps_a, ps_b, dy, mean, rstd, dfilt, dpar,
 # ----------------------------------------------------------------------------------------------
 #                                         tokens / loss / optimizer
 # ----------------------------------------------------------------------------------------------
-def gather_tokens(a, ids, *, cb=1, b=None):
+def gather_tokens(a, ids, *, cb=1, b=None, drop=None):
     """out[n,k,:] = a[n//cb, ids[n,k], :] (+ b[n, ids[n,k], :]);  a (Ba,Ta,D), ids (N,K) int32"""
     N, K = ids.shape
     Ta, D = a.shape[1], a.shape[2]
     out = torch.empty(N, K, D, dtype=a.dtype, device=a.device)
-    rc = _L().a2v_gather_tokens(dt(a), ptr(a), ptr(b), ptr(ids), ptr(out), N, K, D, Ta, cb, stream())
+    rc = _L().a2v_gather_tokens(dt(a), ptr(a), ptr(b), ptr(ids), ptr(out), N, K, D, Ta, cb, *(_drop(drop)), stream())
     check(rc, "a2v_gather_tokens")
     return out
 
@@ -277,11 +296,11 @@ def clone_reduce(dxm, dtok, restore, cb):
     return out
 
 
-def decoder_input(x, noise, restore):
+def decoder_input(x, noise, restore, drop=None):
     N, K, D = x.shape
     T = restore.shape[1]
     out = torch.empty(N, T, D, dtype=x.dtype, device=x.device)
-    rc = _L().a2v_decoder_input(dt(x), ptr(x), ptr(noise), ptr(restore), ptr(out), N, K, D, T, stream())
+    rc = _L().a2v_decoder_input(dt(x), ptr(x), ptr(noise), ptr(restore), ptr(out), N, K, D, T, *(_drop(drop)), stream())
     check(rc, "a2v_decoder_input")
     return out
 
@@ -294,6 +313,14 @@ def d2v_loss(x, y, mask_u8, cb, *, stats, want_dx=True, gscale=1.0, loss_rows=No
                            D ** -0.5, gscale, stream())
     check(rc, "a2v_d2v_loss")
     return dx
+
+
+def dropout_mask(n, p, seed, device="cuda"):
+    """keep-mask (uint8) of linear indices [0,n) for a dropout site -- what every kernel regenerates."""
+    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    rc = _L().a2v_dropout_mask(ptr(keep), n, float(p), int(seed) & 0xFFFFFFFF, stream())
+    check(rc, "a2v_dropout_mask")
+    return keep
 
 
 def ema_update(ema, p, decay):

@@ -43,7 +43,7 @@ def get_annealed_rate(start, end, curr_step, total_steps):
 
 class PretrainTrainer:
     def __init__(self, cfg: Data2VecMultiConfig, optim: Optional[OptimConfig] = None, dtype=torch.bfloat16,
-                 device="cuda", seed: int = 0, process_group=None):
+                 device="cuda", seed: int = 0, process_group=None, dropout: bool = True):
         self.cfg, self.optim = cfg, optim or OptimConfig()
         self.store = ParamStore(cfg, device=device)
         self.store.init_reference(seed)
@@ -52,6 +52,8 @@ class PretrainTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.num_updates = 0
         self.ema_decay = cfg.ema_decay
+        self.dropout = dropout
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
         self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device
@@ -98,7 +100,8 @@ class PretrainTrainer:
                 T = mb["ids_restore"].shape[1]
                 noise = torch.empty(N, T - K, self.cfg.embed_dim, dtype=torch.float32, device=st.device).normal_(
                     0, self.cfg.audio.mask_noise_std)
-            eng.forward_backward(mb["source"], mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise)
+            dseed = ((self.num_updates * 131 + j) * 257 + self.rank + 1) if self.dropout else None
+            eng.forward_backward(mb["source"], mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise, dropout_seed=dseed)
         self.sync.arm(False)
         D = self.cfg.embed_dim
         self.sync.finish(eng.stats)            # wait buckets; loss / count / variance sums in one packed call

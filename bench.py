@@ -129,7 +129,9 @@ def cpu_baseline(model_name, L, K):
     import a2v_oracle as O
     dims = O.LARGE if model_name == "large" else O.BASE_STAR
     cfg = O.OracleConfig(**dims)
-    ncores = os.cpu_count()
+    # bounded: many-socket hosts run this small-op-dominated graph SLOWER with every core (608 s on 256 threads
+    # vs 52 s on 8), so cap the thread pool; `cores` reports what was actually used
+    ncores = min(os.cpu_count(), 16)
     torch.set_num_threads(ncores)
     p = O.init_params(cfg, seed=0)
     ema = O.make_teacher(p)
@@ -223,7 +225,7 @@ def main():
         finally:
             rec.unwrap(ops)
         nt = s["nt"]
-        roof = dict(bound="mfma", kernel="gemm_nt_bf16_kernel" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
+        roof = dict(bound="mfma", kernel="gemm_nt_bf16_fast_kernel<*> (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
                     achieved=round(nt["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=None,
                     launches_per_microbatch=nt["launches"], avg_launch_us=round(nt["avg_us"], 2),

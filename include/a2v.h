@@ -38,6 +38,7 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 #define A2V_EPI_GELU_BWD 8  /* * gelu'(R[m][.]) : R holds the saved pre-activation */
 #define A2V_EPI_STORE_PRE 16 /* also store the pre-activation (acc + bias) to C2 */
 #define A2V_EPI_COLSUM 32   /* atomically add column sums of the output to colsum (bias gradient) */
+#define A2V_EPI_DROPOUT 64  /* counter-based dropout(drop_p, drop_seed) of (acc+bias[gelu]) before the residual */
 
 /* ---------------------------------------------------------------- implicit-GEMM (MFMA) family
  * C[m][g*c_goff + n] = epi( sum_kk A_g[m][kk] * Bw[g][n][kk] ),  kk = tap*Cg + ci,
@@ -51,8 +52,8 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in, int T_out,
                   int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv, const void* Bw,
                   long long ldb, long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
-                  long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
-                  a2v_stream_t stream);
+                  long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags, float drop_p,
+                  unsigned drop_seed, a2v_stream_t stream);
 
 /* W[g][n][kk] += sum_m P[m][g*p_goff + n] * A_g[m][kk]   (fp32 atomics; zero W first)
  * Replaces autograd's weight gradients of the ops above. */
@@ -67,12 +68,14 @@ int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstr
  * Replaces AltAttention.forward's q@k^T + alibi + softmax + @v (modules.py:391-407) together with
  * get_alibi_bias / masked_alibi (base.py:292-314,553-698): no (N,H,S,S) tensor is ever built. */
 int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const int* pos, const float* slopes,
-                      const float* alibi_scale, int N, int S, int H, int HD, float scale, a2v_stream_t stream);
+                      const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
+                      unsigned drop_seed, a2v_stream_t stream);
 /* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dq32 (N,S,H,HD) fp32 must be zero on entry and
  * receives dQ; dalibi (H) fp32 accumulates d loss / d alibi_scale. */
 int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse, float* delta,
                       void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
-                      const float* alibi_scale, int N, int S, int H, int HD, float scale, a2v_stream_t stream);
+                      const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p, unsigned drop_seed,
+                      a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- normalisation
  * y = act( LN(x [+ res]) * gamma + beta ), act 0 none / 1 GELU; optional sum_out = x + res;
@@ -81,11 +84,14 @@ int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d
  * modules.py:85,152,330,333. */
 int a2v_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma, const float* beta, void* y,
                       void* sum_out, float* mean, float* rstd, const void* post, long long M, int C, long long ldx,
-                      long long ldy, float eps, int act, a2v_stream_t stream);
-/* dx [+ dres]; dgamma/dbeta (C) and dxsum (C, column sums of dx) are accumulated with atomics. */
+                      long long ldy, float eps, int act, float drop_p, unsigned drop_seed, a2v_stream_t stream);
+/* dx [+ dres]; dgamma/dbeta (C) and dxsum (C, column sums of dx) are accumulated with atomics.
+ * drop_mode 1: the forward applied dropout after this LN -> dy is masked first; drop_mode 2: additionally
+ * writes dx_drop = dropout(dx) (gradient of a dropped branch added to this LN's input) and dxsum sums it. */
 int a2v_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, void* dx, const void* dres, float* dgamma, float* dbeta,
-                      float* dxsum, long long M, int C, long long ldx, long long lddy, int act, a2v_stream_t stream);
+                      float* dxsum, long long M, int C, long long ldx, long long lddy, int act, float drop_p,
+                      unsigned drop_seed, int drop_mode, void* dx_drop, a2v_stream_t stream);
 /* y (B,T,D) fp32 = mean_l instance_norm_T(layers[l])   -- make_targets, nn/data2vec2.py:1023-1066.
  * layers: HOST array of L device pointers (B,T,D); mean_ws/rstd_ws (L*B*D) fp32 scratch. */
 int a2v_instnorm_targets(int dtype, const void* const* layers, int L, float* mean_ws, float* rstd_ws, float* y, int B,
@@ -116,14 +122,14 @@ int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, const float
  * out[n,k,:] = a[n/cb, ids[n,k], :] (+ b[n, ids[n,k], :])  -- make_maskinfo gather + x_unmasked +
  * gather_unmasked(x_pos) (base.py:244,447,277-280). */
 int a2v_gather_tokens(int dtype, const void* a, const void* b, const int* ids, void* out, int N, int K, int D, int Ta,
-                      int cb, a2v_stream_t stream);
+                      int cb, float drop_p, unsigned drop_seed, a2v_stream_t stream);
 int a2v_scatter_tokens(int dtype, const void* dtok, const int* restore, void* dpos, int N, int K, int D, int T,
                        a2v_stream_t stream);
 int a2v_clone_reduce(int dtype, const void* dxm, const void* dtok, const int* restore, void* dfeat, int B, int cb,
                      int K, int D, int T, a2v_stream_t stream);
 /* decoder_input (base.py:162-192): out[n,t] = restore<K ? x[n,restore] : noise[n,restore-K] */
 int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K, int D,
-                      int T, a2v_stream_t stream);
+                      int T, float drop_p, unsigned drop_seed, a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- loss (data2vec2.py:850-864,904-909,
  * 1005-1021) + compute_var sums (:1095-1110).  stats: double[4*D+2] accumulated (zero first):
@@ -152,6 +158,9 @@ int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, 
                long long lda, long long ldo, a2v_stream_t stream);
 int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out, long long M, int C, long long ldi,
                long long ldo, a2v_stream_t stream);
+
+/* keep[i] = 1 if linear index i survives dropout(drop_p, drop_seed) -- the mask every kernel regenerates */
+int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, unsigned drop_seed, a2v_stream_t stream);
 
 /* library version / build info */
 int a2v_abi_version(void);

@@ -462,3 +462,70 @@ def test_ema_adam_cast(ops):
     b = torch.zeros(37, 96, dtype=torch.bfloat16, device="cuda")
     ops.cast2d(a.cuda(), b[:, :64])
     assert torch.equal(b[:, :64].float().cpu(), a.to(torch.bfloat16).float()) and float(b[:, 64:].float().abs().max()) == 0
+
+
+# ------------------------------------------------------------------------------------------ dropout
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_dropout_sites_regenerate_one_mask(ops, dtype):
+    """Counter-based dropout: every kernel recomputes keep(seed, linear index); a2v_dropout_mask exposes it."""
+    p_, seed = 0.1, 1234567
+    M, N, K = 192, 128, 64
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b, r = rnd(N, dtype=torch.float32, seed=3), rnd(M, N, dtype=dtype, seed=4)
+    keep = ops.dropout_mask(M * N, p_, seed).view(M, N).float().cpu()
+    assert 0.87 < float(keep.mean()) < 0.93
+    y = ops.linear(dev(x, dtype), dev(w, dtype), dev(b, torch.float32), res=dev(r, dtype), drop=(p_, seed))
+    ref = (x @ w.t() + b) * keep / (1 - p_) + r
+    assert rel_err(y.float(), ref) < tol(dtype)
+    # LayerNorm backward: mode 2 returns (dx, dropout(dx)) with the SAME mask, dxsum sums the masked one
+    xs, dy = rnd(M, N, dtype=dtype, seed=5), rnd(M, N, dtype=dtype, seed=6)
+    g_, b_ = torch.ones(N).cuda(), torch.zeros(N).cuda()
+    _, mean, rstd = ops.layernorm_fwd(dev(xs, dtype), g_, b_, 1e-5)
+    dxs = torch.zeros(N, device="cuda")
+    dx, dxd = ops.layernorm_bwd(dev(dy, dtype), dev(xs, dtype), g_, b_, mean, rstd, drop=(p_, seed), drop_mode=2, dxsum=dxs)
+    assert rel_err(dxd.float().cpu(), dx.float().cpu() * keep / (1 - p_)) < tol(dtype)
+    assert rel_err(dxs, dxd.float().sum(0)) < 1e-3
+    # mode 1: y = drop(LN x)  ->  dx = LNbwd(dy * mask)
+    yf, mean, rstd = ops.layernorm_fwd(dev(xs, dtype), g_, b_, 1e-5, drop=(p_, seed))
+    assert rel_err(yf.float().cpu(), F.layer_norm(xs, (N,)) * keep / (1 - p_)) < tol(dtype)
+    dx1 = ops.layernorm_bwd(dev(dy, dtype), dev(xs, dtype), g_, b_, mean, rstd, drop=(p_, seed), drop_mode=1)
+    dym = (dy * keep / (1 - p_)).to(dtype).float()
+    dx_ref = ops.layernorm_bwd(dev(dym, dtype), dev(xs, dtype), g_, b_, mean, rstd)
+    assert rel_err(dx1.float(), dx_ref.float()) < tol(dtype, 2)
+    # token gather / decoder input
+    Nn, Kk, T, D = 4, 6, 30, 64
+    tok = rnd(Nn, Kk, D, dtype=dtype, seed=7)
+    mask = O.seeded_mask(Nn, T, Kk, 2)
+    keep_ids, restore = O.make_maskinfo(mask)
+    noise = rnd(Nn, T - Kk, D, dtype=torch.float32, seed=8)
+    km = ops.dropout_mask(Nn * Kk * D, p_, seed).view(Nn, Kk, D).float().cpu()
+    out = ops.decoder_input(dev(tok, dtype), noise.cuda(), restore.int().cuda(), drop=(p_, seed))
+    ref = O.decoder_input((tok * km / (1 - p_)).to(dtype).float(), restore, noise)
+    assert rel_err(out.float(), ref.to(dtype).float()) < 1e-5
+    full = rnd(Nn, T, D, dtype=dtype, seed=9)
+    gth = ops.gather_tokens(dev(full, dtype), keep_ids.int().cuda(), cb=1, drop=(p_, seed))
+    gi = keep_ids.unsqueeze(-1).expand(-1, -1, D)
+    assert rel_err(gth.float(), (torch.gather(full, 1, gi) * km / (1 - p_)).to(dtype).float()) < 1e-5
+
+
+@pytest.mark.parametrize("dtype,hd", [(torch.float32, 16), (torch.bfloat16, 64)])
+def test_attention_dropout(ops, dtype, hd):
+    N, H, S, p_, seed = 2, 2, 100, 0.1, 99
+    qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=1).requires_grad_(True)
+    pos = torch.arange(S).unsqueeze(0).expand(N, -1).int().contiguous()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = torch.tensor([1.0, 0.7], requires_grad=True)
+    keep = ops.dropout_mask(N * H * S * S, p_, seed).view(N, H, S, S).float().cpu()
+    q, k, v = qkv.reshape(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = O.alibi_bias_from_positions(pos.long(), H, sc.view(1, 1, H, 1, 1))
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1) + bias).softmax(-1) * keep / (1 - p_)
+    ref = (att @ v).transpose(1, 2).reshape(N, S, H * hd)
+    do = rnd(N, S, H * hd, dtype=dtype, seed=3)
+    ref.backward(do)
+    qd = dev(qkv.detach(), dtype)
+    out, lse = ops.attention_fwd(qd, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, drop=(p_, seed))
+    assert rel_err(out.float(), ref) < tol(dtype, 2)
+    dal = torch.zeros(H, device="cuda")
+    dqkv = ops.attention_bwd(qd, out, dev(do, dtype), lse, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, dal, drop=(p_, seed))
+    assert rel_err(dqkv.float(), qkv.grad) < tol(dtype, 3)
+    assert rel_err(dal, sc.grad) < max(tol(dtype, 3), 5e-4)

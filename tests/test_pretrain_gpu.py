@@ -118,6 +118,7 @@ def test_model_surface_dropin(tiny_golden):
     assert set(got) == set(p) | {"_ema"} and set(got["_ema"]) == set(ema)
     assert all(torch.equal(got[k].cpu(), p[k]) for k in p)
     model.train()
+    model.dropout = False        # the reference vectors were produced in eval mode
     model.store.grad.zero_()
     out = model(fx["source"], precomputed_mask=fx["mask"], noise=fx["noise"].cuda())
     assert set(out) >= {"losses", "sample_size", "masked_pct", "pred_var", "target_var", "ema_decay"}
@@ -162,3 +163,49 @@ def test_extract_features(tiny_golden, dtype, tol):
     assert rel_err(res["x"].float(), fx["features_only.x"]) < tol
     lm = sum(t.float() for t in res["layer_results"]) / len(res["layer_results"])
     assert rel_err(lm, fx["features_only.layer_mean"]) < tol
+
+
+def test_dropout_gradients_by_finite_differences(tiny_golden):
+    """Train-mode dropout (deterministic counter-based masks): the hand-written backward must be the gradient of
+    the forward it was run on.  Central differences on a few scalars of the fp32 engine."""
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.masking import make_maskinfo
+    fx = tiny_golden
+    p, ema, _ = split_golden(fx)
+    cfg = tiny_config()
+    store, eng = build(cfg, p, ema, torch.float32)
+    m, keep, restore = make_maskinfo(fx["mask"].cuda())
+    src, noise = fx["source"].cuda(), fx["noise"].cuda()
+    D = cfg.embed_dim
+    SEED = 4242
+
+    def loss():
+        eng.sp.refresh()
+        eng.stats.zero_()
+        eng.forward(src, m, keep, restore, noise, save=False, dropout_seed=SEED)
+        torch.cuda.synchronize()
+        return float(eng.stats[4 * D])
+
+    store.grad.zero_()
+    eng.stats.zero_()
+    eng.forward_backward(src, m, keep, restore, noise, dropout_seed=SEED)
+    l_drop = float(eng.stats[4 * D])
+    assert abs(l_drop - float(fx["loss_sum"])) / float(fx["loss_sum"]) > 1e-4      # dropout really changed the forward
+    probes = [("blocks.1.attn.qkv.weight", (5, 7)), ("blocks.0.mlp.fc2.bias", (3,)),
+              ("modality_encoders.AUDIO.context_encoder.blocks.0.attn.proj.weight", (2, 9)),
+              ("modality_encoders.AUDIO.decoder.blocks.0.0.weight", (4, 3, 2)),
+              ("modality_encoders.AUDIO.context_encoder.norm.weight", (11,)),
+              ("modality_encoders.AUDIO.alibi_scale", (0, 0, 1, 0, 0))]
+    for name, idx in probes:
+        g = float(store.g[name][idx])
+        w = store.p[name]
+        old = float(w[idx])
+        eps = 2e-2 * max(1.0, abs(old))
+        w[idx] = old + eps
+        lp = loss()
+        w[idx] = old - eps
+        lm = loss()
+        w[idx] = old
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - g) <= 0.08 * max(abs(g), abs(fd)) + 2e-2, (name, fd, g)
+    eng.sp.refresh()
