@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "liba2v_hip.so")
-SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip"]
+SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip", "a2v_mixup.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
 
 

@@ -315,6 +315,45 @@ def d2v_loss(x, y, mask_u8, cb, *, stats, want_dx=True, gscale=1.0, loss_rows=No
     return dx
 
 
+def a_weight_table(fs: int, n_fft: int, min_db: float = -80.0):
+    """Linear-power A-weighting per rfft bin, reference data2vec2.py:461-479 (host, numpy, once)."""
+    import numpy as np
+    freq = np.linspace(0, fs // 2, n_fft // 2 + 1)
+    fsq = freq ** 2
+    fsq[0] = 1.0
+    w = 2.0 + 20.0 * (2 * np.log10(12194) + 2 * np.log10(fsq) - np.log10(fsq + 12194 ** 2) - np.log10(fsq + 20.6 ** 2)
+                      - 0.5 * np.log10(fsq + 107.7 ** 2) - 0.5 * np.log10(fsq + 737.9 ** 2))
+    return torch.from_numpy(np.power(10, np.maximum(w, min_db) / 10)).float()
+
+
+class Mixup:
+    """BC-learning source mixup on device (data2vec2.py:536-598): tables once, two launches per batch."""
+
+    def __init__(self, sample_rate: int, window_s: float, device, min_db: float = -80.0):
+        self.n_fft = round(sample_rate * window_s)
+        self.hop = self.n_fft // 2
+        self.window = torch.hann_window(self.n_fft).to(device)
+        self.aw = a_weight_table(sample_rate, self.n_fft, min_db).to(device)
+        self.floor = 10 ** (min_db / 10)
+
+    def gain_db(self, x):
+        B, L = x.shape
+        nframes = (L - self.n_fft) // self.hop + 1
+        g = torch.empty(B, nframes, dtype=torch.float32, device=x.device)
+        rc = _L().a2v_mixup_gain(ptr(x), ptr(self.window), ptr(self.aw), ptr(g), B, L, self.n_fft, self.hop, self.floor,
+                                 stream())
+        check(rc, "a2v_mixup_gain")
+        return g
+
+    def __call__(self, x, perm, r: float):
+        """x (B,L) fp32, perm (B) int32 device tensor, r in (0,1] -> mixed (B,L)"""
+        g = self.gain_db(x)
+        out = torch.empty_like(x)
+        rc = _L().a2v_mixup_apply(ptr(x), ptr(perm), ptr(g), ptr(out), x.shape[0], x.shape[1], g.shape[1], float(r), stream())
+        check(rc, "a2v_mixup_apply")
+        return out
+
+
 def dropout_mask(n, p, seed, device="cuda"):
     """keep-mask (uint8) of linear indices [0,n) for a dropout site -- what every kernel regenerates."""
     keep = torch.empty(n, dtype=torch.uint8, device=device)

@@ -43,7 +43,7 @@ def get_annealed_rate(start, end, curr_step, total_steps):
 
 class PretrainTrainer:
     def __init__(self, cfg: Data2VecMultiConfig, optim: Optional[OptimConfig] = None, dtype=torch.bfloat16,
-                 device="cuda", seed: int = 0, process_group=None, dropout: bool = True):
+                 device="cuda", seed: int = 0, process_group=None, dropout: bool = True, mixup: bool = True):
         self.cfg, self.optim = cfg, optim or OptimConfig()
         self.store = ParamStore(cfg, device=device)
         self.store.init_reference(seed)
@@ -53,6 +53,9 @@ class PretrainTrainer:
         self.num_updates = 0
         self.ema_decay = cfg.ema_decay
         self.dropout = dropout
+        self.mixup = ops.Mixup(cfg.audio.sample_rate, cfg.mixing_window_length, self.store.device) \
+            if (cfg.source_mixup >= 0 and cfg.mixup_prob > 0 and mixup) else None
+        self._np_rng = __import__("numpy").random.default_rng(seed + 17)
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
         self.engine.on_grad_ready = self.sync.on_ready
@@ -101,7 +104,12 @@ class PretrainTrainer:
                 noise = torch.empty(N, T - K, self.cfg.embed_dim, dtype=torch.float32, device=st.device).normal_(
                     0, self.cfg.audio.mask_noise_std)
             dseed = ((self.num_updates * 131 + j) * 257 + self.rank + 1) if self.dropout else None
-            eng.forward_backward(mb["source"], mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise, dropout_seed=dseed)
+            src = mb["source"]
+            if self.mixup is not None:        # BC-learning mixup, train only (data2vec2.py:536-598)
+                r = float(self._np_rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
+                perm = torch.from_numpy(self._np_rng.permutation(src.shape[0]).astype("int32")).to(src.device, non_blocking=True)
+                src = self.mixup(src, perm, r)
+            eng.forward_backward(src, mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise, dropout_seed=dseed)
         self.sync.arm(False)
         D = self.cfg.embed_dim
         self.sync.finish(eng.stats)            # wait buckets; loss / count / variance sums in one packed call

@@ -248,7 +248,7 @@ def main():
                                    f"all-reduce, clip+Adam, EMA) on {L}-sample clips @ {cfg.audio.sample_rate} Hz, "
                                    f"{K}/{cfg.frame_counts(L)[-1]} frames kept, clone_batch {cfg.clone_batch}",
                        "global_batch": args.global_batch, "micro_batch": args.micro_batch, "micro_batches_per_rank": n_mb,
-                       "parallelism": f"dp{world}", "dropout": "off", "mixup": "off"},
+                       "parallelism": f"dp{world}", "dropout": "on (p=0.1, 5 sites)", "mixup": "on (BC, A-weighted gain)"},
             "model_tflops_per_s": round(gf_fb * args.global_batch * args.steps / dt / 1e3, 2),
             "mfu_vs_bf16_dense_peak": round(gf_fb * args.global_batch * args.steps / dt / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "loss_per_sample": round(met["loss"], 5), "pred_var": round(met["pred_var"], 5),

@@ -138,6 +138,14 @@ int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* r
 int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsigned char* mask, void* dx, float* loss_rows,
                  double* stats, int N, int T, int D, int cb, float scale, float gscale, a2v_stream_t stream);
 
+/* ---------------------------------------------------------------- BC-learning source mixup (train only, no grad)
+ * compute_gain_torch (nn/data2vec2.py:453-498): gain_db (B, nframes) of A-weighted framed power spectra;
+ * mixup block (:536-598, same_mixup, mixup_prob 1): out[b] = (p x[b] + (1-p) x[perm[b]]) / sqrt(p^2+(1-p)^2). */
+int a2v_mixup_gain(const float* x, const float* window, const float* aweight, float* gain_db, int B, int L, int n_fft,
+                   int hop, float floor_, a2v_stream_t stream);
+int a2v_mixup_apply(const float* x, const int* perm, const float* gain_db, float* out, int B, int L, int nframes,
+                    float r, a2v_stream_t stream);
+
 /* ---------------------------------------------------------------- optimizer side
  * EMA teacher: fairseq EMAModule.step driven from data2vec2.py:386-410, flat fp32 buffers. */
 int a2v_ema_update(float* ema, const float* p, long long n, float decay, a2v_stream_t stream);

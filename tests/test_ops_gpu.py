@@ -529,3 +529,15 @@ def test_attention_dropout(ops, dtype, hd):
     dqkv = ops.attention_bwd(qd, out, dev(do, dtype), lse, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, dal, drop=(p_, seed))
     assert rel_err(dqkv.float(), qkv.grad) < tol(dtype, 3)
     assert rel_err(dal, sc.grad) < max(tol(dtype, 3), 5e-4)
+
+
+def test_mixup_golden(ops):
+    """BC mixup against the vector dumped from the live reference (oracle/gen_golden.py: G14)."""
+    from conftest import load_golden
+    mx = load_golden("mixup.npz")
+    m = ops.Mixup(8000, 0.05, "cuda")
+    src = mx["source"].cuda()
+    g = m.gain_db(src)
+    assert float((g.cpu() - mx["gain_db"]).abs().max()) < 2e-3          # dB
+    out = m(src, mx["perm"].int().cuda(), float(mx["r"]))
+    assert rel_err(out, mx["mixed"]) < 1e-4
