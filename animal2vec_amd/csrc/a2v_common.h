@@ -148,4 +148,17 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
 }
 
+// Grouped ("supertile") order on top of the XCD remap: consecutive ids walk 8 m-tiles x all n-tiles column by
+// column, so the ~64 tiles resident on one XCD at a time form an 8 x 8 patch that re-uses 8 A panels and 8
+// B panels out of its 4 MiB L2 instead of streaming every B panel from the Infinity Cache (N = 4096: 4x less
+// L2-miss traffic than row-major order).
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int gsz = 8 * tiles_n;
+  const int grp = id / gsz, rem = id - grp * gsz;
+  const int first = grp * 8;
+  const int rows = tiles_m - first < 8 ? tiles_m - first : 8;
+  tn = rem / rows;
+  tm = first + (rem - tn * rows);
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -508,3 +508,10 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }
+
+// debugging / A-B benchmarking knob: key 0 = bf16 NT kernel variant (0 register-staged, 1 LDS-DMA)
+extern int g_a2v_gemm_variant;
+extern "C" int a2v_debug_set(int key, int value) {
+  if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
+  return A2V_ERR_ARG;
+}

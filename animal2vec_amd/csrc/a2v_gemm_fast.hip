@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
   const int tiles_n = (g.N + BN - 1) / BN;
   const int tiles_m = (g.M + BM - 1) / BM;
   const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
-  const int tm = id / tiles_n, tn = id - tm * tiles_n;
+  int tm, tn;
+  tile_coords(id, tiles_m, tiles_n, tm, tn);
   const int grp = blockIdx.y;
   const int m0 = tm * BM, n0 = tn * BN;
   const int crow = tid >> 3, cchunk = tid & 7;
@@ -42,8 +43,9 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
   // schedule barriers below are present.
 #define A2V_REP4(X) X(0) X(1) X(2) X(3)
 #define A2V_REP48(X) X(4) X(5) X(6) X(7)
-#define DECL_A(i) const char* pa##i = safe; int ta##i = 0; const unsigned char* ma##i = nullptr; uint4 ra##i = {0u, 0u, 0u, 0u};
-#define DECL_B(i) const char* pb##i = safe; uint4 rb##i = {0u, 0u, 0u, 0u};
+#define DECL_A(i) const char* pa##i = safe; int ta##i = 0; const unsigned char* ma##i = nullptr; \
+                  uint4 ra##i##_0 = {0u, 0u, 0u, 0u}, ra##i##_1 = {0u, 0u, 0u, 0u};
+#define DECL_B(i) const char* pb##i = safe; uint4 rb##i##_0 = {0u, 0u, 0u, 0u}, rb##i##_1 = {0u, 0u, 0u, 0u};
   A2V_REP4(DECL_A) A2V_REP48(DECL_A) A2V_REP4(DECL_B)
 #define INIT_A(i)                                                                                             \
   if (i < A_CH) {                                                                                             \
@@ -66,22 +68,23 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
   int tap = 0, ci0 = 0;
   const long long tap_step = (a.pitch - (a.Cg - 64)) * 2;
 
-#define LOAD_A(i)                                                              \
+#define LOAD_A(i, S)                                                           \
   if (i < A_CH) {                                                              \
     if constexpr (CONV) {                                                      \
       const int row = ta##i + tap;                                             \
       bool ok = (unsigned)row < (unsigned)a.T_in && (ci0 + cchunk * 8 < a.Cv); \
       if (a.rowmask) ok = ok && (ma##i[ok ? row : 0] == 0);                    \
       const char* p = ok ? pa##i + soffA : safe;                               \
-      ra##i = sel4(ok, *(const uint4*)p);                                      \
+      ra##i##_##S = sel4(ok, *(const uint4*)p);                                \
     } else {                                                                   \
-      ra##i = *(const uint4*)(pa##i + soffA);                                  \
+      ra##i##_##S = *(const uint4*)(pa##i + soffA);                            \
     }                                                                          \
   }
-#define LOAD_B(i) if (i < B_CH) rb##i = *(const uint4*)(pb##i + soffB);
-#define LOAD_TILE()                                                            \
+#define LOAD_B(i, S) if (i < B_CH) rb##i##_##S = *(const uint4*)(pb##i + soffB);
+#define LOAD_TILE(S)                                                           \
   {                                                                            \
-    A2V_REP4(LOAD_A) A2V_REP48(LOAD_A) A2V_REP4(LOAD_B)                        \
+    LOAD_A(0, S) LOAD_A(1, S) LOAD_A(2, S) LOAD_A(3, S) LOAD_A(4, S) LOAD_A(5, S) LOAD_A(6, S) LOAD_A(7, S) \
+    LOAD_B(0, S) LOAD_B(1, S) LOAD_B(2, S) LOAD_B(3, S)                        \
     if (kt_next + 1 < nk) {      /* wave-uniform: stay on the last tile instead of running past K */ \
       soffB += 128;                                                            \
       ci0 += 64;                                                               \
@@ -89,12 +92,13 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
     }                                                                          \
     ++kt_next;                                                                 \
   }
-#define STORE_A(i) if (i < A_CH) *(uint4*)(sa_ + swz128(crow + 32 * i, cchunk)) = ra##i;
-#define STORE_B(i) if (i < B_CH) *(uint4*)(sa_ + A_BYTES + swz128(crow + 32 * i, cchunk)) = rb##i;
-#define STORE_TILE(buf_)                                                       \
+#define STORE_A(i, S) if (i < A_CH) *(uint4*)(sa_ + swz128(crow + 32 * i, cchunk)) = ra##i##_##S;
+#define STORE_B(i, S) if (i < B_CH) *(uint4*)(sa_ + A_BYTES + swz128(crow + 32 * i, cchunk)) = rb##i##_##S;
+#define STORE_TILE(buf_, S)                                                    \
   {                                                                            \
     char* sa_ = smem + (buf_) * STAGE;                                         \
-    A2V_REP4(STORE_A) A2V_REP48(STORE_A) A2V_REP4(STORE_B)                     \
+    STORE_A(0, S) STORE_A(1, S) STORE_A(2, S) STORE_A(3, S) STORE_A(4, S) STORE_A(5, S) STORE_A(6, S) STORE_A(7, S) \
+    STORE_B(0, S) STORE_B(1, S) STORE_B(2, S) STORE_B(3, S)                    \
   }
 
   f32x4 acc[4][4];
@@ -105,36 +109,43 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
 
   const int nk = g.K / 64;
   int kt_next = 0;               // index of the tile the next LOAD_TILE() fetches
-  LOAD_TILE();
-  STORE_TILE(0);
-  __syncthreads();
-
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    LOAD_TILE();                 // tile kt+1 (the last iteration re-reads tile nk-1; never consumed)
-    // keep the global loads ahead of the MFMA block: hipcc otherwise sinks them next to the ds_write
-    // that consumes them and the HBM/L2 latency is no longer hidden behind the matrix work
+#define COMPUTE(buf_)                                                                                   \
+  {                                                                                                     \
+    const char* sa_ = smem + (buf_) * STAGE;                                                            \
+    const char* sb_ = sa_ + A_BYTES;                                                                    \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                  \
+      bf16x8 fa[4], fb[4];                                                                              \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+          fa[i] = *(const bf16x8*)(sa_ + swz128(wm * 64 + i * 16 + fr, ks * 4 + fq));                   \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+          fb[j] = *(const bf16x8*)(sb_ + swz128(wn * 64 + j * 16 + fr, ks * 4 + fq));                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);        \
+    }                                                                                                   \
+  }
+  // Two register sets: the loads of tile kt+2 are issued before tile kt is computed and are only written to
+  // LDS at the end of iteration kt+1, so a global load has ~2 K-tiles of matrix work to land
+  // (one K-tile was not enough: SQ_WAIT_ANY was 27 % of wave time with a single set).
+  LOAD_TILE(0);                  // tile 0
+  STORE_TILE(0, 0);
+  LOAD_TILE(1);                  // tile 1
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt += 2) {
+    LOAD_TILE(0);                // tile kt+2 (clamped to the last tile at the tail; never consumed there)
     __builtin_amdgcn_sched_barrier(0);
-    const char* sa_ = smem + buf * STAGE;
-    const char* sb_ = sa_ + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(sa_ + swz128(wm * 64 + i * 16 + fr, ks * 4 + fq));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb_ + swz128(wn * 64 + j * 16 + fr, ks * 4 + fq));
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
+    COMPUTE(0);
+    STORE_TILE(1, 1);            // tile kt+1
+    __syncthreads();
+    if (kt + 1 >= nk) break;
+    LOAD_TILE(1);                // tile kt+3
     __builtin_amdgcn_sched_barrier(0);
-    STORE_TILE(buf ^ 1);
+    COMPUTE(1);
+    STORE_TILE(0, 0);            // tile kt+2
     __syncthreads();
   }
+#undef COMPUTE
 #undef LOAD_TILE
 #undef STORE_TILE
 #undef LOAD_A
@@ -159,6 +170,182 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
   wave_epilogue<bf16>(g, stage, lane, m0 + wm * 64, n0 + wn * 64, grp);
 }
 
+// =============================================================================================
+//   bf16 NT with direct-to-LDS staging (global_load_lds_dwordx4): no VGPR round trip, no ds_write.
+//   Measured on the register-staged kernel: the VGPR->LDS store path (ds_write_b128 = 13 cycles per KiB per
+//   wave-instruction, ~79 B/clk/CU) plus fragment reads kept the LDS pipe busier than the MFMA pipe
+//   (MFMA busy 39 %).  LDS-DMA writes a wave-instruction's 1 KiB (8 rows x 128 B) linearly, so the XOR
+//   swizzle of the 16-B chunks is applied to the per-lane SOURCE address instead (same involution as
+//   the ds_read side).  Conv / masked A operands (per-row predicates) keep the register path; weights
+//   always go through LDS-DMA.
+// =============================================================================================
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_cvoid_t;
+__device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
+}
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256) void gemm_nt_bf16_glds_kernel(GemmArgs g) {
+  constexpr int WN = BN / 64, WM = 4 / WN;
+  static_assert(BM == 64 * WM, "wave tile is 64x64");
+  constexpr int A_CH = BM / 32;                         // register path: chunks per thread
+  constexpr int A_SL = BM / 32, B_SL = BN / 32;         // LDS-DMA path: 8-row slabs per wave
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid / WN, wn = wid % WN;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  const int tiles_m = (g.M + BM - 1) / BM;
+  const int id = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+  int tm, tn;
+  tile_coords(id, tiles_m, tiles_n, tm, tn);
+  const int grp = blockIdx.y;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int crow = tid >> 3, cchunk = tid & 7;
+  const ConvA& a = g.a;
+  const char* const safe = (const char*)a.ptr;
+  const int lr = lane >> 3;                             // row inside an 8-row slab
+  // source chunk of LDS chunk position (lane & 7) in row r = slab*8 + lr:  c = pos ^ ((r >> 1) & 7)
+#define SRC_CHUNK(slab) (((lane & 7) ^ ((((slab) & 1) << 2) + (lane >> 4))) & 7)
+
+#define A2V_REP4(X) X(0) X(1) X(2) X(3)
+#define A2V_REP48(X) X(4) X(5) X(6) X(7)
+#define DECL_A(i) const char* pa##i = safe; int ta##i = 0; const unsigned char* ma##i = nullptr; uint4 ra##i = {0u, 0u, 0u, 0u};
+#define DECL_B(i) const char* pb##i = safe;
+  A2V_REP4(DECL_A) A2V_REP48(DECL_A) A2V_REP4(DECL_B)
+#define INIT_A(i)                                                                                             \
+  if (i < (CONV ? A_CH : A_SL)) {                                                                             \
+    const int slab = wid + 4 * i;                                                                             \
+    int m = CONV ? m0 + crow + 32 * i : m0 + slab * 8 + lr;                                                   \
+    m = m < g.M ? m : g.M - 1;                                                                                \
+    const int b = m / a.T_out, t = m - b * a.T_out;                                                           \
+    ta##i = t * a.stride - a.pad;                                                                             \
+    const int ch = CONV ? cchunk : SRC_CHUNK(slab);                                                           \
+    pa##i = (const char*)a.ptr + ((long long)(b / a.bdiv) * a.bstride + (long long)grp * a.goff + ch * 8 +    \
+                                  (long long)ta##i * a.pitch) * 2;                                            \
+    ma##i = a.rowmask ? a.rowmask + (long long)b * a.T_in : nullptr;                                          \
+  }
+#define INIT_B(i)                                                                                             \
+  if (i < B_SL) {                                                                                             \
+    const int slab = wid + 4 * i;                                                                             \
+    int n = n0 + slab * 8 + lr;                                                                               \
+    n = n < g.N ? n : g.N - 1;                                                                                \
+    pb##i = (const char*)g.B + ((long long)grp * g.b_gstride + (long long)n * g.ldb + SRC_CHUNK(slab) * 8) * 2; \
+  }
+  A2V_REP4(INIT_A) A2V_REP48(INIT_A) A2V_REP4(INIT_B)
+  long long soffA = 0, soffB = 0;
+  int tap = 0, ci0 = 0;
+  const long long tap_step = (a.pitch - (a.Cg - 64)) * 2;
+
+#define LOAD_A(i)                                                              \
+  if (i < (CONV ? A_CH : A_SL)) {                                              \
+    if constexpr (CONV) {                                                      \
+      const int row = ta##i + tap;                                             \
+      bool ok = (unsigned)row < (unsigned)a.T_in && (ci0 + cchunk * 8 < a.Cv); \
+      if (a.rowmask) ok = ok && (ma##i[ok ? row : 0] == 0);                    \
+      const char* p = ok ? pa##i + soffA : safe;                               \
+      ra##i = sel4(ok, *(const uint4*)p);                                      \
+    } else {                                                                   \
+      glds16(pa##i + soffA, sdst_ + (wid + 4 * i) * 1024);                     \
+    }                                                                          \
+  }
+#define LOAD_B(i) if (i < B_SL) glds16(pb##i + soffB, sdst_ + A_BYTES + (wid + 4 * i) * 1024);
+#define LOAD_TILE(buf_)                                                        \
+  {                                                                            \
+    char* sdst_ = smem + (buf_) * STAGE;                                       \
+    A2V_REP4(LOAD_B) A2V_REP4(LOAD_A) A2V_REP48(LOAD_A)                        \
+    if (kt_next + 1 < nk) {                                                    \
+      soffB += 128;                                                            \
+      ci0 += 64;                                                               \
+      if (ci0 == a.Cg) { ci0 = 0; ++tap; soffA += tap_step; } else { soffA += 128; } \
+    }                                                                          \
+    ++kt_next;                                                                 \
+  }
+#define STORE_A(i) if (i < A_CH) *(uint4*)(sa_ + swz128(crow + 32 * i, cchunk)) = ra##i;
+#define STORE_TILE(buf_)                                                       \
+  if constexpr (CONV) {                                                        \
+    char* sa_ = smem + (buf_) * STAGE;                                         \
+    A2V_REP4(STORE_A) A2V_REP48(STORE_A)                                       \
+  }
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = g.K / 64;
+  int kt_next = 0;
+  LOAD_TILE(0);
+  STORE_TILE(0);
+  __syncthreads();               // also drains the LDS-DMA (vmcnt(0))
+
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    LOAD_TILE(buf ^ 1);          // tile kt+1 straight into the other stage (the tail re-fetches tile nk-1)
+    if constexpr (CONV) __builtin_amdgcn_sched_barrier(0);
+    const char* sa_ = smem + buf * STAGE;
+    const char* sb_ = sa_ + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4], fb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = *(const bf16x8*)(sa_ + swz128(wm * 64 + i * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb_ + swz128(wn * 64 + j * 16 + fr, ks * 4 + fq));
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    STORE_TILE(buf ^ 1);
+    __syncthreads();
+  }
+#undef LOAD_TILE
+#undef STORE_TILE
+#undef LOAD_A
+#undef LOAD_B
+#undef STORE_A
+#undef INIT_A
+#undef INIT_B
+#undef DECL_A
+#undef DECL_B
+#undef SRC_CHUNK
+
+  // epilogue through a per-wave LDS stage (A/B test: a register epilogue with swapped MFMA operands and 8-B
+  // stores was 3-12 % slower -- 32-B store segments and +100 VGPRs)
+  float* stage = (float*)smem + wid * (64 * 68);
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stage[(i * 16 + fq * 4 + r) * 68 + j * 16 + fr] = acc[i][j][r];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  wave_epilogue<bf16>(g, stage, lane, m0 + wm * 64, n0 + wn * 64, grp);
+}
+
+int g_a2v_gemm_variant = 1;      // 0: register-staged kernel, 1: LDS-DMA kernel (a2v_debug_set(0, v))
+
+template <int BM, int BN, bool CONV>
+static void launch_nt_glds(const GemmArgs& g, hipStream_t stream) {
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LDS = 2 * STAGE > NT_LDS_BYTES ? 2 * STAGE : NT_LDS_BYTES;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_glds_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    attr = true;
+  }
+  dim3 grid(cdiv(g.M, BM) * cdiv(g.N, BN), g.G, 1);
+  hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<BM, BN, CONV>), grid, dim3(256), LDS, stream, g);
+}
+
 template <int BM, int BN, bool CONV>
 static void launch_nt(const GemmArgs& g, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * 128;
@@ -176,6 +363,14 @@ bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream) {
   if (g.a.Cg % 64 != 0 || g.K % 64 != 0) return false;
   const bool conv = g.a.taps > 1 || g.a.pad != 0 || g.a.rowmask != nullptr || g.a.stride != 1 || g.a.T_in != g.a.T_out ||
                     g.a.Cv != g.a.Cg;
+  if (g_a2v_gemm_variant == 1) {
+    if (g.N <= 64) {
+      if (conv) launch_nt_glds<256, 64, true>(g, stream); else launch_nt_glds<256, 64, false>(g, stream);
+    } else {
+      if (conv) launch_nt_glds<128, 128, true>(g, stream); else launch_nt_glds<128, 128, false>(g, stream);
+    }
+    return true;
+  }
   if (g.N <= 64) {
     if (conv) launch_nt<256, 64, true>(g, stream); else launch_nt<256, 64, false>(g, stream);
   } else {
@@ -194,13 +389,16 @@ template <int ROWB> __device__ __forceinline__ int tr_off(int r, int col) {   //
   return r * ROWB + ((blk ^ f) << 5) + ((col & 15) << 1);
 }
 
-template <int TNN, int TNK>
+template <int TNN, int TNK>   // (128,128) or (64,128): 4 waves as 2(n) x 2(kk), wave tile (TNN/2) x 64
 __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
   constexpr int PCH = TNN / 8, QCH = TNK / 8;          // 16-B chunks per tile row
   constexpr int NP = PCH / 4, NQ = QCH / 4;            // staged rows per thread
   constexpr int PROWS = 256 / PCH, QROWS = 256 / QCH;  // rows covered per pass
   constexpr int P_BYTES = 64 * TNN * 2, Q_BYTES = 64 * TNK * 2, STAGE = P_BYTES + Q_BYTES;
-  constexpr int WK = TNK / 64;                         // waves along kk
+  constexpr int WK = 2;                                // waves along kk
+  constexpr int WNN = TNN / 2;                         // n extent per wave
+  constexpr int TI = WNN / 16;                         // 16-wide n tiles per wave
+  static_assert(TNK == 128, "kk tile is 128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WK, wn = wid % WK;
@@ -285,9 +483,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
         *(uint4*)(sq_ + tr_off<TNK * 2>(qrow + QROWS * i, qchunk * 8)) = rq[i];                       \
   }
 
-  f32x4 acc[4][4];
+  f32x4 acc[TI][4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -306,12 +504,12 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
     const char* sq_ = sp_ + P_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 fa[4], fb[4];
+      bf16x8 fa[TI], fb[4];
       const int r_lo = ks * 32 + 8 * gq + q;
       const int r_hi = r_lo + 4;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int col = wm * 64 + i * 16 + 4 * p;
+      for (int i = 0; i < TI; ++i) {
+        const int col = wm * WNN + i * 16 + 4 * p;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tr_off<TNN * 2>(r_lo, col)));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sp_ + tr_off<TNN * 2>(r_hi, col)));
         union { struct { s16x4 a, b; } s; bf16x8 v; } u;
@@ -328,7 +526,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
         fb[j] = u.v;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
@@ -342,10 +540,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g) {
 #undef TN_SETUP_ROW
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < TI; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int n = n0 + wm * 64 + i * 16 + fq * 4 + r;
+      const int n = n0 + wm * WNN + i * 16 + fq * 4 + r;
       if (n >= g.N) continue;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -368,11 +566,11 @@ static void launch_tn(const WgradArgs& g, int splits, hipStream_t stream) {
 }
 
 // returns the number of (n, kk) tiles per group so that the caller can size the M split
-int a2v_tn_bf16_tiles(int N, int K) { return N <= 64 ? cdiv(N, 64) * cdiv(K, 256) : cdiv(N, 128) * cdiv(K, 128); }
+int a2v_tn_bf16_tiles(int N, int K) { return N <= 64 ? cdiv(N, 64) * cdiv(K, 128) : cdiv(N, 128) * cdiv(K, 128); }
 
 bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream) {
   if (g.N <= 64)
-    launch_tn<64, 256>(g, splits, stream);
+    launch_tn<64, 128>(g, splits, stream);
   else
     launch_tn<128, 128>(g, splits, stream);
   return true;

@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the implicit-GEMM kernels on the shapes of the large model (one GPU).
+   python tools/gemm_bench.py [--reps 20]
+Each line: shape, epilogue, median microseconds, TFLOP/s.  Random (gaussian) operands, bf16."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from animal2vec_amd import ops  # noqa: E402
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--only", default="")
+    ap.add_argument("--variant", type=int, default=None)
+    a = ap.parse_args()
+    if a.variant is not None:
+        from animal2vec_amd import _lib
+        _lib.load().a2v_debug_set(0, a.variant)
+        print("variant", a.variant)
+    dev, dt = "cuda", torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g, dtype=torch.float32).to(dt)
+    rows = []
+
+    def lin(name, M, N, K, **kw):
+        if a.only and a.only not in name:
+            return
+        x, w = rn(M, K), rn(N, K) * K ** -0.5
+        bias = torch.randn(N, device=dev)
+        extra = {}
+        if kw.get("res"):
+            extra["res"] = rn(M, N)
+        if kw.get("gelu"):
+            extra["gelu"] = True
+        if kw.get("pre"):
+            extra["pre_out"] = torch.empty(M, N, device=dev, dtype=dt)
+        if kw.get("gelu_bwd"):
+            extra["gelu_bwd_aux"] = rn(M, N)
+        if kw.get("colsum"):
+            extra["colsum"] = torch.zeros(N, device=dev)
+        if kw.get("drop"):
+            extra["drop"] = (0.1, 123)
+        out = torch.empty(M, N, device=dev, dtype=dt)
+        ms = timeit(lambda: ops.linear(x, w, bias if not kw.get("gelu_bwd") else None, out=out, **extra), a.reps)
+        rows.append((name, M, N, K, 1, ms, 2.0 * M * N * K / ms / 1e9))
+
+    def wgrad(name, M, N, K):
+        if a.only and a.only not in name:
+            return
+        x, dy = rn(M, K), rn(M, N)
+        gw = torch.zeros(N, K, device=dev)
+        ms = timeit(lambda: ops.linear_wgrad(x, dy, gw), a.reps)
+        rows.append((name, M, N, K, 1, ms, 2.0 * M * N * K / ms / 1e9))
+
+    def conv(name, B, T, D, G, k, wg=False):
+        if a.only and a.only not in name:
+            return
+        Cg = D // G
+        x = rn(B, T, D)
+        if wg:
+            dy = rn(B, T, D)
+            gw = torch.zeros(G, Cg, k * Cg, device=dev)
+            ms = timeit(lambda: ops.conv1d_cl_wgrad(x, dy, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T), a.reps)
+        else:
+            w = rn(G, Cg, k * Cg) * (k * Cg) ** -0.5
+            bias = torch.randn(D, device=dev)
+            out = torch.empty(B, T, D, device=dev, dtype=dt)
+            ms = timeit(lambda: ops.conv1d_cl(x, w, bias, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, out=out), a.reps)
+        rows.append((name, B * T, Cg, k * Cg, G, ms, 2.0 * B * T * Cg * k * Cg * G / ms / 1e9))
+
+    lin("qkv bias", 13440, 3072, 1024)
+    lin("fc1 bias", 13440, 4096, 1024)
+    lin("fc1 bias+gelu", 13440, 4096, 1024, gelu=True)
+    lin("fc1 bias+gelu+pre", 13440, 4096, 1024, gelu=True, pre=True)
+    lin("fc2dgrad gelu_bwd+colsum", 13440, 4096, 1024, gelu_bwd=True, colsum=True)
+    lin("fc2 bias+res", 13440, 1024, 4096, res=True)
+    lin("fc2 bias+res+drop", 13440, 1024, 4096, res=True, drop=True)
+    lin("proj bias+res+drop", 13440, 1024, 1024, res=True, drop=True)
+    lin("teacher fc2", 16000, 1024, 4096)
+    lin("big 8192^3", 8192, 8192, 8192)
+    wgrad("wgrad fc1", 13440, 4096, 1024)
+    wgrad("wgrad fc2", 13440, 1024, 4096)
+    wgrad("wgrad proj", 13440, 1024, 1024)
+    conv("posconv fwd", 96, 2000, 1024, 16, 19)
+    conv("posconv wgrad", 96, 2000, 1024, 16, 19, wg=True)
+    for r in rows:
+        print(f"{r[0]:28s} M={r[1]:7d} N={r[2]:5d} K={r[3]:5d} G={r[4]:3d}  {1e3 * r[5]:9.1f} us  {r[6]:8.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
