@@ -7,7 +7,9 @@
 #define LN_MAXCHUNK 4     // C <= 4*512 = 2048
 #define LN_ROWS_PER_WAVE 8
 
-template <typename T, int NCH>
+// R rows per wave are kept in flight together: short tensors (a transformer block's 13-16 k rows) are latency
+// bound with one row per wave (60 us -> 25 us with R = 2); long ones prefer R = 1 (occupancy).
+template <typename T, int NCH, int R>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
@@ -16,68 +18,102 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
                                                             long long M, int C, long long ldx, long long ldy, float eps,
                                                             int act, Drop drop) {
   const int lane = threadIdx.x & 63;
-  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  float v[NCH][8];
-  float s = 0.f;
+  const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+  if (row0 >= M) return;
+  float v[R][NCH][8];
+  // issue every load of all R rows first
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 64 + lane) * 8;
-    if (col < C) {
-      Vec8<T>::load(x + row * ldx + col, v[c]);
-      if (res) {
-        float r[8];
-        Vec8<T>::load(res + row * ldx + col, r);
+  for (int r = 0; r < R; ++r) {
+    const long long row = row0 + r < M ? row0 + r : M - 1;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[c][i] += r[i];
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < C) {
+        Vec8<T>::load(x + row * ldx + col, v[r][c]);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[r][c][i] = 0.f;
       }
-      if (sum_out) Vec8<T>::store(sum_out + row * ldx + col, v[c]);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += v[c][i];
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[c][i] = 0.f;
     }
   }
-  const float mean = wave_sum(s) / (float)C;
-  float q = 0.f;
+  if (res) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 64 + lane) * 8;
-    if (col < C) {
+    for (int r = 0; r < R; ++r) {
+      const long long row = row0 + r < M ? row0 + r : M - 1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const float d = v[c][i] - mean; q += d * d; }
+      for (int c = 0; c < NCH; ++c) {
+        const int col = (c * 64 + lane) * 8;
+        if (col < C) {
+          float q[8];
+          Vec8<T>::load(res + row * ldx + col, q);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[r][c][i] += q[i];
+        }
+      }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-  if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+  float gm[NCH][8], bt[NCH][8];
+  if (gamma) {
 #pragma unroll
-  for (int c = 0; c < NCH; ++c) {
-    const int col = (c * 64 + lane) * 8;
-    if (col < C) {
-      float o[8];
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < C) { Vec8<float>::load(gamma + col, gm[c]); Vec8<float>::load(beta + col, bt[c]); }
+    }
+  }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        float t = (v[c][i] - mean) * rstd;
-        if (gamma) t = t * gamma[col + i] + beta[col + i];
-        if (act == 1) t = gelu_f(t);
-        if (drop.thresh) t = drop_apply(drop, (unsigned long long)row * C + col + i, t);
-        o[i] = t;
+  for (int r = 0; r < R; ++r) {
+    const long long row = row0 + r;
+    if (row >= M) break;
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < C) {
+        if (sum_out) Vec8<T>::store(sum_out + row * ldx + col, v[r][c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += v[r][c][i];
       }
-      if (post) {
-        float r[8];
-        Vec8<T>::load(post + row * ldy + col, r);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] += r[i];
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < C) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = v[r][c][i] - mean; q += d * d; }
       }
-      Vec8<T>::store(y + row * ldy + col, o);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+    if (lane == 0 && mean_out) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int col = (c * 64 + lane) * 8;
+      if (col < C) {
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t = (v[r][c][i] - mean) * rstd;
+          if (gamma) t = t * gm[c][i] + bt[c][i];
+          if (act == 1) t = gelu_f(t);
+          if (drop.thresh) t = drop_apply(drop, (unsigned long long)row * C + col + i, t);
+          o[i] = t;
+        }
+        if (post) {
+          float pr[8];
+          Vec8<T>::load(post + row * ldy + col, pr);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o[i] += pr[i];
+        }
+        Vec8<T>::store(y + row * ldy + col, o);
+      }
     }
   }
 }
 
 // Backward of y = act(LN(x)*gamma+beta).  dx; dgamma/dbeta and (optionally) column sums of dx are
 // accumulated with one atomic per column per workgroup (each lane owns fixed columns).
-template <typename T, int NCH>
+template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
@@ -87,6 +123,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             float* __restrict__ dbeta, float* __restrict__ dxsum,
                                                             long long M, int C, long long ldx, long long lddy,
                                                             int act, Drop drop, int drop_mode, T* __restrict__ dx_drop) {
+  constexpr int rows_per_wave = RPW;
   // drop_mode 1: the forward applied dropout AFTER this LN (y = drop(act(LN x))): mask the incoming dy.
   // drop_mode 2: also emit dx_drop = dropout-masked dx (gradient of a branch x -> drop(f(x)) summed into this
   //              LN's input); dxsum then sums dx_drop (the branch's bias gradient).
@@ -98,8 +135,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
     for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; as_[c][i] = 0.f; }
 
-  const long long row0 = ((long long)blockIdx.x * 4 + wid) * LN_ROWS_PER_WAVE;
-  for (int rr = 0; rr < LN_ROWS_PER_WAVE; ++rr) {
+  const long long row0 = ((long long)blockIdx.x * 4 + wid) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
     const long long row = row0 + rr;
     if (row >= M) break;
     const float mean = mean_in[row], rstd = rstd_in[row];
@@ -112,13 +149,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         float xv[8], dv[8];
         Vec8<T>::load(x + row * ldx + col, xv);
         Vec8<T>::load(dy + row * lddy + col, dv);
+        float gm8[8], bt8[8];
+        if (NCH == 1 && gamma) { Vec8<float>::load(gamma + col, gm8); Vec8<float>::load(beta + col, bt8); }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float h = (xv[i] - mean) * rstd;
-          const float ga = gamma ? gamma[col + i] : 1.f;
+          const float ga = gamma ? (NCH == 1 ? gm8[i] : gamma[col + i]) : 1.f;   // wider rows: keep VGPRs low
           float d = dv[i];
           if (drop_mode == 1) d = drop_apply(drop, (unsigned long long)row * C + col + i, d);
-          if (act == 1) d *= gelu_grad_f(gamma ? h * ga + beta[col + i] : h);
+          if (act == 1) d *= gelu_grad_f(gamma ? h * ga + (NCH == 1 ? bt8[i] : beta[col + i]) : h);
           ag[c][i] += d * h;
           ab[c][i] += d;
           const float dg = d * ga;
@@ -264,10 +303,15 @@ static int ln_fwd_launch(const void* x, const void* res, const float* gamma, con
                          float* mean, float* rstd, const void* post, long long M, int C, long long ldx, long long ldy, float eps, int act,
                          Drop drop, hipStream_t st) {
   const int nch = (C + 511) / 512;
-  dim3 grid((unsigned)((M + 3) / 4)), blk(256);
-#define LN_F(N)                                                                                                      \
-  hipLaunchKernelGGL((layernorm_fwd_kernel<T, N>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
-                     (T*)sum_out, mean, rstd, (const T*)post, M, C, ldx, ldy, eps, act, drop)
+  const bool two = M <= 65536;
+  dim3 grid((unsigned)((M + (two ? 8 : 4) - 1) / (two ? 8 : 4))), blk(256);
+#define LN_F(N)                                                                                                        \
+  if (two)                                                                                                             \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, N, 2>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
+                       (T*)sum_out, mean, rstd, (const T*)post, M, C, ldx, ldy, eps, act, drop);                       \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T, N, 1>), grid, blk, 0, st, (const T*)x, (const T*)res, gamma, beta, (T*)y, \
+                       (T*)sum_out, mean, rstd, (const T*)post, M, C, ldx, ldy, eps, act, drop)
   switch (nch) {
     case 1: LN_F(1); break;
     case 2: LN_F(2); break;
@@ -299,9 +343,14 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
                          long long M, int C, long long ldx, long long lddy, int act, Drop drop, int drop_mode,
                          void* dx_drop, hipStream_t st) {
   const int nch = (C + 511) / 512;
-  dim3 grid((unsigned)((M + 4 * LN_ROWS_PER_WAVE - 1) / (4 * LN_ROWS_PER_WAVE))), blk(256);
+  const int rpw = LN_ROWS_PER_WAVE;     // 4 was measured slower for short tensors (dgamma atomics dominate)
+  dim3 grid((unsigned)((M + 4 * rpw - 1) / (4 * rpw))), blk(256);
 #define LN_B(N)                                                                                                  \
-  hipLaunchKernelGGL((layernorm_bwd_kernel<T, N>), grid, blk, 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, \
+  if (rpw == 4)                                                                                                  \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, 4>), grid, blk, 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, \
+                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, (T*)dx_drop); \
+  else                                                                                                           \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, LN_ROWS_PER_WAVE>), grid, blk, 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, \
                      rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, (T*)dx_drop)
   switch (nch) {
     case 1: LN_B(1); break;

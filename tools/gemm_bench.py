@@ -104,6 +104,29 @@ def main():
     wgrad("wgrad proj", 13440, 1024, 1024)
     conv("posconv fwd", 96, 2000, 1024, 16, 19)
     conv("posconv wgrad", 96, 2000, 1024, 16, 19, wg=True)
+    def ln(name, M, C, res=False, act=0, affine=True):
+        if a.only and a.only not in name:
+            return
+        x = rn(M, C)
+        r_ = rn(M, C) if res else None
+        g_ = torch.ones(C, device=dev) if affine else None
+        b_ = torch.zeros(C, device=dev) if affine else None
+        out = torch.empty_like(x)
+        ms = timeit(lambda: ops.layernorm_fwd(x, g_, b_, 1e-5, res=r_, act=act, out=out), a.reps)
+        byt = M * C * 2 * (3 if res else 2)
+        print(f"{name:28s} M={M:7d} C={C:5d}  {1e3 * ms:9.1f} us  {byt / ms / 1e6:8.1f} GB/s")
+        _, mean, rstd = ops.layernorm_fwd(x, g_, b_, 1e-5, res=r_, act=act)
+        dy = rn(M, C)
+        dg = torch.zeros(C, device=dev) if affine else None
+        db = torch.zeros(C, device=dev) if affine else None
+        dxo = torch.empty_like(x)
+        ms = timeit(lambda: ops.layernorm_bwd(dy, x, g_, b_, mean, rstd, act=act, dgamma=dg, dbeta=db, out=dxo), a.reps)
+        print(f"{name + ' bwd':28s} M={M:7d} C={C:5d}  {1e3 * ms:9.1f} us  {M * C * 2 * 3 / ms / 1e6:8.1f} GB/s")
+
+    ln("ln block", 13440, 1024)
+    ln("ln teacher res", 16000, 1024, res=True)
+    ln("ln posconv gelu", 192000, 1024, act=1, affine=False)
+    ln("ln conv512 gelu", 128000, 512, act=1)
     for r in rows:
         print(f"{r[0]:28s} M={r[1]:7d} N={r[2]:5d} K={r[3]:5d} G={r[4]:3d}  {1e3 * r[5]:9.1f} us  {r[6]:8.1f} TFLOP/s")
 
