@@ -263,8 +263,12 @@ struct AttnBwdArgs {
   Drop drop;
 };
 
-template <typename T, int HD>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
+// NT = 0: one workgroup per 64-key block, dQ summed across key blocks with fp32 atomics into dq32 (any S).
+// NT > 0: S <= 64*NT; one workgroup per (n, h) walks every key block, dQ of all NT query tiles stays in
+//         registers and is stored once into the q slot of dqkv: no atomics, no dq32 zero-fill, no cast pass
+//         (the student's 140-token sequences: 324 us -> see DESIGN.md).
+template <typename T, int HD, int NT>
+__global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdArgs a) {
   constexpr bool BF = std::is_same<T, bf16>::value;
   constexpr int ND = HD / 16;
   constexpr int TILE_BYTES = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
@@ -283,7 +287,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int kv0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int h = blockIdx.y, n = blockIdx.z;
   const int S = a.S, H = a.H;
   const long long rowstride = 3LL * H * HD;
   const long long orow = (long long)H * HD;
@@ -293,6 +297,18 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   const float asc = a.alibi_scale[h];
   const float coef = -slope * fmaxf(asc, 0.f);
 
+  static_assert(NT == 0 || NT == 3, "whole-sequence mode keeps exactly three dQ tiles");
+  // dQ of the three query tiles: separately named so that the (rolled) query loop selects them with v_cndmask
+  // instead of dynamic indexing (scratch) or a 3x unroll (370 VGPRs)
+  f32x4 dq0[ND], dq1[ND], dq2[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) { dq0[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq1[i] = dq0[i]; dq2[i] = dq0[i]; }
+  float dal = 0.f;
+  const int ntile = (S + 63) / 64;
+  const int nkb = NT > 0 ? ntile : 1;
+  for (int kb = 0; kb < nkb; ++kb) {
+  const int kv0 = (NT > 0 ? kb : (int)blockIdx.x) * 64;
+  if (NT > 0 && kb > 0) __syncthreads();   // the previous key block's dQ product has finished with sKt / sDS
   const int kv = kv0 + wid * 16 + fr;            // this lane's key column
   const int kvc = kv < S ? kv : S - 1;
   const bool kv_ok = kv < S;
@@ -336,9 +352,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
   f32x4 dk[ND], dv[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-  float dal = 0.f;
 
-  const int ntile = (S + 63) / 64;
+#pragma unroll 1
   for (int qt = 0; qt < ntile; ++qt) {
     const int q0 = qt * 64;
     __syncthreads();
@@ -478,7 +493,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
     // ---- dQ[q rows 16*wid..][d] += dS K * scale : A = dS rows, B = K (k = kv, col = d)
     f32x4 dq[ND];
 #pragma unroll
-    for (int i = 0; i < ND; ++i) dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < ND; ++i) {
+      dq[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (NT > 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq[i][r] = qt == 0 ? dq0[i][r] : (qt == 1 ? dq1[i][r] : dq2[i][r]);
+      }
+    }
     if constexpr (BF) {
       const int qq = (lane & 15) >> 2, pp = lane & 3;
 #pragma unroll
@@ -505,13 +526,24 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
       }
     }
     // D: row q = q0 + 16*wid + 4g + r, col d = 16i + fr
+    if constexpr (NT > 0) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq2 = q0 + wid * 16 + 4 * g + r;
-      if (qq2 < S) {
-        float* dst = a.dq32 + (((long long)n * S + qq2) * H + h) * HD;
+      for (int i = 0; i < ND; ++i)
 #pragma unroll
-        for (int i = 0; i < ND; ++i) atomicAdd(dst + 16 * i + fr, dq[i][r] * a.scale);
+        for (int r = 0; r < 4; ++r) {
+          dq0[i][r] = qt == 0 ? dq[i][r] : dq0[i][r];
+          dq1[i][r] = qt == 1 ? dq[i][r] : dq1[i][r];
+          dq2[i][r] = qt == 2 ? dq[i][r] : dq2[i][r];
+        }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq2 = q0 + wid * 16 + 4 * g + r;
+        if (qq2 < S) {
+          float* dst = a.dq32 + (((long long)n * S + qq2) * H + h) * HD;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) atomicAdd(dst + 16 * i + fr, dq[i][r] * a.scale);
+        }
       }
     }
   }
@@ -524,6 +556,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdArgs a) {
       Vec4<T>::store(dkv + (long long)H * HD + 16 * i + 4 * g, kk);
       Vec4<T>::store(dkv + 2LL * H * HD + 16 * i + 4 * g, dv[i]);
     }
+  }
+  }   // key blocks
+  if constexpr (NT > 0) {   // dQ straight into the q slot of dqkv
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq2 = t * 64 + wid * 16 + 4 * g + r;
+        if (qq2 < S) {
+          T* dst = (T*)a.dqkv + ((long long)n * S + qq2) * rowstride + (long long)h * HD;
+#pragma unroll
+          for (int i = 0; i < ND; ++i) dst[16 * i + fr] = (T)((t == 0 ? dq0[i][r] : (t == 1 ? dq1[i][r] : dq2[i][r])) * a.scale);
+        }
+      }
   }
   // ---- d alibi_scale_h = slope_h * [scale_h >= 0] * sum dS * (-dist)
   dal = wave_sum(dal);
@@ -558,20 +604,33 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
   return A2V_ERR_DTYPE;
 }
 
+#define A2V_ATTN_SEQ_TILES 3      // sequences up to 192 tokens take the atomic-free whole-sequence backward (bf16)
+
 template <typename T, int HD>
 static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, hipStream_t st) {
   const long long total = (long long)a.N * a.S * a.H;
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3(g), dim3(256), 0, st, (const T*)out, (const T*)a.d_out, delta, a.N, a.S, a.H);
-  dim3 grid((a.S + 63) / 64, a.H, a.N);
   constexpr bool BF = std::is_same<T, bf16>::value;
   constexpr int TILE = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
   constexpr int LDS = (BF ? 5 : 3) * TILE + (BF ? 64 * 64 * 2 : 64 * 68 * 4) + 3 * 64 * 4;
-  (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-  hipLaunchKernelGGL((attn_bwd_kernel<T, HD>), grid, dim3(256), LDS, st, a);
+  if (BF && a.S <= 64 * A2V_ATTN_SEQ_TILES) {
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD, BF ? A2V_ATTN_SEQ_TILES : 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, BF ? A2V_ATTN_SEQ_TILES : 0>), dim3(1, a.H, a.N), dim3(256), LDS, st, a);
+  } else {
+    if (!a.dq32) return A2V_ERR_ARG;
+    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, 0>), dim3((a.S + 63) / 64, a.H, a.N), dim3(256), LDS, st, a);
+  }
   A2V_CHECK_LAUNCH();
   return A2V_OK;
+}
+
+// 1 when a2v_attention_bwd writes dQ directly into the q slot of dqkv for this (dtype, S) (dq32 unused, may be
+// NULL); 0 when dQ is left in dq32 (fp32, zeroed by the caller) and must be cast into dqkv afterwards.
+extern "C" int a2v_attention_bwd_direct_dq(int dtype, int S) {
+  return dtype == A2V_BF16 && S <= 64 * A2V_ATTN_SEQ_TILES ? 1 : 0;
 }
 
 // dq32 must be zero on entry; delta is (N,H,S) fp32 scratch.  dQ is left in dq32 (fp32, (N,S,H,HD));
@@ -580,7 +639,7 @@ extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, co
                                  float* delta, void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
                                  const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
                                  unsigned drop_seed, hipStream_t stream) {
-  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || !dq32 || drop_p < 0.f || drop_p >= 1.f)
+  if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || drop_p < 0.f || drop_p >= 1.f)
     return A2V_ERR_ARG;
   AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale,
                 make_drop(drop_p, drop_seed)};

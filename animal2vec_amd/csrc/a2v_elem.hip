@@ -150,13 +150,23 @@ __global__ __launch_bounds__(256) void d2v_loss_kernel(const T* __restrict__ x, 
       }
       if (dx) Vec8<T>::store(dx + row * D + col, o);
     }
-    if (col < D) {
+    // the 4 waves of the workgroup combine through LDS, then one double atomic per column and statistic
+    __shared__ float red[4][4][512];
+    __syncthreads();
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        atomicAdd(stats + col + j, (double)sx[j]);
-        atomicAdd(stats + D + col + j, (double)sxx[j]);
-        atomicAdd(stats + 2 * D + col + j, (double)sy[j]);
-        atomicAdd(stats + 3 * D + col + j, (double)syy[j]);
+    for (int j = 0; j < 8; ++j) {
+      red[wid][0][lane * 8 + j] = sx[j];
+      red[wid][1][lane * 8 + j] = sxx[j];
+      red[wid][2][lane * 8 + j] = sy[j];
+      red[wid][3][lane * 8 + j] = syy[j];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * 512; e += 256) {
+      const int which = e >> 9, cc = e & 511;
+      const int gc = c * 512 + cc;
+      if (gc < D) {
+        const float v = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
+        atomicAdd(stats + which * D + gc, (double)v);
       }
     }
     ls = wave_sum(ls);
@@ -356,9 +366,11 @@ extern "C" int a2v_decoder_input(int dtype, const void* x, const float* noise, c
 extern "C" int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsigned char* mask, void* dx, float* loss_rows,
                             double* stats, int N, int Tn, int D, int cb, float scale, float gscale, hipStream_t st) {
   if (N <= 0 || Tn <= 0 || D % 8 || cb <= 0 || !stats) return A2V_ERR_ARG;
-  const int rpw = 32;
   const long long rows = (long long)N * Tn;
-  const int g = (int)((rows + 4 * rpw - 1) / (4 * rpw));
+  // ~512 workgroups (2 waves per SIMD) stream the rows; statistics leave each workgroup as one double atomic per column
+  int rpw = (int)((rows + 2047) / 2048);
+  if (rpw < 8) rpw = 8;
+  const int g = (int)((rows + 4LL * rpw - 1) / (4LL * rpw));
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(d2v_loss_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, y, mask, (bf16*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw),
              hipLaunchKernelGGL(d2v_loss_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, y, mask, (float*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw));
@@ -460,4 +472,4 @@ extern "C" int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, 
   return A2V_OK;
 }
 
-extern "C" int a2v_abi_version(void) { return 2; }
+extern "C" int a2v_abi_version(void) { return 3; }

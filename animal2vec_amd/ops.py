@@ -163,13 +163,15 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, dro
     N, S, W = qkv.shape
     HD = W // (3 * H)
     dqkv = torch.empty_like(qkv)
-    dq32 = torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
+    direct = bool(_L().a2v_attention_bwd_direct_dq(dt(qkv), S))
+    dq32 = None if direct else torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
     delta = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
     rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(delta), ptr(dqkv), ptr(dq32),
                                 ptr(dalibi), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)),
                                 stream())
     check(rc, "a2v_attention_bwd")
-    cast2d(dq32, dqkv.view(N * S, W)[:, : H * HD])
+    if not direct:
+        cast2d(dq32, dqkv.view(N * S, W)[:, : H * HD])
     return dqkv
 
 

@@ -70,12 +70,16 @@ int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstr
 int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const int* pos, const float* slopes,
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
                       unsigned drop_seed, a2v_stream_t stream);
-/* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dq32 (N,S,H,HD) fp32 must be zero on entry and
- * receives dQ; dalibi (H) fp32 accumulates d loss / d alibi_scale. */
+/* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dalibi (H) fp32 accumulates d loss / d alibi_scale.
+ * dQ: when a2v_attention_bwd_direct_dq(dtype, S) is 1 (bf16, S <= 192: the student's kept-token sequences)
+ * the kernel owns a whole (n,h) sequence and writes dQ into the q slot of dqkv itself (dq32 may be NULL);
+ * otherwise dq32 (N,S,H,HD) fp32 must be zero on entry, receives dQ through atomics, and the caller casts it
+ * into dqkv (a2v_cast2d). */
 int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse, float* delta,
                       void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p, unsigned drop_seed,
                       a2v_stream_t stream);
+int a2v_attention_bwd_direct_dq(int dtype, int S);
 
 /* ---------------------------------------------------------------- normalisation
  * y = act( LN(x [+ res]) * gamma + beta ), act 0 none / 1 GELU; optional sum_out = x + res;

@@ -242,7 +242,7 @@ def attn_ref(qkv, pos, slopes, scale_h, H):
 
 
 @pytest.mark.parametrize("dtype,hd", [(torch.float32, 16), (torch.float32, 64), (torch.bfloat16, 64), (torch.bfloat16, 32)])
-@pytest.mark.parametrize("S", [37, 140, 200])
+@pytest.mark.parametrize("S", [37, 140, 192, 200])
 def test_attention_fwd_bwd(ops, dtype, hd, S):
     N, H = 3, 4
     qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=1).requires_grad_(True)

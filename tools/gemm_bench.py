@@ -104,6 +104,26 @@ def main():
     wgrad("wgrad proj", 13440, 1024, 1024)
     conv("posconv fwd", 96, 2000, 1024, 16, 19)
     conv("posconv wgrad", 96, 2000, 1024, 16, 19, wg=True)
+    def attn(name, N, S, H=16, HD=64, drop=None):
+        if a.only and a.only not in name:
+            return
+        qkv = rn(N, S, 3 * H * HD)
+        pos = torch.arange(S, device=dev, dtype=torch.int32).repeat(N, 1).contiguous()
+        slopes = torch.rand(H, device=dev)
+        asc = torch.ones(H, device=dev)
+        ms = timeit(lambda: ops.attention_fwd(qkv, pos, slopes, asc, H, drop=drop), a.reps)
+        fl = 4.0 * N * H * S * S * HD
+        rows.append((name + " fwd", N * S, HD, S, H, ms, fl / ms / 1e9))
+        out, lse = ops.attention_fwd(qkv, pos, slopes, asc, H, drop=drop)
+        do = rn(N, S, H * HD)
+        dal = torch.zeros(H, device=dev)
+        ms = timeit(lambda: ops.attention_bwd(qkv, out, do, lse, pos, slopes, asc, H, dal, drop=drop), a.reps)
+        rows.append((name + " bwd", N * S, HD, S, H, ms, 2.5 * fl / ms / 1e9))
+
+    attn("attn student", 96, 140, drop=(0.1, 7))
+    attn("attn student nodrop", 96, 140)
+    attn("attn teacher", 8, 2000)
+
     def ln(name, M, C, res=False, act=0, affine=True):
         if a.only and a.only not in name:
             return
