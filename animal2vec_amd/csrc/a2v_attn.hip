@@ -228,6 +228,182 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16 forward, software pipelined: the K/V tile kt+1 is fetched into registers while tile kt (in LDS) is
+// consumed and is written into the other LDS buffer afterwards -> one barrier per tile and no exposed global
+// latency (the un-pipelined kernel above sat in s_waitcnt/s_barrier for ~50 % of its wave cycles).
+// Scores are kept in the log2 domain (scale*log2e and coef*log2e folded into one fma) so that p = exp2(s - m)
+// is a v_sub + v_exp; the key-padding select only runs on the last tile.
+__device__ __forceinline__ float max3f(float a, float b, float c) {   // no canonicalising v_max in front (MFMA / fma results are never sNaN)
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+template <int HD, bool DROP>
+__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
+  typedef bf16 T;
+  constexpr int ND = HD / 16;
+  constexpr int NCH = HD / 8;                 // 16-B chunks per row
+  constexpr int TILE_BYTES = 64 * HD * 2;
+  constexpr int CPT = 64 * NCH / 256;         // chunks per thread per tile (2 for HD 64, 1 for HD 32)
+  __shared__ __attribute__((aligned(16))) char sK[2][TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char sV[2][TILE_BYTES];
+  __shared__ float sPos[2][64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const T* qkv = (const T*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float coef2 = -a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f) * LOG2E;
+  const float scale2 = a.scale * LOG2E;
+
+  const int q = q0 + wid * 16 + fr;
+  const int qc = q < S ? q : S - 1;
+  const float pos_q = a.pos ? (float)a.pos[(long long)n * S + qc] : (float)qc;
+
+  bf16x8 qf[HD / 32];
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *(const bf16x8*)(qkv + (long long)qc * rowstride + ks * 32 + g * 8);
+
+  f32x4 o[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const unsigned long long drop_base = (((unsigned long long)n * H + h) * S + qc) * (unsigned long long)S;
+
+  // this thread's staging slots: chunk c = tid + 256*u -> row c / NCH, 16-B chunk c % NCH
+  uint4 kreg[CPT], vreg[CPT];
+  float preg = 0.f;
+  const int ntile = (S + 63) / 64;
+#define AF_LOAD(kt_)                                                                              \
+  {                                                                                               \
+    const int kv0_ = (kt_) * 64;                                                                  \
+    const T* tbase = qkv + (long long)kv0_ * rowstride;                                           \
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                             \
+      const int c = tid + 256 * u;                                                                \
+      const int r = c / NCH, ch = c % NCH;                                                        \
+      kreg[u] = make_uint4(0u, 0u, 0u, 0u);                                                       \
+      vreg[u] = kreg[u];                                                                          \
+      if (kv0_ + r < S) {                                                                         \
+        const T* base = tbase + (unsigned)(r * (int)rowstride + ch * 8);                          \
+        kreg[u] = *(const uint4*)(base + H * HD);                                                 \
+        vreg[u] = *(const uint4*)(base + 2 * H * HD);                                             \
+      }                                                                                           \
+    }                                                                                             \
+    if (tid < 64) {                                                                               \
+      const int kv = kv0_ + tid;                                                                  \
+      preg = kv < S ? (a.pos ? (float)a.pos[(long long)n * S + kv] : (float)kv) : 0.f;            \
+    }                                                                                             \
+  }
+#define AF_STORE(buf_)                                                                            \
+  {                                                                                               \
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                             \
+      const int c = tid + 256 * u;                                                                \
+      const int r = c / NCH, ch = c % NCH;                                                        \
+      *(uint4*)(sK[buf_] + rowimg_off<HD>(r, ch)) = kreg[u];                                      \
+      *(uint4*)(sV[buf_] + trimg_off<HD>(r, ch * 8)) = vreg[u];                                   \
+    }                                                                                             \
+    if (tid < 64) sPos[buf_][tid] = preg;                                                         \
+  }
+  AF_LOAD(0);
+  AF_STORE(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int buf = kt & 1;
+    const int kv0 = kt * 64;
+    const bool more = kt + 1 < ntile;
+    if (more) AF_LOAD(kt + 1);
+    const char* const bK = sK[buf];
+    const char* const bV = sV[buf];
+
+    // ---- S^T tiles: s[j][r] = score(kv = kv0+16j+4g+r, q), log2 domain
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(bK + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
+      }
+      const f32x4 pk = *(const f32x4*)(&sPos[buf][16 * j + 4 * g]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s[j][r] = fmaf(acc[r], scale2, coef2 * fabsf(pos_q - pk[r]));
+    }
+    if (kv0 + 64 > S) {   // last tile: padded keys -> -inf
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (kv0 + 16 * j + 4 * g + r >= S) s[j][r] = -INFINITY;
+    }
+    float mx = max3f(s[0][0], s[0][1], s[0][2]);
+    mx = max3f(mx, s[0][3], s[1][0]);
+    mx = max3f(mx, s[1][1], s[1][2]);
+    mx = max3f(mx, s[1][3], s[2][0]);
+    mx = max3f(mx, s[2][1], s[2][2]);
+    mx = max3f(mx, s[2][3], s[3][0]);
+    mx = max3f(mx, s[3][1], s[3][2]);
+    mx = fmaxf(mx, s[3][3]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32, 64));
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __builtin_amdgcn_exp2f(s[j][r] - m_new);
+        ps += p;                                  // the normaliser is dropout-free
+        if (DROP) p = drop_apply(a.drop, drop_base + (unsigned)(kv0 + 16 * j + 4 * g + r), p);
+        s[j][r] = p;
+      }
+    l_run = l_run * alpha + ps;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] *= alpha;
+
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 pf;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pf[r] = (bf16)s[2 * st][r]; pf[4 + r] = (bf16)s[2 * st + 1][r]; }
+      const int qq = (lane & 15) >> 2, pp = lane & 3;
+      const int r_lo = 32 * st + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const bf16x8 vf = tr_frag(bV + trimg_off<HD>(r_lo, 16 * i + 4 * pp), bV + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[i], 0, 0, 0);
+      }
+    }
+    // buffer buf^1 was last read in iteration kt-1; every wave has passed that iteration's barrier
+    if (more) AF_STORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef AF_LOAD
+#undef AF_STORE
+  // ---- finish: O = O^T / l ; lse = (m + log2(l)) * ln2  (natural-log LSE, as the backward expects)
+  float l_tot = l_run;
+  l_tot += __shfl_xor(l_tot, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q < S) {
+    T* orow = (T*)a.out + ((long long)n * S + q) * ((long long)H * HD) + (long long)h * HD;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      f32x4 v = o[i] * inv;
+      Vec4<T>::store(orow + 16 * i + 4 * g, v);
+    }
+    if (g == 0 && a.lse) a.lse[((long long)n * H + h) * S + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+}
+
 // =============================================================================================
 //                                            backward
 // =============================================================================================
@@ -591,9 +767,15 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
   AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed)};
   if (dtype == A2V_BF16) {
-    if (HD == 64) return attn_fwd_launch<bf16, 64>(a, stream);
-    if (HD == 32) return attn_fwd_launch<bf16, 32>(a, stream);
-    return A2V_ERR_ARG;
+    dim3 grid((S + 63) / 64, H, N);
+    const bool dr = a.drop.thresh != 0;
+    if (HD == 64 && dr) hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, true>), grid, dim3(256), 0, stream, a);
+    else if (HD == 64) hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, stream, a);
+    else if (HD == 32 && dr) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, true>), grid, dim3(256), 0, stream, a);
+    else if (HD == 32) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, stream, a);
+    else return A2V_ERR_ARG;
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
   }
   if (dtype == A2V_F32) {
     if (HD == 64) return attn_fwd_launch<float, 64>(a, stream);
