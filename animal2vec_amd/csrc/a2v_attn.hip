@@ -240,7 +240,9 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {   // no cano
   return d;
 }
 
-template <int HD, bool DROP>
+// QB = 16-row query blocks per wave (workgroup = 64*QB query rows): with QB = 2 every K / V fragment read from
+// LDS feeds two MFMAs -- the QB = 1 kernel was LDS-bandwidth bound (16 KB of fragment reads per 16 MFMAs).
+template <int HD, bool DROP, int QB>
 __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   typedef bf16 T;
   constexpr int ND = HD / 16;
@@ -253,29 +255,32 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int q0 = blockIdx.x * (64 * QB), h = blockIdx.y, n = blockIdx.z;
   const int S = a.S, H = a.H;
   const long long rowstride = 3LL * H * HD;
   const T* qkv = (const T*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
   constexpr float LOG2E = 1.4426950408889634f;
-  const float coef2 = -a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f) * LOG2E;
-  const float scale2 = a.scale * LOG2E;
+  const float scale2 = a.scale * LOG2E;                                            // accumulator units -> log2 units
+  const float c_rel = -a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f) / a.scale;       // ALiBi slope in accumulator units
+  const float thr_acc = 4.f / scale2;
 
-  const int q = q0 + wid * 16 + fr;
-  const int qc = q < S ? q : S - 1;
-  const float pos_q = a.pos ? (float)a.pos[(long long)n * S + qc] : (float)qc;
-
-  bf16x8 qf[HD / 32];
+  int q[QB], qc[QB];
+  float pos_q[QB], m_run[QB], l_run[QB];
+  bf16x8 qf[QB][HD / 32];
+  f32x4 o[QB][ND];
 #pragma unroll
-  for (int ks = 0; ks < HD / 32; ++ks) qf[ks] = *(const bf16x8*)(qkv + (long long)qc * rowstride + ks * 32 + g * 8);
-
-  f32x4 o[ND];
+  for (int b = 0; b < QB; ++b) {
+    q[b] = q0 + (wid * QB + b) * 16 + fr;
+    qc[b] = q[b] < S ? q[b] : S - 1;
+    pos_q[b] = a.pos ? (float)a.pos[(long long)n * S + qc[b]] : (float)qc[b];
+    m_run[b] = -INFINITY;
+    l_run[b] = 0.f;
 #pragma unroll
-  for (int i = 0; i < ND; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
-  const unsigned long long drop_base = (((unsigned long long)n * H + h) * S + qc) * (unsigned long long)S;
+    for (int ks = 0; ks < HD / 32; ++ks) qf[b][ks] = *(const bf16x8*)(qkv + (long long)qc[b] * rowstride + ks * 32 + g * 8);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
-  // this thread's staging slots: chunk c = tid + 256*u -> row c / NCH, 16-B chunk c % NCH
   uint4 kreg[CPT], vreg[CPT];
   float preg = 0.f;
   const int ntile = (S + 63) / 64;
@@ -321,65 +326,87 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
     const char* const bK = sK[buf];
     const char* const bV = sV[buf];
 
-    // ---- S^T tiles: s[j][r] = score(kv = kv0+16j+4g+r, q), log2 domain
-    f32x4 s[4];
+    // ---- S^T tiles in accumulator units (raw q.k + bias/scale): s[b][j][r] for kv = kv0+16j+4g+r
+    f32x4 s[QB][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      bf16x8 kf[HD / 32];
 #pragma unroll
-      for (int ks = 0; ks < HD / 32; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(bK + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], acc, 0, 0, 0);
-      }
+      for (int ks = 0; ks < HD / 32; ++ks) kf[ks] = *(const bf16x8*)(bK + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
       const f32x4 pk = *(const f32x4*)(&sPos[buf][16 * j + 4 * g]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) s[j][r] = fmaf(acc[r], scale2, coef2 * fabsf(pos_q - pk[r]));
+      for (int b = 0; b < QB; ++b) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < HD / 32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[b][j][r] = fmaf(fabsf(pos_q[b] - pk[r]), c_rel, acc[r]);
+      }
     }
     if (kv0 + 64 > S) {   // last tile: padded keys -> -inf
 #pragma unroll
+      for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kv0 + 16 * j + 4 * g + r >= S) s[b][j][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
+      float mx = max3f(s[b][0][0], s[b][0][1], s[b][0][2]);
+      mx = max3f(mx, s[b][0][3], s[b][1][0]);
+      mx = max3f(mx, s[b][1][1], s[b][1][2]);
+      mx = max3f(mx, s[b][1][3], s[b][2][0]);
+      mx = max3f(mx, s[b][2][1], s[b][2][2]);
+      mx = max3f(mx, s[b][2][3], s[b][3][0]);
+      mx = max3f(mx, s[b][3][1], s[b][3][2]);
+      mx = fmaxf(mx, s[b][3][3]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // deferred maximum: rescale only when some row's maximum grew by more than 2^4 (p stays <= 16: harmless
+      // for fp32 sums and for bf16's scale-free relative precision); the decision is wave-uniform
+      if (__any(mx > m_run[b] + thr_acc)) {
+        const float m_new = fmaxf(m_run[b], mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * scale2);
+        m_run[b] = m_new;
+        l_run[b] *= alpha;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) o[b][i] *= alpha;
+      }
+      const float nm = -m_run[b] * scale2;
+      float ps = 0.f;
+#pragma unroll
       for (int j = 0; j < 4; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (kv0 + 16 * j + 4 * g + r >= S) s[j][r] = -INFINITY;
+        for (int r = 0; r < 4; ++r) {
+          float p = __builtin_amdgcn_exp2f(fmaf(s[b][j][r], scale2, nm));
+          ps += p;                                  // the normaliser is dropout-free
+          if (DROP) {
+            const unsigned long long idx =
+                (((unsigned long long)n * H + h) * S + qc[b]) * (unsigned long long)S + (unsigned)(kv0 + 16 * j + 4 * g + r);
+            p = drop_apply(a.drop, idx, p);
+          }
+          s[b][j][r] = p;
+        }
+      l_run[b] += ps;
     }
-    float mx = max3f(s[0][0], s[0][1], s[0][2]);
-    mx = max3f(mx, s[0][3], s[1][0]);
-    mx = max3f(mx, s[1][1], s[1][2]);
-    mx = max3f(mx, s[1][3], s[2][0]);
-    mx = max3f(mx, s[2][1], s[2][2]);
-    mx = max3f(mx, s[2][3], s[3][0]);
-    mx = max3f(mx, s[3][1], s[3][2]);
-    mx = fmaxf(mx, s[3][3]);
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    const float m_new = max3f(m_run, mx, __shfl_xor(mx, 32, 64));
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    float ps = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = __builtin_amdgcn_exp2f(s[j][r] - m_new);
-        ps += p;                                  // the normaliser is dropout-free
-        if (DROP) p = drop_apply(a.drop, drop_base + (unsigned)(kv0 + 16 * j + 4 * g + r), p);
-        s[j][r] = p;
-      }
-    l_run = l_run * alpha + ps;
-#pragma unroll
-    for (int i = 0; i < ND; ++i) o[i] *= alpha;
 
     // ---- O^T += V^T P^T
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      bf16x8 pf;
+      bf16x8 pf[QB];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { pf[r] = (bf16)s[2 * st][r]; pf[4 + r] = (bf16)s[2 * st + 1][r]; }
+      for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pf[b][r] = (bf16)s[b][2 * st][r]; pf[b][4 + r] = (bf16)s[b][2 * st + 1][r]; }
       const int qq = (lane & 15) >> 2, pp = lane & 3;
       const int r_lo = 32 * st + 4 * g + qq, r_hi = r_lo + 16;
 #pragma unroll
       for (int i = 0; i < ND; ++i) {
         const bf16x8 vf = tr_frag(bV + trimg_off<HD>(r_lo, 16 * i + 4 * pp), bV + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
-        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[i], 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < QB; ++b) o[b][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b], o[b][i], 0, 0, 0);
       }
     }
     // buffer buf^1 was last read in iteration kt-1; every wave has passed that iteration's barrier
@@ -388,19 +415,32 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
   }
 #undef AF_LOAD
 #undef AF_STORE
-  // ---- finish: O = O^T / l ; lse = (m + log2(l)) * ln2  (natural-log LSE, as the backward expects)
-  float l_tot = l_run;
-  l_tot += __shfl_xor(l_tot, 16, 64);
-  l_tot += __shfl_xor(l_tot, 32, 64);
-  const float inv = 1.f / l_tot;
-  if (q < S) {
-    T* orow = (T*)a.out + ((long long)n * S + q) * ((long long)H * HD) + (long long)h * HD;
+  // ---- finish: O = O^T / l ; lse = ln2 * (m*scale2 + log2 l)  (natural-log LSE, as the backward expects)
 #pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      f32x4 v = o[i] * inv;
-      Vec4<T>::store(orow + 16 * i + 4 * g, v);
+  for (int b = 0; b < QB; ++b) {
+    float l_tot = l_run[b];
+    l_tot += __shfl_xor(l_tot, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (q[b] < S) {
+      T* orow = (T*)a.out + ((long long)n * S + q[b]) * ((long long)H * HD) + (long long)h * HD;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        f32x4 v = o[b][i] * inv;
+        Vec4<T>::store(orow + 16 * i + 4 * g, v);
+      }
+      if (g == 0 && a.lse)
+        a.lse[((long long)n * H + h) * S + q[b]] = (m_run[b] * scale2 + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
-    if (g == 0 && a.lse) a.lse[((long long)n * H + h) * S + q] = (m_run + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+}
+
+template <int HD, bool DROP>
+static void attn_fwd_bf16_launch(const AttnArgs& a, hipStream_t st) {
+  if (a.S >= 512) {   // long sequences (the teacher's 2000 frames): 128 query rows per workgroup
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2>), dim3((a.S + 127) / 128, a.H, a.N), dim3(256), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 1>), dim3((a.S + 63) / 64, a.H, a.N), dim3(256), 0, st, a);
   }
 }
 
@@ -767,12 +807,11 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
   AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed)};
   if (dtype == A2V_BF16) {
-    dim3 grid((S + 63) / 64, H, N);
     const bool dr = a.drop.thresh != 0;
-    if (HD == 64 && dr) hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, true>), grid, dim3(256), 0, stream, a);
-    else if (HD == 64) hipLaunchKernelGGL((attn_fwd_bf16_kernel<64, false>), grid, dim3(256), 0, stream, a);
-    else if (HD == 32 && dr) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, true>), grid, dim3(256), 0, stream, a);
-    else if (HD == 32) hipLaunchKernelGGL((attn_fwd_bf16_kernel<32, false>), grid, dim3(256), 0, stream, a);
+    if (HD == 64 && dr) attn_fwd_bf16_launch<64, true>(a, stream);
+    else if (HD == 64) attn_fwd_bf16_launch<64, false>(a, stream);
+    else if (HD == 32 && dr) attn_fwd_bf16_launch<32, true>(a, stream);
+    else if (HD == 32) attn_fwd_bf16_launch<32, false>(a, stream);
     else return A2V_ERR_ARG;
     A2V_CHECK_LAUNCH();
     return A2V_OK;
