@@ -63,6 +63,7 @@ class GemmRecorder:
 
     def __init__(self):
         self.recs = []
+        self.bytes = {}
 
     def wrap(self, ops):
         self._cg, self._wg = ops.conv_gemm, ops.conv_wgrad
@@ -73,8 +74,11 @@ class GemmRecorder:
             e0.record()
             r = rec._cg(x, w, out, **kw)
             e1.record()
-            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1,
-                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1))))
+            G = kw.get("G", 1)
+            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * G, e0, e1, (kw["M"], kw["N"], kw["K"], G)))
+            # algorithmic bytes: every operand element once (the im2col view re-uses each input element `taps` times)
+            rec.bytes["nt"] = rec.bytes.get("nt", 0.0) + x.element_size() * G * (
+                kw["M"] * kw["K"] / kw.get("taps", 1) + kw["N"] * kw["K"] + kw["M"] * kw["N"])
             return r
 
         def wg(x, dy, gw, **kw):
@@ -108,8 +112,27 @@ class GemmRecorder:
             rs = [(f, e0.elapsed_time(e1)) for k, f, e0, e1, _ in self.recs if k == kind]
             if rs:
                 fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
-                out[kind] = dict(launches=len(rs), flops=fl, ms=ms, avg_us=1e3 * ms / len(rs), tflops=fl / ms / 1e9)
+                out[kind] = dict(launches=len(rs), flops=fl, ms=ms, avg_us=1e3 * ms / len(rs), tflops=fl / ms / 1e9,
+                                 alg_bytes=self.bytes.get(kind, 0.0) / len(rs))
         return out
+
+
+def pmc_traffic(kernel_prefix):
+    """Average fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
+    (FETCH_SIZE / WRITE_SIZE cannot be collected from inside this process; tools/pmc_traffic.py makes the file
+    from two separate counter runs of this same command, corrected as MI355X_MICROARCH.md prescribes)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+    except OSError:
+        return None, None
+    n = b = 0
+    for name, v in doc["kernels"].items():
+        if name.startswith(kernel_prefix):
+            n += v["launches"]
+            b += v["launches"] * v["hbm_bytes_per_launch"]
+    return (round(b / n) if n else None), "profiles/r01_pmc_traffic.json"
 
 
 def make_microbatch(cfg, B, L, K, seed, device):
@@ -225,9 +248,11 @@ def main():
         finally:
             rec.unwrap(ops)
         nt = s["nt"]
-        roof = dict(bound="mfma", kernel="gemm_nt_bf16_fast_kernel<*> (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
+        traffic, traffic_src = pmc_traffic("gemm_nt_bf16_glds_kernel") if dtype == torch.bfloat16 else (None, None)
+        roof = dict(bound="mfma", kernel="gemm_nt_bf16_glds_kernel<*> (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
                     achieved=round(nt["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                    frac=round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    frac=round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (HBM+MALL, PMC)",
+                    traffic_source=traffic_src, algorithmic_bytes_per_launch=round(nt["alg_bytes"]),
                     launches_per_microbatch=nt["launches"], avg_launch_us=round(nt["avg_us"], 2),
                     wgrad_kernel=dict(tflops=round(s["tn"]["tflops"], 2), launches=s["tn"]["launches"],
                                       avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None)
