@@ -78,10 +78,11 @@ __device__ __forceinline__ uint4 load_a_chunk(const ConvA& a, const ARow& r, int
 // Shared epilogue: one wave owns a 64x64 fp32 sub-tile staged in LDS (pitch 68 floats).
 template <typename T>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, int lane, int m_base, int n_base,
-                                              int grp) {
-  // stage[r][c] r,c in [0,64)
+                                              int grp, int jump32 = 0) {
+  // stage[r][c] r,c in [0,64); jump32: stage columns 32..63 map to output columns n_base + jump32 + 32.. (the
+  // 256x256 kernel's wave owns two 32-column strips 128 columns apart)
   const int cq = (lane & 15) * 4;
-  const int n = n_base + cq;                 // column inside the group
+  const int n = n_base + cq + (cq >= 32 ? jump32 : 0);                 // column inside the group
   const bool ncol_ok = n < g.N;              // N % 4 == 0 is required
   const long long ccol = (long long)grp * g.c_goff + n;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -151,5 +152,6 @@ __device__ __forceinline__ int tn_off(int r, int col) {   // byte offset of elem
 
 // launchers implemented in a2v_gemm_fast.hip; return false when the shape is not eligible
 bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream);
+bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream);     // a2v_gemm_p8.hip: 256x256 8-phase kernel
 bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream);
 int a2v_tn_bf16_tiles(int N, int K);

@@ -15,6 +15,8 @@
 // TN bf16 reads both operands with ds_read_b64_tr_b16 (hardware transpose) from row-major tiles.
 #include "a2v_gemm.h"
 
+int g_a2v_gemm_p8 = 1;   // a2v_debug_set(1, v): route eligible Linear layers to the 256x256 8-phase kernel
+
 // =============================================================================================
 //                                   bf16  NT   (128 x 128 x 64)
 // =============================================================================================
@@ -447,6 +449,10 @@ extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long l
   if ((flags & F_DROPOUT) && !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
   const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
   dim3 grid(tiles, G, 1);
+  if (dtype == A2V_BF16 && g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16 && a2v_launch_nt_bf16_fast(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
@@ -513,5 +519,6 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
 extern int g_a2v_gemm_variant;
 extern "C" int a2v_debug_set(int key, int value) {
   if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
+  if (key == 1) { g_a2v_gemm_p8 = value; return A2V_OK; }     // 256x256 8-phase kernel on / off
   return A2V_ERR_ARG;
 }

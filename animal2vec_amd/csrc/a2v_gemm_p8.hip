@@ -1,0 +1,299 @@
+// 256 x 256 x 64 bf16 NT GEMM for the plain Linear layers (out[M,N] = epi(x[M,K] @ w[N,K]^T)), gfx950.
+//
+// The 128x128 kernels of a2v_gemm_fast.hip read 16 KB of LDS fragments per 32 MFMAs per wave (wave tile 64x64):
+// the LDS pipe and the MFMA pipe are 1:1, two barriers' worth of latency sits in every K step, and they stop at
+// 600-1080 TFLOP/s.  This kernel follows the deep-pipelined structure of cdna_hip_programming.md section 5
+// ("The 256^2 8-phase template"):
+//   * 8 waves (2 x 4), one workgroup per CU, 128 KiB of LDS = 2 K-tile buffers x {A_lo, A_hi, B_lo, B_hi}
+//     half-tiles of 128 rows x 64 k (16 KiB each, XOR-swizzled 16-B chunks, filled by LDS-DMA with the swizzle
+//     applied to the per-lane SOURCE address);
+//   * every K-tile is 4 phases; in phase p ALL waves work on one 128 x 128 quadrant of the workgroup tile
+//     (lo/lo, lo/hi, hi/hi, hi/lo), each wave a 64 x 32 piece = 16 MFMAs, so a half-tile is dead one or two
+//     phases after it was read and is re-staged while the rest of the K-tile is still being consumed;
+//   * each phase issues ONE half-tile of LDS-DMA (2 x global_load_lds_dwordx4 per thread): A_hi(t+1) in phase 1,
+//     then A_lo / B_lo / B_hi of K-tile t+2; the only wait is a counted s_waitcnt vmcnt(6) in phase 4 (three
+//     half-tiles stay in flight across the barriers), barriers are raw s_barrier + lgkmcnt(0);
+//   * PERSISTENT: one workgroup per CU walks its list of output tiles and the K-tile stream continues across the
+//     tile seam (the last two K-tiles of a tile stage K-tiles 0 / 1 of the next one), so the epilogue -- and the
+//     128 KB burst of output stores every CU would otherwise issue in lock step (measured: 16 us of a 39 us
+//     K = 1024 tile) -- overlaps the next tile's loads and MFMAs.  The epilogue stages 16 rows x 64 columns per
+//     wave at a time through the remaining 32 KiB of LDS.
+// Wave (wr, wc) of quadrant (ha, hb) owns rows ha*128 + wr*64 + [0,64), columns hb*128 + wc*32 + [0,32).
+// Eligibility (else the 128x128 kernel runs): plain row-major A (no taps / padding / masks), K % 128 == 0,
+// K >= 256, N % 256 == 0, operands < 4 GiB.  The M tail is clamped on load and dropped by the epilogue.
+#include "a2v_gemm.h"
+
+typedef __attribute__((address_space(3))) void p8_lds_void_t;
+typedef __attribute__((address_space(1))) const void p8_gbl_cvoid_t;
+__device__ __forceinline__ void p8_glds16(const char* gsrc, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((p8_gbl_cvoid_t*)gsrc, (p8_lds_void_t*)lds_dst, 16, 0, 0);
+}
+
+#define P8_BUF 65536                  // one K-tile: A_lo, A_hi, B_lo, B_hi (16 KiB half-tiles)
+#define P8_ALO 0
+#define P8_AHI 16384
+#define P8_BLO 32768
+#define P8_BHI 49152
+#define P8_STG 131072                 // epilogue staging: 8 waves x 16 rows x 64 fp32
+#define P8_LDS (131072 + 8 * 4096)    // = 160 KiB
+
+struct P8Tile {      // byte offsets (from the A / B base of the group) of the 16-B chunks this thread stages
+  unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
+  int m0, n0;
+};
+
+__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int tiles_n = g.N / 256;
+  const int tiles_m = (g.M + 255) / 256;
+  const int ntiles = tiles_m * tiles_n;
+  const int grp = blockIdx.y;
+  const ConvA& a = g.a;
+  const int lr = lane >> 3;
+  const char* const abase = (const char*)a.ptr + (long long)grp * a.goff * 2;
+  const char* const bbase = (const char*)g.B + (long long)grp * g.b_gstride * 2;
+
+  // source chunk of LDS chunk position (lane & 7) in row r = slab*8 + lr:  c = pos ^ ((r >> 1) & 7)
+#define P8_SRC_CHUNK(slab) (((lane & 7) ^ ((((slab) & 1) << 2) + (lane >> 4))) & 7)
+  auto make_tile = [&](int seq) {
+    P8Tile t;
+    const int id = xcd_remap(seq < ntiles ? seq : ntiles - 1, ntiles);
+    int tm, tn;
+    tile_coords(id, tiles_m, tiles_n, tm, tn);
+    t.m0 = tm * 256;
+    t.n0 = tn * 256;
+    unsigned ao[4], bo[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {          // q = half * 2 + i: rows half*128 + (wid + 8 i) * 8 + lr
+      const int slab = wid + 8 * (q & 1);
+      int m = t.m0 + (q >> 1) * 128 + slab * 8 + lr;
+      m = m < g.M ? m : g.M - 1;
+      const int b = m / a.T_out, tt = m - b * a.T_out;
+      ao[q] = (unsigned)(((long long)(b / a.bdiv) * a.bstride + (long long)tt * a.pitch + P8_SRC_CHUNK(slab) * 8) * 2);
+      const int n = t.n0 + (q >> 1) * 128 + slab * 8 + lr;
+      bo[q] = (unsigned)(((long long)n * g.ldb + P8_SRC_CHUNK(slab) * 8) * 2);
+    }
+    t.al0 = ao[0]; t.al1 = ao[1]; t.ah0 = ao[2]; t.ah1 = ao[3];
+    t.bl0 = bo[0]; t.bl1 = bo[1]; t.bh0 = bo[2]; t.bh1 = bo[3];
+    return t;
+  };
+  char* const dst0 = smem + wid * 1024;            // + buffer + half offset (+ 8192 for the second slab)
+
+  const int nk = g.K / 64;
+  // stage one half-tile: 2 LDS-DMA per thread
+#define P8_STAGE(base, o0, o1, kt, lds_off)                    \
+  {                                                            \
+    const unsigned ko_ = (unsigned)(kt) * 128u;                \
+    p8_glds16(base + (o0 + ko_), dst0 + (lds_off));            \
+    p8_glds16(base + (o1 + ko_), dst0 + (lds_off) + 8192);     \
+  }
+
+  // ---- fragment read addresses (byte offsets inside a half-tile), ks = 0; ks = 1 flips chunk bit 2 (^ 64 B)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int sw = (fr >> 1) & 7;                       // (row >> 1) & 7 for rows base*16 + fr
+  const int lds0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem[0]
+  const int a_off = lds0 + (wr * 64 + fr) * 128 + ((fq ^ sw) << 4);       // + i * 2048
+  const int b_off = lds0 + (wc * 32 + fr) * 128 + ((fq ^ sw) << 4);       // + j * 2048
+
+  f32x4 acc[8][4];
+  bf16x8 fa[4][2], fbl[2][2], fbh[2][2];
+
+// Fragment reads are inline asm: hipcc orders a C++ LDS load after every LDS-DMA it cannot prove disjoint with an
+// s_waitcnt vmcnt(0) -- at the top of every K-tile in this persistent form -- which would drain the three
+// half-tiles deliberately left in flight.  The counted waits below (vmcnt(6) in phase 4, lgkmcnt(0) after each
+// phase's first barrier, tied to the fragment registers so that no MFMA is scheduled above it) order them instead.
+#define P8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define P8_READ_A(cur, half_off)                                                                       \
+  {                                                                                                    \
+    const int a0_ = (cur) ? a_off + P8_BUF : a_off, a1_ = (cur) ? (a_off ^ 64) + P8_BUF : (a_off ^ 64); \
+    P8_DSR(fa[0][0], a0_, (half_off)); P8_DSR(fa[0][1], a1_, (half_off));                              \
+    P8_DSR(fa[1][0], a0_, (half_off) + 2048); P8_DSR(fa[1][1], a1_, (half_off) + 2048);                \
+    P8_DSR(fa[2][0], a0_, (half_off) + 4096); P8_DSR(fa[2][1], a1_, (half_off) + 4096);                \
+    P8_DSR(fa[3][0], a0_, (half_off) + 6144); P8_DSR(fa[3][1], a1_, (half_off) + 6144);                \
+  }
+#define P8_READ_B(fb, cur, half_off)                                                                   \
+  {                                                                                                    \
+    const int b0_ = (cur) ? b_off + P8_BUF : b_off, b1_ = (cur) ? (b_off ^ 64) + P8_BUF : (b_off ^ 64); \
+    P8_DSR(fb[0][0], b0_, (half_off)); P8_DSR(fb[0][1], b1_, (half_off));                              \
+    P8_DSR(fb[1][0], b0_, (half_off) + 2048); P8_DSR(fb[1][1], b1_, (half_off) + 2048);                \
+  }
+#define P8_TIE4(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1])
+#define P8_LGKM0                                                                                        \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                  \
+               : P8_TIE4(fa), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), P8_TIE4(fbl), P8_TIE4(fbh));
+#define P8_MFMA(ibase, jbase, fb)                                                                      \
+  __builtin_amdgcn_s_barrier();                                                                        \
+  P8_LGKM0                                                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                                       \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
+    acc[(ibase) + i][(jbase) + j] =                                                                    \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                       \
+  __builtin_amdgcn_s_barrier();
+
+  // one K-tile held in buffer `cur`; T1 / k1 = tile and K index of the K-tile after it (A_hi goes to `oth`),
+  // T2 / k2 = of the one after that (A_lo, B_lo, B_hi re-stage `cur`)
+#define P8_KTILE(cur, oth, T1, k1, T2, k2)                                                             \
+  /* phase 1: quadrant lo/lo */                                                                        \
+  P8_READ_B(fbl, cur, P8_BLO)                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                   \
+  P8_READ_A(cur, P8_ALO)                                                                               \
+  P8_STAGE(abase, T1.ah0, T1.ah1, k1, (oth) + P8_AHI)                                                  \
+  P8_MFMA(0, 0, fbl)                                                                                   \
+  /* phase 2: lo/hi */                                                                                 \
+  P8_READ_B(fbh, cur, P8_BHI)                                                                          \
+  P8_STAGE(abase, T2.al0, T2.al1, k2, (cur) + P8_ALO)                                                  \
+  P8_MFMA(0, 2, fbh)                                                                                   \
+  /* phase 3: hi/hi */                                                                                 \
+  P8_READ_A(cur, P8_AHI)                                                                               \
+  P8_STAGE(bbase, T2.bl0, T2.bl1, k2, (cur) + P8_BLO)                                                  \
+  P8_MFMA(4, 2, fbh)                                                                                   \
+  /* phase 4: hi/lo (B_lo fragments kept from phase 1) */                                              \
+  P8_STAGE(bbase, T2.bh0, T2.bh1, k2, (cur) + P8_BHI)                                                  \
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                     \
+  P8_MFMA(4, 0, fbl)
+
+  int seq = blockIdx.x;
+  P8Tile T = make_tile(seq);
+  // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
+  P8_STAGE(abase, T.al0, T.al1, 0, P8_ALO)
+  P8_STAGE(bbase, T.bl0, T.bl1, 0, P8_BLO)
+  P8_STAGE(bbase, T.bh0, T.bh1, 0, P8_BHI)
+  P8_STAGE(abase, T.ah0, T.ah1, 0, P8_AHI)
+  P8_STAGE(abase, T.al0, T.al1, 1, P8_BUF + P8_ALO)
+  P8_STAGE(bbase, T.bl0, T.bl1, 1, P8_BUF + P8_BLO)
+  P8_STAGE(bbase, T.bh0, T.bh1, 1, P8_BUF + P8_BHI)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (; seq < ntiles; seq += gridDim.x) {
+    // (at the end of the list the "next tile" is this tile again: harmless re-fetches of valid data into dead
+    // buffers keep the vmcnt accounting uniform)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+      P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2)
+      P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3)
+    }
+    // last two K-tiles: the stream continues with K-tiles 0 / 1 of the next tile (its offsets are formed here, not
+    // at the top of the tile, so that they are not live -- and spilled -- across the main loop)
+    const bool has_next = seq + (int)gridDim.x < ntiles;
+    const P8Tile Tn = has_next ? make_tile(seq + gridDim.x) : T;
+    const int kn0 = has_next ? 0 : nk - 2, kn1 = has_next ? 1 : nk - 1;
+    P8_KTILE(0, P8_BUF, T, nk - 1, Tn, kn0)
+    P8_KTILE(P8_BUF, 0, Tn, kn0, Tn, kn1)
+
+    // ---- epilogue (overlaps the LDS-DMA already in flight for the next tile): 8 passes of 16 rows per wave
+    // lane-derived values are re-formed from an opaque copy of the lane id: hoisted out of the tile loop they
+    // would be live -- and spilled -- across the K loop, and a spill reload is a VMEM load whose wait drains the DMA
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int fre = le & 15, fqe = le >> 4;
+    float* const stg = (float*)(smem + P8_STG) + wid * 1024;
+    const int cq = fre * 4;
+    const int ncol = T.n0 + wc * 32 + cq + (cq >= 32 ? 96 : 0);
+    const long long ccol = (long long)grp * g.c_goff + ncol;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.flags & F_BIAS) bias4 = *(const f32x4*)(g.bias + (long long)grp * g.N + ncol);
+    // consume the load here: a load still pending on some path at the end of the epilogue makes hipcc put an
+    // s_waitcnt vmcnt(0) at the head of the K loop (draining the LDS-DMA pipeline every K-tile)
+    asm volatile("" :: "v"(bias4));
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    bf16* const C = (bf16*)g.C;
+    bf16* const C2 = (bf16*)g.C2;
+    const bf16* const R = (const bf16*)g.R;
+#pragma unroll
+    for (int ps = 0; ps < 8; ++ps) {   // fully unrolled: a rolled loop turns acc[ps] into a scalar branch tree per value
+      // stage[row][col ^ 16*((row >> 2) & 1)]: 2-way (= minimum) on the 4-B writes, conflict-free 16-B reads
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = acc[ps][j][r];
+          stg[(fqe * 4 + r) * 64 + ((j * 16 + fre) ^ ((fqe & 1) << 4))] = v;
+        }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const int mrow0 = T.m0 + (ps >> 2) * 128 + wr * 64 + (ps & 3) * 16;
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int r = it * 4 + fqe;
+        const int m = mrow0 + r;
+        f32x4 v = *(const f32x4*)(stg + r * 64 + (cq ^ (((r >> 2) & 1) << 4)));
+        if (m < g.M) {
+          v += bias4;
+          if (g.flags & F_STORE_PRE) Vec4<bf16>::store(C2 + (long long)m * g.ldc + ccol, v);
+          if (g.flags & F_GELU) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
+          }
+          if (g.flags & F_DROPOUT) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);
+          }
+          if (g.flags & F_RES) v += Vec4<bf16>::load(R + (long long)m * g.ldr + ccol);
+          if (g.flags & F_GELU_BWD) {
+            f32x4 h = Vec4<bf16>::load(R + (long long)m * g.ldr + ccol);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] *= gelu_grad_f(h[i]);
+          }
+          Vec4<bf16>::store(C + (long long)m * g.ldc + ccol, v);
+          if (g.flags & F_COLSUM) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cs[i] += Cvt<bf16>::to(Cvt<bf16>::from(v[i]));
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (g.flags & F_COLSUM) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float s = cs[i];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        cs[i] = s;
+      }
+      if (le < 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) atomicAdd(g.colsum + (long long)grp * g.N + ncol + i, cs[i]);
+      }
+    }
+    T = Tn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
+}
+
+bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
+  const ConvA& a = g.a;
+  const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
+                     a.Cv == a.Cg;
+  if (!plain || g.K % 128 != 0 || g.K < 256 || g.N % 256 != 0 || g.M < 1024) return false;
+  // 32-bit byte offsets inside one group's operands
+  const long long a_span = ((long long)((g.M - 1) / a.T_out / a.bdiv) * a.bstride + (long long)a.T_out * a.pitch + g.K) * 2;
+  const long long b_span = ((long long)g.N * g.ldb + g.K) * 2;
+  if (a_span >= (1LL << 32) || b_span >= (1LL << 32)) return false;
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&p, dev);
+    cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+  }
+  const int ntiles = cdiv(g.M, 256) * (g.N / 256);
+  dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
+  hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel, grid, dim3(512), P8_LDS, stream, g);
+  return true;
+}

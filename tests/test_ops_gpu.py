@@ -74,6 +74,45 @@ def test_linear_epilogues(ops, dtype):
     assert rel_err(cs, y.float().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 512, 256), (1024, 256, 384), (2049, 768, 1024)])
+def test_linear_p8_kernel(ops, M, N, K):
+    """Shapes eligible for the 256x256 8-phase bf16 kernel (N % 256 == 0, K % 128 == 0, M >= 1024): M tails,
+    every epilogue, against fp32 torch and against the 128x128 kernel (a2v_debug_set(1, 0))."""
+    from animal2vec_amd import _lib
+    dtype = torch.bfloat16
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, seed=3)
+    r = rnd(M, N, dtype=dtype, seed=4)
+    xd, wd, bd, rd = dev(x, dtype), dev(w, dtype), dev(b, torch.float32), dev(r, dtype)
+    pre = x @ w.t() + b
+
+    def run_all():
+        out = {}
+        out["plain"] = ops.linear(xd, wd, bd)
+        pre_out = torch.empty(M, N, dtype=dtype, device="cuda")
+        out["gelu"] = ops.linear(xd, wd, bd, gelu=True, pre_out=pre_out)
+        out["pre"] = pre_out
+        out["res"] = ops.linear(xd, wd, bd, res=rd)
+        cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+        out["gbwd"] = ops.linear(xd, wd, None, gelu_bwd_aux=rd, colsum=cs)
+        out["cs"] = cs
+        out["drop"] = ops.linear(xd, wd, bd, res=rd, drop=(0.25, 99))
+        return out
+
+    new = run_all()
+    _lib.load().a2v_debug_set(1, 0)
+    try:
+        old = run_all()
+    finally:
+        _lib.load().a2v_debug_set(1, 1)
+    assert rel_err(new["plain"].float(), pre) < tol(dtype)
+    assert rel_err(new["pre"].float(), pre) < tol(dtype)
+    assert rel_err(new["gelu"].float(), F.gelu(pre)) < tol(dtype)
+    assert rel_err(new["res"].float(), pre + r) < tol(dtype)
+    for k in new:          # same arithmetic order per output element (K accumulated in one chain): bit-identical
+        assert torch.equal(new[k], old[k]) or rel_err(new[k].float(), old[k].float()) < 1e-5, k
+
+
 # ------------------------------------------------------------------------------------------ convs
 def to_cl(x_bct, cp, dtype):
     B, C_, T = x_bct.shape

@@ -12,7 +12,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from animal2vec_amd import ops  # noqa: E402
 
 
-def timeit(fn, reps):
+def timeit(fn, reps, inner=10):
+    """median over `reps` of the per-call time of `inner` back-to-back launches between one event pair (a single
+    launch per pair measures the CPU launch path for kernels shorter than ~50 us)"""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
@@ -20,10 +22,11 @@ def timeit(fn, reps):
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e1.record()
         e1.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / inner)
     ts.sort()
     return ts[len(ts) // 2]
 
@@ -33,11 +36,17 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--p8", type=int, default=None, help="0: disable the 256x256 8-phase kernel")
+    ap.add_argument("--lin", action="append", default=[], help="extra plain linear shape M,N,K (repeatable)")
     a = ap.parse_args()
     if a.variant is not None:
         from animal2vec_amd import _lib
         _lib.load().a2v_debug_set(0, a.variant)
         print("variant", a.variant)
+    if a.p8 is not None:
+        from animal2vec_amd import _lib
+        _lib.load().a2v_debug_set(1, a.p8)
+        print("p8", a.p8)
     dev, dt = "cuda", torch.bfloat16
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g, dtype=torch.float32).to(dt)
@@ -89,6 +98,9 @@ def main():
             ms = timeit(lambda: ops.conv1d_cl(x, w, bias, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, out=out), a.reps)
         rows.append((name, B * T, Cg, k * Cg, G, ms, 2.0 * B * T * Cg * k * Cg * G / ms / 1e9))
 
+    for spec in a.lin:
+        M_, N_, K_ = (int(v) for v in spec.split(","))
+        lin(f"lin {spec}", M_, N_, K_)
     lin("qkv bias", 13440, 3072, 1024)
     lin("fc1 bias", 13440, 4096, 1024)
     lin("fc1 bias+gelu", 13440, 4096, 1024, gelu=True)
