@@ -101,21 +101,33 @@ __device__ __forceinline__ float wave_max(float v) {
 // exact (erf) GELU, as torch.nn.GELU() default.  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 6e-7 evaluated in fp32,
 // i.e. below fp32 round-off of the surrounding arithmetic) -- one v_exp + one v_rcp + 6 FMAs instead of
 // libm's branchy erff, which made GELU epilogues as expensive as a K=1024 main loop.
-__device__ __forceinline__ float erf_fast(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float y = 1.f - p * t * __expf(-ax * ax);
-  return copysignf(y, x);
+// gelu_parts: cdf = Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and e = exp(-x^2 / 2) (shared by the pdf of the gradient);
+// v_rcp_f32 (1 ulp) instead of __frcp_rn, whose correctly-rounded expansion is an 11-instruction division.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+  const float ax = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);       // polynomial pre-scaled by 1/2
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);          // exp(-x^2/2) = 2^(-x^2 log2(e) / 2)
+  const float h = p * t * e;                                          // (1 - erf(|x|/sqrt2)) / 2
+  cdf = x >= 0.f ? 1.f - h : h;
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float erf_fast(float x) {
+  float cdf, e;
+  gelu_parts(x * 1.41421356237309505f, cdf, e);
+  return 2.f * cdf - 1.f;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_grad_f(float x) {
-  const float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752f));
-  const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float cdf, e;
+  gelu_parts(x, cdf, e);
+  return fmaf(x * 0.39894228040143268f, e, cdf);
 }
 
 // Counter-based dropout (no mask tensor is ever stored): keep(seed, idx) is a pure function of a per-site

@@ -209,8 +209,21 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
     bf16* const C = (bf16*)g.C;
     bf16* const C2 = (bf16*)g.C2;
     const bf16* const R = (const bf16*)g.R;
+    // residual / pre-activation rows are fetched one pass (16 rows) ahead of their use
+    const bool need_r = (g.flags & (F_RES | F_GELU_BWD)) != 0;
+    uint2 rq[2][4];
+#define P8_RLOAD(ps_, slot)                                                                           \
+  if (need_r) {                                                                                       \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                \
+      int m_ = T.m0 + ((ps_) >> 2) * 128 + wr * 64 + ((ps_) & 3) * 16 + it * 4 + fqe;                 \
+      m_ = m_ < g.M ? m_ : g.M - 1;                                                                   \
+      rq[slot][it] = *(const uint2*)(R + (long long)m_ * g.ldr + ccol);                               \
+    }                                                                                                 \
+  }
+    P8_RLOAD(0, 0)
 #pragma unroll
     for (int ps = 0; ps < 8; ++ps) {   // fully unrolled: a rolled loop turns acc[ps] into a scalar branch tree per value
+      if (ps < 7) P8_RLOAD(ps + 1, (ps + 1) & 1)
       // stage[row][col ^ 16*((row >> 2) & 1)]: 2-way (= minimum) on the 4-B writes, conflict-free 16-B reads
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -239,11 +252,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);
           }
-          if (g.flags & F_RES) v += Vec4<bf16>::load(R + (long long)m * g.ldr + ccol);
-          if (g.flags & F_GELU_BWD) {
-            f32x4 h = Vec4<bf16>::load(R + (long long)m * g.ldr + ccol);
+          if (need_r) {
+            const uint2 q = rq[ps & 1][it];
+            f32x4 h;
+            h[0] = __uint_as_float(q.x << 16); h[1] = __uint_as_float(q.x & 0xffff0000u);
+            h[2] = __uint_as_float(q.y << 16); h[3] = __uint_as_float(q.y & 0xffff0000u);
+            if (g.flags & F_RES) v += h;
+            if (g.flags & F_GELU_BWD) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] *= gelu_grad_f(h[i]);
+              for (int i = 0; i < 4; ++i) v[i] *= gelu_grad_f(h[i]);
+            }
           }
           Vec4<bf16>::store(C + (long long)m * g.ldc + ccol, v);
           if (g.flags & F_COLSUM) {
@@ -269,6 +287,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
         for (int i = 0; i < 4; ++i) atomicAdd(g.colsum + (long long)grp * g.N + ncol + i, cs[i]);
       }
     }
+#undef P8_RLOAD
     T = Tn;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
