@@ -15,6 +15,7 @@
 // TN bf16 reads both operands with ds_read_b64_tr_b16 (hardware transpose) from row-major tiles.
 #include "a2v_gemm.h"
 
+int g_a2v_wgrad_slab = 1;   // a2v_debug_set(2, v): grouped-conv weight grads through the slab kernel
 int g_a2v_gemm_p8 = 1;   // a2v_debug_set(1, v): route eligible Linear layers to the 256x256 8-phase kernel
 
 // =============================================================================================
@@ -494,6 +495,10 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
   if (N % per16 || ldp % per16 || p_goff % per16 || (((uintptr_t)P) & 15)) return A2V_ERR_ARG;
   g.P = P; g.ldp = ldp; g.p_goff = p_goff; g.W = W; g.ldw = ldw; g.w_gstride = w_gstride;
   g.M = M; g.N = N; g.K = K; g.G = G;
+  if (dtype == A2V_BF16 && g_a2v_wgrad_slab && a2v_launch_wgrad_slab(g, stream)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   const int tiles = dtype == A2V_BF16 ? a2v_tn_bf16_tiles(N, K) : cdiv(N, 128) * cdiv(K, 128);
   const int step = dtype == A2V_BF16 ? TN_MSTEP : 16;
   // split M so that the grid has ~>= 1024 workgroups, each split a multiple of the M step
@@ -520,5 +525,6 @@ extern int g_a2v_gemm_variant;
 extern "C" int a2v_debug_set(int key, int value) {
   if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
   if (key == 1) { g_a2v_gemm_p8 = value; return A2V_OK; }     // 256x256 8-phase kernel on / off
+  if (key == 2) { g_a2v_wgrad_slab = value; return A2V_OK; }  // slab weight-gradient kernel on / off
   return A2V_ERR_ARG;
 }

@@ -1,0 +1,150 @@
+// Weight gradient of the grouped 1-D convolutions (pos-conv k19 g16, decoder k7 g16), bf16, gfx950.
+//
+//   dW[g][n][tap*64 + ci] += sum_m dY[m][g*N + n] * X[m + tap - pad][g*Cin + ci]        (stride 1, Cg = 64)
+//
+// The general TN kernel (a2v_gemm_fast.hip, 64 x 128 tiles) treats the im2col view as an ordinary operand: every
+// 128-wide kk tile (two taps) re-reads the same 64 rows of dY and of X, 24 KB of operands per MFLOP, and it sits on
+// the L2 bandwidth at 340 TFLOP/s.  Here one workgroup owns ALL taps of a (group, clip range): per 64-row step it
+// stages the dY tile (64 x 64) and ONE slab of X (64 + taps - 1 rows x 64 channels) and forms the B fragment of
+// tap j by reading the slab j rows further down (ds_read_b64_tr_b16 on both operands, reduction over rows).
+// 18.5 KB staged per 10 MFLOP.  8 waves; wave w owns the kk tiles [w*CPW, (w+1)*CPW) x all 64 n: 4*CPW
+// accumulator tiles (CPW = 10 for 19 taps: 160 VGPRs).  Register-prefetched double buffer, one barrier per step;
+// the result leaves with fp32 atomics (256 units x 311 KB for the pos-conv).
+#include "a2v_gemm.h"
+
+typedef __attribute__((address_space(3))) s16x4 ws_lds_s16x4;
+
+// LDS images are [rows][64] bf16 with a 160-B row pitch (128 B of data + 32 B of padding): the four rows a
+// 16-lane group of a tr read touches land on four different 8-bank groups, and -- unlike an XOR swizzle -- the
+// address of (row + tap, column tile) is the lane's base address plus a compile-time constant, so the 28 fragment
+// reads of a K step need two base registers instead of 56 hoisted (and spilled) addresses.
+#define WS_PITCH 160
+__device__ __forceinline__ bf16x8 ws_frag(const char* p) {      // rows r .. r+3 (lo) and r+4 .. r+7 (hi) of a 16 x 32 block
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ws_lds_s16x4*)p);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ws_lds_s16x4*)(p + 4 * WS_PITCH));
+  union { struct { s16x4 a, b; } s; bf16x8 v; } u;
+  u.s.a = lo; u.s.b = hi;
+  return u.v;
+}
+
+#define WS_SLAB_ROWS 84                      // 64 + 20 taps
+#define WS_P_BYTES (64 * WS_PITCH)
+#define WS_STAGE (WS_P_BYTES + WS_SLAB_ROWS * WS_PITCH)
+
+template <int CPW>
+__global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int clips_per_unit) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * WS_STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const ConvA& a = g.a;
+  const int grp = blockIdx.y;
+  const int T = a.T_out;
+  const int nclips = g.M / T;
+  const int c0 = blockIdx.x * clips_per_unit;
+  const int c1 = min(nclips, c0 + clips_per_unit);
+  if (c0 >= c1) return;
+  const int spc = (T + 63) / 64;                       // steps per clip
+  const int nsteps = (c1 - c0) * spc;
+  const int taps = a.taps;
+  const int CT = taps * 4;                             // 16-wide kk tiles
+
+  // staging slots: dY chunk (row tid>>3, chunk tid&7); X slab rows tid>>3 and 64 + (tid>>3)
+  const int srow = tid >> 3, sch = tid & 7;
+  const bool p_ok = sch * 8 < g.N;
+  const bool x_ok = sch * 8 < a.Cv;
+  const bool x2 = srow < taps - 1;                     // this thread also stages slab row 64 + srow
+  uint4 rp, rx0, rx1;
+  const uint4 zero4 = {0u, 0u, 0u, 0u};
+#define WS_LOAD(s_)                                                                                      \
+  {                                                                                                      \
+    const int cl = c0 + (s_) / spc;                                                                      \
+    const int t0 = ((s_) - ((s_) / spc) * spc) * 64;                                                     \
+    rp = zero4; rx0 = zero4; rx1 = zero4;                                                                \
+    if (p_ok && t0 + srow < T)                                                                           \
+      rp = *(const uint4*)((const bf16*)g.P + ((long long)cl * T + t0 + srow) * g.ldp + (long long)grp * g.p_goff + sch * 8); \
+    const bf16* xb = (const bf16*)a.ptr + (long long)(cl / a.bdiv) * a.bstride + (long long)grp * a.goff + sch * 8; \
+    const unsigned char* mk = a.rowmask ? a.rowmask + (long long)cl * a.T_in : nullptr;                  \
+    const int ra = t0 - a.pad + srow;                                                                    \
+    if (x_ok && (unsigned)ra < (unsigned)a.T_in && !(mk && mk[ra])) rx0 = *(const uint4*)(xb + (long long)ra * a.pitch); \
+    const int rb = ra + 64;                                                                              \
+    if (x2 && x_ok && (unsigned)rb < (unsigned)a.T_in && !(mk && mk[rb])) rx1 = *(const uint4*)(xb + (long long)rb * a.pitch); \
+  }
+#define WS_STORE(buf_)                                                                                   \
+  {                                                                                                      \
+    char* sp_ = smem + (buf_) * WS_STAGE;                                                                \
+    *(uint4*)(sp_ + srow * WS_PITCH + sch * 16) = rp;                                                    \
+    *(uint4*)(sp_ + WS_P_BYTES + srow * WS_PITCH + sch * 16) = rx0;                                      \
+    if (x2) *(uint4*)(sp_ + WS_P_BYTES + (64 + srow) * WS_PITCH + sch * 16) = rx1;                       \
+  }
+
+  f32x4 acc[4][CPW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  WS_LOAD(0);
+  WS_STORE(0);
+  __syncthreads();
+
+  const int gq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int lane_base = (8 * gq + q) * WS_PITCH + 8 * p;
+  const int ct0 = wid * CPW;
+  for (int st = 0; st < nsteps; ++st) {
+    const int buf = st & 1;
+    if (st + 1 < nsteps) WS_LOAD(st + 1);
+    const char* sp_ = smem + buf * WS_STAGE + lane_base;          // this lane's (row 8 gq + q, column 4 p) of the dY tile
+    const char* sx_ = sp_ + WS_P_BYTES;                           // ... and of the X slab
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fa[i] = ws_frag(sp_ + ks * 32 * WS_PITCH + i * 32);
+      // kk tile c = wid*CPW + j: tap c >> 2, channel block c & 3; wid is wave-uniform, so the tile's offset from the
+      // lane base is a scalar (one v_add per fragment)
+#pragma unroll
+      for (int j = 0; j < CPW; ++j) {
+        const int c = ct0 + j;
+        const bf16x8 fb = ws_frag(sx_ + ks * 32 * WS_PITCH + ((c >> 2) * WS_PITCH + (c & 3) * 32));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+      }
+    }
+    if (st + 1 < nsteps) WS_STORE(buf ^ 1);
+    __syncthreads();
+  }
+#undef WS_LOAD
+#undef WS_STORE
+
+  const int fr = lane & 15, fq = lane >> 4;
+#pragma unroll
+  for (int j = 0; j < CPW; ++j) {
+    const int c = wid * CPW + j;
+    if (c >= CT) continue;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = i * 16 + fq * 4 + r;
+        if (n < g.N) atomicAdd(g.W + (long long)grp * g.w_gstride + (long long)n * g.ldw + c * 16 + fr, acc[i][j][r]);
+      }
+  }
+}
+
+bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream) {
+  const ConvA& a = g.a;
+  if (a.Cg != 64 || a.stride != 1 || a.T_in != a.T_out || a.taps < 2 || a.taps > 20 || g.N > 64 || g.N % 8 || a.Cv % 8 ||
+      g.K != a.taps * 64 || g.M % a.T_out != 0 || a.pad >= a.taps)
+    return false;
+  const int nclips = g.M / a.T_out;
+  int units = 512 / g.G;                               // ~2 units per CU
+  if (units < 1) units = 1;
+  if (units > nclips) units = nclips;
+  const int cpu = cdiv(nclips, units);
+  units = cdiv(nclips, cpu);
+  dim3 grid(units, g.G, 1);
+  if (a.taps * 4 <= 32)
+    hipLaunchKernelGGL((conv_wgrad_slab_kernel<4>), grid, dim3(512), 0, stream, g, cpu);
+  else
+    hipLaunchKernelGGL((conv_wgrad_slab_kernel<10>), grid, dim3(512), 0, stream, g, cpu);
+  return true;
+}
