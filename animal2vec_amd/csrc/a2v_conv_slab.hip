@@ -1,0 +1,134 @@
+// Grouped 1-D convolution (pos-conv k19 g16, decoder k7 g16: forward and input gradient), bf16, gfx950.
+//
+//   out[m][g*N + n] = epi( sum_tap sum_ci  X[m + tap - pad][g*Cin + ci] * W[g][n][tap*64 + ci] )     (stride 1, Cg = 64)
+//
+// The implicit-GEMM kernel (a2v_gemm_fast.hip, 256 x 64 tiles) re-stages the A tile for every tap (19 times the
+// same rows, shifted by one) and reads 16 KB of LDS fragments per 32 MFMAs.  Here a workgroup keeps ONE slab of X
+// (1024 + taps - 1 rows x 64 channels, 133 KB) in LDS for all taps and only streams the 8 KB weight tile of each
+// tap (LDS-DMA, double buffered); the A fragment of tap j is the slab read j rows further down.  8 waves x (128
+// rows x 64 outputs): 24 fragment reads per 64 MFMAs, one barrier per tap.
+// The slab is XOR-swizzled in 16-B chunks by (row >> 1) & 7; rows i*16 + fr + tap share that term for all i, so a
+// tap costs a handful of VALU for its two chunk addresses and the 8 row tiles are immediates.
+#include "a2v_gemm.h"
+
+typedef __attribute__((address_space(3))) void cs_lds_void_t;
+typedef __attribute__((address_space(1))) const void cs_gbl_cvoid_t;
+
+#define CS_BM 1024
+#define CS_SLAB_ROWS (CS_BM + 24)                    // taps <= 24
+#define CS_SLAB_BYTES (CS_SLAB_ROWS * 128)           // 134144
+#define CS_B_BYTES 8192
+#define CS_LDS (CS_SLAB_BYTES + 2 * CS_B_BYTES)      // 150528
+#define CS_NLD ((CS_SLAB_ROWS * 8 + 511) / 512)      // 16-B chunks per thread: 17
+
+__global__ __launch_bounds__(512) void conv_nt_slab_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sB = smem + CS_SLAB_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const ConvA& a = g.a;
+  const int grp = blockIdx.y;
+  const int T = a.T_out;
+  const int bpc = (T + CS_BM - 1) / CS_BM;            // row blocks per clip
+  const int clip = blockIdx.x / bpc;
+  const int t_base = (blockIdx.x - clip * bpc) * CS_BM;
+  const int taps = a.taps;
+  const int rows_needed = min(CS_BM, T - t_base) + taps - 1;
+
+  // ---- weight tile of tap 0 by LDS-DMA: wave w feeds rows n = 8 w .. 8 w + 7, chunk position lane & 7
+  const int lr = lane >> 3;
+  const int bn = wid * 8 + lr;
+  const int bsrc_chunk = ((lane & 7) ^ ((bn >> 1) & 7)) & 7;
+  const char* const bsrc = (const char*)g.B + ((long long)grp * g.b_gstride + (long long)(bn < g.N ? bn : g.N - 1) * g.ldb + bsrc_chunk * 8) * 2;
+  __builtin_amdgcn_global_load_lds((cs_gbl_cvoid_t*)bsrc, (cs_lds_void_t*)(sB + wid * 1024), 16, 0, 0);
+
+  // ---- the X slab through registers (clip edges, masked clone rows and channels >= Cv read as zero)
+  {
+    const bf16* xb = (const bf16*)a.ptr + (long long)(clip / a.bdiv) * a.bstride + (long long)grp * a.goff;
+    const unsigned char* mk = a.rowmask ? a.rowmask + (long long)clip * a.T_in : nullptr;
+    uint4 rg[CS_NLD];
+#pragma unroll
+    for (int u = 0; u < CS_NLD; ++u) {
+      const int idx = tid + 512 * u;
+      const int row = idx >> 3, ch = idx & 7;
+      const int rs = t_base - a.pad + row;
+      rg[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (row < rows_needed && ch * 8 < a.Cv && (unsigned)rs < (unsigned)a.T_in && !(mk && mk[rs]))
+        rg[u] = *(const uint4*)(xb + (long long)rs * a.pitch + ch * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < CS_NLD; ++u) {
+      const int idx = tid + 512 * u;
+      const int row = idx >> 3, ch = idx & 7;
+      if (row < CS_SLAB_ROWS) *(uint4*)(smem + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = rg[u];
+    }
+  }
+  __syncthreads();                                    // also drains the tap-0 weight DMA (vmcnt(0))
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);       // + j * 2048, ks flips chunk bit 2 (^ 64 B)
+  const int a_row0 = wid * 128 + fr;                                // + i * 16 + tap
+  for (int tap = 0; tap < taps; ++tap) {
+    const int buf = tap & 1;
+    if (tap + 1 < taps)
+      __builtin_amdgcn_global_load_lds((cs_gbl_cvoid_t*)(bsrc + (tap + 1) * 128),
+                                       (cs_lds_void_t*)(sB + (buf ^ 1) * CS_B_BYTES + wid * 1024), 16, 0, 0);
+    const char* sb_ = sB + buf * CS_B_BYTES;
+    const int ar = a_row0 + tap;
+    const int a_off = ar * 128 + ((fq ^ ((ar >> 1) & 7)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb_ + (b_off ^ (ks << 6)) + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8 fa = *(const bf16x8*)(smem + (a_off ^ (ks << 6)) + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                  // weight tile tap+1 landed (vmcnt(0)), tile `buf` free
+  }
+
+  // ---- epilogue: two 64 x 64 stages per wave through the (now dead) slab
+  float* stage = (float*)smem + wid * (64 * 68);
+  const int m_limit = (clip + 1) * T;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[(i * 16 + fq * 4 + r) * 68 + j * 16 + fr] = acc[h * 4 + i][j][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wave_epilogue<bf16>(g, stage, lane, clip * T + t_base + wid * 128 + h * 64, 0, grp, 0, m_limit);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+}
+
+bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
+  const ConvA& a = g.a;
+  if (a.Cg != 64 || a.stride != 1 || a.T_in != a.T_out || a.taps < 2 || a.taps > 24 || g.N > 64 || g.N % 4 ||
+      a.Cv % 8 || g.K != a.taps * 64 || g.M % a.T_out != 0 || a.pad >= a.taps || a.T_out < 256)
+    return false;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_nt_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
+    attr = true;
+  }
+  const int nclips = g.M / a.T_out;
+  dim3 grid(nclips * cdiv(a.T_out, CS_BM), g.G, 1);
+  hipLaunchKernelGGL(conv_nt_slab_kernel, grid, dim3(512), CS_LDS, stream, g);
+  return true;
+}

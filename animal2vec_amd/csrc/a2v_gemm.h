@@ -78,7 +78,7 @@ __device__ __forceinline__ uint4 load_a_chunk(const ConvA& a, const ARow& r, int
 // Shared epilogue: one wave owns a 64x64 fp32 sub-tile staged in LDS (pitch 68 floats).
 template <typename T>
 __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, int lane, int m_base, int n_base,
-                                              int grp, int jump32 = 0) {
+                                              int grp, int jump32 = 0, int m_limit = -1) {
   // stage[r][c] r,c in [0,64); jump32: stage columns 32..63 map to output columns n_base + jump32 + 32.. (the
   // 256x256 kernel's wave owns two 32-column strips 128 columns apart)
   const int cq = (lane & 15) * 4;
@@ -96,7 +96,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, i
     const int r = it * 4 + (lane >> 4);
     const int m = m_base + r;
     f32x4 v = *(const f32x4*)(stage + r * 68 + cq);
-    if (m < g.M && ncol_ok) {
+    if (m < (m_limit < 0 ? g.M : m_limit) && ncol_ok) {
       v += bias4;
       if (g.flags & F_STORE_PRE) Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, v);
       if (g.flags & F_GELU) {
@@ -153,6 +153,7 @@ __device__ __forceinline__ int tn_off(int r, int col) {   // byte offset of elem
 // launchers implemented in a2v_gemm_fast.hip; return false when the shape is not eligible
 bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream);
-bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream);    // a2v_wgrad_slab.hip: grouped-conv weight grads     // a2v_gemm_p8.hip: 256x256 8-phase kernel
+bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream);
+bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream);      // a2v_conv_slab.hip: grouped-conv forward / input grads    // a2v_wgrad_slab.hip: grouped-conv weight grads     // a2v_gemm_p8.hip: 256x256 8-phase kernel
 bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream);
 int a2v_tn_bf16_tiles(int N, int K);

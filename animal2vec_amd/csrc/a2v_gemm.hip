@@ -16,6 +16,7 @@
 #include "a2v_gemm.h"
 
 int g_a2v_wgrad_slab = 1;   // a2v_debug_set(2, v): grouped-conv weight grads through the slab kernel
+int g_a2v_conv_slab = 1;    // a2v_debug_set(3, v): grouped-conv forward / input grads through the slab kernel
 int g_a2v_gemm_p8 = 1;   // a2v_debug_set(1, v): route eligible Linear layers to the 256x256 8-phase kernel
 
 // =============================================================================================
@@ -450,6 +451,10 @@ extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long l
   if ((flags & F_DROPOUT) && !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
   const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
   dim3 grid(tiles, G, 1);
+  if (dtype == A2V_BF16 && g_a2v_conv_slab && a2v_launch_conv_slab(g, stream)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16 && g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
@@ -526,5 +531,6 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
   if (key == 1) { g_a2v_gemm_p8 = value; return A2V_OK; }     // 256x256 8-phase kernel on / off
   if (key == 2) { g_a2v_wgrad_slab = value; return A2V_OK; }  // slab weight-gradient kernel on / off
+  if (key == 3) { g_a2v_conv_slab = value; return A2V_OK; }   // slab grouped-conv kernel on / off
   return A2V_ERR_ARG;
 }

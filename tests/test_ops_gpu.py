@@ -223,6 +223,52 @@ def test_conv_clone_mask_view(ops, dtype):
     assert rel_err(y.float(), ref) < tol(dtype)
 
 
+def test_conv_slab_kernels_masked_long(ops):
+    """bf16 slab kernels (a2v_conv_slab.hip / a2v_wgrad_slab.hip): k19 grouped conv with 64 channels per group over
+    clips longer than one 1024-row block, on the never-materialised clone * (1 - mask) view; forward, input gradient
+    and weight gradient against fp32 torch and against the implicit-GEMM kernels (a2v_debug_set 2 / 3)."""
+    from animal2vec_amd import _lib
+    dtype = torch.bfloat16
+    B, cb, T, D, G, k = 2, 2, 1100, 128, 2, 19
+    Cg = D // G
+    x = rnd(B, T, D, dtype=dtype, seed=1)
+    w = rnd(D, Cg, k, dtype=dtype, seed=2, scale=(Cg * k) ** -0.5)
+    bias = rnd(D, dtype=torch.float32, seed=4)
+    mask = (torch.rand(B * cb, T, generator=torch.Generator().manual_seed(3)) < 0.7).to(torch.uint8)
+    xm = (x.repeat_interleave(cb, 0) * (1 - mask.float().unsqueeze(-1))).requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv1d(xm.transpose(1, 2), wr, bias, padding=k // 2, groups=G).transpose(1, 2)
+    dy = rnd(B * cb, T, D, dtype=dtype, seed=5)
+    ref.backward(dy)
+    xd, dyd, md = dev(x, dtype), dev(dy, dtype), mask.cuda()
+    wp = dev(pack_ref(w, G, Cg), dtype)
+    wt = torch.empty(G, Cg, k * Cg, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(w, torch.float32), wt, G=G, N=Cg, Cg=Cg, k=k, Np=Cg, mode=1)
+
+    def run():
+        y = ops.conv1d_cl(xd, wp, dev(bias, torch.float32), k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D,
+                          rowmask=md, bdiv=cb, n_batch=B * cb)
+        dx = ops.conv1d_cl(dyd, wt, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D)
+        gw = torch.zeros(G, Cg, k * Cg, dtype=torch.float32, device="cuda")
+        ops.conv1d_cl_wgrad(xd, dyd, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, rowmask=md, bdiv=cb, n_batch=B * cb)
+        return y, dx, gw
+
+    y, dx, gw = run()
+    lib = _lib.load()
+    lib.a2v_debug_set(2, 0); lib.a2v_debug_set(3, 0)
+    try:
+        y0, dx0, gw0 = run()
+    finally:
+        lib.a2v_debug_set(2, 1); lib.a2v_debug_set(3, 1)
+    assert rel_err(y.float(), ref.detach()) < tol(dtype)
+    assert rel_err(dx.float(), xm.grad) < tol(dtype, 2)
+    gw_un = torch.zeros(D, Cg, k, dtype=torch.float32, device="cuda")
+    ops.unpack_wgrad(gw, gw_un, GN=D, Cg=Cg, k=k, Cgp=Cg)
+    assert rel_err(gw_un, wr.grad) < tol(dtype, 2)
+    assert torch.equal(y, y0) and torch.equal(dx, dx0)        # same per-element accumulation order
+    assert rel_err(gw, gw0) < 1e-4                              # fp32 atomics in a different order
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_dgrad_paths(ops, dtype):
     # stride-1 grouped conv: input gradient as a convolution with flipped/transposed weights (pack mode 1)
