@@ -17,6 +17,7 @@
 
 int g_a2v_wgrad_slab = 1;   // a2v_debug_set(2, v): grouped-conv weight grads through the slab kernel
 int g_a2v_conv_slab = 1;    // a2v_debug_set(3, v): grouped-conv forward / input grads through the slab kernel
+int g_a2v_tn_p8 = 1;        // a2v_debug_set(4, v): Linear weight gradients through the 256x256 TN kernel
 int g_a2v_gemm_p8 = 1;   // a2v_debug_set(1, v): route eligible Linear layers to the 256x256 8-phase kernel
 
 // =============================================================================================
@@ -500,6 +501,10 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
   if (N % per16 || ldp % per16 || p_goff % per16 || (((uintptr_t)P) & 15)) return A2V_ERR_ARG;
   g.P = P; g.ldp = ldp; g.p_goff = p_goff; g.W = W; g.ldw = ldw; g.w_gstride = w_gstride;
   g.M = M; g.N = N; g.K = K; g.G = G;
+  if (dtype == A2V_BF16 && g_a2v_tn_p8 && a2v_launch_tn_bf16_p8(g, stream)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16 && g_a2v_wgrad_slab && a2v_launch_wgrad_slab(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
@@ -532,5 +537,6 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 1) { g_a2v_gemm_p8 = value; return A2V_OK; }     // 256x256 8-phase kernel on / off
   if (key == 2) { g_a2v_wgrad_slab = value; return A2V_OK; }  // slab weight-gradient kernel on / off
   if (key == 3) { g_a2v_conv_slab = value; return A2V_OK; }   // slab grouped-conv kernel on / off
+  if (key == 4) { g_a2v_tn_p8 = value; return A2V_OK; }       // 256x256 TN weight-gradient kernel on / off
   return A2V_ERR_ARG;
 }

@@ -1,0 +1,234 @@
+// 256 x 256 x 64 bf16 TN GEMM for the weight gradients of the Linear layers, gfx950:
+//
+//     W[n][kk] += sum_m dY[m][n] * X[m][kk]        (fp32 accumulate into the flat gradient buffer)
+//
+// Same machine as a2v_gemm_p8.hip (8 waves, 4 phases per 64-row K-tile, one LDS-DMA half-tile per phase, counted
+// vmcnt(6), persistent stream across work units) with the reduction running over ROWS: both operands are staged
+// row-major as [64 m][128 cols] half-tiles (256-B rows, 32-B blocks XOR-swizzled by f(m) = (m & 3) | ((m >> 3) & 1) << 2,
+// the swizzle applied to the LDS-DMA source address) and every MFMA fragment is a ds_read_b64_tr_b16 pair.
+// A work unit is (output tile, M chunk); units = tiles x ceil(CUs / tiles), a unit's result leaves with fp32
+// atomics (the 128x128 kernel with its 1024 smaller units issued 4x the atomic traffic for the same output).
+// Eligibility: plain row-major X (the Linear layers), N % 256 == 0, K % 256 == 0, at least 32 tiles.
+#include "a2v_gemm.h"
+
+typedef __attribute__((address_space(3))) void t8_lds_void_t;
+typedef __attribute__((address_space(1))) const void t8_gbl_cvoid_t;
+__device__ __forceinline__ void t8_glds16(const char* gsrc, char* lds_dst) {
+  __builtin_amdgcn_global_load_lds((t8_gbl_cvoid_t*)gsrc, (t8_lds_void_t*)lds_dst, 16, 0, 0);
+}
+
+#define T8_BUF 65536                  // one K-tile: P_lo, P_hi, Q_lo, Q_hi (16 KiB half-tiles: 64 rows x 256 B)
+#define T8_PLO 0
+#define T8_PHI 16384
+#define T8_QLO 32768
+#define T8_QHI 49152
+#define T8_LDS (2 * T8_BUF)
+
+__device__ uint4 g_t8_zero[1];        // rows past the end of M are fetched from here
+
+struct T8Unit {       // wave-uniform description of a work unit (the per-thread chunk offsets are unit-independent)
+  const char* pb;     // dY + (mbeg * ldp + n0) * 2
+  const char* qb;     // X  + (mbeg * pitch + k0) * 2
+  int n0, k0, nk;     // output tile origin, K-tiles (64 rows) in this unit (even, >= 2)
+  int mbeg;           // first row of the unit
+};
+
+__global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int chunks, int kt_per_chunk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 2, wc = wid & 3;
+  const int tiles_k = g.K / 256;
+  const int tiles = (g.N / 256) * tiles_k;
+  const int units = tiles * chunks;
+  const ConvA& a = g.a;
+  const char* const pbase = (const char*)g.P;
+  const char* const qbase = (const char*)a.ptr;
+  const char* const zsrc = (const char*)g_t8_zero;
+  const int nk_total = (g.M + 63) / 64;
+
+  // LDS position chunk c (16 B) of row r holds source chunk (((c >> 1) ^ f(r)) << 1) | (c & 1); this thread stages
+  // rows mrow0 / mrow1 of every K-tile
+  const int c16 = lane & 15;
+  const int mrow0 = wid * 4 + (lane >> 4), mrow1 = mrow0 + 32;
+  unsigned po0, po1, qo0, qo1;
+  {
+    const int f0 = (mrow0 & 3) | (((mrow0 >> 3) & 1) << 2), f1 = (mrow1 & 3) | (((mrow1 >> 3) & 1) << 2);
+    const int sc0 = (((c16 >> 1) ^ f0) << 1) | (c16 & 1), sc1 = (((c16 >> 1) ^ f1) << 1) | (c16 & 1);
+    po0 = (unsigned)(((long long)mrow0 * g.ldp + sc0 * 8) * 2);
+    po1 = (unsigned)(((long long)mrow1 * g.ldp + sc1 * 8) * 2);
+    qo0 = (unsigned)(((long long)mrow0 * a.pitch + sc0 * 8) * 2);
+    qo1 = (unsigned)(((long long)mrow1 * a.pitch + sc1 * 8) * 2);
+  }
+  auto make_unit = [&](int seq) {
+    T8Unit u;
+    const int id = xcd_remap(seq < units ? seq : units - 1, units);
+    const int chunk = id / tiles, tile = id - chunk * tiles;
+    const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
+    u.n0 = tn * 256;
+    u.k0 = tk * 256;
+    const int kt0 = chunk * kt_per_chunk;
+    u.nk = min(kt_per_chunk, nk_total - kt0);
+    u.nk += u.nk & 1;                               // even; the extra K-tile reads zeros
+    u.mbeg = kt0 * 64;
+    u.pb = pbase + ((long long)u.mbeg * g.ldp + u.n0) * 2;
+    u.qb = qbase + ((long long)u.mbeg * a.pitch + u.k0) * 2;
+    return u;
+  };
+  char* const dst0 = smem + wid * 1024;            // + buffer + half offset (+ 8192 for the second slab)
+  const long long p_kstep = 64LL * g.ldp * 2, q_kstep = 64LL * a.pitch * 2;
+
+  // stage one half-tile of K-tile kt of unit U: 2 LDS-DMA per thread; rows >= M come from the zero page
+#define T8_STAGE(ub, o0, o1, kstep, U, kt, hi, lds_off)                                             \
+  {                                                                                                 \
+    const char* kb_ = U.ub + ((long long)(kt) * (kstep) + (hi) * 256);                              \
+    const int mr_ = U.mbeg + (kt) * 64;                                                             \
+    t8_glds16(mr_ + mrow0 < g.M ? kb_ + o0 : zsrc, dst0 + (lds_off));                               \
+    t8_glds16(mr_ + mrow1 < g.M ? kb_ + o1 : zsrc, dst0 + (lds_off) + 8192);                        \
+  }
+
+  // ---- fragment addresses: lane (gq, q, p) reads rows 8 gq + q (+4 for the upper half, +32 for ks = 1), column
+  //      group 4 p of 16-column tile t; f is the same for all of those rows, so tile t sits at block t ^ f
+  const int gq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+  const int f = q | ((gq & 1) << 2);
+  const int lds0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const int rowb = lds0 + (8 * gq + q) * 256 + 8 * p;
+  int pa[4], qa[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) pa[i] = rowb + (((wr * 4 + i) ^ f) << 5);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) qa[j] = rowb + (((wc * 2 + j) ^ f) << 5);
+
+  f32x4 acc[8][4];
+  bf16x8 fa[4][2], fbl[2][2], fbh[2][2];
+  typedef __attribute__((ext_vector_type(2))) int t8_i2;
+#define T8_FRAG(dst, addr, off)                                                                          \
+  {                                                                                                      \
+    t8_i2 lo_, hi_;                                                                                      \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo_) : "v"(addr), "n"(off));               \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(addr), "n"((off) + 1024));      \
+    union { struct { t8_i2 a, b; } s; bf16x8 v; } u_;                                                    \
+    u_.s.a = lo_; u_.s.b = hi_;                                                                          \
+    dst = u_.v;                                                                                          \
+  }
+#define T8_READ_A(cur, half_off)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                        \
+    const int ad_ = (cur) ? pa[i] + T8_BUF : pa[i];                                                      \
+    T8_FRAG(fa[i][0], ad_, (half_off)) T8_FRAG(fa[i][1], ad_, (half_off) + 8192)                         \
+  }
+#define T8_READ_B(fb, cur, half_off)                                                                     \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+    const int ad_ = (cur) ? qa[j] + T8_BUF : qa[j];                                                      \
+    T8_FRAG(fb[j][0], ad_, (half_off)) T8_FRAG(fb[j][1], ad_, (half_off) + 8192)                         \
+  }
+#define T8_TIE4(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1])
+#define T8_LGKM0                                                                                         \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                                    \
+               : T8_TIE4(fa), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), T8_TIE4(fbl), T8_TIE4(fbh));
+#define T8_MFMA(ibase, jbase, fb)                                                                        \
+  __builtin_amdgcn_s_barrier();                                                                          \
+  T8_LGKM0                                                                                               \
+  __builtin_amdgcn_s_setprio(1);                                                                         \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
+    acc[(ibase) + i][(jbase) + j] =                                                                      \
+        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                         \
+  __builtin_amdgcn_s_barrier();
+
+  // one K-tile held in buffer `cur`; U1 / k1: unit and K index of the K-tile after it (P_hi goes to `oth`),
+  // U2 / k2: of the one after that (P_lo, Q_lo, Q_hi re-stage `cur`)
+#define T8_KTILE(cur, oth, U1, k1, U2, k2)                                                               \
+  T8_READ_B(fbl, cur, T8_QLO)                                                                            \
+  T8_READ_A(cur, T8_PLO)                                                                                 \
+  T8_STAGE(pb, po0, po1, p_kstep, U1, k1, 1, (oth) + T8_PHI)                                      \
+  T8_MFMA(0, 0, fbl)                                                                                     \
+  T8_READ_B(fbh, cur, T8_QHI)                                                                            \
+  T8_STAGE(pb, po0, po1, p_kstep, U2, k2, 0, (cur) + T8_PLO)                                      \
+  T8_MFMA(0, 2, fbh)                                                                                     \
+  T8_READ_A(cur, T8_PHI)                                                                                 \
+  T8_STAGE(qb, qo0, qo1, q_kstep, U2, k2, 0, (cur) + T8_QLO)                                      \
+  T8_MFMA(4, 2, fbh)                                                                                     \
+  T8_STAGE(qb, qo0, qo1, q_kstep, U2, k2, 1, (cur) + T8_QHI)                                      \
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
+  T8_MFMA(4, 0, fbl)
+
+  int seq = blockIdx.x;
+  T8Unit U = make_unit(seq);
+  T8_STAGE(pb, po0, po1, p_kstep, U, 0, 0, T8_PLO)
+  T8_STAGE(qb, qo0, qo1, q_kstep, U, 0, 0, T8_QLO)
+  T8_STAGE(qb, qo0, qo1, q_kstep, U, 0, 1, T8_QHI)
+  T8_STAGE(pb, po0, po1, p_kstep, U, 0, 1, T8_PHI)
+  T8_STAGE(pb, po0, po1, p_kstep, U, 1, 0, T8_BUF + T8_PLO)
+  T8_STAGE(qb, qo0, qo1, q_kstep, U, 1, 0, T8_BUF + T8_QLO)
+  T8_STAGE(qb, qo0, qo1, q_kstep, U, 1, 1, T8_BUF + T8_QHI)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (; seq < units; seq += gridDim.x) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nk = U.nk;
+    for (int kt = 0; kt < nk - 2; kt += 2) {
+      T8_KTILE(0, T8_BUF, U, kt + 1, U, kt + 2)
+      T8_KTILE(T8_BUF, 0, U, kt + 2, U, kt + 3)
+    }
+    // last two K-tiles: the stream continues with K-tiles 0 / 1 of the next unit (or re-fetches this unit's last
+    // two K-tiles into dead buffers when there is none)
+    const bool has_next = seq + (int)gridDim.x < units;
+    const T8Unit Un = has_next ? make_unit(seq + gridDim.x) : U;
+    const int kn0 = has_next ? 0 : nk - 2, kn1 = has_next ? 1 : nk - 1;
+    T8_KTILE(0, T8_BUF, U, nk - 1, Un, kn0)
+    T8_KTILE(T8_BUF, 0, Un, kn0, Un, kn1)
+
+    // ---- epilogue: fp32 atomics; D rows n = 4 fq + r, columns kk = fr
+    int le = lane;
+    asm volatile("" : "+v"(le));                     // keeps the lane-derived addresses out of the K loop's live set
+    const int fre = le & 15, fqe = le >> 4;
+    float* const wt = g.W + (long long)(U.n0 + wr * 64 + fqe * 4) * g.ldw + U.k0 + wc * 32 + fre;
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * g.ldw + hb * 128 + j * 16, acc[ha * 4 + i][hb * 2 + j][r]);
+    U = Un;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
+  const ConvA& a = g.a;
+  const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
+                     a.Cv == a.Cg && a.bdiv == 1 && g.G == 1;
+  if (!plain || g.N % 256 || g.K % 256 || g.M < 2048) return false;
+  const int tiles = (g.N / 256) * (g.K / 256);
+  if (tiles < 32) return false;
+  static int cus = 0;
+  if (!cus) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&p, dev);
+    cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+    (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS);
+  }
+  const int nk_total = cdiv(g.M, 64);
+  int chunks = cus / tiles;
+  if (chunks < 1) chunks = 1;
+  int kpc = cdiv(nk_total, chunks);
+  kpc += kpc & 1;                                     // even number of K-tiles per chunk
+  if (kpc < 4) kpc = 4;
+  chunks = cdiv(nk_total, kpc);
+  const int units = tiles * chunks;
+  dim3 grid(units < cus ? units : cus, 1, 1);
+  hipLaunchKernelGGL(gemm_tn_bf16_p8_kernel, grid, dim3(512), T8_LDS, stream, g, chunks, kpc);
+  return true;
+}

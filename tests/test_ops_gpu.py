@@ -113,6 +113,28 @@ def test_linear_p8_kernel(ops, M, N, K):
         assert torch.equal(new[k], old[k]) or rel_err(new[k].float(), old[k].float()) < 1e-5, k
 
 
+@pytest.mark.parametrize("M,N,K", [(2100, 2048, 1024), (4096, 1024, 2048), (2048 + 64 * 3, 2048, 1024)])
+def test_linear_wgrad_p8_kernel(ops, M, N, K):
+    """256x256 TN weight-gradient kernel (N, K % 256 == 0, >= 32 tiles): ragged M (rows past M come from the zero
+    page), accumulation into a non-zero buffer, against fp32 torch and the 128x128 kernel (a2v_debug_set(4, 0))."""
+    from animal2vec_amd import _lib
+    dtype = torch.bfloat16
+    x, dy = rnd(M, K, dtype=dtype, seed=1), rnd(M, N, dtype=dtype, seed=2)
+    g0 = rnd(N, K, dtype=torch.float32, seed=3)
+    ref = g0 + dy.t() @ x
+    xd, dyd = dev(x, dtype), dev(dy, dtype)
+    gw = g0.clone().cuda()
+    ops.linear_wgrad(xd, dyd, gw)
+    _lib.load().a2v_debug_set(4, 0)
+    try:
+        gw_old = g0.clone().cuda()
+        ops.linear_wgrad(xd, dyd, gw_old)
+    finally:
+        _lib.load().a2v_debug_set(4, 1)
+    assert rel_err(gw, ref) < tol(dtype)
+    assert rel_err(gw, gw_old) < 1e-5
+
+
 # ------------------------------------------------------------------------------------------ convs
 def to_cl(x_bct, cp, dtype):
     B, C_, T = x_bct.shape
