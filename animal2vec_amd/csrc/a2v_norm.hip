@@ -113,6 +113,41 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 
 // Backward of y = act(LN(x)*gamma+beta).  dx; dgamma/dbeta and (optionally) column sums of dx are
 // accumulated with one atomic per column per workgroup (each lane owns fixed columns).
+// ----------------------------------------------------------------------------------------------
+// Column sums (dgamma / dbeta / bias gradients) leave every workgroup as atomics onto the SAME few KB: thousands of
+// workgroups adding into one row run ~14x below the chip's atomic rate (MI355X_MICROARCH.md, Global float
+// atomics).  For large grids workgroup b therefore adds into copy b % SPREAD of a library-owned, self-cleaning
+// scratch ([SPREAD][3][SPREAD_C] fp32) and a small second kernel folds the copies into the caller's destination
+// (one uncontended atomic per column) and zeroes them again.
+#define SPREAD 64
+#define SPREAD_C 4096
+static float* spread_ws(hipStream_t st) {
+  static float* ws = nullptr;
+  if (!ws) {
+    if (hipMalloc((void**)&ws, sizeof(float) * SPREAD * 3 * SPREAD_C) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(ws, 0, sizeof(float) * SPREAD * 3 * SPREAD_C, st);
+  }
+  return ws;
+}
+__global__ __launch_bounds__(256) void spread_fold_kernel(float* __restrict__ ws, float* __restrict__ d0,
+                                                          float* __restrict__ d1, float* __restrict__ d2, int C) {
+  const int which = blockIdx.y;
+  float* const dst = which == 0 ? d0 : (which == 1 ? d1 : d2);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (!dst || c >= C) return;
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < SPREAD; ++k) {
+    float* p = ws + ((long long)k * 3 + which) * SPREAD_C + c;
+    s += *p;
+    *p = 0.f;
+  }
+  atomicAdd(dst + c, s);
+}
+static void spread_fold(float* ws, float* d0, float* d1, float* d2, int C, hipStream_t st) {
+  hipLaunchKernelGGL(spread_fold_kernel, dim3((C + 255) / 256, 3), dim3(256), 0, st, ws, d0, d1, d2, C);
+}
+
 template <typename T, int NCH, int RPW>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ gamma,
@@ -122,7 +157,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const T* __restrict__ dres, float* __restrict__ dgamma,
                                                             float* __restrict__ dbeta, float* __restrict__ dxsum,
                                                             long long M, int C, long long ldx, long long lddy,
-                                                            int act, Drop drop, int drop_mode, T* __restrict__ dx_drop) {
+                                                            int act, Drop drop, int drop_mode, T* __restrict__ dx_drop,
+                                                            float* __restrict__ spread) {
   constexpr int rows_per_wave = RPW;
   // drop_mode 1: the forward applied dropout AFTER this LN (y = drop(act(LN x))): mask the incoming dy.
   // drop_mode 2: also emit dx_drop = dropout-masked dx (gradient of a branch x -> drop(f(x)) summed into this
@@ -205,6 +241,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     if (which < 2 && !dgamma) continue;
     if (which == 2 && !dxsum) continue;
     float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    if (spread) dst = spread + ((long long)(blockIdx.x % SPREAD) * 3 + which) * SPREAD_C;
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       __syncthreads();
@@ -280,21 +317,38 @@ __global__ __launch_bounds__(256) void instnorm_apply_kernel(PtrList layers, con
   }
 }
 
-// column sums: out[c] += sum_m x[m][c]
+// column sums: out[c] += sum_m x[m][c].  One workgroup = 512 columns x rows_per_block rows: every wave reads whole
+// 1-KiB row segments (16 B per lane), the four waves take interleaved rows; partial sums meet in LDS and leave as
+// one atomic per column into the workgroup's spread copy.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long long M,
-                                                     int C, long long ld, int rows_per_block) {
-  __shared__ float red[4][64];
+                                                     int C, long long ld, int rows_per_block, float* __restrict__ spread) {
+  constexpr int V = 16 / sizeof(T);                  // elements per lane
+  __shared__ float red[4][64 * V];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int c0 = (blockIdx.x * 64 + lane) * V;
   const long long m0 = (long long)blockIdx.y * rows_per_block;
   const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
-  float s = 0.f;
-  if (c < C)
-    for (long long m = m0 + wid; m < m1; m += 4) s += ldf(x + m * ld + c);
-  red[wid][lane] = s;
+  float s[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) s[i] = 0.f;
+  if (c0 < C) {
+    for (long long m = m0 + wid; m < m1; m += 4) {
+      float v[V];
+      if constexpr (V == 8) Vec8<T>::load(x + m * ld + c0, v);
+      else { const f32x4 q = *(const f32x4*)(x + m * ld + c0); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
+#pragma unroll
+      for (int i = 0; i < V; ++i) s[i] += v[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) red[wid][lane * V + i] = s[i];
   __syncthreads();
-  if (wid == 0 && c < C) atomicAdd(out + c, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
+  float* dst = spread ? spread + ((long long)((blockIdx.y * gridDim.x + blockIdx.x) % SPREAD) * 3) * SPREAD_C : out;
+  for (int k = threadIdx.x; k < 64 * V; k += 256) {
+    const int c = blockIdx.x * 64 * V + k;
+    if (c < C) atomicAdd(dst + c, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+  }
 }
 
 // =============================================================================================
@@ -345,13 +399,18 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
   const int nch = (C + 511) / 512;
   const int rpw = LN_ROWS_PER_WAVE;     // 4 was measured slower for short tensors (dgamma atomics dominate)
   dim3 grid((unsigned)((M + 4 * rpw - 1) / (4 * rpw))), blk(256);
+  float* spread = nullptr;
+  if (grid.x >= 16 * SPREAD && (dgamma || dxsum)) {     // short tensors: the fold launch costs more than the contention
+    spread = spread_ws(st);
+    if (!spread) return A2V_ERR_LAUNCH;
+  }
 #define LN_B(N)                                                                                                  \
   if (rpw == 4)                                                                                                  \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, 4>), grid, blk, 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, \
-                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, (T*)dx_drop); \
+                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, (T*)dx_drop, spread); \
   else                                                                                                           \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T, N, LN_ROWS_PER_WAVE>), grid, blk, 0, st, (const T*)dy, (const T*)x, gamma, beta, mean, \
-                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, (T*)dx_drop)
+                     rstd, (T*)dx, (const T*)dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop, drop_mode, (T*)dx_drop, spread)
   switch (nch) {
     case 1: LN_B(1); break;
     case 2: LN_B(2); break;
@@ -360,6 +419,7 @@ static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, cons
     default: return A2V_ERR_ARG;
   }
 #undef LN_B
+  if (spread) spread_fold(spread, dgamma, dbeta, dxsum, C, st);
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }
@@ -402,15 +462,21 @@ extern "C" int a2v_instnorm_targets(int dtype, const void* const* layers, int L,
 }
 
 extern "C" int a2v_colsum(int dtype, const void* x, float* out, long long M, int C, long long ld, hipStream_t stream) {
-  if (M <= 0 || C <= 0) return A2V_ERR_ARG;
-  int rows = 512;
-  dim3 grid((C + 63) / 64, (unsigned)((M + rows - 1) / rows)), blk(256);
+  if (dtype != A2V_BF16 && dtype != A2V_F32) return A2V_ERR_DTYPE;
+  const int V = dtype == A2V_BF16 ? 8 : 4;
+  if (M <= 0 || C <= 0 || C > SPREAD_C || C % V || ld % V || (((uintptr_t)x) & 15)) return A2V_ERR_ARG;
+  const int rows = 256;
+  dim3 grid((C + 64 * V - 1) / (64 * V), (unsigned)((M + rows - 1) / rows)), blk(256);
+  float* spread = nullptr;
+  if ((long long)grid.x * grid.y >= 2 * SPREAD) {
+    spread = spread_ws(stream);
+    if (!spread) return A2V_ERR_LAUNCH;
+  }
   if (dtype == A2V_BF16)
-    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, stream, (const bf16*)x, out, M, C, ld, rows);
-  else if (dtype == A2V_F32)
-    hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, stream, (const float*)x, out, M, C, ld, rows);
+    hipLaunchKernelGGL(colsum_kernel<bf16>, grid, blk, 0, stream, (const bf16*)x, out, M, C, ld, rows, spread);
   else
-    return A2V_ERR_DTYPE;
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, blk, 0, stream, (const float*)x, out, M, C, ld, rows, spread);
+  if (spread) spread_fold(spread, out, nullptr, nullptr, C, stream);
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }
