@@ -825,6 +825,241 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
   return A2V_ERR_DTYPE;
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, HD = 64, S <= 192: the whole (n, h) sequence is resident.  Q and dO (all S rows, zero padded to 192) sit in
+// LDS once, each as ONE image that serves both the row reads (S, dP) and the transposed reads (dK^T, dV^T):
+// 16-B chunks XOR-swizzled by (row & 7).  Per key block only the K tile for dQ is staged; inside the query loop
+// there is no global load and one barrier per (key block, query tile) step (dS double buffered), where the tiled
+// kernel above re-staged Q / dO for every key block and sat in s_waitcnt / s_barrier for 61 % of its cycles.
+// delta = rowsum(dO * O) is computed here too (no separate pass).
+__device__ __forceinline__ int dual_off(int r, int chunk) { return r * 128 + ((chunk ^ (r & 7)) << 4); }   // [rows][64] bf16
+
+#define ABS_ROWS 192
+#define ABS_LDS (2 * ABS_ROWS * 128 + 64 * 128 + 2 * 64 * 128 + 3 * ABS_ROWS * 4)
+
+template <bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, const bf16* __restrict__ o_fwd) {
+  constexpr int HD = 64, ND = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sQ = smem;                                   // [192][64] dual-use image
+  char* const sDO = sQ + ABS_ROWS * 128;
+  char* const sKt = sDO + ABS_ROWS * 128;                  // [64][64] tr image of the current key block
+  char* const sDS = sKt + 64 * 128;                        // 2 x [64 q][64 kv] row image
+  float* const sLse = (float*)(sDS + 2 * 64 * 128);
+  float* const sDelta = sLse + ABS_ROWS;
+  float* const sPosQ = sDelta + ABS_ROWS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const long long orow = (long long)H * HD;
+  const bf16* qkv = (const bf16*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  const bf16* dO = (const bf16*)a.d_out + (long long)n * S * orow + (long long)h * HD;
+  const bf16* Of = o_fwd + (long long)n * S * orow + (long long)h * HD;
+  const float slope = a.slopes[h];
+  const float asc = a.alibi_scale[h];
+  const float coef = -slope * fmaxf(asc, 0.f);
+
+  // ---- stage Q and dO (zero padded), delta, lse, pos
+  {
+    uint4 qz[ABS_ROWS * 8 / 256], dz[ABS_ROWS * 8 / 256];      // all 12 loads in flight before the first LDS write
+#pragma unroll
+    for (int u = 0; u < ABS_ROWS * 8 / 256; ++u) {
+      const int c = tid + 256 * u, r = c >> 3, ch = c & 7;
+      qz[u] = make_uint4(0u, 0u, 0u, 0u);
+      dz[u] = qz[u];
+      if (r < S) {
+        qz[u] = *(const uint4*)(qkv + (long long)r * rowstride + ch * 8);
+        dz[u] = *(const uint4*)(dO + (long long)r * orow + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ABS_ROWS * 8 / 256; ++u) {
+      const int c = tid + 256 * u, r = c >> 3, ch = c & 7;
+      *(uint4*)(sQ + dual_off(r, ch)) = qz[u];
+      *(uint4*)(sDO + dual_off(r, ch)) = dz[u];
+    }
+  }
+  if (tid < ABS_ROWS) {
+    const bool ok = tid < S;
+    float dl = 0.f;
+    if (ok) {
+#pragma unroll
+      for (int d = 0; d < HD; d += 8) {
+        float x[8], y[8];
+        Vec8<bf16>::load(Of + (long long)tid * orow + d, x);
+        Vec8<bf16>::load(dO + (long long)tid * orow + d, y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dl += x[i] * y[i];
+      }
+    }
+    sDelta[tid] = dl;
+    sLse[tid] = ok ? a.lse[((long long)n * H + h) * S + tid] : INFINITY;     // exp(x - inf) = 0: padded queries vanish
+    sPosQ[tid] = ok ? (a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid) : 0.f;
+  }
+
+  f32x4 dq0[ND], dq1[ND], dq2[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) { dq0[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq1[i] = dq0[i]; dq2[i] = dq0[i]; }
+  float dal = 0.f;
+  const int ntile = (S + 63) / 64;
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+
+#pragma unroll 1
+  for (int kb = 0; kb < ntile; ++kb) {
+    const int kv0 = kb * 64;
+    const int kv = kv0 + wid * 16 + fr;            // this lane's key column
+    const int kvc = kv < S ? kv : S - 1;
+    const bool kv_ok = kv < S;
+    const float pos_kv = a.pos ? (float)a.pos[(long long)n * S + kvc] : (float)kvc;
+    bf16x8 kf_b[2], vf_b[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf_b[ks] = *(const bf16x8*)(qkv + (long long)kvc * rowstride + (long long)H * HD + ks * 32 + g * 8);
+      vf_b[ks] = *(const bf16x8*)(qkv + (long long)kvc * rowstride + 2LL * H * HD + ks * 32 + g * 8);
+    }
+    __syncthreads();                               // previous key block's dQ products are done with sKt
+    for (int c = tid; c < 64 * 8; c += 256) {
+      const int r = c >> 3, ch = c & 7;
+      uint4 kz = {0u, 0u, 0u, 0u};
+      if (kv0 + r < S) kz = *(const uint4*)(qkv + (long long)(kv0 + r) * rowstride + (long long)H * HD + ch * 8);
+      *(uint4*)(sKt + trimg_off<HD>(r, ch * 8)) = kz;
+    }
+    __syncthreads();                               // (first pass: also publishes Q / dO / delta / lse / pos)
+
+    f32x4 dk[ND], dv[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll 1
+    for (int qt = 0; qt < ntile; ++qt) {
+      const int q0 = qt * 64;
+      char* const dsb = sDS + (qt & 1) * (64 * 128);
+      // ---- S, P, dP, dS for the 4 query sub-blocks; rows q = q0 + 16i + 4g + r, col kv = fr
+      // only 16-row query sub-blocks below S and key columns below S do work (S = 140: the third tile holds 12 rows)
+      const int ni = min(4, (S - q0 + 15) >> 4);
+      const bool wave_has_keys = kv0 + wid * 16 < S;         // wave-uniform
+      f32x4 p[4], ds[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        p[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        ds[i] = p[i];
+        if (i >= ni || !wave_has_keys) continue;
+        f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 qa = *(const bf16x8*)(sQ + dual_off(q0 + 16 * i + fr, ks * 4 + g));
+          const bf16x8 da = *(const bf16x8*)(sDO + dual_off(q0 + 16 * i + fr, ks * 4 + g));
+          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf_b[ks], sacc, 0, 0, 0);
+          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf_b[ks], pacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = q0 + 16 * i + 4 * g + r;
+          const float dist = fabsf(sPosQ[ql] - pos_kv);
+          const float sc = sacc[r] * a.scale + coef * dist;
+          const float pv = kv_ok ? __expf(sc - sLse[ql]) : 0.f;
+          float pdrop = pv, dpe = pacc[r];
+          if (DROP) {                                // same mask as the forward
+            const int qg = ql < S ? ql : S - 1;
+            const unsigned long long idx = (((unsigned long long)n * H + h) * S + qg) * (unsigned long long)S + kvc;
+            pdrop = drop_apply(a.drop, idx, pv);
+            dpe = drop_apply(a.drop, idx, pacc[r]);
+          }
+          const float dsv = pv * (dpe - sDelta[ql]);
+          p[i][r] = pdrop;
+          ds[i][r] = dsv;
+          dal -= dsv * dist;
+        }
+      }
+      // ---- dS -> LDS (for dQ), as [q][kv]
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ql = 16 * i + 4 * g + r;
+          const int col = wid * 16 + fr;
+          *(bf16*)(dsb + ql * 128 + ((((col >> 3) ^ ((ql >> 1) & 7)) & 7) << 4) + ((col & 7) << 1)) = (bf16)ds[i][r];
+        }
+      // ---- dV^T += dO^T P ; dK^T += Q^T dS      (k = q, permuted order shared by both operands)
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        if (2 * st >= ni || !wave_has_keys) continue;
+        bf16x8 pf, df;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[r] = (bf16)p[2 * st][r]; pf[4 + r] = (bf16)p[2 * st + 1][r];
+          df[r] = (bf16)ds[2 * st][r]; df[4 + r] = (bf16)ds[2 * st + 1][r];
+        }
+        const int r_lo = q0 + 32 * st + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const int chl = 2 * i + (pp >> 1), sub = (pp & 1) << 3;       // column 16 i + 4 pp: chunk, byte inside it
+          const bf16x8 dof = tr_frag(sDO + dual_off(r_lo, chl) + sub, sDO + dual_off(r_hi, chl) + sub);
+          const bf16x8 qf = tr_frag(sQ + dual_off(r_lo, chl) + sub, sQ + dual_off(r_hi, chl) + sub);
+          dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[i], 0, 0, 0);
+          dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, df, dk[i], 0, 0, 0);
+        }
+      }
+      __syncthreads();   // dS tile complete (and the other dS buffer's readers of step - 1 are past)
+
+      // ---- dQ[q rows q0 + 16 wid ..][d] += dS K : A = dS rows, B = K (k = kv, col = d)
+      f32x4 dq[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dq[i][r] = qt == 0 ? dq0[i][r] : (qt == 1 ? dq1[i][r] : dq2[i][r]);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (q0 + wid * 16 >= S || kv0 + 32 * ks >= S) continue;     // no valid query rows in this wave / no keys in this half
+        const int rq = wid * 16 + fr;
+        const int ch = ks * 4 + g;
+        const bf16x8 af = *(const bf16x8*)(dsb + rq * 128 + (((ch ^ ((rq >> 1) & 7)) & 7) << 4));
+        const int r_lo = 32 * ks + 8 * g + qq, r_hi = r_lo + 4;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          const bf16x8 kf = tr_frag(sKt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sKt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+          dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, dq[i], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dq0[i][r] = qt == 0 ? dq[i][r] : dq0[i][r];
+          dq1[i][r] = qt == 1 ? dq[i][r] : dq1[i][r];
+          dq2[i][r] = qt == 2 ? dq[i][r] : dq2[i][r];
+        }
+    }
+    // ---- dK, dV of this key block: D rows d = 16i+4g+r, col kv = fr
+    if (kv_ok) {
+      bf16* dkv = (bf16*)a.dqkv + ((long long)n * S + kv) * rowstride + (long long)h * HD;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        f32x4 kk = dk[i] * a.scale;
+        Vec4<bf16>::store(dkv + (long long)H * HD + 16 * i + 4 * g, kk);
+        Vec4<bf16>::store(dkv + 2LL * H * HD + 16 * i + 4 * g, dv[i]);
+      }
+    }
+  }
+  // ---- dQ into the q slot of dqkv: rows q = 64 t + 16 wid + 4g + r, col d = 16i + fr
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq2 = t * 64 + wid * 16 + 4 * g + r;
+      if (qq2 < S) {
+        bf16* dst = (bf16*)a.dqkv + ((long long)n * S + qq2) * rowstride + (long long)h * HD;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dst[16 * i + fr] = (bf16)((t == 0 ? dq0[i][r] : (t == 1 ? dq1[i][r] : dq2[i][r])) * a.scale);
+      }
+    }
+  dal = wave_sum(dal);
+  if (lane == 0 && a.dalibi && asc >= 0.f) atomicAdd(a.dalibi + h, dal * slope);
+}
+
 #define A2V_ATTN_SEQ_TILES 3      // sequences up to 192 tokens take the atomic-free whole-sequence backward (bf16)
 
 template <typename T, int HD>
@@ -832,10 +1067,23 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
   const long long total = (long long)a.N * a.S * a.H;
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3(g), dim3(256), 0, st, (const T*)out, (const T*)a.d_out, delta, a.N, a.S, a.H);
   constexpr bool BF = std::is_same<T, bf16>::value;
+  const bool seq64 = BF && HD == 64 && a.S <= ABS_ROWS;       // attn_bwd_seq_kernel forms delta itself
+  if (!seq64)
+    hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3(g), dim3(256), 0, st, (const T*)out, (const T*)a.d_out, delta, a.N, a.S, a.H);
   constexpr int TILE = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
   constexpr int LDS = (BF ? 5 : 3) * TILE + (BF ? 64 * 64 * 2 : 64 * 68 * 4) + 3 * 64 * 4;
+  if constexpr (BF && HD == 64) {
+    if (a.S <= ABS_ROWS) {
+      const bool dr = a.drop.thresh != 0;
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ABS_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ABS_LDS);
+      if (dr) hipLaunchKernelGGL((attn_bwd_seq_kernel<true>), dim3(1, a.H, a.N), dim3(256), ABS_LDS, st, a, (const bf16*)out);
+      else hipLaunchKernelGGL((attn_bwd_seq_kernel<false>), dim3(1, a.H, a.N), dim3(256), ABS_LDS, st, a, (const bf16*)out);
+      A2V_CHECK_LAUNCH();
+      return A2V_OK;
+    }
+  }
   if (BF && a.S <= 64 * A2V_ATTN_SEQ_TILES) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD, BF ? A2V_ATTN_SEQ_TILES : 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     hipLaunchKernelGGL((attn_bwd_kernel<T, HD, BF ? A2V_ATTN_SEQ_TILES : 0>), dim3(1, a.H, a.N), dim3(256), LDS, st, a);
