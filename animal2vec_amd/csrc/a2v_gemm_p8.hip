@@ -42,12 +42,17 @@ struct P8Tile {      // byte offsets (from the A / B base of the group) of the 1
   int m0, n0;
 };
 
+// IH = 16-row MFMA tiles per wave in the upper A half: the workgroup tile is BM = 128 + 32 IH rows (256 / 224 / 192).
+// M = 13440 (96 clips x 140 kept frames) is 60 x 224: with BM = 224 the student's Linears fill 240 of 256 CUs per
+// round with no M tail, 12.5 % less work per round than 53 ragged 256-row tiles.
+template <int IH>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
+  constexpr int BM = 128 + 32 * IH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
   const int tiles_n = g.N / 256;
-  const int tiles_m = (g.M + 255) / 256;
+  const int tiles_m = (g.M + BM - 1) / BM;
   const int ntiles = tiles_m * tiles_n;
   const int grp = blockIdx.y;
   const ConvA& a = g.a;
@@ -62,42 +67,47 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
     const int id = xcd_remap(seq < ntiles ? seq : ntiles - 1, ntiles);
     int tm, tn;
     tile_coords(id, tiles_m, tiles_n, tm, tn);
-    t.m0 = tm * 256;
+    t.m0 = tm * BM;
     t.n0 = tn * 256;
     unsigned ao[4], bo[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {          // q = half * 2 + i: rows half*128 + (wid + 8 i) * 8 + lr
-      const int slab = wid + 8 * (q & 1);
+      int slab = wid + 8 * (q & 1);
+      if ((q >> 1) && slab >= IH * 4) slab = wid & 3;     // short upper half: the spare DMA re-fetches a slab in place
       int m = t.m0 + (q >> 1) * 128 + slab * 8 + lr;
       m = m < g.M ? m : g.M - 1;
       const int b = m / a.T_out, tt = m - b * a.T_out;
       ao[q] = (unsigned)(((long long)(b / a.bdiv) * a.bstride + (long long)tt * a.pitch + P8_SRC_CHUNK(slab) * 8) * 2);
-      const int n = t.n0 + (q >> 1) * 128 + slab * 8 + lr;
-      bo[q] = (unsigned)(((long long)n * g.ldb + P8_SRC_CHUNK(slab) * 8) * 2);
+      const int bslab = wid + 8 * (q & 1);            // B halves are always 128 rows
+      const int n = t.n0 + (q >> 1) * 128 + bslab * 8 + lr;
+      bo[q] = (unsigned)(((long long)n * g.ldb + P8_SRC_CHUNK(bslab) * 8) * 2);
     }
     t.al0 = ao[0]; t.al1 = ao[1]; t.ah0 = ao[2]; t.ah1 = ao[3];
     t.bl0 = bo[0]; t.bl1 = bo[1]; t.bh0 = bo[2]; t.bh1 = bo[3];
     return t;
   };
   char* const dst0 = smem + wid * 1024;            // + buffer + half offset (+ 8192 for the second slab)
+  const int ah_second = (wid + 8 < IH * 4) ? 8192 : ((wid & 3) - wid) * 1024;   // A_hi: second DMA's slab relative to dst0
 
   const int nk = g.K / 64;
   // stage one half-tile: 2 LDS-DMA per thread
-#define P8_STAGE(base, o0, o1, kt, lds_off)                    \
+#define P8_STAGE2(base, o0, o1, kt, lds_off, second)            \
   {                                                            \
     const unsigned ko_ = (unsigned)(kt) * 128u;                \
     p8_glds16(base + (o0 + ko_), dst0 + (lds_off));            \
-    p8_glds16(base + (o1 + ko_), dst0 + (lds_off) + 8192);     \
+    p8_glds16(base + (o1 + ko_), dst0 + (lds_off) + (second)); \
   }
+#define P8_STAGE(base, o0, o1, kt, lds_off) P8_STAGE2(base, o0, o1, kt, lds_off, 8192)
 
   // ---- fragment read addresses (byte offsets inside a half-tile), ks = 0; ks = 1 flips chunk bit 2 (^ 64 B)
   const int fr = lane & 15, fq = lane >> 4;
   const int sw = (fr >> 1) & 7;                       // (row >> 1) & 7 for rows base*16 + fr
   const int lds0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem[0]
   const int a_off = lds0 + (wr * 64 + fr) * 128 + ((fq ^ sw) << 4);       // + i * 2048
+  const int ah_off = lds0 + (wr * IH * 16 + fr) * 128 + ((fq ^ sw) << 4);  // upper half: IH row tiles per wave
   const int b_off = lds0 + (wc * 32 + fr) * 128 + ((fq ^ sw) << 4);       // + j * 2048
 
-  f32x4 acc[8][4];
+  f32x4 acc[4 + IH][4];
   bf16x8 fa[4][2], fbl[2][2], fbh[2][2];
 
 // Fragment reads are inline asm: hipcc orders a C++ LDS load after every LDS-DMA it cannot prove disjoint with an
@@ -113,6 +123,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
     P8_DSR(fa[2][0], a0_, (half_off) + 4096); P8_DSR(fa[2][1], a1_, (half_off) + 4096);                \
     P8_DSR(fa[3][0], a0_, (half_off) + 6144); P8_DSR(fa[3][1], a1_, (half_off) + 6144);                \
   }
+#define P8_READ_AH(cur)                                                                                 \
+  {                                                                                                    \
+    const int a0_ = (cur) ? ah_off + P8_BUF : ah_off, a1_ = (cur) ? (ah_off ^ 64) + P8_BUF : (ah_off ^ 64); \
+    P8_DSR(fa[0][0], a0_, P8_AHI); P8_DSR(fa[0][1], a1_, P8_AHI);                                      \
+    P8_DSR(fa[1][0], a0_, P8_AHI + 2048); P8_DSR(fa[1][1], a1_, P8_AHI + 2048);                        \
+    if (IH > 2) { P8_DSR(fa[2][0], a0_, P8_AHI + 4096); P8_DSR(fa[2][1], a1_, P8_AHI + 4096); }        \
+    if (IH > 3) { P8_DSR(fa[3][0], a0_, P8_AHI + 6144); P8_DSR(fa[3][1], a1_, P8_AHI + 6144); }        \
+  }
 #define P8_READ_B(fb, cur, half_off)                                                                   \
   {                                                                                                    \
     const int b0_ = (cur) ? b_off + P8_BUF : b_off, b1_ = (cur) ? (b_off ^ 64) + P8_BUF : (b_off ^ 64); \
@@ -123,12 +141,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
 #define P8_LGKM0                                                                                        \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                  \
                : P8_TIE4(fa), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), P8_TIE4(fbl), P8_TIE4(fbh));
-#define P8_MFMA(ibase, jbase, fb)                                                                      \
+#define P8_MFMA(ibase, jbase, fb, NI)                                                                  \
   __builtin_amdgcn_s_barrier();                                                                        \
   P8_LGKM0                                                                                             \
   __builtin_amdgcn_s_setprio(1);                                                                       \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+  _Pragma("unroll") for (int i = 0; i < (NI); ++i)                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
     acc[(ibase) + i][(jbase) + j] =                                                                    \
         __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
@@ -142,20 +160,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
   P8_READ_B(fbl, cur, P8_BLO)                                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                                   \
   P8_READ_A(cur, P8_ALO)                                                                               \
-  P8_STAGE(abase, T1.ah0, T1.ah1, k1, (oth) + P8_AHI)                                                  \
-  P8_MFMA(0, 0, fbl)                                                                                   \
+  P8_STAGE2(abase, T1.ah0, T1.ah1, k1, (oth) + P8_AHI, ah_second)                                      \
+  P8_MFMA(0, 0, fbl, 4)                                                                                  \
   /* phase 2: lo/hi */                                                                                 \
   P8_READ_B(fbh, cur, P8_BHI)                                                                          \
   P8_STAGE(abase, T2.al0, T2.al1, k2, (cur) + P8_ALO)                                                  \
-  P8_MFMA(0, 2, fbh)                                                                                   \
+  P8_MFMA(0, 2, fbh, 4)                                                                                  \
   /* phase 3: hi/hi */                                                                                 \
-  P8_READ_A(cur, P8_AHI)                                                                               \
+  P8_READ_AH(cur)                                                                                      \
   P8_STAGE(bbase, T2.bl0, T2.bl1, k2, (cur) + P8_BLO)                                                  \
-  P8_MFMA(4, 2, fbh)                                                                                   \
+  P8_MFMA(4, 2, fbh, IH)                                                                                  \
   /* phase 4: hi/lo (B_lo fragments kept from phase 1) */                                              \
   P8_STAGE(bbase, T2.bh0, T2.bh1, k2, (cur) + P8_BHI)                                                  \
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                     \
-  P8_MFMA(4, 0, fbl)
+  P8_MFMA(4, 0, fbl, IH)
 
   int seq = blockIdx.x;
   P8Tile T = make_tile(seq);
@@ -163,7 +181,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
   P8_STAGE(abase, T.al0, T.al1, 0, P8_ALO)
   P8_STAGE(bbase, T.bl0, T.bl1, 0, P8_BLO)
   P8_STAGE(bbase, T.bh0, T.bh1, 0, P8_BHI)
-  P8_STAGE(abase, T.ah0, T.ah1, 0, P8_AHI)
+  P8_STAGE2(abase, T.ah0, T.ah1, 0, P8_AHI, ah_second)
   P8_STAGE(abase, T.al0, T.al1, 1, P8_BUF + P8_ALO)
   P8_STAGE(bbase, T.bl0, T.bl1, 1, P8_BUF + P8_BLO)
   P8_STAGE(bbase, T.bh0, T.bh1, 1, P8_BUF + P8_BHI)
@@ -174,7 +192,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
     // (at the end of the list the "next tile" is this tile again: harmless re-fetches of valid data into dead
     // buffers keep the vmcnt accounting uniform)
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4 + IH; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -215,15 +233,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
 #define P8_RLOAD(ps_, slot)                                                                           \
   if (need_r) {                                                                                       \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                \
-      int m_ = T.m0 + ((ps_) >> 2) * 128 + wr * 64 + ((ps_) & 3) * 16 + it * 4 + fqe;                 \
+      int m_ = T.m0 + ((ps_) < 4 ? wr * 64 + (ps_) * 16 : 128 + wr * IH * 16 + ((ps_) - 4) * 16) + it * 4 + fqe; \
       m_ = m_ < g.M ? m_ : g.M - 1;                                                                   \
       rq[slot][it] = *(const uint2*)(R + (long long)m_ * g.ldr + ccol);                               \
     }                                                                                                 \
   }
     P8_RLOAD(0, 0)
 #pragma unroll
-    for (int ps = 0; ps < 8; ++ps) {   // fully unrolled: a rolled loop turns acc[ps] into a scalar branch tree per value
-      if (ps < 7) P8_RLOAD(ps + 1, (ps + 1) & 1)
+    for (int ps = 0; ps < 4 + IH; ++ps) {   // fully unrolled: a rolled loop turns acc[ps] into a scalar branch tree per value
+      if (ps < 3 + IH) P8_RLOAD(ps + 1, (ps + 1) & 1)
       // stage[row][col ^ 16*((row >> 2) & 1)]: 2-way (= minimum) on the 4-B writes, conflict-free 16-B reads
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -235,7 +253,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const int mrow0 = T.m0 + (ps >> 2) * 128 + wr * 64 + (ps & 3) * 16;
+      const int mrow0 = T.m0 + (ps < 4 ? wr * 64 + ps * 16 : 128 + wr * IH * 16 + (ps - 4) * 16);
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         const int r = it * 4 + fqe;
@@ -293,6 +311,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
 }
 
+int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
   const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
@@ -309,10 +328,25 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     (void)hipGetDeviceProperties(&p, dev);
     cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
   }
-  const int ntiles = cdiv(g.M, 256) * (g.N / 256);
+  // tile height: rounds x rows per round is what one CU executes; ties go to the taller tile
+  int best_ih = 4;
+  long long best = -1;
+  for (int ih = 4; ih >= 2; --ih) {
+    if (g_a2v_p8_ih && ih != g_a2v_p8_ih) continue;
+    const int bm = 128 + 32 * ih;
+    const long long nt = (long long)cdiv(g.M, bm) * (g.N / 256);
+    const long long cost = (long long)cdiv(nt, cus) * bm;
+    if (best < 0 || cost < best) { best = cost; best_ih = ih; }
+  }
+  const int bm = 128 + 32 * best_ih;
+  const int ntiles = cdiv(g.M, bm) * (g.N / 256);
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
-  hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel, grid, dim3(512), P8_LDS, stream, g);
+  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g);
+  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g);
+  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g);
   return true;
 }

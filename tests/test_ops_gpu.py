@@ -74,8 +74,9 @@ def test_linear_epilogues(ops, dtype):
     assert rel_err(cs, y.float().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("ih", [0, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(1100, 512, 256), (1024, 256, 384), (2049, 768, 1024)])
-def test_linear_p8_kernel(ops, M, N, K):
+def test_linear_p8_kernel(ops, M, N, K, ih):
     """Shapes eligible for the 256x256 8-phase bf16 kernel (N % 256 == 0, K % 128 == 0, M >= 1024): M tails,
     every epilogue, against fp32 torch and against the 128x128 kernel (a2v_debug_set(1, 0))."""
     from animal2vec_amd import _lib
@@ -99,7 +100,11 @@ def test_linear_p8_kernel(ops, M, N, K):
         out["drop"] = ops.linear(xd, wd, bd, res=rd, drop=(0.25, 99))
         return out
 
-    new = run_all()
+    _lib.load().a2v_debug_set(5, ih)          # tile height 192 / 224 / 256 rows, 0 = the launcher's choice
+    try:
+        new = run_all()
+    finally:
+        _lib.load().a2v_debug_set(5, 0)
     _lib.load().a2v_debug_set(1, 0)
     try:
         old = run_all()
