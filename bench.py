@@ -248,8 +248,8 @@ def main():
         finally:
             rec.unwrap(ops)
         nt = s["nt"]
-        traffic, traffic_src = pmc_traffic("gemm_nt_bf16_glds_kernel") if dtype == torch.bfloat16 else (None, None)
-        roof = dict(bound="mfma", kernel="gemm_nt_bf16_glds_kernel<*> (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
+        traffic, traffic_src = pmc_traffic("gemm_nt_bf16_p8_kernel") if dtype == torch.bfloat16 else (None, None)
+        roof = dict(bound="mfma", kernel="gemm_nt_bf16_p8_kernel<*> + conv_nt_slab_kernel (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
                     achieved=round(nt["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (HBM+MALL, PMC)",
                     traffic_source=traffic_src, algorithmic_bytes_per_launch=round(nt["alg_bytes"]),
