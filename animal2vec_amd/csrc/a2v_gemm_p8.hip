@@ -46,7 +46,7 @@ struct P8Tile {      // byte offsets (from the A / B base of the group) of the 1
 // M = 13440 (96 clips x 140 kept frames) is 60 x 224: with BM = 224 the student's Linears fill 240 of 256 CUs per
 // round with no M tail, 12.5 % less work per round than 53 ragged 256-row tiles.
 template <int IH>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger) {
   constexpr int BM = 128 + 32 * IH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                  \
                : P8_TIE4(fa), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), P8_TIE4(fbl), P8_TIE4(fbh));
 #define P8_MFMA(ibase, jbase, fb, NI)                                                                  \
+  P8_LGKM0            /* before the barrier: the other wave group may re-stage what was just read one phase later */ \
   __builtin_amdgcn_s_barrier();                                                                        \
-  P8_LGKM0                                                                                             \
   __builtin_amdgcn_s_setprio(1);                                                                       \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
   _Pragma("unroll") for (int i = 0; i < (NI); ++i)                                                     \
@@ -187,6 +187,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
   P8_STAGE(bbase, T.bh0, T.bh1, 1, P8_BUF + P8_BHI)
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  // The two waves that share a SIMD (w and w + 4, i.e. wr = 0 / 1) run half a phase apart from here on: one extra
+  // barrier for the wr = 1 group pairs its "reads done" barrier with the other group's "MFMAs done" barrier, so one
+  // wave of a SIMD issues LDS reads / DMA while the other owns the MFMA pipe (in lock step both queue for it at once).
+  if (stagger && wr == 1) __builtin_amdgcn_s_barrier();
 
   for (; seq < ntiles; seq += gridDim.x) {
     // (at the end of the list the "next tile" is this tile again: harmless re-fetches of valid data into dead
@@ -308,9 +312,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g) {
 #undef P8_RLOAD
     T = Tn;
   }
+  if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
 }
 
+int g_a2v_p8_stagger = 1;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
@@ -344,9 +350,12 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   }
   const int bm = 128 + 32 * best_ih;
   const int ntiles = cdiv(g.M, bm) * (g.N / 256);
+  // measured: staggering the wave groups pays for long K loops (K = 4096: +5..9 %, 8192^3: 1379 -> 1538 TFLOP/s) and
+  // costs a few per cent at K = 1024, where the epilogue dominates (g_a2v_p8_stagger: 0 off, 1 by shape, 2 always)
+  const int stagger = g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048);
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
-  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g);
-  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g);
-  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g);
+  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g, stagger);
+  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g, stagger);
+  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g, stagger);
   return true;
 }

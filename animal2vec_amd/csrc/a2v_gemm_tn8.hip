@@ -33,7 +33,7 @@ struct T8Unit {       // wave-uniform description of a work unit (the per-thread
   int mbeg;           // first row of the unit
 };
 
-__global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int chunks, int kt_per_chunk) {
+__global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int chunks, int kt_per_chunk, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
@@ -125,8 +125,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                    \
                : T8_TIE4(fa), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), T8_TIE4(fbl), T8_TIE4(fbh));
 #define T8_MFMA(ibase, jbase, fb)                                                                        \
+  T8_LGKM0            /* before the barrier: the other wave group may re-stage what was just read one phase later */ \
   __builtin_amdgcn_s_barrier();                                                                          \
-  T8_LGKM0                                                                                               \
   __builtin_amdgcn_s_setprio(1);                                                                         \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
   T8_STAGE(qb, qo0, qo1, q_kstep, U, 1, 1, T8_BUF + T8_QHI)
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (stagger && wr == 1) __builtin_amdgcn_s_barrier();         // wave groups half a phase apart (see a2v_gemm_p8.hip)
 
   for (; seq < units; seq += gridDim.x) {
 #pragma unroll
@@ -201,9 +202,11 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
               atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * g.ldw + hb * 128 + j * 16, acc[ha * 4 + i][hb * 2 + j][r]);
     U = Un;
   }
+  if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+extern int g_a2v_p8_stagger;
 bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
   const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
@@ -229,6 +232,6 @@ bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
   chunks = cdiv(nk_total, kpc);
   const int units = tiles * chunks;
   dim3 grid(units < cus ? units : cus, 1, 1);
-  hipLaunchKernelGGL(gemm_tn_bf16_p8_kernel, grid, dim3(512), T8_LDS, stream, g, chunks, kpc);
+  hipLaunchKernelGGL(gemm_tn_bf16_p8_kernel, grid, dim3(512), T8_LDS, stream, g, chunks, kpc, g_a2v_p8_stagger == 2 ? 1 : 0);
   return true;
 }

@@ -187,6 +187,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--debug-set", action="append", default=[], help="key=value for a2v_debug_set (A/B experiments)")
     ap.add_argument("--gemm-table", default=None, help="dump per-shape GEMM timings (json) from the roofline leg")
     args = ap.parse_args()
 
@@ -195,6 +196,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local)
+    if args.debug_set:
+        from animal2vec_amd import _lib
+        for kv in args.debug_set:
+            k, v = kv.split("=")
+            _lib.load().a2v_debug_set(int(k), int(v))
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
