@@ -87,10 +87,20 @@ template <> struct Vec8<float> {
   }
 };
 
+// 64-lane sum, result in every lane.  DPP adds inside the 16-lane rows (quad_perm, row_half_mirror, row_mirror), then
+// row_bcast15 / row_bcast31 carry the row sums up to lane 63, which is broadcast through an SGPR: six VALU ops and
+// one v_readlane instead of six dependent ds_bpermute round trips through the LDS crossbar.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+#define A2V_DPP_ADD(ctrl, rmask, bctrl) \
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, bctrl))
+  A2V_DPP_ADD(0xB1, 0xF, true);     // quad_perm [1,0,3,2]
+  A2V_DPP_ADD(0x4E, 0xF, true);     // quad_perm [2,3,0,1]
+  A2V_DPP_ADD(0x141, 0xF, true);    // row_half_mirror
+  A2V_DPP_ADD(0x140, 0xF, true);    // row_mirror: every lane of a row holds the row sum
+  A2V_DPP_ADD(0x142, 0xA, false);   // row_bcast15 into rows 1 and 3
+  A2V_DPP_ADD(0x143, 0xC, false);   // row_bcast31 into rows 2 and 3: lane 63 holds the total
+#undef A2V_DPP_ADD
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
