@@ -102,6 +102,27 @@ __device__ __forceinline__ float wave_sum(float v) {
 #undef A2V_DPP_ADD
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// raw 8-element load kept packed (bf16: 4 VGPRs, float: 8) so that a prefetched row costs little until it is used
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16> {
+  uint4 v;
+  __device__ __forceinline__ void load(const bf16* p) { v = *(const uint4*)p; }
+  __device__ __forceinline__ void unpack(float* o) const {
+    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  }
+};
+template <> struct Raw8<float> {
+  f32x4 a, b;
+  __device__ __forceinline__ void load(const float* p) { a = *(const f32x4*)p; b = *(const f32x4*)(p + 4); }
+  __device__ __forceinline__ void unpack(float* o) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a[i]; o[4 + i] = b[i]; }
+  }
+};
+
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

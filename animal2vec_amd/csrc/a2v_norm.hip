@@ -174,6 +174,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     for (int i = 0; i < 8; ++i) { ag[c][i] = 0.f; ab[c][i] = 0.f; as_[c][i] = 0.f; }
 
   const long long row0 = ((long long)blockIdx.x * 4 + wid) * rows_per_wave;
+  // gamma is loaded once per wave: fetched per row it put a dependent global load into every row's critical path
+  float gmr[NCH][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int col = (c * 64 + lane) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gmr[c][i] = 1.f;
+    if (gamma && col < C) Vec8<float>::load(gamma + col, gmr[c]);
+  }
   for (int rr = 0; rr < rows_per_wave; ++rr) {
     const long long row = row0 + rr;
     if (row >= M) break;
@@ -187,15 +196,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         float xv[8], dv[8];
         Vec8<T>::load(x + row * ldx + col, xv);
         Vec8<T>::load(dy + row * lddy + col, dv);
-        float gm8[8], bt8[8];
-        if (NCH == 1 && gamma) { Vec8<float>::load(gamma + col, gm8); Vec8<float>::load(beta + col, bt8); }
+        float bt8[8];
+        if (ACT == 1 && gamma) Vec8<float>::load(beta + col, bt8);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float h = (xv[i] - mean) * rstd;
-          const float ga = gamma ? (NCH == 1 ? gm8[i] : gamma[col + i]) : 1.f;   // wider rows: keep VGPRs low
+          const float ga = gmr[c][i];
           float d = dv[i];
           if (DM == 1) d = drop_apply(drop, (unsigned long long)row * C + col + i, d);
-          if (ACT == 1) d *= gelu_grad_f(gamma ? h * ga + (NCH == 1 ? bt8[i] : beta[col + i]) : h);
+          if (ACT == 1) d *= gelu_grad_f(gamma ? h * ga + bt8[i] : h);
           ag[c][i] += d * h;
           ab[c][i] += d;
           const float dg = d * ga;
