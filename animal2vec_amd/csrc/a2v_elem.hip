@@ -255,6 +255,55 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* __restric
   }
 }
 
+// All operand images of one parameter set in ONE launch: desc holds 10 int64 per weight (src, dst, G, N, Cg, k, Cgp,
+// Np, mode, total); blockIdx.y picks the weight.  (658 separate ~12 us launches per optimizer step were launch bound.)
+template <typename T>
+__global__ __launch_bounds__(256) void pack_weight_batch_kernel(const long long* __restrict__ desc) {
+  const long long* d = desc + (long long)blockIdx.y * 10;
+  const float* __restrict__ w = (const float*)d[0];
+  T* __restrict__ out = (T*)d[1];
+  const int G = (int)d[2], N = (int)d[3], Cg = (int)d[4], k = (int)d[5], Cgp = (int)d[6], Np = (int)d[7], mode = (int)d[8];
+  const long long total = d[9];
+  (void)G;
+  if (mode == 1 && k == 1 && Cg % 32 == 0 && N % 32 == 0 && Np == N && d[2] == 1) {
+    // Linear transpose out[ci][n] = w[n][ci]: 32 x 32 tiles through LDS, coalesced on both sides
+    __shared__ float tile[32][33];
+    const int tiles_c = Cg / 32, tiles_n = N / 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int t = blockIdx.x; t < tiles_c * tiles_n; t += gridDim.x) {
+      const int tn = t / tiles_c, tc = t - tn * tiles_c;
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 32; r += 8) tile[ty + r][tx] = w[(long long)(tn * 32 + ty + r) * Cg + tc * 32 + tx];
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 32; r += 8) out[(long long)(tc * 32 + ty + r) * N + tn * 32 + tx] = Cvt<T>::from(tile[tx][ty + r]);
+    }
+    return;
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float val = 0.f;
+    if (mode == 0) {
+      const int ci = (int)(i % Cgp);
+      const int j = (int)((i / Cgp) % k);
+      const long long gn = i / ((long long)Cgp * k);
+      if (ci < Cg) val = w[(gn * Cg + ci) * k + j];
+    } else if (mode == 1) {
+      const int n = (int)(i % Np);
+      const int j = (int)((i / Np) % k);
+      const int ci = (int)((i / ((long long)Np * k)) % Cg);
+      const int g = (int)(i / ((long long)Np * k * Cg));
+      if (n < N) val = w[(((long long)g * N + n) * Cg + ci) * k + (k - 1 - j)];
+    } else {
+      const int n = (int)(i % Np);
+      const int ci = (int)((i / Np) % Cgp);
+      const int j = (int)(i / ((long long)Np * Cgp));
+      if (n < N && ci < Cg) val = w[((long long)n * Cg + ci) * k + j];
+    }
+    out[i] = Cvt<T>::from(val);
+  }
+}
+
 // gw[(g*N+n)][ci][j] += packed[g][n][j*Cgp + ci]     (fp32 both)
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ gw,
                                                            int Cg, int k, int Cgp, long long total) {
@@ -418,6 +467,15 @@ extern "C" int a2v_pack_weight(int dtype, const float* w, void* out, int G, int 
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(pack_weight_kernel<bf16>, dim3(g), dim3(256), 0, st, w, (bf16*)out, G, N, Cg, k, Cgp, Np, mode, total),
              hipLaunchKernelGGL(pack_weight_kernel<float>, dim3(g), dim3(256), 0, st, w, (float*)out, G, N, Cg, k, Cgp, Np, mode, total));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_pack_weight_batch(int dtype, const long long* desc_dev, int n, hipStream_t st) {
+  if (!desc_dev || n <= 0) return A2V_ERR_ARG;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(pack_weight_batch_kernel<bf16>, dim3(128, n), dim3(256), 0, st, desc_dev),
+             hipLaunchKernelGGL(pack_weight_batch_kernel<float>, dim3(128, n), dim3(256), 0, st, desc_dev));
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }

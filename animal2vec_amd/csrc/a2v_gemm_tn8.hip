@@ -213,7 +213,7 @@ bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
                      a.Cv == a.Cg && a.bdiv == 1 && g.G == 1;
   if (!plain || g.N % 256 || g.K % 256 || g.M < 2048) return false;
   const int tiles = (g.N / 256) * (g.K / 256);
-  if (tiles < 32) return false;
+  if (tiles < 16) return false;
   static int cus = 0;
   if (!cus) {
     hipDeviceProp_t p;

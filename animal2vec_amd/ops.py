@@ -390,6 +390,13 @@ def pack_weight(w, out, *, G, N, Cg, k, Cgp=None, Np=None, mode=0):
     return out
 
 
+def pack_weight_batch(desc: torch.Tensor, dtype: torch.dtype):
+    """desc: (n, 10) int64 device tensor of (src, dst, G, N, Cg, k, Cgp, Np, mode, total) -- see a2v.h."""
+    code = BF16 if dtype == torch.bfloat16 else F32
+    rc = _L().a2v_pack_weight_batch(code, ptr(desc), desc.shape[0], stream())
+    check(rc, "a2v_pack_weight_batch")
+
+
 def unpack_wgrad(packed, gw, *, GN, Cg, k, Cgp):
     rc = _L().a2v_unpack_wgrad(ptr(packed), ptr(gw), GN, Cg, k, Cgp, stream())
     check(rc, "a2v_unpack_wgrad")

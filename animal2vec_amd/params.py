@@ -320,8 +320,39 @@ class Packs:
                         assert Cg % 8 == 0, "grouped / stride-1 convs need Cg % 8 == 0"
                         self.wt[name] = torch.empty(G, Cg, k * Np, dtype=dtype, device=dev)    # mode 1
 
+    def _descriptors(self) -> torch.Tensor:
+        rows = []
+        for name, m in self.meta.items():
+            src = self.src[name]
+            if m["kind"] == "linear":
+                N, K = m["N"], m["K"]
+                if self.dtype != torch.float32:
+                    rows.append([src.data_ptr(), self.w[name].data_ptr(), 1, N, K, 1, K, N, 0, N * K])
+                if self.need_grad:
+                    rows.append([src.data_ptr(), self.wt[name].data_ptr(), 1, N, K, 1, K, N, 1, N * K])
+            else:
+                G, N, Cg, k, Cgp, Np = m["G"], m["N"], m["Cg"], m["k"], m["Cgp"], m["Np"]
+                rows.append([src.data_ptr(), self.w[name].data_ptr(), G, N, Cg, k, Cgp, N, 0, self.w[name].numel()])
+                if self.need_grad:
+                    if G == 1 and m["stride"] > 1:
+                        rows.append([src.data_ptr(), self.wt[name].data_ptr(), 1, N, Cg, k, Cgp, N, 2, self.wt[name].numel()])
+                    else:
+                        rows.append([src.data_ptr(), self.wt[name].data_ptr(), G, N, Cg, k, Cg, Np, 1, self.wt[name].numel()])
+        return torch.tensor(rows, dtype=torch.int64, device=self.store.device)
+
     @torch.no_grad()
     def refresh(self):
+        """one launch for all operand images (the descriptor table is built once: buffers never move)"""
+        import os
+        if os.environ.get("A2V_PACK_SINGLE") == "1":        # A/B switch: one launch per weight
+            return self.refresh_one_by_one()
+        if getattr(self, "_desc", None) is None:
+            self._desc = self._descriptors()
+        if self._desc.shape[0]:
+            ops.pack_weight_batch(self._desc, self.dtype)
+
+    @torch.no_grad()
+    def refresh_one_by_one(self):
         for name, m in self.meta.items():
             src = self.src[name]
             if m["kind"] == "linear":

@@ -165,6 +165,11 @@ int a2v_sumsq(const float* x, long long n, double* out, a2v_stream_t stream);
  * mode 2 (G==1): [tap*Cgp+ci][n]. */
 int a2v_pack_weight(int dtype, const float* w, void* out, int G, int N, int Cg, int k, int Cgp, int Np, int mode,
                     a2v_stream_t stream);
+/* Batched form of a2v_pack_weight: desc_dev = n x 10 int64 on the device
+ * (src fp32 ptr, dst ptr, G, N, Cg, k, Cgp, Np, mode, total elements of dst); one launch rebuilds every operand
+ * image of a parameter set after the optimizer / EMA step (fairseq has no counterpart: its modules read the fp32
+ * parameters directly). */
+int a2v_pack_weight_batch(int dtype, const long long* desc_dev, int n, a2v_stream_t stream);
 int a2v_unpack_wgrad(const float* packed, float* gw, int GN, int Cg, int k, int Cgp, a2v_stream_t stream);
 int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, int C, int k, int s, int p,
                long long lda, long long ldo, a2v_stream_t stream);

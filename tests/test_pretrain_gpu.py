@@ -209,3 +209,24 @@ def test_dropout_gradients_by_finite_differences(tiny_golden):
         fd = (lp - lm) / (2 * eps)
         assert abs(fd - g) <= 0.08 * max(abs(g), abs(fd)) + 2e-2, (name, fd, g)
     eng.sp.refresh()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_operand_packing_matches_single_launches(tiny_golden, dtype):
+    """a2v_pack_weight_batch (one launch per parameter set, tiled Linear transpose) against a2v_pack_weight per weight."""
+    from animal2vec_amd.config import tiny_config
+    cfg = tiny_config()
+    p, ema, _ = split_golden(tiny_golden)
+    _, eng = build(cfg, p, ema, dtype)
+    for packs in (eng.sp, eng.tp):
+        packs.refresh_one_by_one()
+        ref = {("w", k): v.clone() for k, v in packs.w.items()}
+        ref.update({("wt", k): v.clone() for k, v in packs.wt.items()})
+        for v in list(packs.w.values()) + list(packs.wt.values()):
+            if v.data_ptr() not in {s.data_ptr() for s in packs.src.values()}:      # fp32 Linear operands alias the params
+                v.zero_()
+        packs.refresh()
+        torch.cuda.synchronize()
+        for (kind, k), v in ref.items():
+            got = (packs.w if kind == "w" else packs.wt)[k]
+            assert torch.equal(got, v), (kind, k)
