@@ -230,3 +230,36 @@ def test_batched_operand_packing_matches_single_launches(tiny_golden, dtype):
         for (kind, k), v in ref.items():
             got = (packs.w if kind == "w" else packs.wt)[k]
             assert torch.equal(got, v), (kind, k)
+
+
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 5e-2, 2.5e-1)])
+def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
+    """BASELINE.json's configuration at full size (large model: D 1024, 16 heads, 8 + 16 blocks, decoder 4 x 768,
+    clone_batch 12, one 10 s clip @ 8 kHz, 140 of 2000 frames kept): HIP path against the oracle run on this box's
+    CPU.  fp32 mode carries the north-star's 1e-3; the bf16 throughput mode is held to bf16-level bounds."""
+    from animal2vec_amd.config import large_config
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ocfg = O.OracleConfig(**O.LARGE)
+    p = O.init_params(ocfg, seed=0)
+    g = torch.Generator().manual_seed(9)
+    ema = {k: v + torch.randn(v.shape, generator=g) * 0.002 for k, v in O.make_teacher(p).items()}
+    L, keep = 80000, 140
+    T = O.frame_counts(L, ocfg.conv_feature_layers)[-1]
+    src = torch.nn.functional.layer_norm(torch.randn(1, L, generator=g), (L,))
+    mask = O.seeded_mask(ocfg.clone_batch, T, keep, 11)
+    noise = torch.randn(ocfg.clone_batch, T - keep, ocfg.embed_dim, generator=g) * 0.01
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    res = O.pretrain_forward(po, ema, src, mask, noise, ocfg)
+    res["losses"]["AUDIO_regression"].sum().backward()
+
+    cfg = large_config()
+    store, eng = build(cfg, p, ema, dtype)
+    dbg = run(eng, src, mask, noise)
+    assert rel_err(dbg["local_features"].float(), res["_dbg"]["local_features"]) < tol_y
+    assert rel_err(dbg["targets"], res["_dbg"]["targets"]) < tol_y
+    assert rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]) < tol_y
+    D = cfg.embed_dim
+    ls = float(res["losses"]["AUDIO_regression"].sum())
+    assert abs(float(eng.stats[4 * D]) - ls) / ls < tol_y
+    errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
+    assert errs[0][0] < tol_g, errs[:8]
