@@ -67,11 +67,16 @@ __global__ __launch_bounds__(256) void clone_reduce_kernel(const T* __restrict__
       const int n = b * cb + c;
       const int r = restore[(long long)n * Tn + t];
       if (r < K) {
-        float x[8], y[8];
-        Vec8<T>::load(dxm + ((long long)n * Tn + t) * D + v * 8, x);
+        float y[8];
         Vec8<T>::load(dtok + ((long long)n * K + r) * D + v * 8, y);
+        if (dxm) {       // NULL: the pos-conv input gradient was formed at the kept rows only and is already inside dtok
+          float x[8];
+          Vec8<T>::load(dxm + ((long long)n * Tn + t) * D + v * 8, x);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += x[j] + y[j];
+          for (int j = 0; j < 8; ++j) y[j] += x[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += y[j];
       }
     }
     Vec8<T>::store(dfeat + bt * D + v * 8, acc);

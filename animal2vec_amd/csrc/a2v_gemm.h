@@ -16,6 +16,10 @@ struct ConvA {
   // never materialised.
   const unsigned char* rowmask;
   int bdiv;
+  // row gather: GEMM row m reads the im2col row of flat index rowidx[m] (= b*T_out + t) instead of m itself -- the
+  // output (NT) / dY (TN) stay compact.  Used where only the kept frames of a sequence are needed (the last pos-conv
+  // layer, the first layer's input gradient): 140 of 2000 rows.
+  const int* rowidx;
 };
 
 struct GemmArgs {
@@ -54,7 +58,8 @@ template <typename T>
 __device__ __forceinline__ ARow make_arow(const ConvA& a, int m, int M, int g) {
   ARow r;
   r.valid = m < M;
-  const int mm = r.valid ? m : 0;
+  int mm = r.valid ? m : 0;
+  if (a.rowidx) mm = a.rowidx[mm];
   const int b = mm / a.T_out, t = mm - b * a.T_out;
   r.base = (const char*)a.ptr + ((long long)(b / a.bdiv) * a.bstride + (long long)g * a.goff) * (long long)sizeof(T);
   r.mrow = a.rowmask ? a.rowmask + (long long)b * a.T_in : nullptr;

@@ -426,7 +426,7 @@ static int check_conv(const ConvA& a, int esz) {
   return A2V_OK;
 }
 
-extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
                              int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
                              const void* Bw, long long ldb,
                              long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
@@ -436,7 +436,7 @@ extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long l
   if (dtype != A2V_F32 && dtype != A2V_BF16) return A2V_ERR_DTYPE;
   const int esz = dtype == A2V_F32 ? 4 : 2;
   GemmArgs g;
-  g.a = ConvA{A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, (Cv <= 0 || Cv > Cg) ? Cg : Cv, rowmask, bdiv < 1 ? 1 : bdiv};
+  g.a = ConvA{A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, (Cv <= 0 || Cv > Cg) ? Cg : Cv, rowmask, bdiv < 1 ? 1 : bdiv, rowidx};
   int rc = check_conv(g.a, esz);
   if (rc) return rc;
   if (K != taps * Cg) return A2V_ERR_ARG;
@@ -452,11 +452,11 @@ extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long l
   if ((flags & F_DROPOUT) && !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
   const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
   dim3 grid(tiles, G, 1);
-  if (dtype == A2V_BF16 && g_a2v_conv_slab && a2v_launch_conv_slab(g, stream)) {
+  if (dtype == A2V_BF16 && !rowidx && g_a2v_conv_slab && a2v_launch_conv_slab(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
-  if (dtype == A2V_BF16 && g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
+  if (dtype == A2V_BF16 && !rowidx && g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
@@ -484,7 +484,24 @@ extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long l
   return A2V_OK;
 }
 
-extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+extern "C" int a2v_conv_gemm(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                             int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                             const void* Bw, long long ldb,
+                             long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
+                             long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
+                             float drop_p, unsigned drop_seed, hipStream_t stream) {
+  return conv_gemm_impl(nullptr, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, Bw, ldb, b_gstride, C, ldc, c_goff, C2, R, ldr, bias, colsum, M, N, K, G, flags, drop_p, drop_seed, stream);
+}
+extern "C" int a2v_conv_gemm_rows(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                             int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                             const void* Bw, long long ldb,
+                             long long b_gstride, void* C, long long ldc, int c_goff, void* C2, const void* R,
+                             long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
+                             float drop_p, unsigned drop_seed, hipStream_t stream) {
+  return conv_gemm_impl(rowidx, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, Bw, ldb, b_gstride, C, ldc, c_goff, C2, R, ldr, bias, colsum, M, N, K, G, flags, drop_p, drop_seed, stream);
+}
+
+static int conv_wgrad_impl(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
                               int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
                               const void* P, long long ldp,
                               int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
@@ -493,7 +510,7 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
   if (dtype != A2V_F32 && dtype != A2V_BF16) return A2V_ERR_DTYPE;
   const int esz = dtype == A2V_F32 ? 4 : 2;
   WgradArgs g;
-  g.a = ConvA{A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, (Cv <= 0 || Cv > Cg) ? Cg : Cv, rowmask, bdiv < 1 ? 1 : bdiv};
+  g.a = ConvA{A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, (Cv <= 0 || Cv > Cg) ? Cg : Cv, rowmask, bdiv < 1 ? 1 : bdiv, rowidx};
   int rc = check_conv(g.a, esz);
   if (rc) return rc;
   if (K != taps * Cg) return A2V_ERR_ARG;
@@ -501,11 +518,11 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
   if (N % per16 || ldp % per16 || p_goff % per16 || (((uintptr_t)P) & 15)) return A2V_ERR_ARG;
   g.P = P; g.ldp = ldp; g.p_goff = p_goff; g.W = W; g.ldw = ldw; g.w_gstride = w_gstride;
   g.M = M; g.N = N; g.K = K; g.G = G;
-  if (dtype == A2V_BF16 && g_a2v_tn_p8 && a2v_launch_tn_bf16_p8(g, stream)) {
+  if (dtype == A2V_BF16 && !rowidx && g_a2v_tn_p8 && a2v_launch_tn_bf16_p8(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
-  if (dtype == A2V_BF16 && g_a2v_wgrad_slab && a2v_launch_wgrad_slab(g, stream)) {
+  if (dtype == A2V_BF16 && !rowidx && g_a2v_wgrad_slab && a2v_launch_wgrad_slab(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
@@ -528,6 +545,21 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
   }
   A2V_CHECK_LAUNCH();
   return A2V_OK;
+}
+
+extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                              int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                              const void* P, long long ldp,
+                              int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
+                              hipStream_t stream) {
+  return conv_wgrad_impl(nullptr, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
+}
+extern "C" int a2v_conv_wgrad_rows(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                              int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                              const void* P, long long ldp,
+                              int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
+                              hipStream_t stream) {
+  return conv_wgrad_impl(rowidx, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
 }
 
 // debugging / A-B benchmarking knob: key 0 = bf16 NT kernel variant (0 register-staged, 1 LDS-DMA)

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
   if (i < A_CH) {                                                                                             \
     int m = m0 + crow + 32 * i;                                                                               \
     m = m < g.M ? m : g.M - 1;                                                                                \
+    if (a.rowidx) m = a.rowidx[m];                                                                            \
     const int b = m / a.T_out, t = m - b * a.T_out;                                                           \
     ta##i = t * a.stride - a.pad;                                                                             \
     pa##i = (const char*)a.ptr + ((long long)(b / a.bdiv) * a.bstride + (long long)grp * a.goff + cchunk * 8 + \
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_glds_kernel(GemmArgs g) {
     const int slab = wid + 4 * i;                                                                             \
     int m = CONV ? m0 + crow + 32 * i : m0 + slab * 8 + lr;                                                   \
     m = m < g.M ? m : g.M - 1;                                                                                \
+    if (a.rowidx) m = a.rowidx[m];                                                                            \
     const int b = m / a.T_out, t = m - b * a.T_out;                                                           \
     ta##i = t * a.stride - a.pad;                                                                             \
     const int ch = CONV ? cchunk : SRC_CHUNK(slab);                                                           \
@@ -361,7 +363,8 @@ static void launch_nt(const GemmArgs& g, hipStream_t stream) {
 
 bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream) {
   if (g.a.Cg % 64 != 0 || g.K % 64 != 0) return false;
-  const bool conv = g.a.taps > 1 || g.a.pad != 0 || g.a.rowmask != nullptr || g.a.stride != 1 || g.a.T_in != g.a.T_out ||
+  const bool conv = g.a.taps > 1 || g.a.pad != 0 || g.a.rowmask != nullptr || g.a.rowidx != nullptr || g.a.stride != 1 ||
+                    g.a.T_in != g.a.T_out ||
                     g.a.Cv != g.a.Cg;
   if (g_a2v_gemm_variant == 1) {
     if (g.N <= 64) {
@@ -444,7 +447,8 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g, int
   const unsigned char* mk[NQ];
 #define TN_SETUP_ROW(i)                                                                                \
   {                                                                                                    \
-    const int mm = mq[i] < g.M ? mq[i] : g.M - 1;                                                      \
+    int mm = mq[i] < g.M ? mq[i] : g.M - 1;                                                            \
+    if (a.rowidx) mm = a.rowidx[mm];                                                                   \
     const int b = mm / a.T_out;                                                                        \
     tq[i] = mm - b * a.T_out;                                                                          \
     rowq[i] = tq[i] * a.stride - a.pad + tapq;                                                         \
@@ -479,7 +483,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g, int
       tq[i] += 64;                                                                                    \
       rowq[i] += 64 * a.stride;                                                                       \
       qp[i] += q_step;                                                                                \
-      if (tq[i] >= a.T_out) TN_SETUP_ROW(i);      /* crossed into the next batch item (rare) */       \
+      if (a.rowidx || tq[i] >= a.T_out) TN_SETUP_ROW(i);   /* gathered rows, or crossed into the next batch item */ \
     }                                                                                                 \
   }
 #define STORE_TILE(buf_)                                                                              \

@@ -211,50 +211,65 @@ class Engine:
         return dxin.view(N, S, D)
 
     # ------------------------------------------------------------------ grouped conv + LN + GELU stacks
-    def posconv_fwd(self, feats, pk: Packs, params, mask_u8, cb, save: bool):
+    def posconv_fwd(self, feats, pk: Packs, params, mask_u8, cb, save: bool, rows=None, post=None):
         """relative_positional_encoder (audio.py:90-113) on x.repeat_interleave(cb)*(1-mask) (student) or
-        on feats (teacher); the clone/mask view is taken by the A-operand loader, never materialised."""
+        on feats (teacher); the clone/mask view is taken by the A-operand loader, never materialised.
+        rows (int32, flat n*T + t of the kept frames): the reference gathers the kept frames from the (N,T,D)
+        output (base.py:300-314), so the LAST layer (conv, LayerNorm, GELU) is evaluated at those rows only and the
+        result is compact (len(rows), D); `post` (compact) is added to it in the LayerNorm kernel."""
         cfg = self.cfg
         a = cfg.audio
         B, T, D = feats.shape
         k = cfg.pos_kernel
         N = B * cb
         x = feats
-        for i in range(1, a.conv_pos_depth + 1):
+        depth = a.conv_pos_depth
+        for i in range(1, depth + 1):
             w = P + f"relative_positional_encoder.{i}.0.weight"
             first = i == 1 and mask_u8 is not None
+            ri = rows if i == depth else None
             c = ops.conv1d_cl(x, pk.w[w], params[P + f"relative_positional_encoder.{i}.0.bias"], k=k, stride=1, pad=k // 2,
                               groups=a.conv_pos_groups, T_out=T, n_out=D, rowmask=mask_u8 if first else None,
-                              bdiv=cb if first else 1, n_batch=N if first else None, cv=pk.meta[w]["Cg"])
-            y, mean, rstd = ops.layernorm_fwd(c, None, None, 1e-5, act=1, save_stats=save)
+                              bdiv=cb if first else 1, n_batch=N if first else None, cv=pk.meta[w]["Cg"], rowidx=ri)
+            y, mean, rstd = ops.layernorm_fwd(c, None, None, 1e-5, act=1, save_stats=save,
+                                              post=post if ri is not None else None)
             if save:
                 self.sv[f"pc{i}"] = dict(x=x, c=c, st=(mean, rstd))
             x = y
         return x
 
-    def posconv_bwd(self, dy, mask_u8, cb):
+    def posconv_bwd(self, dtok, mask_u8, cb, rows, ids_restore, T):
+        """dtok (N,K,D): gradient of the kept tokens = gradient of the compact last-layer output.  Returns the
+        gradient wrt the (masked, cloned) pos-conv input AT THE KEPT ROWS, with dtok already added (N,K,D): the
+        masked rows of that input are constants (zeros), so the first layer's input gradient is only formed there."""
         cfg, st, sp = self.cfg, self.store, self.sp
         a = cfg.audio
         g = st.g
         k = cfg.pos_kernel
         G = a.conv_pos_groups
-        N, T, D = dy.shape
-        for i in reversed(range(1, a.conv_pos_depth + 1)):
+        N, K, D = dtok.shape
+        depth = a.conv_pos_depth
+        dy = dtok.view(N * K, D)
+        for i in reversed(range(1, depth + 1)):
             sv = self.sv.pop(f"pc{i}")
             w = P + f"relative_positional_encoder.{i}.0.weight"
             m = sp.meta[w]
-            first = i == 1
+            first, last = i == 1, i == depth
             dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1,
                                    dxsum=g[P + f"relative_positional_encoder.{i}.0.bias"])
             gw = sp.gw[w]
             gw.zero_()
             ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T,
                                 rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None,
-                                cv=m["Cg"])
+                                cv=m["Cg"], rowidx=rows if last else None)
             ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
+            if last:                                   # the input gradient needs dc as a dense (N,T,D) operand
+                dc = ops.scatter_tokens(dc.view(N, K, D), ids_restore, T)
+            if first:
+                return ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D,
+                                     cv=m["N"], rowidx=rows, res=dtok.view(N * K, D)).view(N, K, D)
             dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D,
                                cv=m["N"])
-        return dy        # gradient wrt the (masked, cloned) pos-conv input (N,T,D)
 
     def decoder_fwd(self, dec_in, save: bool):
         """Decoder1d (modules.py:137-192): grouped conv + LN(no affine) + GELU (+ residual) x L, then proj."""
@@ -352,8 +367,12 @@ class Engine:
         # ---- teacher targets from the student's local features (data2vec2.py:811-818)
         y = self.teacher_targets(feats)
         # ---- student context encoder (base.py:215-344)
-        x_pos = self.posconv_fwd(feats, sp, p, mask_u8, cb, save=save)         # (N,T,D)
-        tok = ops.gather_tokens(feats, ids_keep, cb=cb, b=x_pos)               # (N,K,D)
+        # kept frames as flat rows n*T + t: the last pos-conv layer is only evaluated there (compact), with the
+        # gathered local features added in its LayerNorm kernel
+        rows = (torch.arange(N, device=ids_keep.device, dtype=torch.int32).unsqueeze(1) * T + ids_keep).reshape(-1)
+        tok_f = ops.gather_tokens(feats, ids_keep, cb=cb)                      # (N,K,D)
+        tok = self.posconv_fwd(feats, sp, p, mask_u8, cb, save=save, rows=rows, post=tok_f.view(N * K, D)).view(N, K, D)
+        x_pos = tok
         db = dropout_seed
         d_pre = (a.prenet_dropout, self._site(db, 9000)) if db is not None and a.prenet_dropout > 0 else None
         d_dec = (a.decoder.input_dropout, self._site(db, 9001)) if db is not None and a.decoder.input_dropout > 0 else None
@@ -381,7 +400,7 @@ class Engine:
                        loss_rows=loss_rows)
         if save:
             self.sv["ctx"] = dict(dx=dx, mask_u8=mask_u8, ids_keep=ids_keep, ids_restore=ids_restore, T=T, d_pre=d_pre,
-                                  d_dec=d_dec)
+                                  d_dec=d_dec, rows=rows)
         return dbg
 
     def backward(self, gscale: float = 1.0):
@@ -407,10 +426,9 @@ class Engine:
                                  p[P + "context_encoder.norm.bias"], *self.sv.pop("tok_st"),
                                  dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"],
                                  drop=c["d_pre"], drop_mode=1)
-        dxpos = ops.scatter_tokens(dtok, ids_restore, T)                       # (N,T,D)
-        dxm = self.posconv_bwd(dxpos, mask_u8, cb)                             # (N,T,D)
+        dxk = self.posconv_bwd(dtok, mask_u8, cb, c["rows"], ids_restore, T)   # (N,K,D): pos-conv path + dtok, kept rows
         self._ready("posconv")
-        dfeat = ops.clone_reduce(dxm, dtok, ids_restore, cb)                   # (B,T,D)
+        dfeat = ops.clone_reduce(None, dxk, ids_restore, cb)                   # (B,T,D)
         self.frontend_bwd(dfeat)
         self.sv.clear()
 

@@ -53,8 +53,9 @@ def _drop(drop):
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride,
               a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
-              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None):
-    """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add."""
+              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None):
+    """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add.
+    rowidx (int32, M entries): GEMM row m reads the im2col row of flat index rowidx[m]; out stays compact."""
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS
@@ -71,10 +72,11 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
     if drop is not None and drop[0] > 0:
         flags |= EPI_DROPOUT
     dp, ds = (drop if drop is not None and drop[0] > 0 else (0.0, 0))
-    rc = _L().a2v_conv_gemm(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
-                            ptr(rowmask), bdiv, ptr(w), ldb, b_gstride, ptr(out), ldc, c_goff, ptr(pre_out),
-                            ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
-                            dp, ds & 0xFFFFFFFF, stream())
+    args = (dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
+            ptr(rowmask), bdiv, ptr(w), ldb, b_gstride, ptr(out), ldc, c_goff, ptr(pre_out),
+            ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
+            dp, ds & 0xFFFFFFFF, stream())
+    rc = _L().a2v_conv_gemm(*args) if rowidx is None else _L().a2v_conv_gemm_rows(ptr(rowidx), *args)
     check(rc, "a2v_conv_gemm")
     return out
 
@@ -93,7 +95,7 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
 
 
 def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=None, rowmask=None, bdiv=1,
-              n_batch=None, res=None, colsum=None, cv=None):
+              n_batch=None, res=None, colsum=None, cv=None, rowidx=None):
     """Channels-last Conv1d as implicit GEMM.  x (Bsrc,T_in,Cp); w_packed (G, n_out/G, k*Cg) where Cg is
     the (possibly zero-padded) tap width; cv = real input channels per group (default Cg);
     out (B,T_out,n_out) with B = n_batch or Bsrc."""
@@ -103,18 +105,21 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
     Cg = w_packed.shape[-1] // k
     cv = Cg if cv is None else cv
     N = n_out // G
+    M = B * T_out if rowidx is None else rowidx.numel()       # rowidx: only these rows (flat b*T_out + t), compact output
     if out is None:
-        out = torch.empty(B, T_out, n_out, dtype=x.dtype, device=x.device)
-    return conv_gemm(x, w_packed, out, M=B * T_out, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride,
+        out = torch.empty((B, T_out, n_out) if rowidx is None else (M, n_out), dtype=x.dtype, device=x.device)
+    return conv_gemm(x, w_packed, out, M=M, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride,
                      pad=pad, taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=cv if G > 1 else 0,
                      rowmask=rowmask, bdiv=bdiv, ldb=w_packed.stride(-2), b_gstride=w_packed.stride(0) if G > 1 else 0,
-                     ldc=n_out, c_goff=N, bias=bias, res=res, ldr=n_out if res is not None else 0, colsum=colsum)
+                     ldc=n_out, c_goff=N, bias=bias, res=res, ldr=n_out if res is not None else 0, colsum=colsum,
+                     rowidx=rowidx)
 
 
 def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride, a_goff=0,
-               rowmask=None, bdiv=1, ldp, p_goff=0, ldw, w_gstride=0):
-    rc = _L().a2v_conv_wgrad(dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
-                             ptr(rowmask), bdiv, ptr(dy), ldp, p_goff, ptr(gw), ldw, w_gstride, M, N, K, G, stream())
+               rowmask=None, bdiv=1, ldp, p_goff=0, ldw, w_gstride=0, rowidx=None):
+    args = (dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
+            ptr(rowmask), bdiv, ptr(dy), ldp, p_goff, ptr(gw), ldw, w_gstride, M, N, K, G, stream())
+    rc = _L().a2v_conv_wgrad(*args) if rowidx is None else _L().a2v_conv_wgrad_rows(ptr(rowidx), *args)
     check(rc, "a2v_conv_wgrad")
     return gw
 
@@ -128,8 +133,9 @@ def linear_wgrad(x, dy, gw):
                       ldp=dy.stride(0), ldw=gw.stride(0))
 
 
-def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=None, bdiv=1, n_batch=None, cv=None):
-    """gw_packed (G, N, k*Cg) fp32 += implicit-im2col(x)^T dy."""
+def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=None, bdiv=1, n_batch=None, cv=None,
+                    rowidx=None):
+    """gw_packed (G, N, k*Cg) fp32 += implicit-im2col(x)^T dy.  rowidx: dy holds only those rows (compact)."""
     Bsrc, T_in, Cp = x.shape
     B = n_batch if n_batch is not None else Bsrc
     G = groups
@@ -137,7 +143,8 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
     N = gw_packed.shape[-2]
     n_out = dy.shape[-1]
     cv = Cg if cv is None else cv
-    return conv_wgrad(x, dy, gw_packed, M=B * T_out, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride, pad=pad,
+    return conv_wgrad(x, dy, gw_packed, M=B * T_out if rowidx is None else rowidx.numel(), N=N, K=k * Cg, G=G, T_in=T_in,
+                      T_out=T_out, stride=stride, pad=pad, rowidx=rowidx,
                       taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=cv if G > 1 else 0,
                       rowmask=rowmask, bdiv=bdiv, ldp=n_out, p_goff=N, ldw=gw_packed.stride(-2),
                       w_gstride=gw_packed.stride(0) if G > 1 else 0)
@@ -290,10 +297,12 @@ def scatter_tokens(dtok, restore, T):
 
 
 def clone_reduce(dxm, dtok, restore, cb):
-    N, T, D = dxm.shape
-    K = dtok.shape[1]
-    out = torch.empty(N // cb, T, D, dtype=dxm.dtype, device=dxm.device)
-    rc = _L().a2v_clone_reduce(dt(dxm), ptr(dxm), ptr(dtok), ptr(restore), ptr(out), N // cb, cb, K, D, T, stream())
+    """dfeat[b,t] = sum over the clones n of b that keep frame t of (dxm[n,t] + dtok[n, restore[n,t]]); dxm None:
+    only the dtok term (it then already carries the pos-conv input gradient of the kept rows)."""
+    N, K, D = dtok.shape
+    T = restore.shape[1]
+    out = torch.empty(N // cb, T, D, dtype=dtok.dtype, device=dtok.device)
+    rc = _L().a2v_clone_reduce(dt(dtok), ptr(dxm), ptr(dtok), ptr(restore), ptr(out), N // cb, cb, K, D, T, stream())
     check(rc, "a2v_clone_reduce")
     return out
 

@@ -61,6 +61,20 @@ int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long long a_bstr
                    int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv, const void* P,
                    long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
                    a2v_stream_t stream);
+/* Row-gathered forms: GEMM row m reads the im2col row of flat index rowidx[m] (= b*T_out + t, int32 on the device)
+ * instead of row m; C (a2v_conv_gemm_rows) / P = dY (a2v_conv_wgrad_rows) stay compact with M = number of gathered
+ * rows.  The reference computes the whole (N, T, D) positional-encoder output and then gathers the kept frames
+ * (base.py:300-314); the last layer only needs those rows, and the first layer's input gradient only matters at
+ * them, so the engine evaluates 140 of 2000 rows there.  rowidx = NULL is the dense form. */
+int a2v_conv_gemm_rows(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                       int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                       const void* Bw, long long ldb, long long b_gstride, void* C, long long ldc, int c_goff, void* C2,
+                       const void* R, long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
+                       float drop_p, unsigned drop_seed, a2v_stream_t stream);
+int a2v_conv_wgrad_rows(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                        int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                        const void* P, long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N,
+                        int K, int G, a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- attention with analytic ALiBi
  * qkv (N,S,3,H,HD); out (N,S,H*HD); lse (N,H,S) fp32; pos (N,S) int32 original frame index or NULL

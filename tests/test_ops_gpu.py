@@ -297,6 +297,41 @@ def test_conv_slab_kernels_masked_long(ops):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("D,G", [(128, 2), (64, 4)])
+def test_conv_row_gather(ops, dtype, D, G):
+    """a2v_conv_gemm_rows / a2v_conv_wgrad_rows: only a subset of output rows (the kept frames) is evaluated, on the
+    clone * (1 - mask) view; equals the dense result gathered at those rows / fed with dY scattered to them."""
+    B, cb, T, k = 2, 3, 300, 19
+    Cg = D // G
+    x = rnd(B, T, D, dtype=dtype, seed=1)
+    w = rnd(D, Cg, k, dtype=dtype, seed=2, scale=(Cg * k) ** -0.5)
+    bias = rnd(D, dtype=torch.float32, seed=4)
+    gen = torch.Generator().manual_seed(3)
+    mask = (torch.rand(B * cb, T, generator=gen) < 0.7).to(torch.uint8)
+    keep = torch.stack([torch.randperm(T, generator=gen)[:40].sort().values for _ in range(B * cb)])      # (N, 40)
+    rowidx = (torch.arange(B * cb).unsqueeze(1) * T + keep).reshape(-1).to(torch.int32)
+    xm = (x.repeat_interleave(cb, 0) * (1 - mask.float().unsqueeze(-1)))
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv1d(xm.transpose(1, 2), wr, bias, padding=k // 2, groups=G).transpose(1, 2).reshape(B * cb * T, D)
+    ref_rows = ref[rowidx.long()]
+    dyk = rnd(rowidx.numel(), D, dtype=dtype, seed=5)
+    ref_rows.backward(dyk)
+    xd, md, ri = dev(x, dtype), mask.cuda(), rowidx.cuda()
+    cgp = Cg if Cg % 64 == 0 or dtype == torch.float32 else (Cg + 7) // 8 * 8
+    wp = dev(pack_ref(w, G, cgp), dtype)
+    y = ops.conv1d_cl(xd, wp, dev(bias, torch.float32), k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D,
+                      rowmask=md, bdiv=cb, n_batch=B * cb, rowidx=ri, cv=Cg)
+    assert y.shape == (rowidx.numel(), D)
+    assert rel_err(y.float(), ref_rows.detach()) < tol(dtype)
+    gw = torch.zeros(G, D // G, k * cgp, dtype=torch.float32, device="cuda")
+    ops.conv1d_cl_wgrad(xd, dev(dyk, dtype), gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, rowmask=md, bdiv=cb,
+                        n_batch=B * cb, rowidx=ri, cv=Cg)
+    gw_un = torch.zeros(D, Cg, k, dtype=torch.float32, device="cuda")
+    ops.unpack_wgrad(gw, gw_un, GN=D, Cg=Cg, k=k, Cgp=cgp)
+    assert rel_err(gw_un, wr.grad) < tol(dtype, 2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_dgrad_paths(ops, dtype):
     # stride-1 grouped conv: input gradient as a convolution with flipped/transposed weights (pack mode 1)
     B, T, D, G, k = 2, 120, 64, 4, 7
