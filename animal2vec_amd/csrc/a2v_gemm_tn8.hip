@@ -8,7 +8,7 @@
 // the swizzle applied to the LDS-DMA source address) and every MFMA fragment is a ds_read_b64_tr_b16 pair.
 // A work unit is (output tile, M chunk); units = tiles x ceil(CUs / tiles), a unit's result leaves with fp32
 // atomics (the 128x128 kernel with its 1024 smaller units issued 4x the atomic traffic for the same output).
-// Eligibility: plain row-major X (the Linear layers), N % 256 == 0, K % 256 == 0, at least 32 tiles.
+// Eligibility: plain row-major X (the Linear layers), N % 256 == 0, K % 256 == 0, at least 12 K-tiles per unit.
 #include "a2v_gemm.h"
 
 typedef __attribute__((address_space(3))) void t8_lds_void_t;
@@ -213,7 +213,6 @@ bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
                      a.Cv == a.Cg && a.bdiv == 1 && g.G == 1;
   if (!plain || g.N % 256 || g.K % 256 || g.M < 2048) return false;
   const int tiles = (g.N / 256) * (g.K / 256);
-  if (tiles < 16) return false;
   static int cus = 0;
   if (!cus) {
     hipDeviceProp_t p;
@@ -228,7 +227,7 @@ bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
   if (chunks < 1) chunks = 1;
   int kpc = cdiv(nk_total, chunks);
   kpc += kpc & 1;                                     // even number of K-tiles per chunk
-  if (kpc < 4) kpc = 4;
+  if (kpc < 12) return false;                         // too few K-tiles per unit: the atomics of a 256x256 tile would dominate
   chunks = cdiv(nk_total, kpc);
   const int units = tiles * chunks;
   dim3 grid(units < cus ? units : cus, 1, 1);

@@ -274,34 +274,46 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // the (L2-resident) column strip for accuracy.
 struct PtrList { const void* p[32]; };
 
+// One pass with 16-B loads: a workgroup owns 512 channels of one (layer, batch item), its four waves take
+// interleaved rows.  The moments are accumulated about the first row's value c (s1 = sum(x - c), s2 = sum((x - c)^2)):
+// the same shift in every wave makes the partials additive and keeps var = s2/n - (s1/n)^2 free of the cancellation
+// a raw second moment would have.  (The two-pass, 128-B-per-row version read the 524 MB twice at 1 TB/s.)
 template <typename T>
 __global__ __launch_bounds__(256) void instnorm_stats_kernel(PtrList layers, float* __restrict__ mean,
                                                              float* __restrict__ rstd, int B, int Tn, int D,
                                                              float eps) {
-  __shared__ float red[4][64];
+  __shared__ float red[2][4][512];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
+  const int c0 = (blockIdx.x * 64 + lane) * 8;
   const int b = blockIdx.y, l = blockIdx.z;
   const T* base = (const T*)layers.p[l] + (long long)b * Tn * D;
-  const bool ok = c < D;
-  float s = 0.f;
-  for (int t = wid; t < Tn; t += 4) s += ok ? ldf(base + (long long)t * D + c) : 0.f;
-  red[wid][lane] = s;
-  __syncthreads();
-  const float mu = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)Tn;
-  __syncthreads();
-  float q = 0.f;
-  for (int t = wid; t < Tn; t += 4) {
-    const float d = ok ? ldf(base + (long long)t * D + c) - mu : 0.f;
-    q += d * d;
+  const bool ok = c0 < D;
+  float c[8], s1[8], s2[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { c[i] = 0.f; s1[i] = 0.f; s2[i] = 0.f; }
+  if (ok) {
+    Vec8<T>::load(base + c0, c);
+    for (int t = wid; t < Tn; t += 4) {
+      float v[8];
+      Vec8<T>::load(base + (long long)t * D + c0, v);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const float d = v[i] - c[i]; s1[i] += d; s2[i] += d * d; }
+    }
   }
-  red[wid][lane] = q;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { red[0][wid][lane * 8 + i] = s1[i]; red[1][wid][lane * 8 + i] = s2[i]; }
   __syncthreads();
   if (wid == 0 && ok) {
-    const float var = (red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]) / (float)Tn;
-    const long long o = ((long long)l * B + b) * D + c;
-    mean[o] = mu;
-    rstd[o] = rsqrtf(var + eps);
+    const float inv = 1.f / (float)Tn;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = lane * 8 + i;
+      const float m1 = (red[0][0][k] + red[0][1][k] + red[0][2][k] + red[0][3][k]) * inv;
+      const float m2 = (red[1][0][k] + red[1][1][k] + red[1][2][k] + red[1][3][k]) * inv;
+      const long long o = ((long long)l * B + b) * D + c0 + i;
+      mean[o] = c[i] + m1;
+      rstd[o] = rsqrtf(fmaxf(m2 - m1 * m1, 0.f) + eps);
+    }
   }
 }
 
@@ -454,10 +466,10 @@ extern "C" int a2v_layernorm_bwd(int dtype, const void* dy, const void* x, const
 
 extern "C" int a2v_instnorm_targets(int dtype, const void* const* layers, int L, float* mean_ws, float* rstd_ws,
                                     float* y, int B, int Tn, int D, float eps, hipStream_t stream) {
-  if (L <= 0 || L > 32 || B <= 0 || Tn <= 0 || D <= 0 || D % 4) return A2V_ERR_ARG;
+  if (L <= 0 || L > 32 || B <= 0 || Tn <= 0 || D <= 0 || D % 8) return A2V_ERR_ARG;
   PtrList pl;
   for (int i = 0; i < 32; ++i) pl.p[i] = i < L ? layers[i] : nullptr;
-  dim3 g1((D + 63) / 64, B, L), blk(256);
+  dim3 g1((D + 511) / 512, B, L), blk(256);
   long long nvec = (long long)B * Tn * D / 4;
   int g2 = (int)((nvec + 255) / 256);
   if (g2 > 4096) g2 = 4096;
