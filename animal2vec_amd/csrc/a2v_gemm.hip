@@ -562,6 +562,30 @@ extern "C" int a2v_conv_wgrad_rows(const int* rowidx, int dtype, const void* A, 
   return conv_wgrad_impl(rowidx, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
 }
 
+// Two Linear weight gradients over the same M rows (gw_a[Na,Ka] += dy_a^T x_a, gw_b[Nb,Kb] += dy_b^T x_b) in one launch
+// when the 256x256 TN kernel takes both (fewer M chunks -> fewer fp32 atomic adds per element); otherwise two launches.
+extern "C" int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long lda, const void* dya, long long ldpa, float* gwa,
+                                     long long ldwa, int Na, int Ka, const void* xb, long long ldb_, const void* dyb,
+                                     long long ldpb, float* gwb, long long ldwb, int Nb, int Kb, hipStream_t stream) {
+  if (dtype == A2V_BF16 && g_a2v_tn_p8 && M > 0) {
+    WgradArgs a, b;
+    a.a = ConvA{xa, lda, 0, 0, M, M, 1, 0, 1, Ka, Ka, nullptr, 1, nullptr};
+    a.P = dya; a.ldp = ldpa; a.p_goff = 0; a.W = gwa; a.ldw = ldwa; a.w_gstride = 0; a.M = M; a.N = Na; a.K = Ka; a.G = 1; a.m_chunk = 0;
+    b.a = ConvA{xb, ldb_, 0, 0, M, M, 1, 0, 1, Kb, Kb, nullptr, 1, nullptr};
+    b.P = dyb; b.ldp = ldpb; b.p_goff = 0; b.W = gwb; b.ldw = ldwb; b.w_gstride = 0; b.M = M; b.N = Nb; b.K = Kb; b.G = 1; b.m_chunk = 0;
+    const int per16 = 8;
+    const bool ok = !(Na % per16 || ldpa % per16 || lda % per16 || Nb % per16 || ldpb % per16 || ldb_ % per16 ||
+                      ((((uintptr_t)xa) | ((uintptr_t)dya) | ((uintptr_t)xb) | ((uintptr_t)dyb)) & 15));
+    if (ok && a2v_launch_tn_bf16_p8_pair(&a, &b, stream)) {
+      A2V_CHECK_LAUNCH();
+      return A2V_OK;
+    }
+  }
+  int rc = conv_wgrad_impl(nullptr, dtype, xa, lda, 0, 0, M, M, 1, 0, 1, Ka, 0, nullptr, 1, dya, ldpa, 0, gwa, ldwa, 0, M, Na, Ka, 1, stream);
+  if (rc) return rc;
+  return conv_wgrad_impl(nullptr, dtype, xb, ldb_, 0, 0, M, M, 1, 0, 1, Kb, 0, nullptr, 1, dyb, ldpb, 0, gwb, ldwb, 0, M, Nb, Kb, 1, stream);
+}
+
 // debugging / A-B benchmarking knob: key 0 = bf16 NT kernel variant (0 register-staged, 1 LDS-DMA)
 extern int g_a2v_gemm_variant;
 extern int g_a2v_p8_ih;

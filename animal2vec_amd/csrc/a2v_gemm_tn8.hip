@@ -26,23 +26,31 @@ __device__ __forceinline__ void t8_glds16(const char* gsrc, char* lds_dst) {
 
 __device__ uint4 g_t8_zero[1];        // rows past the end of M are fetched from here
 
-struct T8Unit {       // wave-uniform description of a work unit (the per-thread chunk offsets are unit-independent)
-  const char* pb;     // dY + (mbeg * ldp + n0) * 2
-  const char* qb;     // X  + (mbeg * pitch + k0) * 2
-  int n0, k0, nk;     // output tile origin, K-tiles (64 rows) in this unit (even, >= 2)
+struct T8Prob {       // one weight-gradient problem of a (possibly paired) launch; all share M
+  const char* P;      // dY (M x N, row pitch ldp elements)
+  const char* Q;      // X  (M x K, row pitch ldq elements)
+  float* W;           // fp32 (N x K, row pitch ldw)
+  long long ldp, ldq, ldw;
+  int N, K, tiles;    // tiles = (N/256) * (K/256)
+};
+struct T8Args { T8Prob pr[2]; int nprob; int M; };
+
+struct T8Unit {       // wave-uniform description of a work unit
+  const char* pb;     // P + (mbeg * ldp + n0) * 2
+  const char* qb;     // Q + (mbeg * ldq + k0) * 2
+  float* wb;          // W + n0 * ldw + k0
+  unsigned ldp2, ldq2;  // row pitches in bytes
+  long long ldw;
+  int nk;             // K-tiles (64 rows) in this unit (even, >= 2)
   int mbeg;           // first row of the unit
 };
 
-__global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int chunks, int kt_per_chunk, int stagger) {
+__global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chunks, int kt_per_chunk, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
-  const int tiles_k = g.K / 256;
-  const int tiles = (g.N / 256) * tiles_k;
+  const int tiles = g.pr[0].tiles + (g.nprob > 1 ? g.pr[1].tiles : 0);
   const int units = tiles * chunks;
-  const ConvA& a = g.a;
-  const char* const pbase = (const char*)g.P;
-  const char* const qbase = (const char*)a.ptr;
   const char* const zsrc = (const char*)g_t8_zero;
   const int nk_total = (g.M + 63) / 64;
 
@@ -50,40 +58,43 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
   // rows mrow0 / mrow1 of every K-tile
   const int c16 = lane & 15;
   const int mrow0 = wid * 4 + (lane >> 4), mrow1 = mrow0 + 32;
-  unsigned po0, po1, qo0, qo1;
+  unsigned sc0, sc1;
   {
     const int f0 = (mrow0 & 3) | (((mrow0 >> 3) & 1) << 2), f1 = (mrow1 & 3) | (((mrow1 >> 3) & 1) << 2);
-    const int sc0 = (((c16 >> 1) ^ f0) << 1) | (c16 & 1), sc1 = (((c16 >> 1) ^ f1) << 1) | (c16 & 1);
-    po0 = (unsigned)(((long long)mrow0 * g.ldp + sc0 * 8) * 2);
-    po1 = (unsigned)(((long long)mrow1 * g.ldp + sc1 * 8) * 2);
-    qo0 = (unsigned)(((long long)mrow0 * a.pitch + sc0 * 8) * 2);
-    qo1 = (unsigned)(((long long)mrow1 * a.pitch + sc1 * 8) * 2);
+    sc0 = (unsigned)(((((c16 >> 1) ^ f0) << 1) | (c16 & 1)) * 16);
+    sc1 = (unsigned)(((((c16 >> 1) ^ f1) << 1) | (c16 & 1)) * 16);
   }
   auto make_unit = [&](int seq) {
     T8Unit u;
     const int id = xcd_remap(seq < units ? seq : units - 1, units);
-    const int chunk = id / tiles, tile = id - chunk * tiles;
+    const int chunk = id / tiles;
+    int tile = id - chunk * tiles;
+    const bool second = g.nprob > 1 && tile >= g.pr[0].tiles;
+    if (second) tile -= g.pr[0].tiles;
+    const T8Prob& pr = g.pr[second ? 1 : 0];
+    const int tiles_k = pr.K / 256;
     const int tn = tile / tiles_k, tk = tile - tn * tiles_k;
-    u.n0 = tn * 256;
-    u.k0 = tk * 256;
     const int kt0 = chunk * kt_per_chunk;
     u.nk = min(kt_per_chunk, nk_total - kt0);
     u.nk += u.nk & 1;                               // even; the extra K-tile reads zeros
     u.mbeg = kt0 * 64;
-    u.pb = pbase + ((long long)u.mbeg * g.ldp + u.n0) * 2;
-    u.qb = qbase + ((long long)u.mbeg * a.pitch + u.k0) * 2;
+    u.pb = pr.P + ((long long)u.mbeg * pr.ldp + tn * 256) * 2;
+    u.qb = pr.Q + ((long long)u.mbeg * pr.ldq + tk * 256) * 2;
+    u.wb = pr.W + (long long)tn * 256 * pr.ldw + tk * 256;
+    u.ldp2 = (unsigned)(pr.ldp * 2);
+    u.ldq2 = (unsigned)(pr.ldq * 2);
+    u.ldw = pr.ldw;
     return u;
   };
   char* const dst0 = smem + wid * 1024;            // + buffer + half offset (+ 8192 for the second slab)
-  const long long p_kstep = 64LL * g.ldp * 2, q_kstep = 64LL * a.pitch * 2;
 
   // stage one half-tile of K-tile kt of unit U: 2 LDS-DMA per thread; rows >= M come from the zero page
-#define T8_STAGE(ub, o0, o1, kstep, U, kt, hi, lds_off)                                             \
+#define T8_STAGE(ub, ld2, U, kt, hi, lds_off)                                                       \
   {                                                                                                 \
-    const char* kb_ = U.ub + ((long long)(kt) * (kstep) + (hi) * 256);                              \
+    const char* kb_ = U.ub + ((long long)(kt) * 64 * U.ld2 + (hi) * 256);                           \
     const int mr_ = U.mbeg + (kt) * 64;                                                             \
-    t8_glds16(mr_ + mrow0 < g.M ? kb_ + o0 : zsrc, dst0 + (lds_off));                               \
-    t8_glds16(mr_ + mrow1 < g.M ? kb_ + o1 : zsrc, dst0 + (lds_off) + 8192);                        \
+    t8_glds16(mr_ + mrow0 < g.M ? kb_ + ((unsigned)mrow0 * U.ld2 + sc0) : zsrc, dst0 + (lds_off));  \
+    t8_glds16(mr_ + mrow1 < g.M ? kb_ + ((unsigned)mrow1 * U.ld2 + sc1) : zsrc, dst0 + (lds_off) + 8192); \
   }
 
   // ---- fragment addresses: lane (gq, q, p) reads rows 8 gq + q (+4 for the upper half, +32 for ks = 1), column
@@ -141,27 +152,27 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
 #define T8_KTILE(cur, oth, U1, k1, U2, k2)                                                               \
   T8_READ_B(fbl, cur, T8_QLO)                                                                            \
   T8_READ_A(cur, T8_PLO)                                                                                 \
-  T8_STAGE(pb, po0, po1, p_kstep, U1, k1, 1, (oth) + T8_PHI)                                      \
+  T8_STAGE(pb, ldp2, U1, k1, 1, (oth) + T8_PHI)                                      \
   T8_MFMA(0, 0, fbl)                                                                                     \
   T8_READ_B(fbh, cur, T8_QHI)                                                                            \
-  T8_STAGE(pb, po0, po1, p_kstep, U2, k2, 0, (cur) + T8_PLO)                                      \
+  T8_STAGE(pb, ldp2, U2, k2, 0, (cur) + T8_PLO)                                      \
   T8_MFMA(0, 2, fbh)                                                                                     \
   T8_READ_A(cur, T8_PHI)                                                                                 \
-  T8_STAGE(qb, qo0, qo1, q_kstep, U2, k2, 0, (cur) + T8_QLO)                                      \
+  T8_STAGE(qb, ldq2, U2, k2, 0, (cur) + T8_QLO)                                      \
   T8_MFMA(4, 2, fbh)                                                                                     \
-  T8_STAGE(qb, qo0, qo1, q_kstep, U2, k2, 1, (cur) + T8_QHI)                                      \
+  T8_STAGE(qb, ldq2, U2, k2, 1, (cur) + T8_QHI)                                      \
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
   T8_MFMA(4, 0, fbl)
 
   int seq = blockIdx.x;
   T8Unit U = make_unit(seq);
-  T8_STAGE(pb, po0, po1, p_kstep, U, 0, 0, T8_PLO)
-  T8_STAGE(qb, qo0, qo1, q_kstep, U, 0, 0, T8_QLO)
-  T8_STAGE(qb, qo0, qo1, q_kstep, U, 0, 1, T8_QHI)
-  T8_STAGE(pb, po0, po1, p_kstep, U, 0, 1, T8_PHI)
-  T8_STAGE(pb, po0, po1, p_kstep, U, 1, 0, T8_BUF + T8_PLO)
-  T8_STAGE(qb, qo0, qo1, q_kstep, U, 1, 0, T8_BUF + T8_QLO)
-  T8_STAGE(qb, qo0, qo1, q_kstep, U, 1, 1, T8_BUF + T8_QHI)
+  T8_STAGE(pb, ldp2, U, 0, 0, T8_PLO)
+  T8_STAGE(qb, ldq2, U, 0, 0, T8_QLO)
+  T8_STAGE(qb, ldq2, U, 0, 1, T8_QHI)
+  T8_STAGE(pb, ldp2, U, 0, 1, T8_PHI)
+  T8_STAGE(pb, ldp2, U, 1, 0, T8_BUF + T8_PLO)
+  T8_STAGE(qb, ldq2, U, 1, 0, T8_BUF + T8_QLO)
+  T8_STAGE(qb, ldq2, U, 1, 1, T8_BUF + T8_QHI)
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (stagger && wr == 1) __builtin_amdgcn_s_barrier();         // wave groups half a phase apart (see a2v_gemm_p8.hip)
@@ -188,7 +199,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
     int le = lane;
     asm volatile("" : "+v"(le));                     // keeps the lane-derived addresses out of the K loop's live set
     const int fre = le & 15, fqe = le >> 4;
-    float* const wt = g.W + (long long)(U.n0 + wr * 64 + fqe * 4) * g.ldw + U.k0 + wc * 32 + fre;
+    float* const wt = U.wb + (long long)(wr * 64 + fqe * 4) * U.ldw + wc * 32 + fre;
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -199,7 +210,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
           for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * g.ldw + hb * 128 + j * 16, acc[ha * 4 + i][hb * 2 + j][r]);
+              atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * U.ldw + hb * 128 + j * 16, acc[ha * 4 + i][hb * 2 + j][r]);
     U = Un;
   }
   if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
@@ -207,12 +218,30 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(WgradArgs g, int c
 }
 
 extern int g_a2v_p8_stagger;
-bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
+static bool t8_eligible(const WgradArgs& g) {
   const ConvA& a = g.a;
-  const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
-                     a.Cv == a.Cg && a.bdiv == 1 && g.G == 1;
-  if (!plain || g.N % 256 || g.K % 256 || g.M < 2048) return false;
-  const int tiles = (g.N / 256) * (g.K / 256);
+  const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.rowidx == nullptr && a.stride == 1 &&
+                     a.T_in == a.T_out && a.Cv == a.Cg && a.bdiv == 1 && g.G == 1;
+  return plain && g.N % 256 == 0 && g.K % 256 == 0 && g.M >= 2048 && g.ldp * 2 * 64 < (1LL << 31) && a.pitch * 2 * 64 < (1LL << 31);
+}
+static T8Prob t8_prob(const WgradArgs& g) {
+  T8Prob p;
+  p.P = (const char*)g.P; p.Q = (const char*)g.a.ptr; p.W = g.W;
+  p.ldp = g.ldp; p.ldq = g.a.pitch; p.ldw = g.ldw;
+  p.N = g.N; p.K = g.K; p.tiles = (g.N / 256) * (g.K / 256);
+  return p;
+}
+
+// one or two weight-gradient problems over the same M rows in one launch: the units of both share the CUs, so the M
+// range is cut into fewer chunks and every output element receives fewer fp32 atomic adds
+bool a2v_launch_tn_bf16_p8_pair(const WgradArgs* ga, const WgradArgs* gb, hipStream_t stream) {
+  if (!t8_eligible(*ga) || (gb && (!t8_eligible(*gb) || gb->M != ga->M))) return false;
+  T8Args args;
+  args.pr[0] = t8_prob(*ga);
+  args.pr[1] = gb ? t8_prob(*gb) : args.pr[0];
+  args.nprob = gb ? 2 : 1;
+  args.M = ga->M;
+  const int tiles = args.pr[0].tiles + (gb ? args.pr[1].tiles : 0);
   static int cus = 0;
   if (!cus) {
     hipDeviceProp_t p;
@@ -222,7 +251,7 @@ bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
     cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
     (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_p8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, T8_LDS);
   }
-  const int nk_total = cdiv(g.M, 64);
+  const int nk_total = cdiv(args.M, 64);
   int chunks = cus / tiles;
   if (chunks < 1) chunks = 1;
   int kpc = cdiv(nk_total, chunks);
@@ -231,6 +260,8 @@ bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) {
   chunks = cdiv(nk_total, kpc);
   const int units = tiles * chunks;
   dim3 grid(units < cus ? units : cus, 1, 1);
-  hipLaunchKernelGGL(gemm_tn_bf16_p8_kernel, grid, dim3(512), T8_LDS, stream, g, chunks, kpc, g_a2v_p8_stagger == 2 ? 1 : 0);
+  hipLaunchKernelGGL(gemm_tn_bf16_p8_kernel, grid, dim3(512), T8_LDS, stream, args, chunks, kpc, g_a2v_p8_stagger == 2 ? 1 : 0);
   return true;
 }
+
+bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream) { return a2v_launch_tn_bf16_p8_pair(&g, nullptr, stream); }

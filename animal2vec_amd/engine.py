@@ -193,20 +193,19 @@ class Engine:
         ds2, ds2d = ops.layernorm_bwd(dx, sv["s2"], p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], *sv["st2"],
                                       dgamma=g[prefix + "norm2.weight"], dbeta=g[prefix + "norm2.bias"],
                                       dxsum=g[prefix + "mlp.fc2.bias"], drop=d_mlp, drop_mode=2)
-        ops.linear_wgrad(sv["g"], ds2d, g[prefix + "mlp.fc2.weight"])
         dh = ops.linear(ds2d, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"])
-        ops.linear_wgrad(sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
+        ops.linear_wgrad_pair(sv["g"], ds2d, g[prefix + "mlp.fc2.weight"], sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
         dx1 = ops.linear(dh, sp.wt[prefix + "mlp.fc1.weight"], res=ds2)
         ds1, ds1d = ops.layernorm_bwd(dx1, sv["s1"], p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], *sv["st1"],
                                       dgamma=g[prefix + "norm1.weight"], dbeta=g[prefix + "norm1.bias"],
                                       dxsum=g[prefix + "attn.proj.bias"], drop=d_proj, drop_mode=2)
-        ops.linear_wgrad(sv["att"].view(N * S, D), ds1d, g[prefix + "attn.proj.weight"])
         datt = ops.linear(ds1d, sp.wt[prefix + "attn.proj.weight"])
         dqkv = ops.attention_bwd(sv["qkv"].view(N, S, 3 * D), sv["att"], datt.view(N, S, D), sv["lse"], pos,
                                  st.alibi_slopes, alibi_scale, H, g[P + "alibi_scale"].view(-1), drop=d_att)
         dq2 = dqkv.view(N * S, 3 * D)
         ops.colsum(dq2, g[prefix + "attn.qkv.bias"])
-        ops.linear_wgrad(sv["x"], dq2, g[prefix + "attn.qkv.weight"])
+        ops.linear_wgrad_pair(sv["att"].view(N * S, D), ds1d, g[prefix + "attn.proj.weight"],
+                              sv["x"], dq2, g[prefix + "attn.qkv.weight"])
         dxin = ops.linear(dq2, sp.wt[prefix + "attn.qkv.weight"], res=ds1)
         return dxin.view(N, S, D)
 

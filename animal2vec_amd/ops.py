@@ -133,6 +133,17 @@ def linear_wgrad(x, dy, gw):
                       ldp=dy.stride(0), ldw=gw.stride(0))
 
 
+def linear_wgrad_pair(xa, dya, gwa, xb, dyb, gwb):
+    """gwa[Na,Ka] += dya^T @ xa and gwb[Nb,Kb] += dyb^T @ xb (same M rows) in one launch where the kernel allows."""
+    M, Ka = xa.shape
+    Na, Nb, Kb = dya.shape[1], dyb.shape[1], xb.shape[1]
+    assert xb.shape[0] == M and dya.shape[0] == M and dyb.shape[0] == M and xa.dtype == xb.dtype
+    assert gwa.dtype == torch.float32 and gwb.dtype == torch.float32 and gwa.shape == (Na, Ka) and gwb.shape == (Nb, Kb)
+    rc = _L().a2v_linear_wgrad_pair(dt(xa), M, ptr(xa), xa.stride(0), ptr(dya), dya.stride(0), ptr(gwa), gwa.stride(0), Na, Ka,
+                                    ptr(xb), xb.stride(0), ptr(dyb), dyb.stride(0), ptr(gwb), gwb.stride(0), Nb, Kb, stream())
+    check(rc, "a2v_linear_wgrad_pair")
+
+
 def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=None, bdiv=1, n_batch=None, cv=None,
                     rowidx=None):
     """gw_packed (G, N, k*Cg) fp32 += implicit-im2col(x)^T dy.  rowidx: dy holds only those rows (compact)."""

@@ -76,6 +76,13 @@ int a2v_conv_wgrad_rows(const int* rowidx, int dtype, const void* A, long long a
                         const void* P, long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N,
                         int K, int G, a2v_stream_t stream);
 
+/* Two Linear weight gradients over the same M rows in one launch (gw_a[Na,Ka] += dy_a^T x_a, gw_b[Nb,Kb] += dy_b^T x_b;
+ * torch.autograd's two separate addmm in the reference).  Sharing the launch lets the 256x256 TN kernel cut M into
+ * fewer chunks, i.e. fewer fp32 atomic adds per gradient element; shapes it does not take run as two launches. */
+int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long lda, const void* dya, long long ldpa, float* gwa,
+                          long long ldwa, int Na, int Ka, const void* xb, long long ldb, const void* dyb, long long ldpb,
+                          float* gwb, long long ldwb, int Nb, int Kb, a2v_stream_t stream);
+
 /* ---------------------------------------------------------------- attention with analytic ALiBi
  * qkv (N,S,3,H,HD); out (N,S,H*HD); lse (N,H,S) fp32; pos (N,S) int32 original frame index or NULL
  * (= arange); slopes (H) fp32; alibi_scale (H) fp32 (clamped at 0 inside).

@@ -140,6 +140,19 @@ def test_linear_wgrad_p8_kernel(ops, M, N, K):
     assert rel_err(gw, gw_old) < 1e-5
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,Na,Ka,Nb,Kb", [(2100, 1024, 256, 256, 1024), (4160, 768, 256, 256, 256), (300, 96, 64, 40, 72)])
+def test_linear_wgrad_pair(ops, dtype, M, Na, Ka, Nb, Kb):
+    """two weight gradients over the same rows in one call (one 256x256 TN launch when eligible, else two launches)"""
+    xa, dya = rnd(M, Ka, dtype=dtype, seed=1), rnd(M, Na, dtype=dtype, seed=2)
+    xb, dyb = rnd(M, Kb, dtype=dtype, seed=3), rnd(M, Nb, dtype=dtype, seed=4)
+    ga0, gb0 = rnd(Na, Ka, dtype=torch.float32, seed=5), rnd(Nb, Kb, dtype=torch.float32, seed=6)
+    ga, gb = ga0.clone().cuda(), gb0.clone().cuda()
+    ops.linear_wgrad_pair(dev(xa, dtype), dev(dya, dtype), ga, dev(xb, dtype), dev(dyb, dtype), gb)
+    assert rel_err(ga, ga0 + dya.t() @ xa) < tol(dtype)
+    assert rel_err(gb, gb0 + dyb.t() @ xb) < tol(dtype)
+
+
 # ------------------------------------------------------------------------------------------ convs
 def to_cl(x_bct, cp, dtype):
     B, C_, T = x_bct.shape
