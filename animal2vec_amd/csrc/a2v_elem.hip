@@ -535,4 +535,4 @@ extern "C" int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, 
   return A2V_OK;
 }
 
-extern "C" int a2v_abi_version(void) { return 3; }
+extern "C" int a2v_abi_version(void) { return 4; }
