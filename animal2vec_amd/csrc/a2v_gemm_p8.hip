@@ -217,29 +217,30 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     // would be live -- and spilled -- across the K loop, and a spill reload is a VMEM load whose wait drains the DMA
     int le = lane;
     asm volatile("" : "+v"(le));
-    const int fre = le & 15, fqe = le >> 4;
+    const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
+    const int er = le >> 3, ec = (le & 7) * 8;           // read-out: 8 rows x 8 lanes, 8 columns (16 B of bf16) per lane
     float* const stg = (float*)(smem + P8_STG) + wid * 1024;
-    const int cq = fre * 4;
-    const int ncol = T.n0 + wc * 32 + cq + (cq >= 32 ? 96 : 0);
+    const int ncol = T.n0 + wc * 32 + ec + (ec >= 32 ? 96 : 0);
     const long long ccol = (long long)grp * g.c_goff + ncol;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (g.flags & F_BIAS) bias4 = *(const f32x4*)(g.bias + (long long)grp * g.N + ncol);
+    float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + ncol, bias8);
     // consume the load here: a load still pending on some path at the end of the epilogue makes hipcc put an
     // s_waitcnt vmcnt(0) at the head of the K loop (draining the LDS-DMA pipeline every K-tile)
-    asm volatile("" :: "v"(bias4));
-    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(bias8[i]));
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     bf16* const C = (bf16*)g.C;
     bf16* const C2 = (bf16*)g.C2;
     const bf16* const R = (const bf16*)g.R;
     // residual / pre-activation rows are fetched one pass (16 rows) ahead of their use
     const bool need_r = (g.flags & (F_RES | F_GELU_BWD)) != 0;
-    uint2 rq[2][4];
+    Raw8<bf16> rq[2][2];
 #define P8_RLOAD(ps_, slot)                                                                           \
   if (need_r) {                                                                                       \
-    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                                                \
-      int m_ = T.m0 + ((ps_) < 4 ? wr * 64 + (ps_) * 16 : 128 + wr * IH * 16 + ((ps_) - 4) * 16) + it * 4 + fqe; \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                                \
+      int m_ = T.m0 + ((ps_) < 4 ? wr * 64 + (ps_) * 16 : 128 + wr * IH * 16 + ((ps_) - 4) * 16) + it * 8 + er; \
       m_ = m_ < g.M ? m_ : g.M - 1;                                                                   \
-      rq[slot][it] = *(const uint2*)(R + (long long)m_ * g.ldr + ccol);                               \
+      rq[slot][it].load(R + (long long)m_ * g.ldr + ccol);                                            \
     }                                                                                                 \
   }
     P8_RLOAD(0, 0)
@@ -259,36 +260,40 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const int mrow0 = T.m0 + (ps < 4 ? wr * 64 + ps * 16 : 128 + wr * IH * 16 + (ps - 4) * 16);
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int r = it * 4 + fqe;
+      for (int it = 0; it < 2; ++it) {
+        const int r = it * 8 + er;
         const int m = mrow0 + r;
-        f32x4 v = *(const f32x4*)(stg + r * 64 + (cq ^ (((r >> 2) & 1) << 4)));
+        const float* sp_ = stg + r * 64 + (ec ^ (((r >> 2) & 1) << 4));
+        const f32x4 va = *(const f32x4*)sp_, vb = *(const f32x4*)(sp_ + 4);
+        float v[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
         if (m < g.M) {
-          v += bias4;
-          if (g.flags & F_STORE_PRE) Vec4<bf16>::store(C2 + (long long)m * g.ldc + ccol, v);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] += bias8[i];
+          if (g.flags & F_STORE_PRE) Vec8<bf16>::store(C2 + (long long)m * g.ldc + ccol, v);
           if (g.flags & F_GELU) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
           }
           if (g.flags & F_DROPOUT) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);
           }
           if (need_r) {
-            const uint2 q = rq[ps & 1][it];
-            f32x4 h;
-            h[0] = __uint_as_float(q.x << 16); h[1] = __uint_as_float(q.x & 0xffff0000u);
-            h[2] = __uint_as_float(q.y << 16); h[3] = __uint_as_float(q.y & 0xffff0000u);
-            if (g.flags & F_RES) v += h;
+            float h[8];
+            rq[ps & 1][it].unpack(h);
+            if (g.flags & F_RES) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] += h[i];
+            }
             if (g.flags & F_GELU_BWD) {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) v[i] *= gelu_grad_f(h[i]);
+              for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(h[i]);
             }
           }
-          Vec4<bf16>::store(C + (long long)m * g.ldc + ccol, v);
+          Vec8<bf16>::store(C + (long long)m * g.ldc + ccol, v);
           if (g.flags & F_COLSUM) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cs[i] += Cvt<bf16>::to(Cvt<bf16>::from(v[i]));
+            for (int i = 0; i < 8; ++i) cs[i] += Cvt<bf16>::to(Cvt<bf16>::from(v[i]));
           }
         }
       }
@@ -298,15 +303,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     }
     if (g.flags & F_COLSUM) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float s = cs[i];
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        cs[i] = s;
+      for (int i = 0; i < 8; ++i) {
+        float s_ = cs[i];
+        s_ += __shfl_xor(s_, 8, 64);
+        s_ += __shfl_xor(s_, 16, 64);
+        s_ += __shfl_xor(s_, 32, 64);
+        cs[i] = s_;
       }
-      if (le < 16) {
+      if (le < 8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) atomicAdd(g.colsum + (long long)grp * g.N + ncol + i, cs[i]);
+        for (int i = 0; i < 8; ++i) atomicAdd(g.colsum + (long long)grp * g.N + ncol + i, cs[i]);
       }
     }
 #undef P8_RLOAD
