@@ -178,9 +178,17 @@ def project_features(p, x):
     return F.linear(x, p[P + "project_features.2.weight"], p[P + "project_features.2.bias"])
 
 
-def local_features(p, source, cfg):
-    """nn/modalities/base.py:194-213 with local_grad_mult == 1."""
-    return project_features(p, feature_extractor(p, source, cfg))
+def local_features(p, source, cfg, local_grad_mult: float = 1.0):
+    """nn/modalities/base.py:194-213: local_grad_mult == 1 (pretrain) runs the conv feature extractor with
+    gradients; local_grad_mult == 0 (finetune: feature_grad_mult 0.0, finetune_mixup_100.yaml:85 ->
+    wav2vec2.py:122) runs it under no_grad -- project_features keeps its gradients either way."""
+    if local_grad_mult > 0:
+        assert local_grad_mult == 1.0, "GradMultiply with a fractional factor is not on the benchmarked path"
+        x = feature_extractor(p, source, cfg)
+    else:
+        with torch.no_grad():
+            x = feature_extractor(p, source, cfg)
+    return project_features(p, x)
 
 
 # ------------------------------------------------------------------------------ masking (a8)
@@ -399,6 +407,44 @@ def features_only_forward(p, source, cfg: OracleConfig):
         x, t = alt_block(p, f"blocks.{i}.", x, bias, cfg.num_heads, cfg.norm_eps)
         lrs.append(t)
     return x, lrs
+
+
+# ------------------------------------------------------------------------------ finetune path
+def sigmoid_focal_loss(inputs, targets, alpha: float = 0.25, gamma: float = 2, reduction: str = "none"):
+    """nn/utils.py:971-1010 (RetinaNet focal loss on logits; criterion 'finetunecriterion' calls it with
+    reduction='sum', criterions.py:243-248)."""
+    inputs, targets = inputs.float(), targets.float()
+    pr = torch.sigmoid(inputs)
+    ce = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
+    p_t = pr * targets + (1 - pr) * (1 - targets)
+    loss = ce * ((1 - p_t) ** gamma)
+    if alpha >= 0:
+        loss = (alpha * targets + (1 - alpha) * (1 - targets)) * loss
+    if reduction == "mean":
+        return loss.mean()
+    if reduction == "sum":
+        return loss.sum()
+    return loss
+
+
+def finetune_forward(p, head_w, head_b, source, cfg: OracleConfig, top_k=None, local_grad_mult: float = 0.0):
+    """Wav2VecEncoderModOut.forward in eval mode (wav2vec2.py:430-482): extract_features(mask=False) of the student,
+    mean of the last `average_top_k_layers` layer results (the blocks' FFN outputs t, modules.py:328-337),
+    final_dropout (0.0), Linear(D -> n_labels).  Returns logits (B, T, C)."""
+    top_k = cfg.average_top_k_layers if top_k is None else top_k
+    feats = local_features(p, source, cfg, local_grad_mult)
+    B, T, D = feats.shape
+    x = feats + pos_conv(p, P, feats, cfg)
+    pos = torch.arange(T).unsqueeze(0).expand(B, -1)
+    bias = alibi_bias_from_positions(pos, cfg.num_heads, p[P + "alibi_scale"])
+    x = prenet(p, P, x, bias, cfg)
+    lrs = []
+    for i in range(cfg.depth):
+        x, t = alt_block(p, f"blocks.{i}.", x, bias, cfg.num_heads, cfg.norm_eps)
+        lrs.append(t)
+    sel = lrs[-top_k:]
+    xm = sum(sel) / len(sel)
+    return F.linear(xm, head_w, head_b)
 
 
 def pretrain_forward(p, ema, source, mask, noise, cfg: OracleConfig):

@@ -255,6 +255,69 @@ def mixup_fixture(refnn):
     return {"source": src, "perm": perm, "r": torch.tensor(r), "gain_db": G_ref, "mixed": mixed_ref}
 
 
+def finetune_fixture(refnn, model, cfg, seed=21, n_labels=12, tol=2e-5):
+    """G15: the finetune path's logits, focal loss and gradients.  The encoder side is the
+    LIVE reference (Data2VecMultiModel.extract_features with local_grad_mult = 0, as wav2vec2.py:122 sets it from
+    feature_grad_mult 0.0) and the loss is the LIVE nn.utils.sigmoid_focal_loss; the glue between them (mean of the
+    last average_top_k_layers layer results, Linear(D -> n_labels)) is the five lines of wav2vec2.py:448-475,
+    restated here because Wav2VecEncoderModOut itself needs a fairseq checkpoint + task to construct."""
+    import importlib
+    ref_utils = importlib.import_module("nn.utils")
+    g = torch.Generator().manual_seed(seed)
+    B, L = 2, 8000
+    D = cfg.embed_dim
+    T = O.frame_counts(L, cfg.conv_feature_layers)[-1]
+    source = torch.nn.functional.layer_norm(torch.randn(B, L, generator=g), (L,))
+    target = (torch.rand(B, T, n_labels, generator=g) < 0.15).float()
+    head_w = torch.randn(n_labels, D, generator=g) * 0.1
+    head_b = torch.randn(n_labels, generator=g) * 0.1
+    model.eval()
+    enc = model.modality_encoders["AUDIO"]
+    old = enc.local_grad_mult
+    enc.local_grad_mult = 0.0
+    hw, hb = head_w.clone().requires_grad_(True), head_b.clone().requires_grad_(True)
+    model.zero_grad()
+    res = model.extract_features(source)
+    lrs = res["layer_results"][-cfg.average_top_k_layers:]
+    xm = (sum(lrs) / len(lrs)).to(res["x"].dtype)
+    logits_ref = torch.nn.functional.linear(xm, hw, hb)
+    loss_ref = ref_utils.sigmoid_focal_loss(logits_ref, target, reduction="sum")
+    loss_ref.backward()
+    gref = {n: prm.grad.detach().clone() for n, prm in model.named_parameters() if prm.grad is not None}
+    enc.local_grad_mult = old
+    # oracle
+    p, _ = state_to_flat(model)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ow, ob = head_w.clone().requires_grad_(True), head_b.clone().requires_grad_(True)
+    logits = O.finetune_forward(po, ow, ob, source, cfg)
+    loss = O.sigmoid_focal_loss(logits, target, reduction="sum")
+    loss.backward()
+    check("finetune logits", logits, logits_ref, tol * 5)
+    check("finetune focal loss", loss, loss_ref, tol * 5)
+    check("finetune head grads", ow.grad, hw.grad, tol * 25)
+    worst, n_g = 0.0, 0
+    for n, gr in gref.items():
+        go = po[n].grad
+        assert go is not None, n
+        r = rel(go, gr)
+        worst = max(worst, r)
+        n_g += 1
+        assert r < 5e-4, (n, r)
+    no_grad = [n for n in po if po[n].grad is None]
+    # no gradient: the frozen conv feature extractor, the (unused) decoder, and the last block's norm2 (its output x
+    # is not part of any layer result)
+    last_norm2 = f"blocks.{cfg.depth - 1}.norm2."
+    odd = [n for n in no_grad if not (("local_encoder" in n) or ("decoder" in n) or n.startswith(last_norm2))]
+    assert not odd, odd[:5]
+    assert set(no_grad) == {n for n in po if n not in gref}, "reference and oracle disagree on which parameters get gradients"
+    print(f"  [ok ] finetune: {n_g} encoder grads worst rel={worst:.3e}; {len(no_grad)} params correctly without gradient")
+    fx = {"source": source, "target": target, "head_w": head_w, "head_b": head_b, "logits": logits_ref.detach(),
+          "loss_sum": loss_ref.detach(), "g.head_w": hw.grad, "g.head_b": hb.grad}
+    for k, v in gref.items():
+        fx["g." + k] = v
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also validate large dims at L=80000 (slow)")
@@ -267,6 +330,7 @@ def main():
     model, cfg, fx = run_pair(refnn, O.TINY, TINY_LAYERS, TINY_LAYERS_STR, B=2, L=8000, keep=16, seed=1)
     ex = ema_fixture(model, cfg, fx)
     mx = mixup_fixture(refnn)
+    ftx = finetune_fixture(refnn, model, cfg)
     # second pair: real front end (127x63 sinc, 512-wide convs), small transformer; validated, not stored
     mid = dict(O.TINY, embed_dim=128, num_heads=8, conv_pos_groups=16, decoder_groups=16, decoder_dim=64)
     run_pair(refnn, mid, O.LARGE_LAYERS, ref_shims.LARGE_LAYERS, B=1, L=16000, keep=28, seed=2)
@@ -278,6 +342,7 @@ def main():
         save("tiny_pretrain.npz", fx)
         save("tiny_ema.npz", ex)
         save("mixup.npz", mx)
+        save("tiny_finetune.npz", ftx)
 
 
 if __name__ == "__main__":

@@ -123,3 +123,34 @@ def test_features_only_golden(tiny_golden):
     x, lrs = O.features_only_forward(p, tiny_golden["source"], tiny_cfg())
     assert rel_err(x, tiny_golden["features_only.x"]) < 1e-5
     assert rel_err(sum(lrs) / len(lrs), tiny_golden["features_only.layer_mean"]) < 1e-5
+
+
+def test_finetune_path_golden(tiny_golden):
+    """G15: logits, focal loss and every gradient of the finetune path (wav2vec2.py:430-482 in eval mode with the
+    conv feature extractor frozen, criterions.py:243-248) against the live reference's extract_features +
+    sigmoid_focal_loss."""
+    ft = load_golden("tiny_finetune.npz")
+    p, _, _ = split_golden(tiny_golden)
+    cfg = tiny_cfg()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    hw, hb = ft["head_w"].clone().requires_grad_(True), ft["head_b"].clone().requires_grad_(True)
+    logits = O.finetune_forward(po, hw, hb, ft["source"], cfg)
+    loss = O.sigmoid_focal_loss(logits, ft["target"], reduction="sum")
+    loss.backward()
+    assert rel_err(logits, ft["logits"]) < 1e-5
+    assert abs(float(loss) - float(ft["loss_sum"])) / float(ft["loss_sum"]) < 1e-5
+    assert rel_err(hw.grad, ft["g.head_w"]) < 1e-4 and rel_err(hb.grad, ft["g.head_b"]) < 1e-4
+    gk = [k[2:] for k in ft if k.startswith("g.") and not k.startswith("g.head_")]
+    assert len(gk) > 40
+    for k in gk:
+        assert rel_err(po[k].grad, ft["g." + k]) < 5e-4, k
+    # the frozen front end and the last block's unused norm2 carry no gradient, as in the reference
+    assert all(po[k].grad is None for k in po if "local_encoder" in k)
+    assert set(k for k in po if po[k].grad is not None) == set(gk)
+
+
+def test_focal_loss_known_values():
+    # nn/utils.py:971-1010 at logit 0: p = 0.5, ce = ln 2, (1 - p_t)^2 = 0.25, alpha_t = 0.25 (positive) / 0.75
+    l = O.sigmoid_focal_loss(torch.zeros(2), torch.tensor([1.0, 0.0]))
+    assert l[0].item() == pytest.approx(0.25 * 0.25 * math.log(2), rel=1e-6)
+    assert l[1].item() == pytest.approx(0.75 * 0.25 * math.log(2), rel=1e-6)
