@@ -4,6 +4,8 @@
 // All rows are channels-last; every thread moves 16 bytes where the layout allows it.
 #include "a2v_common.h"
 
+struct PtrList32 { const void* p[32]; };
+
 // ---------------------------------------------------------------------------------- gather tokens
 // out[n,k,:] = a[n/cb, ids[n,k], :] (+ b[n, ids[n,k], :])        reference base.py:244,447,277-280
 template <typename T>
@@ -179,6 +181,61 @@ __global__ __launch_bounds__(256) void d2v_loss_kernel(const T* __restrict__ x, 
       atomicAdd(stats + 4 * D, (double)ls);
       if (c == 0) atomicAdd(stats + 4 * D + 1, (double)cnt);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------- finetune path
+// sigmoid focal loss on logits, summed (nn/utils.py:971-1010 as called by criterions.py:243-248), with its gradient:
+//   p = sigmoid(x), ce = -[t log p + (1-t) log(1-p)], p_t = p t + (1-p)(1-t), L = alpha_t ce (1-p_t)^gamma
+//   dL/dx = alpha_t [ (p - t)(1-p_t)^gamma - gamma ce (1-p_t)^(gamma-1) p (1-p) (2t - 1) ]
+// targets are floats (target mixup makes them soft).  logits / dlogits are (M, ld) with C valid columns; padded
+// columns of dlogits are written as zero.
+template <typename T>
+__global__ __launch_bounds__(256) void focal_loss_kernel(const T* __restrict__ logits, const float* __restrict__ targets,
+                                                         T* __restrict__ dlogits, double* __restrict__ loss_sum, long long M,
+                                                         int C, int ld, float alpha, float gamma, float gscale) {
+  const long long total = M * ld;
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld);
+    const long long m = i / ld;
+    float d = 0.f;
+    if (c < C) {
+      const float x = Cvt<T>::to(logits[i]);
+      const float t = targets[m * C + c];
+      const float pr = 1.f / (1.f + __expf(-x));
+      // numerically stable BCE-with-logits: max(x,0) - x t + log(1 + exp(-|x|))
+      const float ce = fmaxf(x, 0.f) - x * t + log1pf(__expf(-fabsf(x)));
+      const float p_t = pr * t + (1.f - pr) * (1.f - t);
+      const float om = 1.f - p_t;
+      const float f = powf(om, gamma);
+      const float a_t = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+      acc += a_t * ce * f;
+      const float fm1 = gamma == 2.f ? om : powf(om, gamma - 1.f);
+      d = a_t * ((pr - t) * f - gamma * ce * fm1 * pr * (1.f - pr) * (2.f * t - 1.f)) * gscale;
+    }
+    if (dlogits) dlogits[i] = Cvt<T>::from(d);
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss_sum, (double)acc);
+}
+
+// out = scale * sum_l x_l   (the finetune head's input: mean of the last average_top_k_layers layer results,
+// wav2vec2.py:448-466); elementwise over n values, n % 8 == 0
+template <typename T>
+__global__ __launch_bounds__(256) void mean_layers_kernel(PtrList32 layers, T* __restrict__ out, int L, long long n, float scale) {
+  const long long nv = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int l = 0; l < L; ++l) {
+      float v[8];
+      Vec8<T>::load((const T*)layers.p[l] + i * 8, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] *= scale;
+    Vec8<T>::store(out + i * 8, acc);
   }
 }
 
@@ -428,6 +485,29 @@ extern "C" int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsi
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(d2v_loss_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, y, mask, (bf16*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw),
              hipLaunchKernelGGL(d2v_loss_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, y, mask, (float*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_focal_loss(int dtype, const void* logits, const float* targets, void* dlogits, double* loss_sum, long long M,
+                              int C, int ld, float alpha, float gamma, float gscale, hipStream_t st) {
+  if (M <= 0 || C <= 0 || ld < C || !logits || !targets || !loss_sum) return A2V_ERR_ARG;
+  const int g = grid_for(M * ld);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(focal_loss_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)logits, targets, (bf16*)dlogits, loss_sum, M, C, ld, alpha, gamma, gscale),
+             hipLaunchKernelGGL(focal_loss_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)logits, targets, (float*)dlogits, loss_sum, M, C, ld, alpha, gamma, gscale));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_mean_layers(int dtype, const void* const* layers, int L, void* out, long long n, float scale, hipStream_t st) {
+  if (L <= 0 || L > 32 || n <= 0 || n % 8 || !out) return A2V_ERR_ARG;
+  PtrList32 pl;
+  for (int i = 0; i < 32; ++i) pl.p[i] = i < L ? layers[i] : nullptr;
+  const int g = grid_for(n / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(mean_layers_kernel<bf16>, dim3(g), dim3(256), 0, st, pl, (bf16*)out, L, n, scale),
+             hipLaunchKernelGGL(mean_layers_kernel<float>, dim3(g), dim3(256), 0, st, pl, (float*)out, L, n, scale));
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }

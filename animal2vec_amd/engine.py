@@ -87,7 +87,9 @@ class Engine:
             sv["pf_ln"], sv["pf_st"] = ln, (mean, rstd)
         return feats.view(B, T_in, D)
 
-    def frontend_bwd(self, dfeat: torch.Tensor):
+    def frontend_bwd(self, dfeat: torch.Tensor, project_only: bool = False):
+        """project_only: stop after project_features (finetune runs the conv feature extractor under no_grad,
+        local_grad_mult = 0, base.py:196-206)."""
         cfg, st, sp, sv = self.cfg, self.store, self.sp, self.sv
         p, g = st.p, st.g
         pre = P + "local_encoder.conv_layers."
@@ -103,6 +105,8 @@ class Engine:
                                p[P + "project_features.1.bias"], *sv["pf_st"], dgamma=g[P + "project_features.1.weight"],
                                dbeta=g[P + "project_features.1.bias"])
         self._ready("project")
+        if project_only:
+            return
         for i in reversed(range(1, nl)):
             dim, k, s = self.layers[i]
             pl = self._pads(i)
@@ -168,10 +172,13 @@ class Engine:
         hpre = torch.empty(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
         gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre)
         t = None
-        if want_t:
+        s2 = None
+        if want_t:          # the FFN output t is a result of its own (layer_results): keep it apart from the residual sum
+            assert d_mlp is None, "layer results with post-MLP dropout are not implemented"
             t = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"])
+            s2 = torch.empty_like(t) if save is not None else None
             x2o, m2, r2 = ops.layernorm_fwd(t, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps, res=x1,
-                                            save_stats=False)
+                                            save_stats=save is not None, sum_out=s2)
         else:
             s2 = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"], res=x1, drop=d_mlp)
             x2o, m2, r2 = ops.layernorm_fwd(s2, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
@@ -181,7 +188,9 @@ class Engine:
                                  st2=(m2, r2), N=N, S=S, drops=(d_att, d_proj, d_mlp))
         return x2o.view(N, S, D), (t.view(N, S, D) if t is not None else None)
 
-    def block_bwd(self, dx, prefix, pos, alibi_scale, H, key):
+    def block_bwd(self, dx, prefix, pos, alibi_scale, H, key, dt=None):
+        """dt: gradient arriving directly at the block's FFN output t (finetune: the head reads the mean of the last
+        average_top_k_layers layer results)."""
         sv = self.sv.pop(key)
         st, sp = self.store, self.sp
         p, g = st.p, st.g
@@ -193,6 +202,9 @@ class Engine:
         ds2, ds2d = ops.layernorm_bwd(dx, sv["s2"], p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], *sv["st2"],
                                       dgamma=g[prefix + "norm2.weight"], dbeta=g[prefix + "norm2.bias"],
                                       dxsum=g[prefix + "mlp.fc2.bias"], drop=d_mlp, drop_mode=2)
+        if dt is not None:
+            ds2d = ops.mean_layers([ds2d, dt.reshape(N * S, D)], scale=1.0)
+            ops.colsum(dt.reshape(N * S, D), g[prefix + "mlp.fc2.bias"])          # dxsum above only saw the LN2 path
         dh = ops.linear(ds2d, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"])
         ops.linear_wgrad_pair(sv["g"], ds2d, g[prefix + "mlp.fc2.weight"], sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
         dx1 = ops.linear(dh, sp.wt[prefix + "mlp.fc1.weight"], res=ds2)
@@ -269,6 +281,89 @@ class Engine:
                                      cv=m["N"], rowidx=rows, res=dtok.view(N * K, D)).view(N, K, D)
             dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D,
                                cv=m["N"])
+
+    def posconv_bwd_dense(self, dy):
+        """All T frames (finetune: no masking, no clones).  dy (B,T,D) -> gradient wrt the pos-conv input."""
+        cfg, st, sp = self.cfg, self.store, self.sp
+        a = cfg.audio
+        g = st.g
+        k = cfg.pos_kernel
+        G = a.conv_pos_groups
+        N, T, D = dy.shape
+        for i in reversed(range(1, a.conv_pos_depth + 1)):
+            sv = self.sv.pop(f"pc{i}")
+            w = P + f"relative_positional_encoder.{i}.0.weight"
+            m = sp.meta[w]
+            dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1,
+                                   dxsum=g[P + f"relative_positional_encoder.{i}.0.bias"])
+            gw = sp.gw[w]
+            gw.zero_()
+            ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, cv=m["Cg"])
+            ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
+            dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D,
+                               cv=m["N"])
+        return dy
+
+    # ------------------------------------------------------------------ finetune path (SURVEY 8f rank 1)
+    def finetune_forward_backward(self, source, target, head, *, backward=True, gscale=1.0, top_k=None):
+        """Wav2VecEncoderModOut.forward in eval form (wav2vec2.py:430-482: extract_features(mask=False), mean of the
+        last average_top_k_layers layer results, Linear head) + the summed sigmoid focal loss of
+        FinetuneCrossEntropyCriterion (criterions.py:243-248), and -- with backward -- every gradient: encoder and
+        project_features into store.grad, head into head.gw / head.gb.  The conv feature extractor is frozen
+        (feature_grad_mult 0.0, finetune_mixup_100.yaml:85).  source (B,L) fp32, target (B,T,C) fp32 multi-hot (soft
+        after target mixup).  Returns logits (B,T,C); the loss sum is accumulated into head.loss_sum.
+        Not here yet: train-mode masking / channel masking, layerdrop, dropouts (all 0 in eval)."""
+        cfg, st, sp = self.cfg, self.store, self.sp
+        p, g = st.p, st.g
+        H, D = cfg.num_heads, cfg.embed_dim
+        a = cfg.audio
+        top_k = cfg.average_top_k_layers if top_k is None else top_k
+        save = backward
+        feats = self.frontend_fwd(source, save=save)
+        B, T, _ = feats.shape
+        asc = p[P + "alibi_scale"].view(-1)
+        x_pos = self.posconv_fwd(feats, sp, p, None, 1, save=save)
+        tok = torch.empty_like(feats) if save else None
+        x, m0, r0 = ops.layernorm_fwd(feats, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
+                                      cfg.norm_eps, res=x_pos, save_stats=save, sum_out=tok)
+        for i in range(a.prenet_depth):
+            x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, None, asc, H, save=f"fpb{i}" if save else None)
+        ts = []
+        for i in range(cfg.depth):
+            x, t = self.block_fwd(x, f"blocks.{i}.", sp, p, None, asc, H, save=f"fmb{i}" if save else None, want_t=True)
+            ts.append(t)
+        sel = ts[-top_k:]
+        xm = ops.mean_layers(sel).view(B * T, D)
+        logits = ops.linear(xm, head.w_op, head.b_op)                           # (B*T, Cp), Cp = classes padded to 16
+        C_ = head.n_labels
+        tgt = target.reshape(B * T, C_).contiguous()
+        dlog = ops.focal_loss(logits, tgt, head.loss_sum, alpha=head.alpha, gamma=head.gamma, gscale=gscale, want_grad=backward)
+        out = logits.view(B, T, -1)[..., :C_]
+        if not backward:
+            return out
+        # ---- head
+        ops.linear_wgrad(xm, dlog, head.gw)
+        ops.colsum(dlog, head.gb)
+        dxm = ops.linear(dlog, head.wt_op)                                       # (B*T, D)
+        dt = ops.mean_layers([dxm], scale=1.0 / len(sel)).view(B, T, D)
+        # ---- blocks: the last block's output x feeds nothing; every selected block receives dt at its FFN output
+        dxe = torch.zeros(B, T, D, dtype=self.dtype, device=feats.device)
+        first_sel = cfg.depth - len(sel)
+        for i in reversed(range(cfg.depth)):
+            dxe = self.block_bwd(dxe, f"blocks.{i}.", None, asc, H, f"fmb{i}", dt=dt if i >= first_sel else None)
+            self._ready(f"block{i}")
+        for i in reversed(range(a.prenet_depth)):
+            dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", None, asc, H, f"fpb{i}")
+            self._ready(f"prenet{i}")
+        dtok = ops.layernorm_bwd(dxe, tok, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"], m0, r0,
+                                 dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"])
+        dpos_in = self.posconv_bwd_dense(dtok)
+        self._ready("posconv")
+        dfeat = ops.mean_layers([dtok, dpos_in], scale=1.0)                      # x = feats + pos_conv(feats)
+        self.frontend_bwd(dfeat, project_only=True)
+        self._ready("frontend")
+        self.sv.clear()
+        return out
 
     def decoder_fwd(self, dec_in, save: bool):
         """Decoder1d (modules.py:137-192): grouped conv + LN(no affine) + GELU (+ residual) x L, then proj."""

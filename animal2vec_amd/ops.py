@@ -240,6 +240,29 @@ def instnorm_targets(layers: Sequence[torch.Tensor], eps=1e-5):
     return y
 
 
+def mean_layers(layers: Sequence[torch.Tensor], scale=None):
+    """scale * sum of same-shaped tensors (default 1/L: the mean)."""
+    L = len(layers)
+    arr = (C.c_void_p * L)(*[ptr(t) for t in layers])
+    out = torch.empty_like(layers[0])
+    rc = _L().a2v_mean_layers(dt(layers[0]), arr, L, ptr(out), out.numel(), 1.0 / L if scale is None else scale, stream())
+    check(rc, "a2v_mean_layers")
+    return out
+
+
+def focal_loss(logits2d, targets2d, loss_sum, *, alpha=0.25, gamma=2.0, gscale=1.0, want_grad=True):
+    """logits2d (M, ld) activation dtype with targets2d.shape[1] valid columns; loss_sum (1,) float64 accumulated.
+    Returns dlogits (M, ld) or None."""
+    M, ld = logits2d.shape
+    C_ = targets2d.shape[1]
+    assert targets2d.dtype == torch.float32 and targets2d.shape[0] == M and loss_sum.dtype == torch.float64
+    dl = torch.empty_like(logits2d) if want_grad else None
+    rc = _L().a2v_focal_loss(dt(logits2d), ptr(logits2d), ptr(targets2d), ptr(dl), ptr(loss_sum), M, C_, ld, alpha, gamma,
+                             gscale, stream())
+    check(rc, "a2v_focal_loss")
+    return dl
+
+
 def colsum(x2d, out):
     M, C_ = x2d.shape
     rc = _L().a2v_colsum(dt(x2d), ptr(x2d), ptr(out), M, C_, x2d.stride(0), stream())

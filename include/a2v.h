@@ -204,6 +204,17 @@ int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, unsigned dr
 int a2v_debug_set(int key, int value);
 
 /* library version / build info */
+/* ---------------------------------------------------------------- finetune path
+ * Sum-reduced sigmoid focal loss on logits and its gradient (nn/utils.py:971-1010, called with reduction="sum" by
+ * FinetuneCrossEntropyCriterion.forward, criterions.py:243-248).  logits / dlogits (M, ld) in the activation dtype
+ * with C valid columns (padded columns of dlogits are written as zero; dlogits may be NULL), targets (M, C) fp32
+ * (soft after target mixup), loss_sum double accumulated atomically, gscale multiplied into dlogits. */
+int a2v_focal_loss(int dtype, const void* logits, const float* targets, void* dlogits, double* loss_sum, long long M, int C,
+                   int ld, float alpha, float gamma, float gscale, a2v_stream_t stream);
+/* out = scale * sum of L same-shaped tensors (L <= 32, n elements, n % 8 == 0): the mean of the last
+ * average_top_k_layers layer results that feeds the classification head (wav2vec2.py:448-466). */
+int a2v_mean_layers(int dtype, const void* const* layers, int L, void* out, long long n, float scale, a2v_stream_t stream);
+
 int a2v_abi_version(void);
 
 #ifdef __cplusplus

@@ -263,3 +263,80 @@ def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     assert abs(float(eng.stats[4 * D]) - ls) / ls < tol_y
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
     assert errs[0][0] < tol_g, errs[:8]
+
+
+# ------------------------------------------------------------------------------------------ finetune path (8f rank 1)
+def _finetune_run(cfg, p, ema, dtype, source, target, head_w, head_b):
+    from animal2vec_amd.finetune import FinetuneHead, finetune_step
+    store, eng = build(cfg, p, ema, dtype)
+    head = FinetuneHead(cfg.embed_dim, head_w.shape[0], dtype=dtype)
+    head.load(head_w.cuda(), head_b.cuda())
+    store.grad.zero_()
+    head.zero_grad()
+    logits, loss = finetune_step(eng, head, source.cuda(), target.cuda())
+    torch.cuda.synchronize()
+    return store, head, logits, float(loss)
+
+
+def test_finetune_tiny_fp32_vs_reference_golden(tiny_golden):
+    """logits, summed focal loss and every gradient of the finetune path against the vectors dumped from the live
+    reference (extract_features + nn.utils.sigmoid_focal_loss): the north-star's 1e-3."""
+    from animal2vec_amd.config import tiny_config
+    from conftest import load_golden
+    ft = load_golden("tiny_finetune.npz")
+    p, ema, _ = split_golden(tiny_golden)
+    store, head, logits, loss = _finetune_run(tiny_config(), p, ema, torch.float32, ft["source"], ft["target"],
+                                              ft["head_w"], ft["head_b"])
+    assert rel_err(logits.float(), ft["logits"]) < 1e-3
+    assert abs(loss - float(ft["loss_sum"])) / float(ft["loss_sum"]) < 1e-3
+    assert rel_err(head.grad_w, ft["g.head_w"]) < 1e-3 and rel_err(head.grad_b, ft["g.head_b"]) < 1e-3
+    gk = [k[2:] for k in ft if k.startswith("g.") and not k.startswith("g.head_")]
+    bad = [(k, rel_err(store.g[k], ft["g." + k])) for k in gk if rel_err(store.g[k], ft["g." + k]) > 1e-3]
+    assert not bad, bad[:8]
+    # parameters the reference leaves without gradient (frozen conv feature extractor, decoder, last norm2) stay zero
+    for k in store.g:
+        if k not in gk:
+            assert float(store.g[k].abs().max()) == 0.0, k
+
+
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 1.5e-1)])
+def test_finetune_hd64_vs_oracle(dtype, tol_y, tol_g):
+    """Real front end, head_dim 64, S = T = 400 (the attention backward with dQ atomics): HIP finetune step vs oracle."""
+    from animal2vec_amd.config import Data2VecMultiConfig, D2vAudioConfig, D2vDecoderConfig
+    dims = dict(embed_dim=128, num_heads=2, depth=3, prenet_depth=1, decoder_dim=64, decoder_layers=2,
+                decoder_kernel=7, decoder_groups=8, clone_batch=3, conv_pos_groups=8, average_top_k_layers=2)
+    ocfg = O.OracleConfig(**dims)
+    p = O.init_params(ocfg, seed=4)
+    g = torch.Generator().manual_seed(6)
+    for k in p:
+        if "alibi_scale" in k:
+            p[k] = p[k] + torch.rand(p[k].shape, generator=g) * 0.5
+        elif "low_hz_" not in k and "band_hz_" not in k:
+            p[k] = p[k] + torch.randn(p[k].shape, generator=g) * 0.02
+    ema = O.make_teacher(p)
+    B, L, C = 2, 16000, 12
+    T = O.frame_counts(L, ocfg.conv_feature_layers)[-1]
+    src = torch.nn.functional.layer_norm(torch.randn(B, L, generator=g), (L,))
+    target = (torch.rand(B, T, C, generator=g) < 0.2).float() * torch.rand(B, T, C, generator=g)     # soft labels
+    hw, hb = torch.randn(C, 128, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ow, ob = hw.clone().requires_grad_(True), hb.clone().requires_grad_(True)
+    logits_o = O.finetune_forward(po, ow, ob, src, ocfg)
+    loss_o = O.sigmoid_focal_loss(logits_o, target, reduction="sum")
+    loss_o.backward()
+    a = D2vAudioConfig(conv_pos_groups=8, prenet_depth=1,
+                       decoder=D2vDecoderConfig(decoder_dim=64, decoder_groups=8, decoder_layers=2))
+    cfg = Data2VecMultiConfig(depth=3, embed_dim=128, num_heads=2, clone_batch=3, average_top_k_layers=2, audio=a)
+    store, head, logits, loss = _finetune_run(cfg, p, ema, dtype, src, target, hw, hb)
+    assert rel_err(logits.float(), logits_o.detach()) < tol_y
+    assert abs(loss - float(loss_o)) / float(loss_o) < tol_y
+    assert rel_err(head.grad_w, ow.grad) < tol_g and rel_err(head.grad_b, ob.grad) < tol_g
+    bad = []
+    for k, v in po.items():
+        if v.grad is None:
+            assert float(store.g[k].abs().max()) == 0.0, k
+            continue
+        e = rel_err(store.g[k], v.grad)
+        if e > tol_g:
+            bad.append((k, e))
+    assert not bad, bad[:8]
