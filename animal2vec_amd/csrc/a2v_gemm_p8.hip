@@ -37,6 +37,13 @@ __device__ __forceinline__ void p8_glds16(const char* gsrc, char* lds_dst) {
 #define P8_STG 131072                 // epilogue staging: 8 waves x 16 rows x 64 fp32
 #define P8_LDS (131072 + 8 * 4096)    // = 160 KiB
 
+// Dynamic tile hand-out: [x] (x < 8) = tiles handed out to the workgroups of XCD x beyond their first one (ids keep the
+// residue x mod 8, so xcd_remap still gives every XCD a contiguous, L2-friendly chunk of the tile space), [8] =
+// workgroups finished (the last one resets all, so the next launch on the stream starts from zero).  A workgroup that starts late -- its CU held by
+// another kernel, e.g. RCCL's all-reduce overlapping the backward pass -- then simply takes fewer tiles instead of
+// stretching the launch by a whole extra round of its statically assigned ones.
+__device__ unsigned g_p8_ctr[9];
+
 struct P8Tile {      // byte offsets (from the A / B base of the group) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
   int m0, n0;
@@ -46,7 +53,7 @@ struct P8Tile {      // byte offsets (from the A / B base of the group) of the 1
 // M = 13440 (96 clips x 140 kept frames) is 60 x 224: with BM = 224 the student's Linears fill 240 of 256 CUs per
 // round with no M tail, 12.5 % less work per round than 53 ragged 256-row tiles.
 template <int IH>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger) {
+__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles) {
   constexpr int BM = 128 + 32 * IH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -175,6 +182,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                     \
   P8_MFMA(4, 0, fbl, IH)
 
+  const bool dynamic = gridDim.y == 1 && dyn_tiles;
+  unsigned* const slot = (unsigned*)(smem + P8_STG);      // id of the tile after the current one (word 0 of wave 0's staging)
+  unsigned fetched = 0;
+  const unsigned xcd = blockIdx.x & 7u;
+  // next id with this XCD's residue: gridDim.x is a multiple of 8 whenever there is more than one round
+  if (dynamic && tid == 0) *slot = gridDim.x + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;
   int seq = blockIdx.x;
   P8Tile T = make_tile(seq);
   // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
@@ -192,7 +205,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   // wave of a SIMD issues LDS reads / DMA while the other owns the MFMA pipe (in lock step both queue for it at once).
   if (stagger && wr == 1) __builtin_amdgcn_s_barrier();
 
-  for (; seq < ntiles; seq += gridDim.x) {
+  int seq_next = 0;
+  for (; seq < ntiles; seq = seq_next) {
     // (at the end of the list the "next tile" is this tile again: harmless re-fetches of valid data into dead
     // buffers keep the vmcnt accounting uniform)
 #pragma unroll
@@ -206,8 +220,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     }
     // last two K-tiles: the stream continues with K-tiles 0 / 1 of the next tile (its offsets are formed here, not
     // at the top of the tile, so that they are not live -- and spilled -- across the main loop)
-    const bool has_next = seq + (int)gridDim.x < ntiles;
-    const P8Tile Tn = has_next ? make_tile(seq + gridDim.x) : T;
+    seq_next = dynamic ? (int)__builtin_amdgcn_readfirstlane(*(volatile unsigned*)slot) : seq + (int)gridDim.x;
+    const bool has_next = seq_next < ntiles;
+    const P8Tile Tn = has_next ? make_tile(seq_next) : T;
     const int kn0 = has_next ? 0 : nk - 2, kn1 = has_next ? 1 : nk - 1;
     P8_KTILE(0, P8_BUF, T, nk - 1, Tn, kn0)
     P8_KTILE(P8_BUF, 0, Tn, kn0, Tn, kn1)
@@ -215,6 +230,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     // ---- epilogue (overlaps the LDS-DMA already in flight for the next tile): 8 passes of 16 rows per wave
     // lane-derived values are re-formed from an opaque copy of the lane id: hoisted out of the tile loop they
     // would be live -- and spilled -- across the K loop, and a spill reload is a VMEM load whose wait drains the DMA
+    if (dynamic && tid == 0) fetched = gridDim.x + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;   // returns under the epilogue
     int le = lane;
     asm volatile("" : "+v"(le));
     const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
@@ -316,12 +332,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       }
     }
 #undef P8_RLOAD
+    if (dynamic && tid == 0) *slot = fetched;     // read by every wave at the next tile's tail, many barriers later
     T = Tn;
+  }
+  if (dynamic && tid == 0) {
+    if (atomicAdd(&g_p8_ctr[8], 1u) == gridDim.x - 1) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) g_p8_ctr[i] = 0u;
+    }
   }
   if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
 }
 
+int g_a2v_p8_dynamic = 1;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent 8-phase kernels
 int g_a2v_p8_stagger = 1;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
@@ -360,8 +384,8 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   // costs a few per cent at K = 1024, where the epilogue dominates (g_a2v_p8_stagger: 0 off, 1 by shape, 2 always)
   const int stagger = g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048);
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
-  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g, stagger);
-  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g, stagger);
-  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g, stagger);
+  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic);
+  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic);
+  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic);
   return true;
 }
