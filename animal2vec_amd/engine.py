@@ -305,20 +305,16 @@ class Engine:
         return dy
 
     # ------------------------------------------------------------------ finetune path
-    def finetune_forward_backward(self, source, target, head, *, backward=True, gscale=1.0, top_k=None):
+    def finetune_forward(self, source, head, *, save=True, top_k=None):
         """Wav2VecEncoderModOut.forward in eval form (wav2vec2.py:430-482: extract_features(mask=False), mean of the
-        last average_top_k_layers layer results, Linear head) + the summed sigmoid focal loss of
-        FinetuneCrossEntropyCriterion (criterions.py:243-248), and -- with backward -- every gradient: encoder and
-        project_features into store.grad, head into head.gw / head.gb.  The conv feature extractor is frozen
-        (feature_grad_mult 0.0, finetune_mixup_100.yaml:85).  source (B,L) fp32, target (B,T,C) fp32 multi-hot (soft
-        after target mixup).  Returns logits (B,T,C); the loss sum is accumulated into head.loss_sum.
+        last average_top_k_layers layer results, Linear head).  source (B,L) fp32 -> padded logits (B*T, Cp) in the
+        activation dtype; with save=True everything finetune_backward() needs is kept.
         Not here yet: train-mode masking / channel masking, layerdrop, dropouts (all 0 in eval)."""
         cfg, st, sp = self.cfg, self.store, self.sp
-        p, g = st.p, st.g
+        p = st.p
         H, D = cfg.num_heads, cfg.embed_dim
         a = cfg.audio
         top_k = cfg.average_top_k_layers if top_k is None else top_k
-        save = backward
         feats = self.frontend_fwd(source, save=save)
         B, T, _ = feats.shape
         asc = p[P + "alibi_scale"].view(-1)
@@ -335,34 +331,57 @@ class Engine:
         sel = ts[-top_k:]
         xm = ops.mean_layers(sel).view(B * T, D)
         logits = ops.linear(xm, head.w_op, head.b_op)                           # (B*T, Cp), Cp = classes padded to 16
-        C_ = head.n_labels
-        tgt = target.reshape(B * T, C_).contiguous()
-        dlog = ops.focal_loss(logits, tgt, head.loss_sum, alpha=head.alpha, gamma=head.gamma, gscale=gscale, want_grad=backward)
-        out = logits.view(B, T, -1)[..., :C_]
-        if not backward:
-            return out
+        if save:
+            self.sv["ft"] = dict(xm=xm, tok=tok, st=(m0, r0), B=B, T=T, nsel=len(sel))
+        return logits
+
+    def finetune_backward(self, dlog, head):
+        """dlog (B*T, Cp): gradient of the loss wrt the padded logits (padded columns zero).  Accumulates encoder and
+        project_features gradients into store.grad and the head's into head.gw / head.gb; the conv feature extractor is
+        frozen (feature_grad_mult 0.0, finetune_mixup_100.yaml:85 -> local_grad_mult 0, base.py:196-206)."""
+        cfg, st = self.cfg, self.store
+        p, g = st.p, st.g
+        H, D = cfg.num_heads, cfg.embed_dim
+        a = cfg.audio
+        c = self.sv.pop("ft")
+        B, T = c["B"], c["T"]
+        asc = p[P + "alibi_scale"].view(-1)
         # ---- head
-        ops.linear_wgrad(xm, dlog, head.gw)
+        ops.linear_wgrad(c["xm"], dlog, head.gw)
         ops.colsum(dlog, head.gb)
         dxm = ops.linear(dlog, head.wt_op)                                       # (B*T, D)
-        dt = ops.mean_layers([dxm], scale=1.0 / len(sel)).view(B, T, D)
+        dt = ops.mean_layers([dxm], scale=1.0 / c["nsel"]).view(B, T, D)
         # ---- blocks: the last block's output x feeds nothing; every selected block receives dt at its FFN output
-        dxe = torch.zeros(B, T, D, dtype=self.dtype, device=feats.device)
-        first_sel = cfg.depth - len(sel)
+        dxe = torch.zeros(B, T, D, dtype=self.dtype, device=dlog.device)
+        first_sel = cfg.depth - c["nsel"]
         for i in reversed(range(cfg.depth)):
             dxe = self.block_bwd(dxe, f"blocks.{i}.", None, asc, H, f"fmb{i}", dt=dt if i >= first_sel else None)
             self._ready(f"block{i}")
         for i in reversed(range(a.prenet_depth)):
             dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", None, asc, H, f"fpb{i}")
             self._ready(f"prenet{i}")
-        dtok = ops.layernorm_bwd(dxe, tok, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"], m0, r0,
-                                 dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"])
+        dtok = ops.layernorm_bwd(dxe, c["tok"], p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
+                                 *c["st"], dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"])
         dpos_in = self.posconv_bwd_dense(dtok)
         self._ready("posconv")
         dfeat = ops.mean_layers([dtok, dpos_in], scale=1.0)                      # x = feats + pos_conv(feats)
         self.frontend_bwd(dfeat, project_only=True)
         self._ready("frontend")
         self.sv.clear()
+
+    def finetune_forward_backward(self, source, target, head, *, backward=True, gscale=1.0, top_k=None):
+        """finetune_forward + the summed sigmoid focal loss of FinetuneCrossEntropyCriterion (criterions.py:243-248,
+        accumulated into head.loss_sum) + finetune_backward.  target (B,T,C) fp32 multi-hot (soft after target
+        mixup).  Returns logits (B,T,C)."""
+        logits = self.finetune_forward(source, head, save=backward, top_k=top_k)
+        C_ = head.n_labels
+        M = logits.shape[0]
+        tgt = target.reshape(M, C_).contiguous()
+        dlog = ops.focal_loss(logits, tgt, head.loss_sum, alpha=head.alpha, gamma=head.gamma, gscale=gscale, want_grad=backward)
+        B = source.shape[0]
+        out = logits.view(B, M // B, -1)[..., :C_]
+        if backward:
+            self.finetune_backward(dlog, head)
         return out
 
     def decoder_fwd(self, dec_in, save: bool):

@@ -340,3 +340,39 @@ def test_finetune_hd64_vs_oracle(dtype, tol_y, tol_g):
         if e > tol_g:
             bad.append((k, e))
     assert not bad, bad[:8]
+
+
+def test_finetune_model_surface_dropin(tiny_golden):
+    """nn.Wav2VecCcasFinetune + nn.FinetuneCrossEntropyCriterion used the fairseq way (criterion(model, sample) ->
+    loss.backward()): same loss and gradients as the golden vectors of the live reference."""
+    import nn
+    from animal2vec_amd.config import tiny_config
+    from conftest import load_golden
+    ft = load_golden("tiny_finetune.npz")
+    p, ema, _ = split_golden(tiny_golden)
+    enc = nn.Data2VecMultiModel.build_model(tiny_config(), task=None, dtype=torch.float32)
+    enc.store.load_state_dict(p, ema)
+    enc.engine.refresh_student_packs()
+    model = nn.Wav2VecCcasFinetune(enc, n_labels=ft["head_w"].shape[0])
+    with torch.no_grad():
+        model.proj.weight.copy_(ft["head_w"].cuda())
+        model.proj.bias.copy_(ft["head_b"].cuda())
+    model.sync_head()
+    model.train()
+    enc.store.grad.zero_()
+    crit = nn.FinetuneCrossEntropyCriterion(report_accuracy=True)
+    sample = {"net_input": {"source": ft["source"]}, "target": ft["target"].cuda(), "ntokens": ft["target"].numel()}
+    loss, sample_size, log = crit(model, sample)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(ft["loss_sum"])) / float(ft["loss_sum"]) < 1e-3
+    assert rel_err(model.proj.weight.grad, ft["g.head_w"]) < 1e-3 and rel_err(model.proj.bias.grad, ft["g.head_b"]) < 1e-3
+    for k in ("blocks.0.mlp.fc1.weight", "modality_encoders.AUDIO.project_features.2.weight",
+              "modality_encoders.AUDIO.relative_positional_encoder.1.0.weight", "modality_encoders.AUDIO.alibi_scale"):
+        assert rel_err(enc.store.g[k], ft["g." + k]) < 1e-3, k
+    assert log["finetune/total"] == ft["target"].numel()
+    # eval mode: logits only, nothing saved
+    model.eval()
+    with torch.no_grad():
+        out = model(ft["source"])
+    assert rel_err(out["encoder_out"], ft["logits"]) < 1e-3
