@@ -182,13 +182,35 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                     \
   P8_MFMA(4, 0, fbl, IH)
 
-  const bool dynamic = gridDim.y == 1 && dyn_tiles;
+  // (a single round -- ntiles == gridDim.x -- keeps the static first tile: handing it out gains nothing there, and the
+  // claim-one-ahead scheme would give half of the workgroups two tiles and the rest none)
+  const int dmode = gridDim.y == 1 ? ((dyn_tiles == 2 && ntiles <= (int)gridDim.x) ? 1 : dyn_tiles) : 0;
+  const bool dynamic = dmode != 0;
   unsigned* const slot = (unsigned*)(smem + P8_STG);      // id of the tile after the current one (word 0 of wave 0's staging)
   unsigned fetched = 0;
   const unsigned xcd = blockIdx.x & 7u;
-  // next id with this XCD's residue: gridDim.x is a multiple of 8 whenever there is more than one round
-  if (dynamic && tid == 0) *slot = gridDim.x + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;
+  // mode 1: the first tile is blockIdx.x, later ones come from this residue class's counter (gridDim.x is a multiple
+  // of 8 whenever there is more than one round).  mode 2: the first tile is handed out too -- a workgroup that is
+  // placed late (its CU's LDS held by another stream's kernel, e.g. an RCCL ring during backward) then finds its
+  // share already taken by the others instead of adding a whole tile time to the launch.
+  const unsigned id_base = dmode == 2 ? 0u : gridDim.x;
   int seq = blockIdx.x;
+  if (dmode == 2) {
+    if (tid == 0) {
+      const unsigned a = atomicAdd(&g_p8_ctr[xcd], 2u);
+      slot[1] = 8u * a + xcd;
+      slot[0] = 8u * (a + 1u) + xcd;
+    }
+    __syncthreads();
+    seq = (int)__builtin_amdgcn_readfirstlane(((volatile unsigned*)slot)[1]);
+    if (seq >= ntiles) {                                    // cannot happen while residue classes match; stay safe
+      if (tid == 0 && atomicAdd(&g_p8_ctr[8], 1u) == gridDim.x - 1)
+        for (int i = 0; i < 9; ++i) g_p8_ctr[i] = 0u;
+      return;
+    }
+  } else if (dynamic && tid == 0) {
+    *slot = gridDim.x + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;
+  }
   P8Tile T = make_tile(seq);
   // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
   P8_STAGE(abase, T.al0, T.al1, 0, P8_ALO)
@@ -230,7 +252,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     // ---- epilogue (overlaps the LDS-DMA already in flight for the next tile): 8 passes of 16 rows per wave
     // lane-derived values are re-formed from an opaque copy of the lane id: hoisted out of the tile loop they
     // would be live -- and spilled -- across the K loop, and a spill reload is a VMEM load whose wait drains the DMA
-    if (dynamic && tid == 0) fetched = gridDim.x + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;   // returns under the epilogue
+    if (dynamic && tid == 0) fetched = id_base + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;   // returns under the epilogue
     int le = lane;
     asm volatile("" : "+v"(le));
     const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
 }
 
-int g_a2v_p8_dynamic = 1;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent 8-phase kernels
+int g_a2v_p8_dynamic = 2;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent NT kernel (2: first tile too)
 int g_a2v_p8_stagger = 1;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {

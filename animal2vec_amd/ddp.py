@@ -8,6 +8,7 @@ the six small all-reduces of compute_var (reference nn/data2vec2.py:1098-1108) w
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -27,7 +28,10 @@ def make_buckets(starts: Sequence[Tuple[str, int]], total: int) -> Dict[str, Tup
 class GradSync:
     def __init__(self, grad: torch.Tensor, buckets: Dict[str, Tuple[int, int]], process_group=None):
         self.grad, self.buckets, self.pg = grad, buckets, process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        inited = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(process_group) if inited else 1
+        # A2V_DDP_FORCE=1: issue the collectives even at world size 1 (exercises the RCCL path on a one-GPU box)
+        self.active = inited and (self.world > 1 or os.environ.get("A2V_DDP_FORCE") == "1")
         self.handles: List = []
         self.armed = False          # only the LAST micro-batch of an accumulation group reduces
         self.fired = set()
@@ -39,7 +43,7 @@ class GradSync:
             self.handles = []
 
     def on_ready(self, event: str):
-        if not self.armed or self.world == 1:
+        if not self.armed or not self.active:
             return
         lo, hi = self.buckets[event]
         assert event not in self.fired, f"bucket {event} released twice"
@@ -49,7 +53,7 @@ class GradSync:
 
     def finish(self, stats: Optional[torch.Tensor] = None):
         """Wait for every bucket; reduce the packed loss/count/variance sums in one call."""
-        if self.world == 1:
+        if not self.active:
             return
         missing = set(self.buckets) - self.fired
         for ev in missing:                       # never leave a slice un-reduced

@@ -202,7 +202,8 @@ def main():
             k, v = kv.split("=")
             _lib.load().a2v_debug_set(int(k), int(v))
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("A2V_BENCH_FORCE_DIST") == "1"   # the latter: RCCL path on a one-GPU box
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -220,7 +221,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -233,7 +234,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     met = tr.metrics()
@@ -262,7 +263,7 @@ def main():
                     launches_per_microbatch=nt["launches"], avg_launch_us=round(nt["avg_us"], 2),
                     wgrad_kernel=dict(tflops=round(s["tn"]["tflops"], 2), launches=s["tn"]["launches"],
                                       avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None)
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     if rank == 0:
@@ -291,7 +292,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

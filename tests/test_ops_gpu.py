@@ -74,6 +74,28 @@ def test_linear_epilogues(ops, dtype):
     assert rel_err(cs, y.float().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(13440, 1024, 256), (16500, 2048, 256), (3000, 256, 512)])
+def test_linear_p8_tile_handout_modes(ops, M, N, K):
+    """Persistent NT kernel: static tile list (0), dynamic after the first tile (1), every tile handed out
+    (2, default: robust when collectives hold CUs): identical results, several launches back to back (counter reset)."""
+    from animal2vec_amd import _lib
+    dtype = torch.bfloat16
+    xd, wd = dev(rnd(M, K, dtype=dtype, seed=1), dtype), dev(rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5), dtype)
+    bd = dev(rnd(N, dtype=torch.float32, seed=3), torch.float32)
+    outs = {}
+    try:
+        for mode in (0, 1, 2):
+            _lib.load().a2v_debug_set(7, mode)
+            ys = [ops.linear(xd, wd, bd, gelu=True) for _ in range(4)]
+            torch.cuda.synchronize()
+            assert all(torch.equal(ys[0], y) for y in ys[1:]), mode
+            outs[mode] = ys[0]
+    finally:
+        _lib.load().a2v_debug_set(7, 2)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_err(outs[2].float(), F.gelu(xd.float() @ wd.float().t() + bd)) < tol(dtype)
+
+
 @pytest.mark.parametrize("ih", [0, 2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(1100, 512, 256), (1024, 256, 384), (2049, 768, 1024)])
 def test_linear_p8_kernel(ops, M, N, K, ih):

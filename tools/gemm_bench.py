@@ -38,7 +38,12 @@ def main():
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--p8", type=int, default=None, help="0: disable the 256x256 8-phase kernel")
     ap.add_argument("--lin", action="append", default=[], help="extra plain linear shape M,N,K (repeatable)")
+    ap.add_argument("--dyn", type=int, default=None, help="persistent NT kernel tile hand-out mode 0/1/2")
     a = ap.parse_args()
+    if a.dyn is not None:
+        from animal2vec_amd import _lib
+        _lib.load().a2v_debug_set(7, a.dyn)
+        print("dyn", a.dyn)
     if a.variant is not None:
         from animal2vec_amd import _lib
         _lib.load().a2v_debug_set(0, a.variant)
