@@ -43,7 +43,9 @@ SIGNATURES = {
     "a2v_decoder_input": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u, _p],
     "a2v_d2v_loss": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "a2v_ema_update": [_p, _p, _ll, _f, _p],
-    "a2v_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p, _p, _p],
+    "a2v_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p, _p, _p, _p],
+    "a2v_add_drop": [_i, _p, _p, _p, _p, _ll, _f, _u, _p],
+    "a2v_mask_frames": [_i, _p, _p, _p, _p, _i, _i, _i, _f, _u, _i, _p],
     "a2v_sumsq": [_p, _ll, _p, _p],
     "a2v_pack_weight": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p],
     "a2v_unpack_wgrad": [_p, _p, _i, _i, _i, _i, _p],

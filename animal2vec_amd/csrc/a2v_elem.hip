@@ -239,6 +239,77 @@ __global__ __launch_bounds__(256) void mean_layers_kernel(PtrList32 layers, T* _
   }
 }
 
+// out = a + drop(b + c): a, c optional.  Forward: x1 + post_mlp_dropout(t) when t must stay a result of its own
+// (layer results, modules.py:328-337); backward: the gradient arriving at t through the Mlp's own output dropout.
+// The dropout index is the element's linear index (same convention as the GEMM / LayerNorm epilogues).
+template <typename T>
+__global__ __launch_bounds__(256) void add_drop_kernel(const T* __restrict__ a, const T* __restrict__ b,
+                                                       const T* __restrict__ c, T* __restrict__ out, long long n, Drop d) {
+  const long long nv = n / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    float vb[8], va[8];
+    Vec8<T>::load(b + i * 8, vb);
+    if (c) {
+      float vc[8];
+      Vec8<T>::load(c + i * 8, vc);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vb[j] += vc[j];
+    }
+    if (d.thresh) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vb[j] = drop_apply(d, (unsigned long long)(i * 8 + j), vb[j]);
+    }
+    if (a) {
+      Vec8<T>::load(a + i * 8, va);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vb[j] += va[j];
+    }
+    Vec8<T>::store(out + i * 8, vb);
+  }
+}
+
+// Finetune train-mode input masking (base.py:457-485, apply_mask): frames with mask_t[b,t] != 0 are replaced by
+// N(0, noise_std) (or zero: encoder_zero_mask), then channels with mask_c[b,c] != 0 are zeroed for every frame.
+// mode 1 = the backward of the same map (masked positions pass no gradient, nothing is replaced).
+// Noise: Box-Muller on two counter hashes of (seed, element index) -- same distribution as the reference's
+// normal_(), not torch's Philox stream.
+template <typename T>
+__global__ __launch_bounds__(256) void mask_frames_kernel(const T* __restrict__ x, const unsigned char* __restrict__ mask_t,
+                                                          const unsigned char* __restrict__ mask_c, T* __restrict__ out,
+                                                          int B, int Tn, int D, float noise_std, unsigned seed, int mode) {
+  const long long nv = (long long)B * Tn * D / 8;
+  const int dv = D / 8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+    const long long row = i / dv;
+    const int col = (int)(i - row * dv) * 8;
+    const int b = (int)(row / Tn);
+    float v[8];
+    const bool mt = mask_t && mask_t[row];
+    if (mt) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float z = 0.f;
+        if (mode == 0 && noise_std > 0.f) {
+          const unsigned long long e = (unsigned long long)(i * 8 + j);
+          const float u1 = ((float)drop_hash(seed, 2 * e) + 1.f) * 2.3283064365386963e-10f;
+          const float u2 = (float)drop_hash(seed, 2 * e + 1) * 2.3283064365386963e-10f;
+          z = noise_std * sqrtf(-2.f * __logf(u1)) * __cosf(6.283185307179586f * u2);
+        }
+        v[j] = z;
+      }
+    } else {
+      Vec8<T>::load(x + i * 8, v);
+    }
+    if (mask_c) {
+      const unsigned long long mc = *(const unsigned long long*)(mask_c + (long long)b * D + col);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if ((mc >> (8 * j)) & 0xFFull) v[j] = 0.f;
+    }
+    Vec8<T>::store(out + i * 8, v);
+  }
+}
+
 // ---------------------------------------------------------------------------------- optimizer-side
 // EMA teacher (fairseq EMAModule.step): e = e*d + (1-d)*p  (fp32), 4 floats per thread
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ e, const float* __restrict__ p, long long n,
@@ -261,16 +332,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    float* __restrict__ m, float* __restrict__ v, long long n, float lr,
                                                    float b1, float b2, float eps, float wd_, float step_size,
                                                    float gscale_, const unsigned char* __restrict__ decay_mask,
-                                                   const float* __restrict__ gscale_dev) {
+                                                   const float* __restrict__ gscale_dev,
+                                                   const float* __restrict__ lr_scale) {
   const float gscale = gscale_ * (gscale_dev ? *gscale_dev : 1.f);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float wd = (!decay_mask || decay_mask[i >> 6]) ? wd_ : 0.f;
+    const float ls = lr_scale ? lr_scale[i >> 6] : 1.f;      // per-parameter-group lr_scale (wav2vec2.py:214-236)
     const float gr = g[i] * gscale;
     const float mi = m[i] * b1 + gr * (1.f - b1);
     const float vi = v[i] * b2 + gr * gr * (1.f - b2);
     float pi = p[i];
-    pi -= wd * lr * pi;
-    pi -= step_size * mi / (sqrtf(vi) + eps);
+    pi -= wd * (lr * ls) * pi;
+    pi -= (step_size * ls) * mi / (sqrtf(vi) + eps);
     m[i] = mi; v[i] = vi; p[i] = pi;
   }
 }
@@ -512,6 +585,30 @@ extern "C" int a2v_mean_layers(int dtype, const void* const* layers, int L, void
   return A2V_OK;
 }
 
+extern "C" int a2v_add_drop(int dtype, const void* a, const void* b, const void* c, void* out, long long n, float drop_p,
+                            unsigned drop_seed, hipStream_t st) {
+  if (n <= 0 || n % 8 || !b || !out || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
+  const Drop d = make_drop(drop_p, drop_seed);
+  const int g = grid_for(n / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(add_drop_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)a, (const bf16*)b, (const bf16*)c, (bf16*)out, n, d),
+             hipLaunchKernelGGL(add_drop_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, (const float*)c, (float*)out, n, d));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
+extern "C" int a2v_mask_frames(int dtype, const void* x, const unsigned char* mask_t, const unsigned char* mask_c, void* out,
+                               int B, int T, int D, float noise_std, unsigned seed, int mode, hipStream_t st) {
+  if (B <= 0 || T <= 0 || D <= 0 || D % 8 || !x || !out || mode < 0 || mode > 1 || noise_std < 0.f) return A2V_ERR_ARG;
+  const long long n = (long long)B * T * D;
+  const int g = grid_for(n / 8);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(mask_frames_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, mask_t, mask_c, (bf16*)out, B, T, D, noise_std, seed, mode),
+             hipLaunchKernelGGL(mask_frames_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, mask_t, mask_c, (float*)out, B, T, D, noise_std, seed, mode));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
 extern "C" int a2v_ema_update(float* ema, const float* p, long long n, float decay, hipStream_t st) {
   if (n <= 0 || (((uintptr_t)ema | (uintptr_t)p) & 15)) return A2V_ERR_ARG;
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, ema, p, n, decay);
@@ -519,16 +616,18 @@ extern "C" int a2v_ema_update(float* ema, const float* p, long long n, float dec
   return A2V_OK;
 }
 
-// decay_mask: one byte per 64 parameters (0 -> weight decay off for that block) or NULL;
+// decay_mask: one byte per 64 parameters (0 -> weight decay off for that block) or NULL; lr_scale: one float per 64
+// parameters (the composite optimizer's per-group lr_scale, e.g. layer_decay in finetuning) or NULL;
 // grad_scale_dev: optional device scalar multiplied into grad_scale (clip / sample-size factor).
 extern "C" int a2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                              float eps, float weight_decay, int step, float grad_scale,
-                             const unsigned char* decay_mask, const float* grad_scale_dev, hipStream_t st) {
+                             const unsigned char* decay_mask, const float* grad_scale_dev, const float* lr_scale,
+                             hipStream_t st) {
   if (n <= 0 || step <= 0) return A2V_ERR_ARG;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   const float step_size = (float)((double)lr * sqrt(bc2) / bc1);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, st, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay,
-                     step_size, grad_scale, decay_mask, grad_scale_dev);
+                     step_size, grad_scale, decay_mask, grad_scale_dev, lr_scale);
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }
@@ -615,4 +714,4 @@ extern "C" int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, 
   return A2V_OK;
 }
 
-extern "C" int a2v_abi_version(void) { return 4; }
+extern "C" int a2v_abi_version(void) { return 5; }

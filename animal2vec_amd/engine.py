@@ -152,16 +152,24 @@ class Engine:
         return None if base is None else (base * 1000003 + site * 7919 + 12345) & 0xFFFFFFFF
 
     def block_fwd(self, x, prefix, pk: Packs, params, pos, alibi_scale, H, save: Optional[str], want_t=False,
-                  drop_base=None, site=0):
-        """AltBlock post-LN with ffn targets (reference modules.py:328-337).  x (N,S,D)."""
+                  drop_base=None, site=0, dp=None):
+        """AltBlock post-LN with ffn targets (reference modules.py:328-337).  x (N,S,D).
+        dp: dropout probabilities (att, proj, mlp, act) overriding the pretraining config's -- finetuning sets them
+        from its own config (wav2vec2.py:94-131); act = the Mlp's two internal dropouts (timm Mlp drop1 / drop2)."""
         N, S, D = x.shape
         eps = self.cfg.norm_eps
         x2 = x.view(N * S, D)
         qkv = ops.linear(x2, pk.w[prefix + "attn.qkv.weight"], params[prefix + "attn.qkv.bias"])
         c = self.cfg
-        d_att = (c.attention_dropout, self._site(drop_base, 4 * site)) if drop_base is not None else None
-        d_proj = (c.encoder_dropout, self._site(drop_base, 4 * site + 1)) if drop_base is not None else None
-        d_mlp = (c.post_mlp_drop, self._site(drop_base, 4 * site + 2)) if drop_base is not None else None
+        p_att, p_proj, p_mlp, p_act = dp if dp is not None else (c.attention_dropout, c.encoder_dropout, c.post_mlp_drop, 0.0)
+
+        def mk(pv, k, salt=0):
+            if drop_base is None or pv <= 0:
+                return None
+            return (pv, (self._site(drop_base, 4 * site + k) + salt) & 0xFFFFFFFF)
+
+        d_att, d_proj, d_mlp = mk(p_att, 0), mk(p_proj, 1), mk(p_mlp, 2)
+        d_act1, d_act2 = mk(p_act, 3), mk(p_act, 3, 0x632BE5AB)
         att, lse = ops.attention_fwd(qkv.view(N, S, 3 * D), pos, self.store.alibi_slopes, alibi_scale, H,
                                      need_lse=save is not None, drop=d_att)
         s1 = ops.linear(att.view(N * S, D), pk.w[prefix + "attn.proj.weight"], params[prefix + "attn.proj.bias"], res=x2,
@@ -170,22 +178,29 @@ class Engine:
                                        save_stats=save is not None)
         hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
         hpre = torch.empty(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
-        gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre)
+        gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre,
+                          drop=d_act1)
         t = None
         s2 = None
-        if want_t:          # the FFN output t is a result of its own (layer_results): keep it apart from the residual sum
-            assert d_mlp is None, "layer results with post-MLP dropout are not implemented"
-            t = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"])
-            s2 = torch.empty_like(t) if save is not None else None
-            x2o, m2, r2 = ops.layernorm_fwd(t, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps, res=x1,
-                                            save_stats=save is not None, sum_out=s2)
+        if want_t or d_act2 is not None:
+            # the FFN output t (after the Mlp's own output dropout) is a result of its own (layer_results): keep it
+            # apart from the residual sum x1 + post_mlp_dropout(t)
+            t = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"], drop=d_act2)
+            if d_mlp is not None:
+                s2 = ops.add_drop(x1, t, drop=d_mlp)
+                x2o, m2, r2 = ops.layernorm_fwd(s2, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
+                                                save_stats=save is not None)
+            else:
+                s2 = torch.empty_like(t) if save is not None else None
+                x2o, m2, r2 = ops.layernorm_fwd(t, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
+                                                res=x1, save_stats=save is not None, sum_out=s2)
         else:
             s2 = ops.linear(gact, pk.w[prefix + "mlp.fc2.weight"], params[prefix + "mlp.fc2.bias"], res=x1, drop=d_mlp)
             x2o, m2, r2 = ops.layernorm_fwd(s2, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
                                             save_stats=save is not None)
         if save is not None:
             self.sv[save] = dict(x=x2, qkv=qkv, att=att, lse=lse, s1=s1, st1=(m1, r1), x1=x1, hpre=hpre, g=gact, s2=s2,
-                                 st2=(m2, r2), N=N, S=S, drops=(d_att, d_proj, d_mlp))
+                                 st2=(m2, r2), N=N, S=S, drops=(d_att, d_proj, d_mlp), act=(d_act1, d_act2))
         return x2o.view(N, S, D), (t.view(N, S, D) if t is not None else None)
 
     def block_bwd(self, dx, prefix, pos, alibi_scale, H, key, dt=None):
@@ -198,14 +213,20 @@ class Engine:
         D = dx.shape[-1]
         dx = dx.reshape(N * S, D)
         d_att, d_proj, d_mlp = sv["drops"]
+        d_act1, d_act2 = sv["act"]
         # ds2: gradient of (x1 + drop(mlp)) -> residual path; ds2d: the same through the dropout mask -> mlp branch
         ds2, ds2d = ops.layernorm_bwd(dx, sv["s2"], p[prefix + "norm2.weight"], p[prefix + "norm2.bias"], *sv["st2"],
                                       dgamma=g[prefix + "norm2.weight"], dbeta=g[prefix + "norm2.bias"],
-                                      dxsum=g[prefix + "mlp.fc2.bias"], drop=d_mlp, drop_mode=2)
-        if dt is not None:
-            ds2d = ops.mean_layers([ds2d, dt.reshape(N * S, D)], scale=1.0)
-            ops.colsum(dt.reshape(N * S, D), g[prefix + "mlp.fc2.bias"])          # dxsum above only saw the LN2 path
-        dh = ops.linear(ds2d, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"])
+                                      dxsum=g[prefix + "mlp.fc2.bias"] if d_act2 is None else None, drop=d_mlp, drop_mode=2)
+        dt2 = dt.reshape(N * S, D) if dt is not None else None
+        if d_act2 is not None:                 # back through the Mlp's output dropout: everything that arrives at t
+            ds2d = ops.add_drop(None, ds2d, dt2, drop=d_act2)
+            ops.colsum(ds2d, g[prefix + "mlp.fc2.bias"])
+        elif dt2 is not None:
+            ds2d = ops.mean_layers([ds2d, dt2], scale=1.0)
+            ops.colsum(dt2, g[prefix + "mlp.fc2.bias"])          # dxsum above only saw the LN2 path
+        dh = ops.linear(ds2d, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"],
+                        drop=d_act1)
         ops.linear_wgrad_pair(sv["g"], ds2d, g[prefix + "mlp.fc2.weight"], sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
         dx1 = ops.linear(dh, sp.wt[prefix + "mlp.fc1.weight"], res=ds2)
         ds1, ds1d = ops.layernorm_bwd(dx1, sv["s1"], p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], *sv["st1"],
@@ -305,11 +326,18 @@ class Engine:
         return dy
 
     # ------------------------------------------------------------------ finetune path
-    def finetune_forward(self, source, head, *, save=True, top_k=None):
-        """Wav2VecEncoderModOut.forward in eval form (wav2vec2.py:430-482: extract_features(mask=False), mean of the
-        last average_top_k_layers layer results, Linear head).  source (B,L) fp32 -> padded logits (B*T, Cp) in the
+    def finetune_forward(self, source, head, *, save=True, top_k=None, aug=None):
+        """Wav2VecEncoderModOut.forward (wav2vec2.py:430-482): extract_features, mean of the last
+        average_top_k_layers layer results, Linear head.  source (B,L) fp32 -> padded logits (B*T, Cp) in the
         activation dtype; with save=True everything finetune_backward() needs is kept.
-        Not here yet: train-mode masking / channel masking, layerdrop, dropouts (all 0 in eval)."""
+        aug=None: eval form (mask=False, no layerdrop, no dropout).  aug (dict, train form; finetune.py builds it):
+          mask_t (B,T) uint8 / mask_c (B,D) uint8  -- apply_mask, base.py:457-485: frames replaced by N(0, noise_std)
+                                                      (or zero), then channels zeroed; the mask is applied BEFORE the
+                                                      pos-conv, which therefore sees the masked input (base.py:268-298)
+          noise_std, noise_seed (device hash noise) or replacement ((num_masked, D) explicit rows, for reproducibility)
+          active: list of bool, prenet blocks then main blocks -- layerdrop outcome (modules.py:89-94, data2vec2.py:651-655)
+          drop_seed (int or None), p_drop / p_act / p_att  -- cfg.dropout (prenet, proj, post-mlp), activation_dropout
+                                                      (the Mlp's two dropouts), attention_dropout (wav2vec2.py:94-128)"""
         cfg, st, sp = self.cfg, self.store, self.sp
         p = st.p
         H, D = cfg.num_heads, cfg.embed_dim
@@ -318,27 +346,56 @@ class Engine:
         feats = self.frontend_fwd(source, save=save)
         B, T, _ = feats.shape
         asc = p[P + "alibi_scale"].view(-1)
+        db = dp = d_pre = None
+        n_blocks = a.prenet_depth + cfg.depth
+        active = [True] * n_blocks
+        masks = None
+        if aug is not None:
+            if aug.get("mask_t") is not None or aug.get("mask_c") is not None:
+                masks = (aug.get("mask_t"), aug.get("mask_c"))
+                if aug.get("replacement") is not None:      # reproducibility hook: explicit (num_masked, D) noise rows
+                    feats = feats.clone()
+                    feats[masks[0].bool()] = aug["replacement"].to(feats.dtype)
+                    feats = ops.mask_frames(feats, None, masks[1])
+                else:
+                    feats = ops.mask_frames(feats, masks[0], masks[1], noise_std=aug.get("noise_std", 0.0),
+                                            seed=aug.get("noise_seed", 0))
+            if aug.get("active") is not None:
+                active = list(aug["active"])
+                assert len(active) == n_blocks
+            db = aug.get("drop_seed")
+            if db is not None:
+                dp = (aug.get("p_att", 0.0), aug.get("p_drop", 0.0), aug.get("p_drop", 0.0), aug.get("p_act", 0.0))
+                if aug.get("p_drop", 0.0) > 0:
+                    d_pre = (aug["p_drop"], self._site(db, 9000))
         x_pos = self.posconv_fwd(feats, sp, p, None, 1, save=save)
         tok = torch.empty_like(feats) if save else None
         x, m0, r0 = ops.layernorm_fwd(feats, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
-                                      cfg.norm_eps, res=x_pos, save_stats=save, sum_out=tok)
+                                      cfg.norm_eps, res=x_pos, save_stats=save, sum_out=tok, drop=d_pre)
         for i in range(a.prenet_depth):
-            x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, None, asc, H, save=f"fpb{i}" if save else None)
+            if active[i]:
+                x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, None, asc, H, save=f"fpb{i}" if save else None,
+                                      drop_base=db, site=i, dp=dp)
         ts = []
         for i in range(cfg.depth):
-            x, t = self.block_fwd(x, f"blocks.{i}.", sp, p, None, asc, H, save=f"fmb{i}" if save else None, want_t=True)
-            ts.append(t)
+            if active[a.prenet_depth + i]:
+                x, t = self.block_fwd(x, f"blocks.{i}.", sp, p, None, asc, H, save=f"fmb{i}" if save else None, want_t=True,
+                                      drop_base=db, site=a.prenet_depth + i, dp=dp)
+                ts.append((i, t))
         sel = ts[-top_k:]
-        xm = ops.mean_layers(sel).view(B * T, D)
+        assert sel, "layerdrop removed every block"
+        xm = ops.mean_layers([t for _, t in sel]).view(B * T, D)
         logits = ops.linear(xm, head.w_op, head.b_op)                           # (B*T, Cp), Cp = classes padded to 16
         if save:
-            self.sv["ft"] = dict(xm=xm, tok=tok, st=(m0, r0), B=B, T=T, nsel=len(sel))
+            self.sv["ft"] = dict(xm=xm, tok=tok, st=(m0, r0), B=B, T=T, sel=[i for i, _ in sel], active=active, masks=masks,
+                                 d_pre=d_pre)
         return logits
 
-    def finetune_backward(self, dlog, head):
+    def finetune_backward(self, dlog, head, *, head_only=False):
         """dlog (B*T, Cp): gradient of the loss wrt the padded logits (padded columns zero).  Accumulates encoder and
         project_features gradients into store.grad and the head's into head.gw / head.gb; the conv feature extractor is
-        frozen (feature_grad_mult 0.0, finetune_mixup_100.yaml:85 -> local_grad_mult 0, base.py:196-206)."""
+        frozen (feature_grad_mult 0.0, finetune_mixup_100.yaml:85 -> local_grad_mult 0, base.py:196-206).
+        head_only: the first freeze_finetune_updates updates train the classifier alone (wav2vec2.py:440-445)."""
         cfg, st = self.cfg, self.store
         p, g = st.p, st.g
         H, D = cfg.num_heads, cfg.embed_dim
@@ -349,31 +406,40 @@ class Engine:
         # ---- head
         ops.linear_wgrad(c["xm"], dlog, head.gw)
         ops.colsum(dlog, head.gb)
+        if head_only:
+            self.sv.clear()
+            return
         dxm = ops.linear(dlog, head.wt_op)                                       # (B*T, D)
-        dt = ops.mean_layers([dxm], scale=1.0 / c["nsel"]).view(B, T, D)
-        # ---- blocks: the last block's output x feeds nothing; every selected block receives dt at its FFN output
+        sel, active = c["sel"], c["active"]
+        dt = ops.mean_layers([dxm], scale=1.0 / len(sel)).view(B, T, D)
+        # ---- blocks: the last executed block's output x feeds nothing; every selected block receives dt at its FFN output
         dxe = torch.zeros(B, T, D, dtype=self.dtype, device=dlog.device)
-        first_sel = cfg.depth - c["nsel"]
         for i in reversed(range(cfg.depth)):
-            dxe = self.block_bwd(dxe, f"blocks.{i}.", None, asc, H, f"fmb{i}", dt=dt if i >= first_sel else None)
+            if active[a.prenet_depth + i]:
+                dxe = self.block_bwd(dxe, f"blocks.{i}.", None, asc, H, f"fmb{i}", dt=dt if i in sel else None)
             self._ready(f"block{i}")
         for i in reversed(range(a.prenet_depth)):
-            dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", None, asc, H, f"fpb{i}")
+            if active[i]:
+                dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", None, asc, H, f"fpb{i}")
             self._ready(f"prenet{i}")
         dtok = ops.layernorm_bwd(dxe, c["tok"], p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
-                                 *c["st"], dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"])
+                                 *c["st"], dgamma=g[P + "context_encoder.norm.weight"], dbeta=g[P + "context_encoder.norm.bias"],
+                                 drop=c["d_pre"], drop_mode=1)
         dpos_in = self.posconv_bwd_dense(dtok)
         self._ready("posconv")
-        dfeat = ops.mean_layers([dtok, dpos_in], scale=1.0)                      # x = feats + pos_conv(feats)
+        dfeat = ops.mean_layers([dtok, dpos_in], scale=1.0)                      # x = feats_masked + pos_conv(feats_masked)
+        if c["masks"] is not None:
+            dfeat = ops.mask_frames(dfeat, c["masks"][0], c["masks"][1], backward=True, out=dfeat)
         self.frontend_bwd(dfeat, project_only=True)
         self._ready("frontend")
         self.sv.clear()
 
-    def finetune_forward_backward(self, source, target, head, *, backward=True, gscale=1.0, top_k=None):
+    def finetune_forward_backward(self, source, target, head, *, backward=True, gscale=1.0, top_k=None, aug=None,
+                                  head_only=False):
         """finetune_forward + the summed sigmoid focal loss of FinetuneCrossEntropyCriterion (criterions.py:243-248,
         accumulated into head.loss_sum) + finetune_backward.  target (B,T,C) fp32 multi-hot (soft after target
         mixup).  Returns logits (B,T,C)."""
-        logits = self.finetune_forward(source, head, save=backward, top_k=top_k)
+        logits = self.finetune_forward(source, head, save=backward, top_k=top_k, aug=aug)
         C_ = head.n_labels
         M = logits.shape[0]
         tgt = target.reshape(M, C_).contiguous()
@@ -381,7 +447,7 @@ class Engine:
         B = source.shape[0]
         out = logits.view(B, M // B, -1)[..., :C_]
         if backward:
-            self.finetune_backward(dlog, head)
+            self.finetune_backward(dlog, head, head_only=head_only)
         return out
 
     def decoder_fwd(self, dec_in, save: bool):

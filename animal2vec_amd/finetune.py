@@ -63,11 +63,261 @@ class FinetuneHead:
 
 
 def finetune_step(engine: Engine, head: FinetuneHead, source: torch.Tensor, target: torch.Tensor, *, backward: bool = True,
-                  gscale: float = 1.0, top_k: Optional[int] = None):
+                  gscale: float = 1.0, top_k: Optional[int] = None, aug: Optional[dict] = None, head_only: bool = False):
     """One micro-batch of the finetune objective: returns (logits (B,T,C), loss_sum so far as a device scalar).
-    Gradients accumulate into engine.store.grad (encoder, project_features) and head.gw / head.gb."""
-    logits = engine.finetune_forward_backward(source, target, head, backward=backward, gscale=gscale, top_k=top_k)
+    Gradients accumulate into engine.store.grad (encoder, project_features) and head.gw / head.gb.
+    aug: train-form options (Engine.finetune_forward); head_only: classifier-only update (freeze_finetune_updates)."""
+    logits = engine.finetune_forward_backward(source, target, head, backward=backward, gscale=gscale, top_k=top_k, aug=aug,
+                                              head_only=head_only)
     return logits, head.loss_sum
+
+
+# ---------------------------------------------------------------------------------------------- train form
+import math  # noqa: E402
+from dataclasses import dataclass  # noqa: E402
+from typing import Dict, List, Sequence, Tuple  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from .ddp import GradSync, make_buckets  # noqa: E402
+from .masking import compute_mask_indices  # noqa: E402
+from .params import ALIGN, P, bucket_starts  # noqa: E402
+
+
+@dataclass
+class FinetuneConfig:
+    """configs/MeerKAT/finetune_mixup_100.yaml:60-108 (model / optimization / optimizer / lr_scheduler sections)"""
+    n_labels: int = 12
+    apply_mask: bool = True
+    mask_prob: float = 0.825
+    mask_length: int = 4
+    mask_channel_prob: float = 0.5
+    mask_channel_length: int = 64
+    zero_mask: bool = False                # False: masked frames become N(0, mask_noise_std) (wav2vec2.py:121,127)
+    dropout: float = 0.1                   # -> encoder_dropout, prenet_dropout, post_mlp_drop (wav2vec2.py:116-126)
+    activation_dropout: float = 0.1
+    attention_dropout: float = 0.2
+    layerdrop: float = 0.1                 # -> layerdrop and prenet_layerdrop
+    freeze_finetune_updates: int = 10000
+    layer_decay: float = 1.0               # wav2vec2.py:214-236
+    target_mixup: bool = True
+    source_mixup: float = 0.5
+    mixup_prob: float = 1.0                # only 1.0 (every clip mixed) is implemented, as shipped
+    same_mixup: bool = True
+    mixing_window_length: float = 0.05
+    # The wrapped pretraining model keeps ITS OWN source_mixup / mixup_prob (they are not in arg_overrides,
+    # wav2vec2.py:94-131), so in train() mode data2vec2.py:536-598 mixes the already mixed sources a second time
+    # (targets untouched).  True reproduces that; it uses the encoder config's source_mixup.
+    inner_source_mixup: bool = True
+    # optimizer / schedule
+    lr: float = 3e-5
+    adam_betas: Tuple[float, float] = (0.9, 0.98)
+    adam_eps: float = 1e-8
+    weight_decay: float = 0.0
+    clip_norm: float = 0.0
+    warmup_updates: int = 2000
+    warmup_init_lr: float = 1e-10
+    min_lr: float = 5e-6
+    max_update: int = 30000
+
+
+def cosine_lr(cfg: FinetuneConfig, num_updates: int) -> float:
+    """fairseq CosineLRSchedule (lr_period_updates <= 0 -> period = max_update - warmup, t_mult 1, lr_shrink 0.1);
+    third party, restated from its published semantics."""
+    if num_updates < cfg.warmup_updates:
+        return cfg.warmup_init_lr + num_updates * (cfg.lr - cfg.warmup_init_lr) / cfg.warmup_updates
+    period = max(1, cfg.max_update - cfg.warmup_updates)
+    curr = num_updates - cfg.warmup_updates
+    i = curr // period
+    t_curr = curr - period * i
+    shrink = 0.1 ** i
+    lo, hi = cfg.min_lr * shrink, cfg.lr * shrink
+    return lo + 0.5 * (hi - lo) * (1 + math.cos(math.pi * t_curr / period))
+
+
+def layer_lr_scales(n_blocks: int, layer_decay: float) -> List[float]:
+    """wav2vec2.py:214-224: block i (prenet blocks first, 0-based) trains with lr * layer_decay ** (n_blocks + 1 - (i + 1))."""
+    num_layers = n_blocks + 1
+    scales = [layer_decay ** (num_layers - i) for i in range(num_layers + 1)]
+    return [scales[i + 1] for i in range(n_blocks)]
+
+
+def make_aug(fcfg: FinetuneConfig, B: int, T: int, D: int, n_prenet: int, n_blocks: int, rng: np.random.Generator,
+             noise_std: float, device="cuda", train_dropout: bool = True) -> dict:
+    """The per-micro-batch random draws of the train form (what Engine.finetune_forward takes as `aug`)."""
+    aug: Dict[str, object] = {}
+    if fcfg.apply_mask and fcfg.mask_prob > 0:
+        m = compute_mask_indices((B, T), fcfg.mask_prob, fcfg.mask_length, rng, min_masks=1, require_same_masks=True)
+        aug["mask_t"] = torch.from_numpy(m.astype(np.uint8)).to(device)
+        aug["noise_std"] = 0.0 if fcfg.zero_mask else noise_std
+        aug["noise_seed"] = int(rng.integers(0, 2 ** 31))
+    if fcfg.apply_mask and fcfg.mask_channel_prob > 0:
+        mc = compute_mask_indices((B, D), fcfg.mask_channel_prob, fcfg.mask_channel_length, rng, min_masks=0,
+                                  require_same_masks=True)
+        aug["mask_c"] = torch.from_numpy(mc.astype(np.uint8)).to(device)
+    aug["active"] = [bool(fcfg.layerdrop == 0 or rng.random() > fcfg.layerdrop) for _ in range(n_blocks)]
+    if not any(aug["active"][n_prenet:]):          # the reference divides by zero layer results here; keep one block
+        aug["active"][-1] = True
+    if train_dropout and (fcfg.dropout > 0 or fcfg.activation_dropout > 0 or fcfg.attention_dropout > 0):
+        aug.update(drop_seed=int(rng.integers(0, 2 ** 31)), p_drop=fcfg.dropout, p_act=fcfg.activation_dropout,
+                   p_att=fcfg.attention_dropout)
+    return aug
+
+
+class FinetuneTrainer:
+    """Data-parallel finetune step on the native engine: train-form forward/backward per micro-batch (BC mixup of
+    sources and targets, masking, layerdrop, dropouts), bucketed gradient all-reduce overlapped with backward, Adam
+    with per-block lr scales (layer_decay) on the encoder slice and on the head, classifier-only updates while
+    num_updates < freeze_finetune_updates.  Replaces fairseq Trainer + Wav2VecCcasFinetune + FinetuneCrossEntropyCriterion
+    around the hot path (wav2vec2.py:57-482, criterions.py:137-277); no control plane."""
+
+    def __init__(self, model_cfg, fcfg: Optional[FinetuneConfig] = None, *, store=None, dtype=torch.bfloat16, device="cuda",
+                 seed: int = 0, process_group=None):
+        from .params import ParamStore
+        self.cfg, self.fcfg = model_cfg, fcfg or FinetuneConfig()
+        self.store = store if store is not None else ParamStore(model_cfg, device=device)
+        if store is None:
+            self.store.init_reference(seed)
+        self.engine = Engine(model_cfg, self.store, dtype=dtype)
+        self.head = FinetuneHead(model_cfg.embed_dim, self.fcfg.n_labels, dtype=dtype, device=self.store.device, seed=seed)
+        dev = self.store.device
+        self.head_m = (torch.zeros_like(self.head.w), torch.zeros_like(self.head.b))
+        self.head_v = (torch.zeros_like(self.head.w), torch.zeros_like(self.head.b))
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.num_updates = 0
+        self.rng = np.random.default_rng(seed * 1000 + 17 + self.rank)
+        self.mixup = ops.Mixup(model_cfg.audio.sample_rate, self.fcfg.mixing_window_length, dev) \
+            if self.fcfg.source_mixup >= 0 and self.fcfg.mixup_prob > 0 else None
+        assert self.fcfg.mixup_prob in (0.0, 1.0), "partial mixup (mixup_prob < 1) is not on the shipped configs' path"
+        # trainable slice of the flat buffer: transformer blocks .. project_features (the decoder is removed and the
+        # conv feature extractor frozen, wav2vec2.py:176, finetune_mixup_100.yaml:85)
+        by = self.store.by_name
+        nl = len(model_cfg.conv_layers)
+        self.lo = self.store.sh_lo
+        self.hi = by[P + f"local_encoder.conv_layers.{nl - 1}.2.1.weight"].offset
+        assert self.lo % ALIGN == 0 and self.hi % ALIGN == 0
+        buckets = {k: (max(lo, self.lo), min(hi, self.hi)) for k, (lo, hi) in
+                   make_buckets(bucket_starts(model_cfg, self.store.specs), self.store.total).items()}
+        self.sync = GradSync(self.store.grad, {k: v for k, v in buckets.items() if v[1] > v[0]}, process_group)
+        self.engine.on_grad_ready = self._on_ready
+        self.lr_scale = self._lr_scale_table()
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.last: Dict[str, float] = {}
+
+    def _on_ready(self, event):
+        if event in self.sync.buckets:
+            self.sync.on_ready(event)
+
+    def _lr_scale_table(self):
+        f = self.fcfg
+        if f.layer_decay >= 1:
+            return None
+        a = self.cfg.audio
+        n_blocks = a.prenet_depth + self.cfg.depth
+        sc = layer_lr_scales(n_blocks, f.layer_decay)
+        tab = np.ones((self.hi - self.lo) // ALIGN, dtype=np.float32)
+        for s in self.store.specs:
+            if not (self.lo <= s.offset < self.hi):
+                continue
+            blk = None
+            if s.name.startswith(P + "context_encoder.blocks."):
+                blk = int(s.name[len(P + "context_encoder.blocks."):].split(".")[0])
+            elif s.name.startswith("blocks."):
+                blk = a.prenet_depth + int(s.name.split(".")[1])
+            if blk is not None:
+                tab[(s.offset - self.lo) // ALIGN:(s.offset - self.lo + s.numel + ALIGN - 1) // ALIGN] = sc[blk]
+        return torch.from_numpy(tab).to(self.store.device)
+
+    @property
+    def frozen(self) -> bool:
+        """wav2vec2.py:440: ft = freeze_finetune_updates <= num_updates"""
+        return self.num_updates < self.fcfg.freeze_finetune_updates
+
+    def _mix(self, src, tgt):
+        """BC mixup of sources (wav2vec2.py:362-424) and, with target_mixup, of the targets (:426-432), then the
+        wrapped model's own second source mixup (see FinetuneConfig.inner_source_mixup)."""
+        f = self.fcfg
+        if self.mixup is None:
+            return src, tgt
+        B = src.shape[0]
+        r = float(self.rng.uniform(max(1e-6, f.source_mixup), 1.0))
+        perm = torch.from_numpy(self.rng.permutation(B).astype("int32")).to(src.device)
+        src = self.mixup(src, perm, r)
+        if f.target_mixup:
+            tgt = tgt * r + (1 - r) * tgt[perm.long()]
+        if f.inner_source_mixup and self.cfg.source_mixup >= 0 and self.cfg.mixup_prob > 0:
+            r2 = float(self.rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
+            perm2 = torch.from_numpy(self.rng.permutation(B).astype("int32")).to(src.device)
+            src = self.mixup(src, perm2, r2)
+        return src, tgt
+
+    def train_step(self, micro_batches: Sequence[dict]) -> None:
+        """micro_batches: dicts with source (B,L) fp32 and target (B,T,C) fp32 multi-hot, on the device."""
+        st, eng, f, head = self.store, self.engine, self.fcfg, self.head
+        st.grad[self.lo:self.hi].zero_()
+        head.zero_grad()
+        frozen = self.frozen
+        a = self.cfg.audio
+        n_blocks = a.prenet_depth + self.cfg.depth
+        ntok = 0
+        nmb = len(micro_batches)
+        for j, mb in enumerate(micro_batches):
+            self.sync.arm(j == nmb - 1 and not frozen)
+            src, tgt = self._mix(mb["source"], mb["target"])
+            B, T = tgt.shape[0], tgt.shape[1]
+            aug = make_aug(f, B, T, self.cfg.embed_dim, a.prenet_depth, n_blocks, self.rng, a.mask_noise_std, device=st.device)
+            eng.finetune_forward_backward(src, tgt, head, aug=aug, head_only=frozen)
+            ntok += B * T
+        self.sync.arm(False)
+        # ---- reduce: encoder buckets (already in flight), then the head and the scalars in one small call
+        packed = torch.cat([head.gw.view(-1), head.gb.view(-1), head.loss_sum.float().view(-1),
+                            torch.tensor([float(ntok)], device=st.device)])
+        if self.sync.active:
+            if not frozen:
+                self.sync.finish(None)
+            dist.all_reduce(packed, group=self.pg)
+            ngw = head.gw.numel()
+            head.gw.copy_(packed[:ngw].view_as(head.gw))
+            head.gb.copy_(packed[ngw:ngw + head.gb.numel()])
+        loss_sum, sample_size = packed[-2], packed[-1]
+        inv = 1.0 / sample_size
+        gw, gb = head.grad_w * inv, head.grad_b * inv
+        scale = inv.reshape(1).float()
+        gnorm = None
+        if f.clip_norm > 0:
+            self._sumsq.zero_()
+            if not frozen:
+                ops.sumsq(st.grad[self.lo:self.hi], self._sumsq)
+            gnorm = torch.sqrt(self._sumsq[0].float() * inv * inv + (gw * gw).sum() + (gb * gb).sum())
+            clip = torch.clamp(f.clip_norm / (gnorm + 1e-6), max=1.0)
+            scale = scale * clip
+            gw, gb = gw * clip, gb * clip
+        self.num_updates += 1
+        lr = cosine_lr(f, self.num_updates)
+        b1, b2 = f.adam_betas
+        if not frozen:
+            # fairseq Adam keeps a step count per parameter that starts with its first gradient: the encoder's
+            # bias correction starts when it is unfrozen
+            enc_step = self.num_updates - f.freeze_finetune_updates
+            ops.adam_step(st.flat[self.lo:self.hi], st.grad[self.lo:self.hi], st.adam_m[self.lo:self.hi],
+                          st.adam_v[self.lo:self.hi], lr=lr, beta1=b1, beta2=b2, eps=f.adam_eps, weight_decay=f.weight_decay,
+                          step=max(1, enc_step), decay_mask=st.decay_mask[self.lo // ALIGN:self.hi // ALIGN],
+                          grad_scale_dev=scale, lr_scale=self.lr_scale)
+            eng.refresh_student_packs()
+        for prm, gr, m, v in ((head.w, gw, self.head_m[0], self.head_v[0]), (head.b, gb, self.head_m[1], self.head_v[1])):
+            ops.adam_step(prm.view(-1), gr.contiguous().view(-1), m.view(-1), v.view(-1), lr=lr, beta1=b1, beta2=b2,
+                          eps=f.adam_eps, weight_decay=0.0, step=self.num_updates)
+        head.refresh()
+        self.last = dict(loss_sum=loss_sum, sample_size=sample_size, lr=lr, gnorm=gnorm)
+
+    def metrics(self) -> Dict[str, float]:
+        """loss / sample_size as fairseq logs it (criterions.py:279-295) -- host sync"""
+        n = float(self.last["sample_size"])
+        return dict(loss=float(self.last["loss_sum"]) / n / math.log(2), sample_size=n, lr=self.last["lr"],
+                    gnorm=float(self.last["gnorm"]) if self.last["gnorm"] is not None else None)
 
 
 # ---------------------------------------------------------------------------------------------- drop-in surface

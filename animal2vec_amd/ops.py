@@ -413,9 +413,11 @@ def ema_update(ema, p, decay):
 
 
 def adam_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, decay_mask=None,
-              grad_scale_dev=None):
+              grad_scale_dev=None, lr_scale=None):
+    """decay_mask (uint8) / lr_scale (fp32): one entry per 64 parameters of this slice (the slice must start on a
+    64-parameter boundary of the buffer the tables were built for)."""
     rc = _L().a2v_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
-                            grad_scale, ptr(decay_mask), ptr(grad_scale_dev), stream())
+                            grad_scale, ptr(decay_mask), ptr(grad_scale_dev), ptr(lr_scale), stream())
     check(rc, "a2v_adam_step")
 
 
@@ -459,3 +461,25 @@ def cast2d(src, dst):
     rc = _L().a2v_cast2d(dt(src), dt(dst), ptr(src), ptr(dst), M, C_, src.stride(0), dst.stride(0), stream())
     check(rc, "a2v_cast2d")
     return dst
+
+
+def add_drop(a, b, c=None, *, drop=None, out=None):
+    """out = a + dropout(b + c); a, c optional; drop = (p, seed) or None."""
+    assert b.is_contiguous() and (a is None or a.is_contiguous()) and (c is None or c.is_contiguous())
+    out = torch.empty_like(b) if out is None else out
+    dp, ds = (drop if drop is not None else (0.0, 0))
+    rc = _L().a2v_add_drop(dt(b), ptr(a), ptr(b), ptr(c), ptr(out), b.numel(), float(dp), int(ds) & 0xFFFFFFFF, stream())
+    check(rc, "a2v_add_drop")
+    return out
+
+
+def mask_frames(x, mask_t=None, mask_c=None, *, noise_std=0.0, seed=0, backward=False, out=None):
+    """apply_mask (base.py:457-485): x (B,T,D); mask_t (B,T) uint8, mask_c (B,D) uint8; see a2v.h."""
+    B, T, D = x.shape
+    assert x.is_contiguous() and (mask_t is None or (mask_t.dtype == torch.uint8 and mask_t.is_contiguous()))
+    assert mask_c is None or (mask_c.dtype == torch.uint8 and mask_c.is_contiguous() and mask_c.shape == (B, D))
+    out = torch.empty_like(x) if out is None else out
+    rc = _L().a2v_mask_frames(dt(x), ptr(x), ptr(mask_t), ptr(mask_c), ptr(out), B, T, D, float(noise_std),
+                              int(seed) & 0xFFFFFFFF, 1 if backward else 0, stream())
+    check(rc, "a2v_mask_frames")
+    return out

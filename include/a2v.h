@@ -175,9 +175,12 @@ int a2v_mixup_apply(const float* x, const int* perm, const float* gain_db, float
  * EMA teacher: fairseq EMAModule.step driven from data2vec2.py:386-410, flat fp32 buffers. */
 int a2v_ema_update(float* ema, const float* p, long long n, float decay, a2v_stream_t stream);
 /* fairseq Adam (configs/MeerKAT/a2v_large_pretrain_best.yaml:64-79). */
+/* decay_mask: one byte per 64 parameters (0 = no weight decay: the reference's optim_overrides weight_decay_scale 0,
+ * data2vec2.py:318-322) or NULL; lr_scale: one float per 64 parameters (per-group lr_scale of the composite optimizer,
+ * e.g. layer_decay, wav2vec2.py:214-236) or NULL.  Any contiguous slice may be stepped on its own (own step count). */
 int a2v_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, float grad_scale, const unsigned char* decay_mask,
-                  const float* grad_scale_dev, a2v_stream_t stream);
+                  const float* grad_scale_dev, const float* lr_scale, a2v_stream_t stream);
 int a2v_sumsq(const float* x, long long n, double* out, a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- layout helpers
@@ -214,6 +217,17 @@ int a2v_focal_loss(int dtype, const void* logits, const float* targets, void* dl
 /* out = scale * sum of L same-shaped tensors (L <= 32, n elements, n % 8 == 0): the mean of the last
  * average_top_k_layers layer results that feeds the classification head (wav2vec2.py:448-466). */
 int a2v_mean_layers(int dtype, const void* const* layers, int L, void* out, long long n, float scale, a2v_stream_t stream);
+
+/* out = a + dropout(b + c), n elements (n % 8 == 0); a and c may be NULL.  Keeps the Mlp output t (a layer result,
+ * modules.py:328-337) apart from x1 + post_mlp_dropout(t), and carries gradients back through the Mlp's own output
+ * dropout.  Mask = counter hash of (drop_seed, element index), as in the GEMM epilogues. */
+int a2v_add_drop(int dtype, const void* a, const void* b, const void* c, void* out, long long n, float drop_p,
+                 unsigned drop_seed, a2v_stream_t stream);
+/* ModalitySpecificEncoder.apply_mask (base.py:457-485) on (B,T,D): frames with mask_t[b*T+t] != 0 become N(0, noise_std)
+ * (noise_std 0: zero, encoder_zero_mask), then channels with mask_c[b*D+c] != 0 are zeroed on every frame; either mask
+ * may be NULL.  mode 1: the backward of that map (gradient zeroed at replaced positions).  out may alias x. */
+int a2v_mask_frames(int dtype, const void* x, const unsigned char* mask_t, const unsigned char* mask_c, void* out,
+                    int B, int T, int D, float noise_std, unsigned seed, int mode, a2v_stream_t stream);
 
 int a2v_abi_version(void);
 

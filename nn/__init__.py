@@ -5,7 +5,8 @@ from animal2vec_amd.config import (  # noqa: F401
 from animal2vec_amd.model import Data2VecMultiModel  # noqa: F401
 from animal2vec_amd.criterion import ExpandedModelCriterion, ExpandedModelCriterionConfig  # noqa: F401
 from animal2vec_amd.finetune import (  # noqa: F401
-    Wav2VecCcasFinetune, FinetuneCrossEntropyCriterion, FinetuneHead, finetune_step, sigmoid_focal_loss)
+    Wav2VecCcasFinetune, FinetuneCrossEntropyCriterion, FinetuneHead, FinetuneConfig, FinetuneTrainer, finetune_step,
+    sigmoid_focal_loss)
 from animal2vec_amd.task import AudioTaskCCAS, AudioConfigCCAS  # noqa: F401
 from animal2vec_amd.trainer import PretrainTrainer, OptimConfig, get_annealed_rate  # noqa: F401
 from animal2vec_amd.train_routine import animal2vec_audio_main  # noqa: F401

@@ -427,21 +427,49 @@ def sigmoid_focal_loss(inputs, targets, alpha: float = 0.25, gamma: float = 2, r
     return loss
 
 
-def finetune_forward(p, head_w, head_b, source, cfg: OracleConfig, top_k=None, local_grad_mult: float = 0.0):
-    """Wav2VecEncoderModOut.forward in eval mode (wav2vec2.py:430-482): extract_features(mask=False) of the student,
-    mean of the last `average_top_k_layers` layer results (the blocks' FFN outputs t, modules.py:328-337),
-    final_dropout (0.0), Linear(D -> n_labels).  Returns logits (B, T, C)."""
+def apply_mask(x, mask_t=None, replacement=None, mask_c=None):
+    """ModalitySpecificEncoder.apply_mask (base.py:457-485) with the random draws made explicit: frames where
+    mask_t (B,T) is set take the rows of `replacement` ((num_masked, D), the reference's normal_(0, mask_noise_std)
+    draw; None = encoder_zero_mask), then the channels where mask_c (B,D) is set are zeroed on every frame."""
+    if mask_t is not None:
+        mt = mask_t.bool()
+        if replacement is None:
+            x = x * (1 - mt.unsqueeze(-1).type_as(x))
+        else:
+            x = x.clone()
+            x[mt] = replacement.type_as(x)
+    if mask_c is not None:
+        x = x.masked_fill(mask_c.bool().unsqueeze(1).expand(-1, x.shape[1], -1), 0.0)
+    return x
+
+
+def finetune_forward(p, head_w, head_b, source, cfg: OracleConfig, top_k=None, local_grad_mult: float = 0.0,
+                     mask_t=None, replacement=None, mask_c=None, active=None):
+    """Wav2VecEncoderModOut.forward (wav2vec2.py:430-482): extract_features of the student, mean of the last
+    `average_top_k_layers` layer results (the blocks' FFN outputs t, modules.py:328-337), final_dropout (0.0),
+    Linear(D -> n_labels).  Returns logits (B, T, C).
+    Eval form by default (mask=False).  Train form, dropouts excluded: mask_t / replacement / mask_c as in apply_mask
+    (remove_masked is False with features_only, so the masked input feeds the pos-conv and the encoder at full
+    length, base.py:268-298); active = layerdrop outcome per block, prenet blocks first (modules.py:89-94,
+    data2vec2.py:651-655: a dropped block contributes no layer result)."""
     top_k = cfg.average_top_k_layers if top_k is None else top_k
     feats = local_features(p, source, cfg, local_grad_mult)
+    feats = apply_mask(feats, mask_t, replacement, mask_c)
     B, T, D = feats.shape
     x = feats + pos_conv(p, P, feats, cfg)
     pos = torch.arange(T).unsqueeze(0).expand(B, -1)
     bias = alibi_bias_from_positions(pos, cfg.num_heads, p[P + "alibi_scale"])
-    x = prenet(p, P, x, bias, cfg)
+    active = [True] * (cfg.prenet_depth + cfg.depth) if active is None else list(active)
+    pre = P + "context_encoder."
+    x = F.layer_norm(x, (D,), p[pre + "norm.weight"], p[pre + "norm.bias"], cfg.norm_eps)
+    for i in range(cfg.prenet_depth):
+        if active[i]:
+            x, _ = alt_block(p, pre + f"blocks.{i}.", x, bias, cfg.num_heads, cfg.norm_eps)
     lrs = []
     for i in range(cfg.depth):
-        x, t = alt_block(p, f"blocks.{i}.", x, bias, cfg.num_heads, cfg.norm_eps)
-        lrs.append(t)
+        if active[cfg.prenet_depth + i]:
+            x, t = alt_block(p, f"blocks.{i}.", x, bias, cfg.num_heads, cfg.norm_eps)
+            lrs.append(t)
     sel = lrs[-top_k:]
     xm = sum(sel) / len(sel)
     return F.linear(xm, head_w, head_b)

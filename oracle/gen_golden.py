@@ -318,6 +318,110 @@ def finetune_fixture(refnn, model, cfg, seed=21, n_labels=12, tol=2e-5):
     return fx
 
 
+def finetune_train_fixture(refnn, model, cfg, seed=33, n_labels=12, tol=2e-5):
+    """G16 (train form): noise-replace time masking + channel masking + layerdrop through the LIVE
+    reference -- Data2VecMultiModel.forward(mask=True, features_only=True) in train() mode, which is what
+    extract_features(mask=True) runs (data2vec2.py:1111-1124) plus the `precomputed_mask` hook.  The random draws are
+    pinned from outside: torch seed (the normal_() replacement noise, base.py:468-471), numpy seed (layerdrop,
+    modules.py:93 / data2vec2.py:654), and fairseq's compute_mask_indices (third party, absent) is replaced for the
+    channel mask by a function returning a fixed (B, C) array.  Dropout modules are set to p = 0 and the model's own
+    BC mixup is disabled (source_mixup < 0): dropout is checked on the GPU by finite differences, mixup has its own
+    fixture."""
+    import importlib
+    ref_utils = importlib.import_module("nn.utils")
+    base_mod = importlib.import_module("nn.modalities.base")
+    g = torch.Generator().manual_seed(seed)
+    B, L = 2, 8000
+    D = cfg.embed_dim
+    T = O.frame_counts(L, cfg.conv_feature_layers)[-1]
+    source = torch.nn.functional.layer_norm(torch.randn(B, L, generator=g), (L,))
+    target = (torch.rand(B, T, n_labels, generator=g) < 0.15).float()
+    head_w = torch.randn(n_labels, D, generator=g) * 0.1
+    head_b = torch.randn(n_labels, generator=g) * 0.1
+    mask_t = torch.zeros(B, T, dtype=torch.uint8)
+    n_mask = int(0.6 * T)
+    for b in range(B):
+        mask_t[b, torch.randperm(T, generator=g)[:n_mask]] = 1
+    mask_c = (torch.rand(B, D, generator=g) < 0.3)
+    enc = model.modality_encoders["AUDIO"]
+    mc = enc.modality_cfg
+    saved = dict(lgm=enc.local_grad_mult, zero=mc.encoder_zero_mask, mcp=mc.mask_channel_prob, ld=model.cfg.layerdrop,
+                 pld=enc.context_encoder.layerdrop, mix=model.cfg.source_mixup, cmi=base_mod.compute_mask_indices)
+    drops = [(m, m.p) for m in model.modules() if isinstance(m, torch.nn.Dropout)]
+    try:
+        enc.local_grad_mult = 0.0
+        mc.encoder_zero_mask = False
+        mc.mask_channel_prob = 0.5
+        model.cfg.layerdrop = 0.4
+        enc.context_encoder.layerdrop = 0.4
+        model.cfg.source_mixup = -1.0
+        base_mod.compute_mask_indices = lambda shape, pm, prob, length, **kw: mask_c.numpy()
+        for m, _ in drops:
+            m.p = 0.0
+        model.train()
+        hw, hb = head_w.clone().requires_grad_(True), head_b.clone().requires_grad_(True)
+        model.zero_grad()
+        t_seed = 9
+        nb = cfg.prenet_depth + cfg.depth
+        for np_seed in range(100):          # first seed whose layerdrop outcome drops a main block and keeps another
+            np.random.seed(np_seed)
+            pat = [bool(np.random.random() > 0.4) for _ in range(nb)]
+            if not all(pat[cfg.prenet_depth:]) and any(pat[cfg.prenet_depth:]):
+                break
+        np.random.seed(np_seed)
+        torch.manual_seed(t_seed)
+        res = model(source, mask=True, features_only=True, precomputed_mask=mask_t.clone())
+        lrs = res["layer_results"][-cfg.average_top_k_layers:]
+        xm = (sum(lrs) / len(lrs)).to(res["x"].dtype)
+        logits_ref = torch.nn.functional.linear(xm, hw, hb)
+        loss_ref = ref_utils.sigmoid_focal_loss(logits_ref, target, reduction="sum")
+        loss_ref.backward()
+        gref = {n: prm.grad.detach().clone() for n, prm in model.named_parameters() if prm.grad is not None}
+    finally:
+        enc.local_grad_mult = saved["lgm"]
+        mc.encoder_zero_mask = saved["zero"]
+        mc.mask_channel_prob = saved["mcp"]
+        model.cfg.layerdrop = saved["ld"]
+        enc.context_encoder.layerdrop = saved["pld"]
+        model.cfg.source_mixup = saved["mix"]
+        base_mod.compute_mask_indices = saved["cmi"]
+        for m, pv in drops:
+            m.p = pv
+        model.eval()
+    # replay the draws: the only torch draw before the blocks is the replacement noise; numpy is drawn once per block
+    torch.manual_seed(t_seed)
+    replacement = torch.empty(int(mask_t.sum()), D).normal_(0, mc.mask_noise_std)
+    np.random.seed(np_seed)
+    active = [bool(np.random.random() > 0.4) for _ in range(cfg.prenet_depth + cfg.depth)]
+    assert len(res["layer_results"]) == sum(active[cfg.prenet_depth:]), (len(res["layer_results"]), active)
+    assert not all(active) and any(active[cfg.prenet_depth:]), active
+    p, _ = state_to_flat(model)
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ow, ob = head_w.clone().requires_grad_(True), head_b.clone().requires_grad_(True)
+    logits = O.finetune_forward(po, ow, ob, source, cfg, mask_t=mask_t, replacement=replacement, mask_c=mask_c, active=active)
+    loss = O.sigmoid_focal_loss(logits, target, reduction="sum")
+    loss.backward()
+    check("finetune(train) logits", logits, logits_ref, tol * 5)
+    check("finetune(train) focal loss", loss, loss_ref, tol * 5)
+    check("finetune(train) head grads", ow.grad, hw.grad, tol * 25)
+    worst = 0.0
+    for n, gr in gref.items():
+        go = po[n].grad
+        if go is None:
+            assert float(gr.abs().max()) == 0.0, n        # a dropped block: torch leaves zeros or None
+            continue
+        r = rel(go, gr) if float(gr.abs().max()) > 0 else float(go.abs().max())
+        worst = max(worst, r)
+        assert r < 5e-4, (n, r)
+    print(f"  [ok ] finetune(train): active={''.join('1' if a else '0' for a in active)} {len(gref)} grads worst rel={worst:.3e}")
+    fx = {"source": source, "target": target, "head_w": head_w, "head_b": head_b, "mask_t": mask_t, "mask_c": mask_c.to(torch.uint8),
+          "replacement": replacement, "active": torch.tensor(active, dtype=torch.uint8), "logits": logits_ref.detach(),
+          "loss_sum": loss_ref.detach(), "g.head_w": hw.grad, "g.head_b": hb.grad}
+    for k, v in gref.items():
+        fx["g." + k] = v
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also validate large dims at L=80000 (slow)")
@@ -331,6 +435,7 @@ def main():
     ex = ema_fixture(model, cfg, fx)
     mx = mixup_fixture(refnn)
     ftx = finetune_fixture(refnn, model, cfg)
+    fttx = finetune_train_fixture(refnn, model, cfg)
     # second pair: real front end (127x63 sinc, 512-wide convs), small transformer; validated, not stored
     mid = dict(O.TINY, embed_dim=128, num_heads=8, conv_pos_groups=16, decoder_groups=16, decoder_dim=64)
     run_pair(refnn, mid, O.LARGE_LAYERS, ref_shims.LARGE_LAYERS, B=1, L=16000, keep=28, seed=2)
@@ -343,6 +448,7 @@ def main():
         save("tiny_ema.npz", ex)
         save("mixup.npz", mx)
         save("tiny_finetune.npz", ftx)
+        save("tiny_finetune_train.npz", fttx)
 
 
 if __name__ == "__main__":

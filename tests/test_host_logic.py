@@ -130,3 +130,45 @@ model: {depth: 4, embed_dim: 256, num_heads: 4, clone_batch: 3, ema_decay: 0.999
     assert (cfg.depth, cfg.embed_dim, cfg.audio.prenet_depth, cfg.audio.decoder.decoder_dim) == (4, 256, 2, 64)
     assert cfg.conv_layers == [(127, 63, 1), (512, 10, 5)]
     assert oc.lr == 0.0002 and oc.max_update == 100 and run["update_freq"] == 5
+
+
+def test_finetune_schedule_and_layer_decay():
+    """cosine schedule of finetune_mixup_100.yaml:69-74 and the layer_decay scales of wav2vec2.py:214-224"""
+    from animal2vec_amd.finetune import FinetuneConfig, cosine_lr, layer_lr_scales
+    f = FinetuneConfig()
+    assert cosine_lr(f, 0) == pytest.approx(1e-10)
+    assert cosine_lr(f, 1000) == pytest.approx(1e-10 + 1000 * (3e-5 - 1e-10) / 2000)
+    assert cosine_lr(f, 2000) == pytest.approx(3e-5)
+    assert cosine_lr(f, 16000) == pytest.approx(5e-6 + 0.5 * (3e-5 - 5e-6))
+    assert cosine_lr(f, 29999) == pytest.approx(5e-6, rel=1e-3)
+    lrs = [cosine_lr(f, n) for n in range(2000, 30000, 500)]
+    assert all(a > b for a, b in zip(lrs, lrs[1:]))
+    sc = layer_lr_scales(24, 0.75)
+    assert len(sc) == 24 and sc[-1] == pytest.approx(0.75) and sc[0] == pytest.approx(0.75 ** 24)
+    assert all(a < b for a, b in zip(sc, sc[1:]))
+
+
+def test_finetune_aug_draws():
+    """make_aug: span masks with equal counts per row, channel spans, layerdrop frequencies, dropout settings"""
+    import numpy as np
+    from animal2vec_amd.finetune import FinetuneConfig, make_aug
+    f = FinetuneConfig()
+    rng = np.random.default_rng(0)
+    B, T, D = 8, 2000, 1024
+    drops = np.zeros(24)
+    for _ in range(40):
+        a = make_aug(f, B, T, D, 8, 24, rng, 0.01, device="cpu")
+        mt, mc = a["mask_t"].numpy(), a["mask_c"].numpy()
+        assert mt.shape == (B, T) and mc.shape == (B, D)
+        assert len(set(mt.sum(1).tolist())) == 1                        # require_same_masks
+        assert 0.5 < mt.mean() < 0.9                                     # mask_prob 0.825 with overlapping spans of 4
+        assert 0.2 < mc.mean() < 0.5                                     # 0.5 with overlapping spans of 64
+        runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], mc[0], [0]]))))[::2]
+        assert runs.mean() > 2.0          # spans (thinned by require_same_masks' equalisation), not isolated channels
+        assert a["noise_std"] == 0.01 and a["p_att"] == 0.2 and a["p_drop"] == 0.1 and a["p_act"] == 0.1
+        assert any(a["active"][8:])
+        drops += 1 - np.asarray(a["active"], dtype=float)
+    assert 0.03 < drops.mean() / 40 < 0.2                                # layerdrop 0.1
+    f0 = FinetuneConfig(apply_mask=False, layerdrop=0.0, dropout=0.0, activation_dropout=0.0, attention_dropout=0.0)
+    a = make_aug(f0, B, T, D, 8, 24, rng, 0.01, device="cpu")
+    assert "mask_t" not in a and "mask_c" not in a and all(a["active"]) and "drop_seed" not in a

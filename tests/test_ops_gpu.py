@@ -723,3 +723,84 @@ def test_mixup_golden(ops):
     assert float((g.cpu() - mx["gain_db"]).abs().max()) < 2e-3          # dB
     out = m(src, mx["perm"].int().cuda(), float(mx["r"]))
     assert rel_err(out, mx["mixed"]) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mask_frames(ops, dtype):
+    """apply_mask (base.py:457-485): replaced frames ~ N(0, std), zeroed channels, untouched elsewhere; the backward
+    form zeroes exactly the replaced positions."""
+    B, T, D = 3, 200, 64
+    x = dev(rnd(B, T, D, dtype=dtype, seed=1), dtype)
+    g = torch.Generator().manual_seed(2)
+    mt = (torch.rand(B, T, generator=g) < 0.6).to(torch.uint8).cuda()
+    mc = (torch.rand(B, D, generator=g) < 0.3).to(torch.uint8).cuda()
+    y = ops.mask_frames(x, mt, mc, noise_std=0.25, seed=5)
+    keep_c = (mc == 0).unsqueeze(1).expand(B, T, D)
+    mtb = mt.bool().unsqueeze(-1).expand(B, T, D)
+    assert torch.equal(y[~mtb & keep_c], x[~mtb & keep_c])
+    assert float(y[~keep_c].abs().max()) == 0.0
+    noise = y[mtb & keep_c].float()
+    assert abs(float(noise.mean())) < 0.01 and abs(float(noise.std()) - 0.25) < 0.01
+    assert abs(float((noise.abs() > 0.5).float().mean()) - 0.0455) < 0.01          # two-sigma tail of a gaussian
+    assert torch.equal(y, ops.mask_frames(x, mt, mc, noise_std=0.25, seed=5))         # deterministic in the seed
+    assert not torch.equal(y, ops.mask_frames(x, mt, mc, noise_std=0.25, seed=6))
+    z = ops.mask_frames(x, mt, None, noise_std=0.0)                                   # encoder_zero_mask
+    assert float(z[mtb].abs().max()) == 0.0 and torch.equal(z[~mtb], x[~mtb])
+    d = ops.mask_frames(x, mt, mc, backward=True)
+    assert torch.equal(d, torch.where(~mtb & keep_c, x, torch.zeros_like(x)))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_add_drop(ops, dtype):
+    n, D = 777, 64
+    a, b, c = (dev(rnd(n, D, dtype=dtype, seed=s), dtype) for s in (1, 2, 3))
+    keep = ops.dropout_mask(n * D, 0.2, 31).view(n, D).float()
+    ref = a.float() + (b.float() + c.float()).to(dtype).float() * keep / 0.8 if dtype == torch.float32 else None
+    out = ops.add_drop(a, b, c, drop=(0.2, 31))
+    exp = a.float() + (b.float() + c.float()) * keep / 0.8
+    assert rel_err(out.float(), exp) < tol(dtype)
+    assert rel_err(ops.add_drop(None, b, None, drop=(0.2, 31)).float(), b.float() * keep / 0.8) < tol(dtype)
+    assert rel_err(ops.add_drop(a, b).float(), a.float() + b.float()) < tol(dtype)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 64), (2048, 512, 256)])
+def test_linear_gelu_dropout_epilogues(ops, M, N, K):
+    """The Mlp's activation dropout (timm Mlp drop1): fc1 epilogue GELU then dropout; its backward: the fc2 input
+    gradient epilogue applies the same mask and GELU'."""
+    dtype = torch.bfloat16
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, seed=3)
+    xd, wd, bd = dev(x, dtype), dev(w, dtype), dev(b, torch.float32)
+    keep = ops.dropout_mask(M * N, 0.1, 55).view(M, N).float().cpu()
+    pre_out = torch.empty(M, N, dtype=dtype, device="cuda")
+    y = ops.linear(xd, wd, bd, gelu=True, pre_out=pre_out, drop=(0.1, 55))
+    pre = x @ w.t() + b
+    assert rel_err(y.float(), F.gelu(pre) * keep / 0.9) < tol(dtype)
+    assert rel_err(pre_out.float(), pre) < tol(dtype)
+    # backward epilogue: dh = drop(dy @ W2^T) * gelu'(hpre)
+    dy, w2t = rnd(M, K, dtype=dtype, seed=4), rnd(N, K, dtype=dtype, seed=5, scale=K ** -0.5)
+    hpre = rnd(M, N, dtype=dtype, seed=6)
+    cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+    dh = ops.linear(dev(dy, dtype), dev(w2t, dtype), None, gelu_bwd_aux=dev(hpre, dtype), colsum=cs, drop=(0.1, 55))
+    hp = hpre.clone().requires_grad_(True)
+    F.gelu(hp).sum().backward()
+    exp = (dy @ w2t.t()) * keep / 0.9 * hp.grad
+    assert rel_err(dh.float(), exp) < tol(dtype)
+    assert rel_err(cs, dh.float().sum(0)) < 1e-3
+
+
+def test_adam_lr_scale_table(ops):
+    """per-64-parameter lr_scale (composite optimizer lr_scale, e.g. layer_decay): scales both the decay and the step"""
+    n = 64 * 37
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g)
+    ls = torch.rand(n // 64, generator=g)
+    p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    lr, b1, b2, eps, wd = 1e-2, 0.9, 0.98, 1e-8, 0.1
+    ops.adam_step(p, gr.cuda(), m, v, lr=lr, beta1=b1, beta2=b2, eps=eps, weight_decay=wd, step=1, lr_scale=ls.cuda())
+    lse = ls.repeat_interleave(64)
+    m1, v1 = (1 - b1) * gr, (1 - b2) * gr * gr
+    step_size = lr * math.sqrt(1 - b2) / (1 - b1)
+    exp = p0 - wd * lr * lse * p0 - step_size * lse * m1 / (v1.sqrt() + eps)
+    assert rel_err(p, exp) < 1e-5

@@ -149,6 +149,42 @@ def test_finetune_path_golden(tiny_golden):
     assert set(k for k in po if po[k].grad is not None) == set(gk)
 
 
+def test_finetune_train_form_golden(tiny_golden):
+    """G16: the train form of the finetune forward -- noise-replace time masking, channel masking (base.py:457-485)
+    and layerdrop (modules.py:89-94, data2vec2.py:651-655) -- against the live reference run in train() mode with the
+    random draws pinned (oracle/gen_golden.py::finetune_train_fixture)."""
+    ft = load_golden("tiny_finetune_train.npz")
+    p, _, _ = split_golden(tiny_golden)
+    cfg = tiny_cfg()
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    hw, hb = ft["head_w"].clone().requires_grad_(True), ft["head_b"].clone().requires_grad_(True)
+    active = [bool(v) for v in ft["active"]]
+    assert not all(active)
+    logits = O.finetune_forward(po, hw, hb, ft["source"], cfg, mask_t=ft["mask_t"], replacement=ft["replacement"],
+                                mask_c=ft["mask_c"], active=active)
+    loss = O.sigmoid_focal_loss(logits, ft["target"], reduction="sum")
+    loss.backward()
+    assert rel_err(logits, ft["logits"]) < 1e-5
+    assert abs(float(loss) - float(ft["loss_sum"])) / float(ft["loss_sum"]) < 1e-5
+    assert rel_err(hw.grad, ft["g.head_w"]) < 1e-4 and rel_err(hb.grad, ft["g.head_b"]) < 1e-4
+    n = 0
+    for k in ft:
+        if not k.startswith("g.") or k.startswith("g.head_"):
+            continue
+        ref = ft[k]
+        got = po[k[2:]].grad
+        if got is None:
+            assert float(ref.abs().max()) == 0.0, k          # a dropped block
+            continue
+        assert rel_err(got, ref) < 5e-4, k
+        n += 1
+    assert n > 25
+    # the masks really act: masked frames / channels of the encoder input carry no gradient into project_features' input
+    x = O.apply_mask(torch.ones(2, 5, 4), torch.tensor([[1, 0, 0, 0, 1], [0, 0, 0, 0, 0]]), torch.full((2, 4), 7.0),
+                     torch.tensor([[0, 1, 0, 0], [0, 0, 0, 1]]))
+    assert x[0, 0].tolist() == [7.0, 0.0, 7.0, 7.0] and x[0, 1].tolist() == [1.0, 0.0, 1.0, 1.0] and x[1, 2].tolist() == [1.0, 1.0, 1.0, 0.0]
+
+
 def test_focal_loss_known_values():
     # nn/utils.py:971-1010 at logit 0: p = 0.5, ce = ln 2, (1 - p_t)^2 = 0.25, alpha_t = 0.25 (positive) / 0.75
     l = O.sigmoid_focal_loss(torch.zeros(2), torch.tensor([1.0, 0.0]))

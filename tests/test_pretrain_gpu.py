@@ -266,14 +266,14 @@ def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
 
 
 # ------------------------------------------------------------------------------------------ finetune path (8f rank 1)
-def _finetune_run(cfg, p, ema, dtype, source, target, head_w, head_b):
+def _finetune_run(cfg, p, ema, dtype, source, target, head_w, head_b, aug=None):
     from animal2vec_amd.finetune import FinetuneHead, finetune_step
     store, eng = build(cfg, p, ema, dtype)
     head = FinetuneHead(cfg.embed_dim, head_w.shape[0], dtype=dtype)
     head.load(head_w.cuda(), head_b.cuda())
     store.grad.zero_()
     head.zero_grad()
-    logits, loss = finetune_step(eng, head, source.cuda(), target.cuda())
+    logits, loss = finetune_step(eng, head, source.cuda(), target.cuda(), aug=aug)
     torch.cuda.synchronize()
     return store, head, logits, float(loss)
 
@@ -376,3 +376,150 @@ def test_finetune_model_surface_dropin(tiny_golden):
     with torch.no_grad():
         out = model(ft["source"])
     assert rel_err(out["encoder_out"], ft["logits"]) < 1e-3
+
+
+def test_finetune_train_form_fp32_vs_reference_golden(tiny_golden):
+    """Train form of the finetune step -- noise-replace time masking, channel masking, layerdrop -- against vectors from
+    the live reference in train() mode with pinned draws (tests/golden/tiny_finetune_train.npz): 1e-3."""
+    from animal2vec_amd.config import tiny_config
+    from conftest import load_golden
+    ft = load_golden("tiny_finetune_train.npz")
+    p, ema, _ = split_golden(tiny_golden)
+    aug = dict(mask_t=ft["mask_t"].cuda(), mask_c=ft["mask_c"].cuda(), replacement=ft["replacement"].cuda(),
+               active=[bool(v) for v in ft["active"]])
+    store, head, logits, loss = _finetune_run(tiny_config(), p, ema, torch.float32, ft["source"], ft["target"],
+                                              ft["head_w"], ft["head_b"], aug=aug)
+    assert rel_err(logits.float(), ft["logits"]) < 1e-3
+    assert abs(loss - float(ft["loss_sum"])) / float(ft["loss_sum"]) < 1e-3
+    assert rel_err(head.grad_w, ft["g.head_w"]) < 1e-3 and rel_err(head.grad_b, ft["g.head_b"]) < 1e-3
+    n = 0
+    for k in ft:
+        if not k.startswith("g.") or k.startswith("g.head_"):
+            continue
+        ref = ft[k]
+        if float(ref.abs().max()) == 0.0:
+            assert float(store.g[k[2:]].abs().max()) == 0.0, k
+            continue
+        assert rel_err(store.g[k[2:]], ref) < 1e-3, (k, rel_err(store.g[k[2:]], ref))
+        n += 1
+    assert n > 25
+    dropped = [i for i, a in enumerate(aug["active"]) if not a]
+    assert dropped
+    for k in store.g:          # a dropped block gets no gradient at all
+        for i in dropped:
+            name = f"blocks.{i - tiny_config().audio.prenet_depth}." if i >= tiny_config().audio.prenet_depth else None
+            if name and k.startswith(name):
+                assert float(store.g[k].abs().max()) == 0.0, k
+
+
+def test_finetune_train_form_dropout_by_finite_differences(tiny_golden):
+    """All train-form pieces at once (device-hash replacement noise, channel mask, layerdrop, the dropouts of
+    wav2vec2.py:94-128 incl. the Mlp's two activation dropouts and attention dropout): the hand-written backward is
+    the gradient of the forward it ran, by central differences on the fp32 engine."""
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.finetune import FinetuneHead
+    from conftest import load_golden
+    ft = load_golden("tiny_finetune_train.npz")
+    p, ema, _ = split_golden(tiny_golden)
+    cfg = tiny_config()
+    store, eng = build(cfg, p, ema, torch.float32)
+    head = FinetuneHead(cfg.embed_dim, ft["head_w"].shape[0], dtype=torch.float32)
+    head.load(ft["head_w"].cuda(), ft["head_b"].cuda())
+    src, tgt = ft["source"].cuda(), ft["target"].cuda()
+    aug = dict(mask_t=ft["mask_t"].cuda(), mask_c=ft["mask_c"].cuda(), noise_std=0.5, noise_seed=77,
+               active=[True, True, True], drop_seed=991, p_drop=0.1, p_act=0.1, p_att=0.2)
+
+    def loss():
+        eng.sp.refresh()
+        head.refresh()
+        head.loss_sum.zero_()
+        eng.finetune_forward_backward(src, tgt, head, backward=False, aug=aug)
+        torch.cuda.synchronize()
+        return float(head.loss_sum)
+
+    l_eval = None
+    head.loss_sum.zero_()
+    eng.finetune_forward_backward(src, tgt, head, backward=False)
+    l_eval = float(head.loss_sum)
+    store.grad.zero_()
+    head.zero_grad()
+    eng.finetune_forward_backward(src, tgt, head, aug=aug)
+    l_train = float(head.loss_sum)
+    assert abs(l_train - l_eval) / l_eval > 1e-3                   # the train form really changed the forward
+    assert loss() == pytest.approx(l_train, rel=1e-6)              # and is deterministic in its seeds
+    probes = [("blocks.1.attn.qkv.weight", (5, 7)), ("blocks.0.mlp.fc2.bias", (3,)), ("blocks.0.mlp.fc1.weight", (9, 4)),
+              ("blocks.1.mlp.fc1.bias", (6,)),
+              ("modality_encoders.AUDIO.context_encoder.blocks.0.attn.proj.weight", (2, 9)),
+              ("modality_encoders.AUDIO.context_encoder.norm.weight", (11,)),
+              ("modality_encoders.AUDIO.relative_positional_encoder.1.0.weight", (3, 1, 2)),
+              ("modality_encoders.AUDIO.project_features.2.weight", (4, 6)),
+              ("modality_encoders.AUDIO.alibi_scale", (0, 0, 1, 0, 0))]
+    for name, idx in probes:
+        g = float(store.g[name][idx])
+        w = store.p[name]
+        old = float(w[idx])
+        eps = 2e-2 * max(1.0, abs(old))
+        w[idx] = old + eps
+        lp = loss()
+        w[idx] = old - eps
+        lm = loss()
+        w[idx] = old
+        fd = (lp - lm) / (2 * eps)
+        assert abs(fd - g) <= 0.08 * max(abs(g), abs(fd)) + 2e-2, (name, fd, g)
+    # head: exact (loss is linear in nothing, but the head is the last op) -- finite differences on one weight
+    gw = float(head.grad_w[3, 5])
+    old = float(head.w[3, 5])
+    head.w[3, 5] = old + 1e-2
+    lp = loss()
+    head.w[3, 5] = old - 1e-2
+    lm = loss()
+    head.w[3, 5] = old
+    assert abs((lp - lm) / 2e-2 - gw) <= 0.05 * abs(gw) + 1e-2
+    eng.sp.refresh()
+    head.refresh()
+
+
+def test_finetune_trainer_freeze_and_layer_decay(tiny_golden):
+    """FinetuneTrainer: classifier-only updates while frozen (wav2vec2.py:440-445); then the encoder trains with the
+    per-block lr scales of layer_decay (first Adam step moves every weight by lr x scale); the conv feature extractor
+    and the decoder never move."""
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.finetune import FinetuneConfig, FinetuneTrainer, cosine_lr, layer_lr_scales
+    from animal2vec_amd.params import ParamStore, P
+    from conftest import load_golden
+    ft = load_golden("tiny_finetune.npz")
+    p, ema, _ = split_golden(tiny_golden)
+    cfg = tiny_config()
+    store = ParamStore(cfg)
+    store.load_state_dict(p, ema)
+    f = FinetuneConfig(n_labels=12, freeze_finetune_updates=1, layer_decay=0.5, warmup_updates=1, lr=1e-3, min_lr=1e-4,
+                       max_update=10, mask_length=2, mask_channel_length=4)
+    tr = FinetuneTrainer(cfg, f, store=store, dtype=torch.float32, seed=3)
+    mbs = [dict(source=ft["source"].cuda(), target=ft["target"].cuda()) for _ in range(2)]
+    flat0, w0 = store.flat.clone(), tr.head.w.clone()
+    assert tr.frozen
+    tr.train_step(mbs)
+    torch.cuda.synchronize()
+    assert torch.equal(store.flat, flat0)                       # frozen: encoder untouched
+    assert float((tr.head.w - w0).abs().max()) > 0
+    m1 = tr.metrics()
+    assert m1["sample_size"] == 2 * ft["target"].shape[0] * ft["target"].shape[1] and m1["loss"] > 0
+    assert not tr.frozen
+    tr.train_step(mbs)
+    torch.cuda.synchronize()
+    lr = cosine_lr(f, 2)
+    sc = layer_lr_scales(cfg.audio.prenet_depth + cfg.depth, 0.5)
+    d = (store.flat - flat0).abs()
+
+    def moved(name):
+        s_ = store.by_name[name]
+        return float(d[s_.offset:s_.offset + s_.numel].max())
+
+    assert moved(P + "context_encoder.blocks.0.mlp.fc1.weight") == pytest.approx(lr * sc[0], rel=2e-2)
+    assert moved("blocks.0.mlp.fc1.weight") == pytest.approx(lr * sc[1], rel=2e-2)
+    assert moved("blocks.1.attn.qkv.weight") == pytest.approx(lr * sc[2], rel=2e-2)
+    assert moved(P + "project_features.2.weight") == pytest.approx(lr, rel=2e-2)
+    assert moved(P + "relative_positional_encoder.1.0.weight") == pytest.approx(lr, rel=2e-2)
+    for name in store.by_name:
+        if "local_encoder" in name or "decoder" in name:
+            assert moved(name) == 0.0, name
