@@ -1060,7 +1060,255 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
   if (lane == 0 && a.dalibi && asc >= 0.f) atomicAdd(a.dalibi + h, dal * slope);
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, HD = 64, long sequences (finetuning attends over all T = 2000 frames): two passes, no atomics, no fp32 dQ
+// scratch.  MODE 0 (dK, dV): a workgroup owns 128 keys (32 per wave, as B-operand fragments in registers) and
+// streams the queries; MODE 1 (dQ): it owns 128 queries and streams the keys.  The streamed side comes through LDS
+// in 64-row tiles, double buffered (global -> registers during the tile's math -> LDS, one barrier per tile), each
+// tile ONE dual-use image (row reads for S / dP, transposed reads for the gradient products).  Each A fragment read
+// from LDS feeds both 16-row owner groups of the wave, which halves LDS traffic per MFMA against one group per wave
+// (the limit of the tiled kernel above: 8 KB of fragment reads per 8 MFMAs).  S and P are recomputed in both passes
+// (7 matmuls instead of 5) -- cheaper than 2 GB of fp32 atomics per layer at S = 2000.
+//   MODE 0: S[q][kv] = X1(Q) . own1(K), dP = X2(dO) . own2(V); dV^T += tr(X2) . P, dK^T += tr(X1) . dS
+//   MODE 1: S^T[kv][q] = X1(K) . own1(Q), dP^T = X2(V) . own2(dO); dQ^T += tr(X1) . dS^T
+#define ABL_LDS (2 * 16384 + 2 * 3 * 64 * 4)
+
+template <int MODE, bool DROP>
+__global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
+  constexpr int HD = 64, ND = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* const sRowBase = (float*)(smem + 2 * 16384);     // [buf][neg | delta | pos][64] of the streamed rows
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const long long orow = (long long)H * HD;
+  const bf16* qkv = (const bf16*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  const bf16* dO = (const bf16*)a.d_out + (long long)n * S * orow + (long long)h * HD;
+  const float slope = a.slopes[h];
+  const float asc = a.alibi_scale[h];
+  const float coef = -slope * fmaxf(asc, 0.f);
+  const long long nh = (long long)n * H + h;
+
+  // streamed operands and owner operands
+  const bf16* x1p = MODE == 0 ? qkv : qkv + (long long)H * HD;
+  const bf16* x2p = MODE == 0 ? dO : qkv + 2LL * H * HD;
+  const long long x2s = MODE == 0 ? orow : rowstride;
+  const bf16* o1p = MODE == 0 ? qkv + (long long)H * HD : qkv;
+  const bf16* o2p = MODE == 0 ? qkv + 2LL * H * HD : dO;
+  const long long o2s = MODE == 0 ? rowstride : orow;
+
+  // ---- owner side: 2 groups of 16 rows per wave
+  bf16x8 own1[2][2], own2[2][2];
+  float cneg[2], cdel[2], cpos[2];
+  int orow_i[2];
+#pragma unroll
+  for (int og = 0; og < 2; ++og) {
+    const int o = blockIdx.x * 128 + wid * 32 + og * 16 + fr;
+    const int oc = o < S ? o : S - 1;
+    orow_i[og] = o;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      own1[og][ks] = *(const bf16x8*)(o1p + (long long)oc * rowstride + ks * 32 + g * 8);
+      own2[og][ks] = *(const bf16x8*)(o2p + (long long)oc * o2s + ks * 32 + g * 8);
+    }
+    cpos[og] = a.pos ? (float)a.pos[(long long)n * S + oc] : (float)oc;
+    if (MODE == 0) {
+      cneg[og] = o < S ? 0.f : -INFINITY;
+      cdel[og] = 0.f;
+    } else {
+      cneg[og] = o < S ? -a.lse[nh * S + oc] : -INFINITY;
+      cdel[og] = a.delta[nh * S + oc];
+    }
+  }
+
+  f32x4 accA[2][ND], accB[2][ND];
+#pragma unroll
+  for (int og = 0; og < 2; ++og)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { accA[og][i] = (f32x4){0.f, 0.f, 0.f, 0.f}; accB[og][i] = accA[og][i]; }
+  float dal = 0.f;
+
+  const int ntile = (S + 63) / 64;
+  uint4 r1[2], r2[2];
+  float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f;
+
+#define ABL_FETCH(t_)                                                                               \
+  {                                                                                                 \
+    const int s0_ = (t_) * 64;                                                                      \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                 \
+      const int c = tid + 256 * u, r = c >> 3, ch = c & 7;                                          \
+      r1[u] = make_uint4(0u, 0u, 0u, 0u);                                                           \
+      r2[u] = r1[u];                                                                                \
+      if (s0_ + r < S) {                                                                            \
+        r1[u] = *(const uint4*)(x1p + (long long)(s0_ + r) * rowstride + ch * 8);                   \
+        r2[u] = *(const uint4*)(x2p + (long long)(s0_ + r) * x2s + ch * 8);                         \
+      }                                                                                             \
+    }                                                                                               \
+    if (tid < 64) {                                                                                 \
+      const int row = s0_ + tid;                                                                    \
+      const bool ok = row < S;                                                                      \
+      const int rc = ok ? row : S - 1;                                                              \
+      rs2 = a.pos ? (float)a.pos[(long long)n * S + rc] : (float)rc;                                \
+      if (MODE == 0) {                                                                              \
+        rs0 = ok ? -a.lse[nh * S + rc] : -INFINITY;                                                 \
+        rs1 = a.delta[nh * S + rc];                                                                 \
+      } else {                                                                                      \
+        rs0 = ok ? 0.f : -INFINITY;                                                                 \
+        rs1 = 0.f;                                                                                  \
+      }                                                                                             \
+    }                                                                                               \
+  }
+#define ABL_COMMIT(buf_)                                                                            \
+  {                                                                                                 \
+    char* const b1 = smem + (buf_) * 16384;                                                         \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                 \
+      const int c = tid + 256 * u, r = c >> 3, ch = c & 7;                                          \
+      *(uint4*)(b1 + dual_off(r, ch)) = r1[u];                                                      \
+      *(uint4*)(b1 + 8192 + dual_off(r, ch)) = r2[u];                                               \
+    }                                                                                               \
+    if (tid < 64) {                                                                                 \
+      float* const sr = sRowBase + (buf_) * 192;                                                    \
+      sr[tid] = rs0; sr[64 + tid] = rs1; sr[128 + tid] = rs2;                                       \
+    }                                                                                               \
+  }
+
+  ABL_FETCH(0)
+  ABL_COMMIT(0)
+  __syncthreads();
+
+#pragma unroll 1
+  for (int t = 0; t < ntile; ++t) {
+    const int cur = t & 1;
+    const int s0 = t * 64;
+    if (t + 1 < ntile) ABL_FETCH(t + 1)
+    const char* const X1 = smem + cur * 16384;
+    const char* const X2 = X1 + 8192;
+    const float* const sNeg = sRowBase + cur * 192;
+    const float* const sDel = sNeg + 64;
+    const float* const sPos = sNeg + 128;
+
+    // two halves of the streamed tile (32 rows each), rolled: scores + softmax gradient of the half, then its
+    // gradient products -- only one half's P / dS fragments are live, and the rolled loop keeps the scheduler from
+    // hoisting the second half's fragment reads over the first half's math (register spills otherwise)
+#pragma unroll 1
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 pk[2], dk_[2];              // P and dS as B operands, per owner group
+      f32x4 pprev[2], dprev[2];
+#pragma unroll
+      for (int ih = 0; ih < 2; ++ih) {
+        const int rb = 32 * st + 16 * ih;                 // first streamed row of this 16-row sub-block
+        bf16x8 a1[2], a2[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          a1[ks] = *(const bf16x8*)(X1 + dual_off(rb + fr, ks * 4 + g));
+          a2[ks] = *(const bf16x8*)(X2 + dual_off(rb + fr, ks * 4 + g));
+        }
+        float rneg[4], rdel[4], rpos[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int rl = rb + 4 * g + r;
+          rneg[r] = sNeg[rl];
+          rdel[r] = MODE == 0 ? sDel[rl] : 0.f;
+          rpos[r] = sPos[rl];
+        }
+#pragma unroll
+        for (int og = 0; og < 2; ++og) {
+          f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], own1[og][ks], sacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ks], own2[og][ks], pacc, 0, 0, 0);
+          }
+          f32x4 pcur, dcur;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float dist = fabsf(rpos[r] - cpos[og]);
+            const float sc = sacc[r] * a.scale + coef * dist;
+            const float pv = __expf(sc + rneg[r] + cneg[og]);
+            float pdrop = pv, dpe = pacc[r];
+            if (DROP) {                                // same mask as the forward: index (n, h, q, kv)
+              const int srow = s0 + rb + 4 * g + r;
+              const int sc_ = srow < S ? srow : S - 1;
+              const int oc_ = orow_i[og] < S ? orow_i[og] : S - 1;
+              const unsigned long long qi = MODE == 0 ? sc_ : oc_, ki = MODE == 0 ? oc_ : sc_;
+              const unsigned long long idx = ((unsigned long long)nh * S + qi) * (unsigned long long)S + ki;
+              pdrop = drop_apply(a.drop, idx, pv);
+              dpe = drop_apply(a.drop, idx, pacc[r]);
+            }
+            const float dsv = pv * (dpe - rdel[r] - cdel[og]);
+            pcur[r] = pdrop;
+            dcur[r] = dsv;
+            if (MODE == 0) dal -= dsv * dist;
+          }
+          if (ih) {
+            bf16x8 pf, df;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              pf[r] = (bf16)pprev[og][r]; pf[4 + r] = (bf16)pcur[r];
+              df[r] = (bf16)dprev[og][r]; df[4 + r] = (bf16)dcur[r];
+            }
+            pk[og] = pf;
+            dk_[og] = df;
+          } else {
+            pprev[og] = pcur;
+            dprev[og] = dcur;
+          }
+        }
+      }
+      // ---- gradient products of this half: k = streamed row (permuted order shared by both operands)
+      const int r_lo = 32 * st + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int chl = 2 * i + (pp >> 1), sub = (pp & 1) << 3;       // column 16 i + 4 pp: chunk, byte inside it
+        const bf16x8 x1f = tr_frag(X1 + dual_off(r_lo, chl) + sub, X1 + dual_off(r_hi, chl) + sub);
+#pragma unroll
+        for (int og = 0; og < 2; ++og)
+          accB[og][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1f, dk_[og], accB[og][i], 0, 0, 0);
+        if (MODE == 0) {
+          const bf16x8 x2f = tr_frag(X2 + dual_off(r_lo, chl) + sub, X2 + dual_off(r_hi, chl) + sub);
+#pragma unroll
+          for (int og = 0; og < 2; ++og)
+            accA[og][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2f, pk[og], accA[og][i], 0, 0, 0);
+        }
+      }
+    }
+    if (t + 1 < ntile) ABL_COMMIT(cur ^ 1)
+    __syncthreads();
+  }
+#undef ABL_FETCH
+#undef ABL_COMMIT
+
+  // ---- results: D rows d = 16 i + 4 g + r, column = owner row
+#pragma unroll
+  for (int og = 0; og < 2; ++og) {
+    const int o = orow_i[og];
+    if (o < S) {
+      bf16* dst = (bf16*)a.dqkv + ((long long)n * S + o) * rowstride + (long long)h * HD;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const f32x4 kk = accB[og][i] * a.scale;
+        if (MODE == 0) {
+          Vec4<bf16>::store(dst + (long long)H * HD + 16 * i + 4 * g, kk);
+          Vec4<bf16>::store(dst + 2LL * H * HD + 16 * i + 4 * g, accA[og][i]);
+        } else {
+          Vec4<bf16>::store(dst + 16 * i + 4 * g, kk);
+        }
+      }
+    }
+  }
+  if (MODE == 0) {
+    dal = wave_sum(dal);
+    if (lane == 0 && a.dalibi && asc >= 0.f) atomicAdd(a.dalibi + h, dal * slope);
+  }
+}
+
 #define A2V_ATTN_SEQ_TILES 3      // sequences up to 192 tokens take the atomic-free whole-sequence backward (bf16)
+
+int g_a2v_attn_long = 1;     // a2v_debug_set(8, v): two-pass long-sequence backward on / off (off: tiled kernel + dQ atomics)
 
 template <typename T, int HD>
 static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, hipStream_t st) {
@@ -1074,6 +1322,19 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
   constexpr int TILE = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
   constexpr int LDS = (BF ? 5 : 3) * TILE + (BF ? 64 * 64 * 2 : 64 * 68 * 4) + 3 * 64 * 4;
   if constexpr (BF && HD == 64) {
+    if (a.S > ABS_ROWS && g_a2v_attn_long) {       // long sequences: dK/dV pass + dQ pass, no atomics
+      const bool dr = a.drop.thresh != 0;
+      const dim3 grid((a.S + 127) / 128, a.H, a.N);
+      if (dr) {
+        hipLaunchKernelGGL((attn_bwd_long_kernel<0, true>), grid, dim3(256), ABL_LDS, st, a);
+        hipLaunchKernelGGL((attn_bwd_long_kernel<1, true>), grid, dim3(256), ABL_LDS, st, a);
+      } else {
+        hipLaunchKernelGGL((attn_bwd_long_kernel<0, false>), grid, dim3(256), ABL_LDS, st, a);
+        hipLaunchKernelGGL((attn_bwd_long_kernel<1, false>), grid, dim3(256), ABL_LDS, st, a);
+      }
+      A2V_CHECK_LAUNCH();
+      return A2V_OK;
+    }
     if (a.S <= ABS_ROWS) {
       const bool dr = a.drop.thresh != 0;
       (void)hipFuncSetAttribute((const void*)attn_bwd_seq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ABS_LDS);
@@ -1098,8 +1359,10 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
 
 // 1 when a2v_attention_bwd writes dQ directly into the q slot of dqkv for this (dtype, S) (dq32 unused, may be
 // NULL); 0 when dQ is left in dq32 (fp32, zeroed by the caller) and must be cast into dqkv afterwards.
-extern "C" int a2v_attention_bwd_direct_dq(int dtype, int S) {
-  return dtype == A2V_BF16 && S <= 64 * A2V_ATTN_SEQ_TILES ? 1 : 0;
+extern "C" int a2v_attention_bwd_direct_dq(int dtype, int S, int HD) {
+  if (dtype != A2V_BF16) return 0;
+  if (S <= 64 * A2V_ATTN_SEQ_TILES) return 1;
+  return HD == 64 && g_a2v_attn_long ? 1 : 0;
 }
 
 // dq32 must be zero on entry; delta is (N,H,S) fp32 scratch.  dQ is left in dq32 (fp32, (N,S,H,HD));

@@ -181,7 +181,7 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, dro
     N, S, W = qkv.shape
     HD = W // (3 * H)
     dqkv = torch.empty_like(qkv)
-    direct = bool(_L().a2v_attention_bwd_direct_dq(dt(qkv), S))
+    direct = bool(_L().a2v_attention_bwd_direct_dq(dt(qkv), S, HD))
     dq32 = None if direct else torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
     delta = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
     rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(delta), ptr(dqkv), ptr(dq32),

@@ -92,7 +92,8 @@ int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const i
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
                       unsigned drop_seed, a2v_stream_t stream);
 /* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dalibi (H) fp32 accumulates d loss / d alibi_scale.
- * dQ: when a2v_attention_bwd_direct_dq(dtype, S) is 1 (bf16, S <= 192: the student's kept-token sequences)
+ * dQ: when a2v_attention_bwd_direct_dq(dtype, S, HD) is 1 (bf16 with S <= 192 -- the student's kept-token sequences --
+ * or bf16 with HD = 64 at any S -- the two-pass long-sequence kernels of the finetune path)
  * the kernel owns a whole (n,h) sequence and writes dQ into the q slot of dqkv itself (dq32 may be NULL);
  * otherwise dq32 (N,S,H,HD) fp32 must be zero on entry, receives dQ through atomics, and the caller casts it
  * into dqkv (a2v_cast2d). */
@@ -100,7 +101,7 @@ int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d
                       void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p, unsigned drop_seed,
                       a2v_stream_t stream);
-int a2v_attention_bwd_direct_dq(int dtype, int S);
+int a2v_attention_bwd_direct_dq(int dtype, int S, int HD);
 
 /* ---------------------------------------------------------------- normalisation
  * y = act( LN(x [+ res]) * gamma + beta ), act 0 none / 1 GELU; optional sum_out = x + res;

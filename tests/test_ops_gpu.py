@@ -713,6 +713,47 @@ def test_attention_dropout(ops, dtype, hd):
     assert rel_err(dal, sc.grad) < max(tol(dtype, 3), 5e-4)
 
 
+@pytest.mark.parametrize("S,p_", [(200, 0.0), (333, 0.2), (700, 0.0), (641, 0.1)])
+def test_attention_bwd_long_two_pass(ops, S, p_):
+    """bf16, HD = 64, S > 192: the two-pass backward (dK/dV pass + dQ pass, no atomics) against torch autograd and
+    against the tiled kernel with dQ atomics (a2v_debug_set(8, 0)); ragged S (tails in both the owner and the
+    streamed dimension), sorted random positions, attention dropout."""
+    from animal2vec_amd import _lib
+    dtype, hd, N, H, seed = torch.bfloat16, 64, 2, 3, 17
+    qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=1).requires_grad_(True)
+    g = torch.Generator().manual_seed(2)
+    pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = (torch.rand(H, generator=g) + 0.5).requires_grad_(True)
+    q, k, v = qkv.reshape(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = O.alibi_bias_from_positions(pos.long(), H, sc.view(1, 1, H, 1, 1))
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1) + bias).softmax(-1)
+    drop = None
+    if p_ > 0:
+        keep = ops.dropout_mask(N * H * S * S, p_, seed).view(N, H, S, S).float().cpu()
+        att = att * keep / (1 - p_)
+        drop = (p_, seed)
+    ref = (att @ v).transpose(1, 2).reshape(N, S, H * hd)
+    do = rnd(N, S, H * hd, dtype=dtype, seed=3)
+    ref.backward(do)
+    qd, dod = dev(qkv.detach(), dtype), dev(do, dtype)
+    args = (pos.cuda(), slopes.cuda(), sc.detach().cuda(), H)
+    out, lse = ops.attention_fwd(qd, *args, drop=drop)
+    dal = torch.zeros(H, device="cuda")
+    dqkv = ops.attention_bwd(qd, out, dod, lse, *args, dal, drop=drop)
+    assert rel_err(dqkv.float(), qkv.grad) < tol(dtype, 3)
+    assert rel_err(dal, sc.grad) < max(tol(dtype, 3), 5e-4)
+    for name, sl in (("dq", slice(0, H * hd)), ("dk", slice(H * hd, 2 * H * hd)), ("dv", slice(2 * H * hd, 3 * H * hd))):
+        assert rel_err(dqkv[..., sl].float(), qkv.grad[..., sl]) < tol(dtype, 3), name
+    _lib.load().a2v_debug_set(8, 0)
+    try:
+        dal2 = torch.zeros(H, device="cuda")
+        dqkv2 = ops.attention_bwd(qd, out, dod, lse, *args, dal2, drop=drop)
+    finally:
+        _lib.load().a2v_debug_set(8, 1)
+    assert rel_err(dqkv.float(), dqkv2.float()) < 1e-2 and rel_err(dal, dal2) < 1e-3
+
+
 def test_mixup_golden(ops):
     """BC mixup against the vector dumped from the live reference (oracle/gen_golden.py: G14)."""
     from conftest import load_golden
