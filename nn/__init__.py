@@ -4,6 +4,7 @@ from animal2vec_amd.config import (  # noqa: F401
     Data2VecMultiConfig, D2vAudioConfig, D2vDecoderConfig, large_config, base_star_config)
 from animal2vec_amd.model import Data2VecMultiModel  # noqa: F401
 from animal2vec_amd.criterion import ExpandedModelCriterion, ExpandedModelCriterionConfig  # noqa: F401
+from animal2vec_amd import checkpoint  # noqa: F401  (fairseq-style .pt wire format)
 from animal2vec_amd.finetune import (  # noqa: F401
     Wav2VecCcasFinetune, FinetuneCrossEntropyCriterion, FinetuneHead, FinetuneConfig, FinetuneTrainer, finetune_step,
     sigmoid_focal_loss)

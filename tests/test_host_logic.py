@@ -172,3 +172,96 @@ def test_finetune_aug_draws():
     f0 = FinetuneConfig(apply_mask=False, layerdrop=0.0, dropout=0.0, activation_dropout=0.0, attention_dropout=0.0)
     a = make_aug(f0, B, T, D, 8, 24, rng, 0.01, device="cpu")
     assert "mask_t" not in a and "mask_c" not in a and all(a["active"]) and "drop_seed" not in a
+
+
+def test_checkpoint_wire_format_roundtrip(tmp_path):
+    """fairseq-style .pt: reference parameter names + "_ema" under "model"; pretrain resume, finetune load (with and
+    without load_ema), finetuned-model layout (w2v_encoder.w2v_model.* / w2v_encoder.proj.*), alibi_scale upgrade."""
+    import torch
+    from animal2vec_amd import checkpoint as ck
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.params import ParamStore, P
+    cfg = tiny_config()
+    a = ParamStore(cfg, device="cpu", with_optimizer=False)
+    a.init_reference(3)
+    a.teacher.mul_(0.5)                                         # teacher != student
+    path = tmp_path / "checkpoint_last.pt"
+    st = ck.save_checkpoint(path, a, cfg={"model": {"_name": "data2vec_multi", "embed_dim": cfg.embed_dim}}, num_updates=7)
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) >= {"cfg", "model", "optimizer_history", "extra_state", "last_optimizer_state"}
+    assert raw["optimizer_history"][-1]["num_updates"] == 7
+    assert "_ema" in raw["model"] and "blocks.0.attn.qkv.weight" in raw["model"]
+    assert P + "decoder.proj.weight" in raw["model"] and raw["model"][P + "alibi_scale"].dim() == 5
+    assert all(v.device.type == "cpu" for v in raw["model"].values() if torch.is_tensor(v))
+    # resume
+    b = ParamStore(cfg, device="cpu", with_optimizer=False)
+    ck.load_pretrained(b, ck.load_checkpoint(path))
+    assert torch.equal(a.flat, b.flat) and torch.equal(a.teacher, b.teacher)
+    # old checkpoints carry a 4-d alibi_scale (base.py:152-157)
+    raw["model"][P + "alibi_scale"] = raw["model"][P + "alibi_scale"].squeeze(0)
+    torch.save(raw, path)
+    c = ParamStore(cfg, device="cpu", with_optimizer=False)
+    ck.load_pretrained(c, ck.load_checkpoint(path))
+    assert torch.equal(a.flat, c.flat)
+    # finetune load: decoder keys optional, _ema dropped; load_ema puts the teacher's weights into the encoder
+    for k in [k for k in raw["model"] if ".decoder." in k]:
+        del raw["model"][k]
+    torch.save(raw, path)
+    d = ParamStore(cfg, device="cpu", with_optimizer=False)
+    ck.load_for_finetune(d, ck.load_checkpoint(path))
+    assert torch.equal(d.p["blocks.0.attn.qkv.weight"], a.p["blocks.0.attn.qkv.weight"])
+    e = ParamStore(cfg, device="cpu", with_optimizer=False)
+    ck.load_for_finetune(e, ck.load_checkpoint(path), load_ema=True)
+    assert torch.equal(e.p["blocks.0.attn.qkv.weight"], a.t["blocks.0.attn.qkv.weight"])
+    assert not torch.equal(e.p["blocks.0.attn.qkv.weight"], a.p["blocks.0.attn.qkv.weight"])
+    with pytest.raises(KeyError):
+        del raw["model"]["blocks.0.attn.qkv.weight"]
+        torch.save(raw, path)
+        ck.load_for_finetune(ParamStore(cfg, device="cpu", with_optimizer=False), ck.load_checkpoint(path))
+
+    class Head:                                                    # FinetuneHead's parameter surface
+        def __init__(self):
+            self.w, self.b = torch.randn(12, cfg.embed_dim), torch.randn(12)
+
+        def load(self, w, b):
+            self.w.copy_(w); self.b.copy_(b)
+
+    h = Head()
+    ck.save_checkpoint(path, a, head=h, num_updates=3)
+    raw = torch.load(path, weights_only=False)
+    assert "w2v_encoder.proj.weight" in raw["model"] and "w2v_encoder.w2v_model.blocks.1.mlp.fc2.bias" in raw["model"]
+    assert not any(".decoder." in k for k in raw["model"]) and "_ema" not in raw["model"]
+    f, h2 = ParamStore(cfg, device="cpu", with_optimizer=False), Head()
+    ck.load_finetuned(f, h2, ck.load_checkpoint(path))
+    assert torch.equal(h2.w, h.w) and torch.equal(f.p["blocks.1.mlp.fc2.bias"], a.p["blocks.1.mlp.fc2.bias"])
+
+
+def test_checkpoint_with_foreign_config_objects(tmp_path):
+    """Published checkpoints pickle omegaconf / argparse objects next to the tensors; omegaconf is not installed
+    here, so the loader must still return the tensors and a readable config."""
+    import pickle
+    import sys
+    import types
+    import torch
+    from animal2vec_amd import checkpoint as ck
+    mod = types.ModuleType("fakeconf_pkg")
+
+    class DictConfig:
+        def __init__(self, content):
+            self._content = content
+            self._metadata = "meta"
+
+    DictConfig.__module__ = "fakeconf_pkg"
+    DictConfig.__qualname__ = "DictConfig"
+    mod.DictConfig = DictConfig
+    sys.modules["fakeconf_pkg"] = mod
+    try:
+        state = {"cfg": DictConfig({"model": DictConfig({"_name": "data2vec_multi", "depth": 16})}),
+                 "model": {"blocks.0.norm1.weight": torch.arange(4.0), "_ema": {}}}
+        path = tmp_path / "foreign.pt"
+        torch.save(state, path)
+    finally:
+        del sys.modules["fakeconf_pkg"]
+    got = ck.load_checkpoint(path)
+    assert torch.equal(got["model"]["blocks.0.norm1.weight"], torch.arange(4.0))
+    assert ck.config_to_dict(got["cfg"]) == {"model": {"_name": "data2vec_multi", "depth": 16}}
