@@ -3,8 +3,9 @@
 
     python animal2vec_train.py --config-dir configs/MeerKAT --config-name a2v_large_pretrain_best
 
-reads the hydra-style YAML and runs the pretraining hot loop natively on MI355X (synthetic waveforms of
-the configured shape; the reference's data pipeline / checkpoint policy / loggers are out of scope)."""
+reads the hydra-style YAML and runs the pretraining hot loop natively on MI355X -- on synthetic waveforms of the
+configured shape, or with --data <manifest.tsv> on real clips; --finetune runs the finetune loop on a labelled
+manifest from a --pretrained checkpoint (the reference's checkpoint policy / validation / loggers are out of scope)."""
 import argparse
 import os
 import sys
@@ -17,13 +18,27 @@ def cli_main():
     ap.add_argument("--config-dir", required=True)
     ap.add_argument("--config-name", required=True)
     ap.add_argument("--updates", type=int, default=2)
+    ap.add_argument("--data", default=None, help="manifest TSV (scripts/animal2vec_manifest.py layout)")
+    ap.add_argument("--restore-file", default=None, help="fairseq-style checkpoint to resume pretraining from")
+    ap.add_argument("--save", default=None, help="write a fairseq-style checkpoint here when done")
+    ap.add_argument("--finetune", action="store_true", help="finetune on the labelled manifest (needs --data, --labels)")
+    ap.add_argument("--pretrained", default=None, help="pretraining checkpoint for --finetune (model.w2v_path)")
+    ap.add_argument("--labels", default=None, help="unique labels, e.g. \"['beep','cc','focal']\" (task.unique_labels)")
     a = ap.parse_args()
     import nn
     from animal2vec_amd.train_routine import config_from_yaml
     path = os.path.join(a.config_dir, a.config_name if a.config_name.endswith(".yaml") else a.config_name + ".yaml")
     cfg, optim, run = config_from_yaml(path)
     clips = max(1, run["max_tokens"] // 80000)
-    nn.animal2vec_audio_main(cfg, optim, updates=a.updates, clips_per_micro_batch=clips, update_freq=run["update_freq"])
+    if a.finetune:
+        import ast
+        from animal2vec_amd.train_routine import animal2vec_finetune_main
+        assert a.data and a.labels, "--finetune needs --data and --labels"
+        animal2vec_finetune_main(cfg, data=a.data, unique_labels=list(ast.literal_eval(a.labels)), pretrained=a.pretrained,
+                                 updates=a.updates, update_freq=run["update_freq"], max_tokens=run["max_tokens"], save_path=a.save)
+        return
+    nn.animal2vec_audio_main(cfg, optim, updates=a.updates, clips_per_micro_batch=clips, update_freq=run["update_freq"],
+                             data=a.data, max_tokens=run["max_tokens"], restore_file=a.restore_file, save_path=a.save)
 
 
 if __name__ == "__main__":

