@@ -54,6 +54,7 @@ SIGNATURES = {
     "a2v_mixup_gain": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
     "a2v_mixup_apply": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
     "a2v_dropout_mask": [_p, _ll, _f, _u, _p],
+    "a2v_dropout_mask2d": [_p, _ll, _i, _f, _u, _p],
     "a2v_debug_set": [_i, _i],
     "a2v_attention_bwd_direct_dq": [_i, _i, _i],
     "a2v_pack_weight_batch": [_i, _p, _i, _p],

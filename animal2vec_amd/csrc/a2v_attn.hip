@@ -173,9 +173,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         float p = __expf(s[j][r] - m_new);
         ps += p;                                  // the normaliser is dropout-free
         if (a.drop.thresh) {
-          const unsigned long long idx =
-              (((unsigned long long)n * H + h) * S + qc) * (unsigned long long)S + (kv0 + 16 * j + 4 * g + r);
-          p = drop_apply(a.drop, idx, p);
+          const unsigned rt = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc));
+          p = drop_keep2(a.drop, rt, (unsigned)(kv0 + 16 * j + 4 * g + r)) ? p * a.drop.scale : 0.f;
         }
         s[j][r] = p;
       }
@@ -377,18 +376,24 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
       const float nm = -m_run[b] * scale2;
       float ps = 0.f;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j) {
+        unsigned hp[2] = {0u, 0u};
+        if (DROP) {                                 // keys kv0 + 16 j + 4 g + {0,1} and + {2,3}: one hash per pair
+          const unsigned rt = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc[b]));
+          hp[0] = drop_hash_pair(rt, (unsigned)(kv0 + 16 * j + 4 * g));
+          hp[1] = drop_hash_pair(rt, (unsigned)(kv0 + 16 * j + 4 * g + 2));
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(fmaf(s[b][j][r], scale2, nm));
           ps += p;                                  // the normaliser is dropout-free
           if (DROP) {
-            const unsigned long long idx =
-                (((unsigned long long)n * H + h) * S + qc[b]) * (unsigned long long)S + (unsigned)(kv0 + 16 * j + 4 * g + r);
-            p = drop_apply(a.drop, idx, p);
+            const unsigned h16 = (r & 1) ? (hp[r >> 1] >> 16) : (hp[r >> 1] & 0xFFFFu);
+            p = h16 >= (a.drop.thresh >> 16) ? p * a.drop.scale : 0.f;
           }
           s[b][j][r] = p;
         }
+      }
       l_run[b] += ps;
     }
 
@@ -642,9 +647,9 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
         float pdrop = pv, dpe = pacc[r];
         if (a.drop.thresh) {                       // same mask as the forward: P_drop = P*m/(1-p), dP = (dO V^T)*m/(1-p)
           const int qg = q0 + ql < S ? q0 + ql : S - 1;
-          const unsigned long long idx = (((unsigned long long)n * H + h) * S + qg) * (unsigned long long)S + kvc;
-          pdrop = drop_apply(a.drop, idx, pv);
-          dpe = drop_apply(a.drop, idx, pacc[r]);
+          const bool keep = drop_keep2(a.drop, drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qg)), (unsigned)kvc);
+          pdrop = keep ? pv * a.drop.scale : 0.f;
+          dpe = keep ? pacc[r] * a.drop.scale : 0.f;
         }
         const float dsv = pv * (dpe - sDelta[ql]);
         p[i][r] = pdrop;
@@ -964,9 +969,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
           float pdrop = pv, dpe = pacc[r];
           if (DROP) {                                // same mask as the forward
             const int qg = ql < S ? ql : S - 1;
-            const unsigned long long idx = (((unsigned long long)n * H + h) * S + qg) * (unsigned long long)S + kvc;
-            pdrop = drop_apply(a.drop, idx, pv);
-            dpe = drop_apply(a.drop, idx, pacc[r]);
+            const bool keep = drop_keep2(a.drop, drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qg)), (unsigned)kvc);
+            pdrop = keep ? pv * a.drop.scale : 0.f;
+            dpe = keep ? pacc[r] * a.drop.scale : 0.f;
           }
           const float dsv = pv * (dpe - sDelta[ql]);
           p[i][r] = pdrop;
@@ -1234,10 +1239,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
               const int srow = s0 + rb + 4 * g + r;
               const int sc_ = srow < S ? srow : S - 1;
               const int oc_ = orow_i[og] < S ? orow_i[og] : S - 1;
-              const unsigned long long qi = MODE == 0 ? sc_ : oc_, ki = MODE == 0 ? oc_ : sc_;
-              const unsigned long long idx = ((unsigned long long)nh * S + qi) * (unsigned long long)S + ki;
-              pdrop = drop_apply(a.drop, idx, pv);
-              dpe = drop_apply(a.drop, idx, pacc[r]);
+              const unsigned qi = MODE == 0 ? sc_ : oc_, ki = MODE == 0 ? oc_ : sc_;
+              const bool keep = drop_keep2(a.drop, drop_row_term(a.drop.seed, (unsigned)(nh * S + qi)), ki);
+              pdrop = keep ? pv * a.drop.scale : 0.f;
+              dpe = keep ? pacc[r] * a.drop.scale : 0.f;
             }
             const float dsv = pv * (dpe - rdel[r] - cdel[og]);
             pcur[r] = pdrop;

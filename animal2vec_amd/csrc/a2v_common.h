@@ -170,11 +170,26 @@ struct Drop {
 };
 __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned long long idx) {
   unsigned u = (unsigned)idx * 0x9E3779B1u + seed + (unsigned)(idx >> 32) * 0x7F4A7C15u;
-  u ^= u >> 16; u *= 0x85EBCA6Bu; u ^= u >> 13; u *= 0xC2B2AE35u; u ^= u >> 16;
+  u ^= u >> 16; u *= 0x7FEB352Du; u ^= u >> 15; u *= 0x846CA68Bu; u ^= u >> 16;
   return u;
 }
 __device__ __forceinline__ float drop_apply(const Drop& d, unsigned long long idx, float v) {
   return drop_hash(d.seed, idx) < d.thresh ? 0.f : v * d.scale;
+}
+// Attention probabilities (N*H*S*S elements per layer, the one site where the hash itself shows up in the profile):
+// 2-D form, one hash per PAIR of adjacent key columns of a (n, h, q) row -- 16 bits per element, compared with the
+// upper 16 bits of the threshold (p resolved to 1/65536).  Kernels whose lanes hold consecutive keys (forward, dQ
+// pass) evaluate one hash per two elements; the row term is loop invariant everywhere.
+__device__ __forceinline__ unsigned drop_row_term(unsigned seed, unsigned row) { return row * 0x9E3779B1u + seed; }
+__device__ __forceinline__ unsigned drop_hash_pair(unsigned row_term, unsigned col) {
+  unsigned u = row_term + (col >> 1) * 0x85EBCA6Bu;
+  u ^= u >> 16; u *= 0x7FEB352Du; u ^= u >> 15; u *= 0x846CA68Bu; u ^= u >> 16;
+  return u;
+}
+__device__ __forceinline__ bool drop_keep2(const Drop& d, unsigned row_term, unsigned col) {
+  const unsigned h = drop_hash_pair(row_term, col);
+  const unsigned h16 = (col & 1u) ? (h >> 16) : (h & 0xFFFFu);
+  return h16 >= (d.thresh >> 16);
 }
 static inline Drop make_drop(float p, unsigned seed) {
   Drop d;

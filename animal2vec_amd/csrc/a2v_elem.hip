@@ -714,4 +714,19 @@ extern "C" int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, 
   return A2V_OK;
 }
 
+// keep-mask of the attention-probability dropout (2-D pair hash, a2v_common.h): rows = N*H*S query rows, cols = S keys
+__global__ void dropout_mask2d_kernel(unsigned char* out, long long rows, int cols, Drop d) {
+  const long long n = rows * cols;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / cols;
+    out[i] = drop_keep2(d, drop_row_term(d.seed, (unsigned)r), (unsigned)(i - r * cols)) ? 1 : 0;
+  }
+}
+extern "C" int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop_p, unsigned drop_seed, hipStream_t st) {
+  if (rows <= 0 || cols <= 0 || !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
+  hipLaunchKernelGGL(dropout_mask2d_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, st, keep, rows, cols, make_drop(drop_p, drop_seed));
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}
+
 extern "C" int a2v_abi_version(void) { return 5; }

@@ -407,6 +407,14 @@ def dropout_mask(n, p, seed, device="cuda"):
     return keep
 
 
+def dropout_mask2d(rows, cols, p, seed, device="cuda"):
+    """keep-mask (rows, cols) uint8 of the attention-probability dropout site: rows = (n*H + h)*S + q, cols = key."""
+    keep = torch.empty(rows, cols, dtype=torch.uint8, device=device)
+    rc = _L().a2v_dropout_mask2d(ptr(keep), rows, cols, float(p), int(seed) & 0xFFFFFFFF, stream())
+    check(rc, "a2v_dropout_mask2d")
+    return keep
+
+
 def ema_update(ema, p, decay):
     rc = _L().a2v_ema_update(ptr(ema), ptr(p), ema.numel(), decay, stream())
     check(rc, "a2v_ema_update")

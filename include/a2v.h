@@ -203,6 +203,9 @@ int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out, long long
 
 /* keep[i] = 1 if linear index i survives dropout(drop_p, drop_seed) -- the mask every kernel regenerates */
 int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, unsigned drop_seed, a2v_stream_t stream);
+/* The attention-probability site uses a 2-D form of the same idea (one hash per pair of adjacent keys of a query row,
+ * 16 bits per element): keep-mask of rows x cols with rows = (n*H + h)*S + q, cols = key index. */
+int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop_p, unsigned drop_seed, a2v_stream_t stream);
 
 /* A/B knob for kernel variants (key 0: bf16 NT GEMM, 0 = register-staged, 1 = LDS-DMA staged) */
 int a2v_debug_set(int key, int value);

@@ -697,7 +697,7 @@ def test_attention_dropout(ops, dtype, hd):
     pos = torch.arange(S).unsqueeze(0).expand(N, -1).int().contiguous()
     slopes = torch.tensor(O.alibi_slopes(H))
     sc = torch.tensor([1.0, 0.7], requires_grad=True)
-    keep = ops.dropout_mask(N * H * S * S, p_, seed).view(N, H, S, S).float().cpu()
+    keep = ops.dropout_mask2d(N * H * S, S, p_, seed).view(N, H, S, S).float().cpu()
     q, k, v = qkv.reshape(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
     bias = O.alibi_bias_from_positions(pos.long(), H, sc.view(1, 1, H, 1, 1))
     att = ((q * hd ** -0.5) @ k.transpose(-2, -1) + bias).softmax(-1) * keep / (1 - p_)
@@ -711,6 +711,21 @@ def test_attention_dropout(ops, dtype, hd):
     dqkv = ops.attention_bwd(qd, out, dev(do, dtype), lse, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, dal, drop=(p_, seed))
     assert rel_err(dqkv.float(), qkv.grad) < tol(dtype, 3)
     assert rel_err(dal, sc.grad) < max(tol(dtype, 3), 5e-4)
+
+
+def test_attention_dropout_mask_statistics(ops):
+    """2-D pair hash of the attention-probability site: keep rate 1 - p, no correlation inside a pair, between
+    neighbouring pairs, between rows or between seeds."""
+    rows, cols, p_ = 4096, 600, 0.2
+    k = ops.dropout_mask2d(rows, cols, p_, 7).float()
+    assert abs(float(k.mean()) - (1 - p_)) < 2e-3
+    z = k - k.mean()
+    var = float((z * z).mean())
+    for a_, b_ in ((z[:, 0::2], z[:, 1::2]), (z[:, 1:-1:2], z[:, 2::2]), (z[:-1], z[1:]), (z[:, :-2], z[:, 2:])):
+        assert abs(float((a_ * b_).mean())) / var < 5e-3
+    k2 = ops.dropout_mask2d(rows, cols, p_, 8).float()
+    assert abs(float(((k2 - k2.mean()) * z).mean())) / var < 5e-3
+    assert abs(float(k.mean(0).std()) - (p_ * (1 - p_) / rows) ** 0.5) < 2e-3      # column means spread like binomials
 
 
 @pytest.mark.parametrize("S,p_", [(200, 0.0), (333, 0.2), (700, 0.0), (641, 0.1)])
@@ -730,7 +745,7 @@ def test_attention_bwd_long_two_pass(ops, S, p_):
     att = ((q * hd ** -0.5) @ k.transpose(-2, -1) + bias).softmax(-1)
     drop = None
     if p_ > 0:
-        keep = ops.dropout_mask(N * H * S * S, p_, seed).view(N, H, S, S).float().cpu()
+        keep = ops.dropout_mask2d(N * H * S, S, p_, seed).view(N, H, S, S).float().cpu()
         att = att * keep / (1 - p_)
         drop = (p_, seed)
     ref = (att @ v).transpose(1, 2).reshape(N, S, H * hd)
