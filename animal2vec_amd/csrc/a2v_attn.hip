@@ -1109,6 +1109,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
   // ---- owner side: 2 groups of 16 rows per wave
   bf16x8 own1[2][2], own2[2][2];
   float cneg[2], cdel[2], cpos[2];
+  unsigned own_term[2];
+  int own_sh[2];
   int orow_i[2];
 #pragma unroll
   for (int og = 0; og < 2; ++og) {
@@ -1121,6 +1123,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
       own2[og][ks] = *(const bf16x8*)(o2p + (long long)oc * o2s + ks * 32 + g * 8);
     }
     cpos[og] = a.pos ? (float)a.pos[(long long)n * S + oc] : (float)oc;
+    own_term[og] = MODE == 0 ? drop_col_term((unsigned)oc) : drop_row_term(a.drop.seed, (unsigned)(nh * S) + (unsigned)oc);
+    own_sh[og] = (oc & 1) ? 16 : 0;
     if (MODE == 0) {
       cneg[og] = o < S ? 0.f : -INFINITY;
       cdel[og] = 0.f;
@@ -1220,6 +1224,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
           rdel[r] = MODE == 0 ? sDel[rl] : 0.f;
           rpos[r] = sPos[rl];
         }
+        // dropout hash terms of the streamed rows (rows past S never matter: their P is 0)
+        unsigned rterm[4] = {0u, 0u, 0u, 0u}, hp[2][2] = {{0u, 0u}, {0u, 0u}};
+        if (DROP) {
+          if (MODE == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rterm[r] = drop_row_term(a.drop.seed, (unsigned)(nh * S) + (unsigned)(s0 + rb + 4 * g + r));
+          } else {                                   // streamed rows are keys: 4 g + {0,1} and {2,3} are hash pairs
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              const unsigned ct = drop_col_term((unsigned)(s0 + rb + 4 * g + 2 * pr));
+#pragma unroll
+              for (int og = 0; og < 2; ++og) hp[og][pr] = drop_finalize(own_term[og] + ct);
+            }
+          }
+        }
 #pragma unroll
         for (int og = 0; og < 2; ++og) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
@@ -1235,12 +1254,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
             const float sc = sacc[r] * a.scale + coef * dist;
             const float pv = __expf(sc + rneg[r] + cneg[og]);
             float pdrop = pv, dpe = pacc[r];
-            if (DROP) {                                // same mask as the forward: index (n, h, q, kv)
-              const int srow = s0 + rb + 4 * g + r;
-              const int sc_ = srow < S ? srow : S - 1;
-              const int oc_ = orow_i[og] < S ? orow_i[og] : S - 1;
-              const unsigned qi = MODE == 0 ? sc_ : oc_, ki = MODE == 0 ? oc_ : sc_;
-              const bool keep = drop_keep2(a.drop, drop_row_term(a.drop.seed, (unsigned)(nh * S + qi)), ki);
+            if (DROP) {                                // same mask as the forward (2-D pair hash, a2v_common.h)
+              unsigned hh;
+              if (MODE == 0) hh = (drop_finalize(rterm[r] + own_term[og]) >> own_sh[og]) & 0xFFFFu;
+              else hh = (r & 1) ? (hp[og][r >> 1] >> 16) : (hp[og][r >> 1] & 0xFFFFu);
+              const bool keep = hh >= (a.drop.thresh >> 16);
               pdrop = keep ? pv * a.drop.scale : 0.f;
               dpe = keep ? pacc[r] * a.drop.scale : 0.f;
             }

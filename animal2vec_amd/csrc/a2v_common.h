@@ -181,10 +181,13 @@ __device__ __forceinline__ float drop_apply(const Drop& d, unsigned long long id
 // upper 16 bits of the threshold (p resolved to 1/65536).  Kernels whose lanes hold consecutive keys (forward, dQ
 // pass) evaluate one hash per two elements; the row term is loop invariant everywhere.
 __device__ __forceinline__ unsigned drop_row_term(unsigned seed, unsigned row) { return row * 0x9E3779B1u + seed; }
-__device__ __forceinline__ unsigned drop_hash_pair(unsigned row_term, unsigned col) {
-  unsigned u = row_term + (col >> 1) * 0x85EBCA6Bu;
+__device__ __forceinline__ unsigned drop_col_term(unsigned col) { return (col >> 1) * 0x85EBCA6Bu; }
+__device__ __forceinline__ unsigned drop_finalize(unsigned u) {
   u ^= u >> 16; u *= 0x7FEB352Du; u ^= u >> 15; u *= 0x846CA68Bu; u ^= u >> 16;
   return u;
+}
+__device__ __forceinline__ unsigned drop_hash_pair(unsigned row_term, unsigned col) {
+  return drop_finalize(row_term + drop_col_term(col));
 }
 __device__ __forceinline__ bool drop_keep2(const Drop& d, unsigned row_term, unsigned col) {
   const unsigned h = drop_hash_pair(row_term, col);
