@@ -400,6 +400,42 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const long long*
   const int G = (int)d[2], N = (int)d[3], Cg = (int)d[4], k = (int)d[5], Cgp = (int)d[6], Np = (int)d[7], mode = (int)d[8];
   const long long total = d[9];
   (void)G;
+  if (mode == 0 && k == 1 && Cgp == Cg && total % 8 == 0) {
+    // Linear forward operand: the image is the parameter itself, cast -- 8 elements (32 B in, 16 B out) per thread
+    const long long nv = total / 8;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+      const f32x4 a = *(const f32x4*)(w + i * 8), b = *(const f32x4*)(w + i * 8 + 4);
+      const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+      Vec8<T>::store(out + i * 8, v);
+    }
+    return;
+  }
+  if (mode == 1 && k == 1 && Cg % 64 == 0 && N % 64 == 0 && Np == N && d[2] == 1) {
+    // Linear transpose out[ci][n] = w[n][ci]: 64 x 64 tiles through LDS, 16-B loads and 8 values along n per store --
+    // both sides move whole 128-B+ segments
+    __shared__ float tile64[64][65];
+    const int tiles_c = Cg / 64, tiles_n = N / 64;
+    for (int t = blockIdx.x; t < tiles_c * tiles_n; t += gridDim.x) {
+      const int tn = t / tiles_c, tc = t - tn * tiles_c;
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {                       // 64 rows (n) x 16 float4 (ci)
+        const int c = threadIdx.x + 256 * u, r = c >> 4, q = c & 15;
+        const f32x4 a = *(const f32x4*)(w + (long long)(tn * 64 + r) * Cg + tc * 64 + q * 4);
+        tile64[r][q * 4 + 0] = a[0]; tile64[r][q * 4 + 1] = a[1]; tile64[r][q * 4 + 2] = a[2]; tile64[r][q * 4 + 3] = a[3];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {                       // 64 rows (ci) x 8 chunks of 8 n
+        const int c = threadIdx.x + 256 * u, r = c >> 3, q = c & 7;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile64[q * 8 + j][r];
+        Vec8<T>::store(out + (long long)(tc * 64 + r) * N + tn * 64 + q * 8, v);
+      }
+    }
+    return;
+  }
   if (mode == 1 && k == 1 && Cg % 32 == 0 && N % 32 == 0 && Np == N && d[2] == 1) {
     // Linear transpose out[ci][n] = w[n][ci]: 32 x 32 tiles through LDS, coalesced on both sides
     __shared__ float tile[32][33];
