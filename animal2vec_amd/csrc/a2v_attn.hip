@@ -1339,13 +1339,13 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
   constexpr bool BF = std::is_same<T, bf16>::value;
-  const bool seq64 = BF && HD == 64 && a.S <= ABS_ROWS;       // attn_bwd_seq_kernel forms delta itself
+  const bool seq64 = BF && HD == 64 && a.S <= ABS_ROWS && g_a2v_attn_long != 2;       // attn_bwd_seq_kernel forms delta itself
   if (!seq64)
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3(g), dim3(256), 0, st, (const T*)out, (const T*)a.d_out, delta, a.N, a.S, a.H);
   constexpr int TILE = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
   constexpr int LDS = (BF ? 5 : 3) * TILE + (BF ? 64 * 64 * 2 : 64 * 68 * 4) + 3 * 64 * 4;
   if constexpr (BF && HD == 64) {
-    if (a.S > ABS_ROWS && g_a2v_attn_long) {       // long sequences: dK/dV pass + dQ pass, no atomics
+    if ((a.S > ABS_ROWS && g_a2v_attn_long) || g_a2v_attn_long == 2) {       // long sequences: dK/dV pass + dQ pass, no atomics (2: every S, experiments)
       const bool dr = a.drop.thresh != 0;
       const dim3 grid((a.S + 127) / 128, a.H, a.N);
       if (dr) {

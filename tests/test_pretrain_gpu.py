@@ -582,3 +582,49 @@ def test_real_data_pretrain_checkpoint_finetune_end_to_end(tmp_path):
     a_ = ft.engine.finetune_forward(src, ft.head, save=False)
     b_ = eng2.finetune_forward(src, head2, save=False)
     assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 5e-2, 2.5e-1)])
+def test_finetune_large_full_size_vs_oracle(dtype, tol_y, tol_g):
+    """BASELINE config 4 at full size (large model, one 10 s clip, all 2000 frames, 12 labels), train form with
+    explicit draws (time mask with noise replacement, channel mask, two dropped blocks): HIP path -- the two-pass
+    long-sequence attention backward in bf16 -- against the oracle on this box's CPU."""
+    from animal2vec_amd.config import large_config
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ocfg = O.OracleConfig(**O.LARGE)
+    p = O.init_params(ocfg, seed=0)
+    g = torch.Generator().manual_seed(12)
+    for k in p:                                           # a trained-looking model: learned alibi scales, perturbed weights
+        if "alibi_scale" in k:
+            p[k] = p[k] + torch.rand(p[k].shape, generator=g) * 0.5
+    ema = O.make_teacher(p)
+    L, C = 80000, 12
+    D = ocfg.embed_dim
+    T = O.frame_counts(L, ocfg.conv_feature_layers)[-1]
+    src = torch.nn.functional.layer_norm(torch.randn(1, L, generator=g), (L,))
+    target = (torch.rand(1, T, C, generator=g) < 0.1).float()
+    hw, hb = torch.randn(C, D, generator=g) * 0.05, torch.randn(C, generator=g) * 0.1
+    mask_t = (torch.rand(1, T, generator=g) < 0.6).to(torch.uint8)
+    mask_c = (torch.rand(1, D, generator=g) < 0.3).to(torch.uint8)
+    repl = torch.randn(int(mask_t.sum()), D, generator=g) * 0.01
+    active = [True] * (ocfg.prenet_depth + ocfg.depth)
+    active[3] = False
+    active[ocfg.prenet_depth + 5] = False
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ow, ob = hw.clone().requires_grad_(True), hb.clone().requires_grad_(True)
+    logits_o = O.finetune_forward(po, ow, ob, src, ocfg, mask_t=mask_t, replacement=repl, mask_c=mask_c, active=active)
+    loss_o = O.sigmoid_focal_loss(logits_o, target, reduction="sum")
+    loss_o.backward()
+    aug = dict(mask_t=mask_t.cuda(), mask_c=mask_c.cuda(), replacement=repl.cuda(), active=active)
+    store, head, logits, loss = _finetune_run(large_config(), p, ema, dtype, src, target, hw, hb, aug=aug)
+    assert rel_err(logits.float(), logits_o.detach()) < tol_y
+    assert abs(loss - float(loss_o.detach())) / float(loss_o.detach()) < tol_y
+    assert rel_err(head.grad_w, ow.grad) < tol_g and rel_err(head.grad_b, ob.grad) < tol_g
+    errs = []
+    for k, v in po.items():
+        if v.grad is None:
+            assert float(store.g[k].abs().max()) == 0.0, k
+            continue
+        errs.append((rel_err(store.g[k], v.grad), k))
+    errs.sort(reverse=True)
+    assert len(errs) > 250 and errs[0][0] < tol_g, errs[:8]

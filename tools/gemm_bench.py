@@ -39,7 +39,14 @@ def main():
     ap.add_argument("--p8", type=int, default=None, help="0: disable the 256x256 8-phase kernel")
     ap.add_argument("--lin", action="append", default=[], help="extra plain linear shape M,N,K (repeatable)")
     ap.add_argument("--dyn", type=int, default=None, help="persistent NT kernel tile hand-out mode 0/1/2")
+    ap.add_argument("--debug-set", action="append", default=[], help="key=value for a2v_debug_set")
+    ap.add_argument("--attn", action="append", default=[], help="extra attention shape N,S (repeatable)")
     a = ap.parse_args()
+    for kv in a.debug_set:
+        from animal2vec_amd import _lib
+        k_, v_ = kv.split("=")
+        _lib.load().a2v_debug_set(int(k_), int(v_))
+        print("debug_set", kv)
     if a.dyn is not None:
         from animal2vec_amd import _lib
         _lib.load().a2v_debug_set(7, a.dyn)
@@ -137,6 +144,9 @@ def main():
         ms = timeit(lambda: ops.attention_bwd(qkv, out, do, lse, pos, slopes, asc, H, dal, drop=drop), a.reps)
         rows.append((name + " bwd", N * S, HD, S, H, ms, 2.5 * fl / ms / 1e9))
 
+    for spec in a.attn:
+        N_, S_ = (int(v) for v in spec.split(","))
+        attn(f"attn {spec}", N_, S_)
     attn("attn student", 96, 140, drop=(0.1, 7))
     attn("attn student nodrop", 96, 140)
     attn("attn teacher", 8, 2000)
