@@ -361,6 +361,291 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------- general shapes
+// More than 128 filters or more than 63 taps (BASELINE config 5: 296 filters x 149 taps at 44.1 kHz): the
+// same two kernels, blocked.  Forward: all 16 NJC channels of a time step stay in one lane column (LayerNorm statistics
+// remain in-lane sums), the taps are walked in chunks of 64 with the filter chunk re-staged in LDS per chunk, and the
+// result goes out straight from registers (8 / 16 B per lane).  Backward: a workgroup recomputes the whole conv tile
+// (all channels, all taps -- the LayerNorm backward needs every channel) but reduces the filter gradient only for
+// its (channel group, tap chunk) = blockIdx.y, so dW fits in registers; the per-channel parameter gradients are
+// accumulated in LDS by the blockIdx.y = 0 workgroups.
+#define SINC_GEN_NJC 20                 // channels padded to 320
+#define SINC_GEN_CP (16 * SINC_GEN_NJC)
+#define SINC_GEN_MAXCH 4                // tap chunks of 64: k <= 255
+#define SINC_GEN_CGB 4                  // channel blocks (of 16) per backward channel group
+
+template <typename T, int NJC>
+__global__ __launch_bounds__(256) void sinc_fused_fwd_gen_kernel(const float* __restrict__ x, const float* __restrict__ filt,
+                                                                 const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                                 const float* __restrict__ ps_a, const float* __restrict__ ps_b,
+                                                                 T* __restrict__ y, float* __restrict__ mean_out,
+                                                                 float* __restrict__ rstd_out, int B, int L, int C, int k,
+                                                                 float eps, int tiles_per_blk, int nchunks) {
+  constexpr int CP = 16 * NJC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sF = (float*)smem;                         // [CP][SINC_FP]: the current chunk of 64 taps
+  float* sPar = sF + CP * SINC_FP;                  // [4][CP]
+  float* sX = sPar + 4 * CP;                        // [64 + 64 nchunks]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int half = k / 2;
+  for (int i = tid; i < CP; i += 256) {
+    const bool ok = i < C;
+    sPar[i] = ok ? ln_w[i] : 0.f;
+    sPar[CP + i] = ok ? ln_b[i] : 0.f;
+    sPar[2 * CP + i] = ok ? ps_a[i] : 0.f;
+    sPar[3 * CP + i] = ok ? ps_b[i] : 0.f;
+  }
+  const int tiles_per_clip = (L + 63) / 64;
+  const long long ntiles = (long long)B * tiles_per_clip;
+  const int win = 64 + 64 * nchunks;
+  for (int it = 0; it < tiles_per_blk; ++it) {
+    const long long tile = (long long)blockIdx.x * tiles_per_blk + it;
+    if (tile >= ntiles) break;
+    const int b = (int)(tile / tiles_per_clip);
+    const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
+    __syncthreads();
+    for (int i = tid; i < win; i += 256) sX[i] = x[(long long)b * L + reflect_idx(t0 - half + i, L)];
+    f32x4 acc[NJC];
+#pragma unroll
+    for (int jc = 0; jc < NJC; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int tl = wid * 16 + fr;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      __syncthreads();                                // the previous chunk's readers are done (first pass: sX / sPar ordering)
+      for (int i = tid; i < CP * 64; i += 256) {
+        const int c = i >> 6, j = ch * 64 + (i & 63);
+        sF[c * SINC_FP + (i & 63)] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int ks = 0; ks < 16; ++ks) {
+        const float xb = sX[tl + ch * 64 + ks * 4 + g];
+#pragma unroll
+        for (int jc = 0; jc < NJC; ++jc) {
+          const float wa = sF[(16 * jc + fr) * SINC_FP + ks * 4 + g];
+          acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xb, acc[jc], 0, 0, 0);
+        }
+      }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int jc = 0; jc < NJC; ++jc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s += (16 * jc + 4 * g + r < C) ? acc[jc][r] : 0.f;
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int jc = 0; jc < NJC; ++jc)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = acc[jc][r] - mean;
+        q += (16 * jc + 4 * g + r < C) ? d * d : 0.f;
+      }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    const int t = t0 + tl;
+    if (g == 0 && t < L && mean_out) {
+      mean_out[(long long)b * L + t] = mean;
+      rstd_out[(long long)b * L + t] = rstd;
+    }
+    if (t < L) {
+#pragma unroll
+      for (int jc = 0; jc < NJC; ++jc) {
+        const int c0 = 16 * jc + 4 * g;
+        const f32x4 w = *(const f32x4*)(sPar + c0), bb = *(const f32x4*)(sPar + CP + c0);
+        const f32x4 pa = *(const f32x4*)(sPar + 2 * CP + c0), pb = *(const f32x4*)(sPar + 3 * CP + c0);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float yl = (acc[jc][r] - mean) * rstd * w[r] + bb[r];
+          const float sg = 1.f / (1.f + __expf(-pb[r] * yl));
+          o[r] = (c0 + r < C) ? yl * pa[r] * sg : 0.f;
+        }
+        Vec4<T>::store(y + ((long long)b * L + t) * CP + c0, o);
+      }
+    }
+  }
+}
+
+template <typename T, int NJC, int CGB>
+__global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __restrict__ x, const float* __restrict__ filt,
+                                                                 const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                                 const float* __restrict__ ps_a, const float* __restrict__ ps_b,
+                                                                 const T* __restrict__ dy, const float* __restrict__ mean_in,
+                                                                 const float* __restrict__ rstd_in, float* __restrict__ dfilt,
+                                                                 float* __restrict__ dpar, int B, int L, int C, int k,
+                                                                 int tiles_per_blk, int nchunks) {
+  constexpr int CP = 16 * NJC;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* sF = (float*)smem;                         // [CP][SINC_FP]
+  float* sPar = sF + CP * SINC_FP;                  // [4][CP] parameters
+  float* sG = sPar + 4 * CP;                        // [4][CP] parameter gradients (blockIdx.y == 0)
+  float* sX = sG + 4 * CP;                          // [64 + 64 nchunks]
+  float* sMean = sX + 64 + 64 * SINC_GEN_MAXCH;     // [64]
+  float* sRstd = sMean + 64;                        // [64]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int half = k / 2;
+  const int tg = blockIdx.y % nchunks, cg = blockIdx.y / nchunks;     // this workgroup's tap chunk / channel group for dW
+  const bool grads = blockIdx.y == 0;
+  for (int i = tid; i < CP; i += 256) {
+    const bool ok = i < C;
+    sPar[i] = ok ? ln_w[i] : 0.f;
+    sPar[CP + i] = ok ? ln_b[i] : 0.f;
+    sPar[2 * CP + i] = ok ? ps_a[i] : 0.f;
+    sPar[3 * CP + i] = ok ? ps_b[i] : 0.f;
+    sG[i] = 0.f; sG[CP + i] = 0.f; sG[2 * CP + i] = 0.f; sG[3 * CP + i] = 0.f;
+  }
+  f32x4 dW[CGB][4];                                 // rows c = 16 (cg CGB + jl) + 4g + r, cols tap = 64 tg + 16 jt + fr
+#pragma unroll
+  for (int jl = 0; jl < CGB; ++jl)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dW[jl][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int tiles_per_clip = (L + 63) / 64;
+  const long long ntiles = (long long)B * tiles_per_clip;
+  const float invC = 1.f / (float)C;
+  const int win = 64 + 64 * nchunks;
+
+  for (int it = 0; it < tiles_per_blk; ++it) {
+    const long long tile = (long long)blockIdx.x * tiles_per_blk + it;
+    if (tile >= ntiles) break;
+    const int b = (int)(tile / tiles_per_clip);
+    const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
+    __syncthreads();
+    for (int i = tid; i < win; i += 256) sX[i] = x[(long long)b * L + reflect_idx(t0 - half + i, L)];
+    if (tid < 64) {
+      const int t = t0 + tid;
+      sMean[tid] = t < L ? mean_in[(long long)b * L + t] : 0.f;
+      sRstd[tid] = t < L ? rstd_in[(long long)b * L + t] : 0.f;
+    }
+    // conv recompute: D[row t = 4g+r][col c = fr + 16 jc]
+    f32x4 acc[NJC];
+#pragma unroll
+    for (int jc = 0; jc < NJC; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < nchunks; ++ch) {
+      __syncthreads();
+      for (int i = tid; i < CP * 64; i += 256) {
+        const int c = i >> 6, j = ch * 64 + (i & 63);
+        sF[c * SINC_FP + (i & 63)] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 2
+      for (int ks = 0; ks < 16; ++ks) {
+        const float xa = sX[wid * 16 + fr + ch * 64 + ks * 4 + g];
+#pragma unroll
+        for (int jc = 0; jc < NJC; ++jc) {
+          const float wb = sF[(16 * jc + fr) * SINC_FP + ks * 4 + g];
+          acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[jc], 0, 0, 0);
+        }
+      }
+    }
+    // pass 1 over all channels: LayerNorm-backward row sums (+ parameter gradients in the y == 0 workgroups)
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mrow[4], rrow[4];
+    bool tok[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tl = wid * 16 + 4 * g + r;
+      mrow[r] = sMean[tl]; rrow[r] = sRstd[tl]; tok[r] = t0 + tl < L;
+    }
+#pragma unroll
+    for (int jc = 0; jc < NJC; ++jc) {
+      const int c = fr + 16 * jc;
+      const bool cok = c < C;
+      const float pw = sPar[c], pb_ = sPar[CP + c], pa = sPar[2 * CP + c], pbs = sPar[3 * CP + c];
+      float gw = 0.f, gb = 0.f, ga = 0.f, gbs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tl = wid * 16 + 4 * g + r;
+        const float h = (acc[jc][r] - mrow[r]) * rrow[r];
+        const float yl = h * pw + pb_;
+        const float sg = 1.f / (1.f + __expf(-pbs * yl));
+        float dz = (cok && tok[r]) ? Cvt<T>::to(dy[((long long)b * L + t0 + tl) * CP + c]) : 0.f;
+        const float dyl = dz * pa * (sg + yl * pbs * sg * (1.f - sg));
+        ga += dz * yl * sg;
+        gbs += dz * yl * pa * sg * (1.f - sg) * yl;
+        gw += dyl * h;
+        gb += dyl;
+        const float d = dyl * pw;
+        s1[r] += d;
+        s2[r] += cok ? d * h : 0.f;
+      }
+      if (grads) {
+        gw += __shfl_xor(gw, 16, 64); gw += __shfl_xor(gw, 32, 64);
+        gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+        ga += __shfl_xor(ga, 16, 64); ga += __shfl_xor(ga, 32, 64);
+        gbs += __shfl_xor(gbs, 16, 64); gbs += __shfl_xor(gbs, 32, 64);
+        if (g == 0 && cok) {
+          atomicAdd(sG + c, gw); atomicAdd(sG + CP + c, gb); atomicAdd(sG + 2 * CP + c, ga); atomicAdd(sG + 3 * CP + c, gbs);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
+      s1[r] *= invC; s2[r] *= invC;
+    }
+    // pass 2 over this workgroup's channel group: dconv, then dW[c][tap] += sum_t dconv[t][c] * xpad[t + tap]
+    f32x4 dh[CGB];
+#pragma unroll
+    for (int jl = 0; jl < CGB; ++jl) {
+      const int jc = cg * CGB + jl;
+      const int c = fr + 16 * jc;
+      const bool cok = jc < NJC && c < C;
+      const int cc = cok ? c : 0;
+      const float pw = sPar[cc], pb_ = sPar[CP + cc], pa = sPar[2 * CP + cc], pbs = sPar[3 * CP + cc];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int tl = wid * 16 + 4 * g + r;
+        float a_ = 0.f;
+#pragma unroll
+        for (int j2 = 0; j2 < NJC; ++j2) a_ = (j2 == jc) ? acc[j2][r] : a_;       // select without dynamic indexing
+        const float h = (a_ - mrow[r]) * rrow[r];
+        const float yl = h * pw + pb_;
+        const float sg = 1.f / (1.f + __expf(-pbs * yl));
+        const float dz = (cok && tok[r]) ? Cvt<T>::to(dy[((long long)b * L + t0 + tl) * CP + cc]) : 0.f;
+        const float d = dz * pa * (sg + yl * pbs * sg * (1.f - sg)) * pw;
+        const float v = rrow[r] * (d - s1[r] - h * s2[r]);
+        dh[jl][r] = (cok && tok[r]) ? v : 0.f;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int tl = wid * 16 + 4 * g + r;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const float xb = sX[tl + tg * 64 + 16 * jt + fr];
+#pragma unroll
+        for (int jl = 0; jl < CGB; ++jl)
+          dW[jl][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[jl][r], xb, dW[jl][jt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int jl = 0; jl < CGB; ++jl)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = 16 * (cg * CGB + jl) + 4 * g + r;
+      if (c >= C) continue;
+#pragma unroll
+      for (int jt = 0; jt < 4; ++jt) {
+        const int tap = tg * 64 + 16 * jt + fr;
+        if (tap < k) atomicAdd(dfilt + (long long)c * k + tap, dW[jl][jt][r]);
+      }
+    }
+  if (grads) {
+    __syncthreads();
+    for (int i = tid; i < 4 * CP; i += 256) {
+      const int c = i % CP;
+      if (c < C && sG[i] != 0.f) atomicAdd(dpar + i, sG[i]);
+    }
+  }
+}
+
 // =============================================================================================
 extern "C" int a2v_sinc_filters_fwd(const float* low_hz, const float* band_hz, const float* n_, const float* window,
                                     float* filt, int C, int Cp, int k, float min_low_hz, float min_band_hz,
@@ -392,7 +677,27 @@ static int sinc_tiles_per_block(long long ntiles) {
 extern "C" int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
                                   const float* ps_alpha, const float* ps_beta, void* y, float* mean, float* rstd, int B,
                                   int L, int C, int k, float eps, hipStream_t st) {
-  if (B <= 0 || L < 128 || C <= 0 || C > SINC_CP || k > 63 || !(k & 1)) return A2V_ERR_ARG;
+  if (B <= 0 || L < 128 || C <= 0 || !(k & 1)) return A2V_ERR_ARG;
+  if (C > SINC_CP || k > 63) {                       // general shapes: y is (B, L, 320)
+    const int nch = (k + 63) / 64;
+    if (C > SINC_GEN_CP || nch > SINC_GEN_MAXCH || L < 64 + 64 * nch) return A2V_ERR_ARG;
+    const long long nt = (long long)B * ((L + 63) / 64);
+    const int tpbg = sinc_tiles_per_block(nt);
+    const int gridg = (int)((nt + tpbg - 1) / tpbg);
+    const int ldsg = (SINC_GEN_CP * SINC_FP + 4 * SINC_GEN_CP + 64 + 64 * SINC_GEN_MAXCH) * 4;
+    if (dtype == A2V_BF16) {
+      (void)hipFuncSetAttribute((const void*)sinc_fused_fwd_gen_kernel<bf16, SINC_GEN_NJC>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
+      hipLaunchKernelGGL((sinc_fused_fwd_gen_kernel<bf16, SINC_GEN_NJC>), dim3(gridg), dim3(256), ldsg, st, x, filt, ln_w, ln_b,
+                         ps_alpha, ps_beta, (bf16*)y, mean, rstd, B, L, C, k, eps, tpbg, nch);
+    } else if (dtype == A2V_F32) {
+      (void)hipFuncSetAttribute((const void*)sinc_fused_fwd_gen_kernel<float, SINC_GEN_NJC>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
+      hipLaunchKernelGGL((sinc_fused_fwd_gen_kernel<float, SINC_GEN_NJC>), dim3(gridg), dim3(256), ldsg, st, x, filt, ln_w, ln_b,
+                         ps_alpha, ps_beta, (float*)y, mean, rstd, B, L, C, k, eps, tpbg, nch);
+    } else
+      return A2V_ERR_DTYPE;
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   const long long ntiles = (long long)B * ((L + 63) / 64);
   const int tpb = sinc_tiles_per_block(ntiles);
   const int grid = (int)((ntiles + tpb - 1) / tpb);
@@ -417,7 +722,29 @@ extern "C" int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, 
                                   const float* ps_alpha, const float* ps_beta, const void* dy, const float* mean,
                                   const float* rstd, float* dfilt, float* dpar, int B, int L, int C, int k,
                                   hipStream_t st) {
-  if (B <= 0 || L < 128 || C <= 0 || C > SINC_CP || k > 63 || !(k & 1)) return A2V_ERR_ARG;
+  if (B <= 0 || L < 128 || C <= 0 || !(k & 1)) return A2V_ERR_ARG;
+  if (C > SINC_CP || k > 63) {                       // general shapes: dy is (B, L, 320), dpar is (4, 320)
+    const int nch = (k + 63) / 64;
+    if (C > SINC_GEN_CP || nch > SINC_GEN_MAXCH || L < 64 + 64 * nch) return A2V_ERR_ARG;
+    const long long nt = (long long)B * ((L + 63) / 64);
+    int tpbg = (int)((nt + 511) / 512);
+    if (tpbg < 1) tpbg = 1;
+    const int ncg = (SINC_GEN_NJC + SINC_GEN_CGB - 1) / SINC_GEN_CGB;
+    const dim3 gridg((unsigned)((nt + tpbg - 1) / tpbg), (unsigned)(ncg * nch));
+    const int ldsg = (SINC_GEN_CP * SINC_FP + 8 * SINC_GEN_CP + 64 + 64 * SINC_GEN_MAXCH + 128) * 4;
+    if (dtype == A2V_BF16) {
+      (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_gen_kernel<bf16, SINC_GEN_NJC, SINC_GEN_CGB>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
+      hipLaunchKernelGGL((sinc_fused_bwd_gen_kernel<bf16, SINC_GEN_NJC, SINC_GEN_CGB>), gridg, dim3(256), ldsg, st, x, filt, ln_w, ln_b,
+                         ps_alpha, ps_beta, (const bf16*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpbg, nch);
+    } else if (dtype == A2V_F32) {
+      (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_gen_kernel<float, SINC_GEN_NJC, SINC_GEN_CGB>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
+      hipLaunchKernelGGL((sinc_fused_bwd_gen_kernel<float, SINC_GEN_NJC, SINC_GEN_CGB>), gridg, dim3(256), ldsg, st, x, filt, ln_w, ln_b,
+                         ps_alpha, ps_beta, (const float*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpbg, nch);
+    } else
+      return A2V_ERR_DTYPE;
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   const long long ntiles = (long long)B * ((L + 63) / 64);
   int tpb = (int)((ntiles + 1023) / 1024);
   if (tpb < 1) tpb = 1;
@@ -436,4 +763,13 @@ extern "C" int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, 
     return A2V_ERR_DTYPE;
   A2V_CHECK_LAUNCH();
   return A2V_OK;
+}
+
+// channel pitch of the fused front end's output / dy / dpar rows for a (filters, taps) spec: 128 for the 8 kHz specs
+// (C <= 128, k <= 63), 320 for the general kernels (C <= 320, k <= 255), -1 if unsupported
+extern "C" int a2v_sinc_out_channels(int C, int k) {
+  if (C <= 0 || k < 3 || !(k & 1)) return -1;
+  if (C <= SINC_CP && k <= 63) return SINC_CP;
+  if (C <= SINC_GEN_CP && (k + 63) / 64 <= SINC_GEN_MAXCH) return SINC_GEN_CP;
+  return -1;
 }

@@ -38,7 +38,8 @@ class Engine:
         c0 = self.layers[0][0]
         k0 = self.layers[0][1]
         self.dfilt = torch.zeros(c0, k0, dtype=torch.float32, device=dev)
-        self.dpar = torch.zeros(4, 128, dtype=torch.float32, device=dev)
+        self.sinc_cp = ops.sinc_out_channels(c0, k0)      # channel pitch of the SincConv output (128, or 320 for the blocked kernels)
+        self.dpar = torch.zeros(4, self.sinc_cp, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ helpers
     def refresh_student_packs(self):
@@ -61,7 +62,7 @@ class Engine:
         B, L = source.shape
         c0, k0, _ = self.layers[0]
         filt = ops.sinc_filters_fwd(p[pre + "0.0.low_hz_"], p[pre + "0.0.band_hz_"], st.sinc_n, st.sinc_window, C_=c0,
-                                    Cp=128, k=k0, min_low_hz=50.0, min_band_hz=st.sinc_min_band,
+                                    Cp=self.sinc_cp, k=k0, min_low_hz=50.0, min_band_hz=st.sinc_min_band,
                                     sample_rate=cfg.audio.sample_rate)
         y, mean, rstd = ops.sinc_fused_fwd(source, filt, p[pre + "0.2.1.weight"], p[pre + "0.2.1.bias"],
                                            p[pre + "0.3.p_swish_alpha"], p[pre + "0.3.p_swish_beta"], C_=c0, k=k0,
@@ -123,8 +124,9 @@ class Engine:
             if s > 1:
                 dA = ops.linear(dc.view(B * T_out, dim), sp.wt[wname])
                 if i == 1:
-                    dy = torch.zeros(B, T_in, 128, dtype=self.dtype, device=dfeat.device) if m["Cgp"] != 128 else \
-                        torch.empty(B, T_in, 128, dtype=self.dtype, device=dfeat.device)
+                    cp = self.sinc_cp
+                    dy = torch.zeros(B, T_in, cp, dtype=self.dtype, device=dfeat.device) if m["Cgp"] != cp else \
+                        torch.empty(B, T_in, cp, dtype=self.dtype, device=dfeat.device)
                     ops.col2im(dA, B=B, T_in=T_in, T_out=T_out, C_=m["Cgp"], k=k, s=s, p=pl, out=dy)
                 else:
                     dy = ops.col2im(dA, B=B, T_in=T_in, T_out=T_out, C_=m["Cgp"], k=k, s=s, p=pl)

@@ -291,9 +291,17 @@ def sinc_filters_bwd(low_hz, band_hz, n_, window, dfilt, *, C_, k, min_low_hz, m
     return dlow, dband
 
 
+def sinc_out_channels(C_, k):
+    """channel pitch of the fused SincConv output for a (filters, taps) spec (128 or 320); raises if unsupported"""
+    cp = _L().a2v_sinc_out_channels(C_, k)
+    if cp < 0:
+        raise ValueError(f"SincConv front end: {C_} filters x {k} taps is outside the kernels' limits (<= 320 x 255, odd k)")
+    return cp
+
+
 def sinc_fused_fwd(x, filt, ln_w, ln_b, ps_a, ps_b, *, C_, k, dtype, eps=1e-5, save_stats=True):
     B, L = x.shape
-    y = torch.empty(B, L, 128, dtype=dtype, device=x.device)
+    y = torch.empty(B, L, sinc_out_channels(C_, k), dtype=dtype, device=x.device)
     mean = torch.empty(B, L, dtype=torch.float32, device=x.device) if save_stats else None
     rstd = torch.empty(B, L, dtype=torch.float32, device=x.device) if save_stats else None
     rc = _L().a2v_sinc_fused_fwd(dt(y), ptr(x), ptr(filt), ptr(ln_w), ptr(ln_b), ptr(ps_a), ptr(ps_b), ptr(y), ptr(mean),

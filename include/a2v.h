@@ -143,6 +143,10 @@ int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, const float
 int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
                        const float* ps_alpha, const float* ps_beta, const void* dy, const float* mean,
                        const float* rstd, float* dfilt, float* dpar, int B, int L, int C, int k, a2v_stream_t stream);
+/* Channel pitch of y / dy and row length of dpar for a (filters C, taps k) front-end spec: 128 for C <= 128, k <= 63
+ * (the shipped 8 kHz spec 127 x 63), 320 for the blocked kernels (C <= 320, k <= 255: e.g. 296 x 149 at 44.1 kHz),
+ * -1 if unsupported. */
+int a2v_sinc_out_channels(int C, int k);
 
 /* ---------------------------------------------------------------- masking / token plumbing
  * out[n,k,:] = a[n/cb, ids[n,k], :] (+ b[n, ids[n,k], :])  -- make_maskinfo gather + x_unmasked +

@@ -505,7 +505,7 @@ def test_instnorm_targets(ops, dtype):
 
 
 # ------------------------------------------------------------------------------------------ sinc
-@pytest.mark.parametrize("C_,k,sr", [(127, 63, 8000), (31, 15, 8000), (127, 63, 44100)])
+@pytest.mark.parametrize("C_,k,sr", [(127, 63, 8000), (31, 15, 8000), (127, 63, 44100), (296, 149, 44100)])
 def test_sinc_filters_fwd_bwd(ops, C_, k, sr):
     lo, band = O.sinc_init(C_, k, sr)
     g = torch.Generator().manual_seed(1)
@@ -515,8 +515,9 @@ def test_sinc_filters_fwd_bwd(ops, C_, k, sr):
     win, n_ = O.sinc_window_and_n(k, sr)
     kw = dict(C_=C_, k=k, min_low_hz=50.0, min_band_hz=float(math.ceil(sr / k)), sample_rate=sr)
     args = (lo.detach().flatten().cuda(), band.detach().flatten().cuda(), n_.flatten().cuda(), win.cuda())
-    f = ops.sinc_filters_fwd(*args, Cp=128, **kw)
-    assert rel_err(f[:C_], ref) < 1e-5 and float(f[C_:].abs().max() if C_ < 128 else 0) == 0
+    Cp = ops.sinc_out_channels(C_, k)
+    f = ops.sinc_filters_fwd(*args, Cp=Cp, **kw)
+    assert rel_err(f[:C_], ref) < 1e-5 and float(f[C_:].abs().max() if C_ < Cp else 0) == 0
     df = torch.randn(C_, k, generator=g)
     ref.backward(df)
     dlow, dband = ops.sinc_filters_bwd(*args, df.cuda(), **kw)
@@ -525,9 +526,12 @@ def test_sinc_filters_fwd_bwd(ops, C_, k, sr):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C_,k,L", [(127, 63, 1000), (31, 15, 640)])
-def test_sinc_fused_fwd_bwd(ops, dtype, C_, k, L):
-    B, sr = 2, 8000
+@pytest.mark.parametrize("C_,k,L,sr", [(127, 63, 1000, 8000), (31, 15, 640, 8000), (296, 149, 1500, 44100), (140, 65, 700, 16000),
+                                        (100, 201, 900, 44100)])
+def test_sinc_fused_fwd_bwd(ops, dtype, C_, k, L, sr):
+    """(127,63), (31,15): the single-pass kernels; the others (more than 128 filters or more than 63 taps) take the
+    blocked kernels -- 2, 3 and 4 tap chunks, ragged channel groups, time tails."""
+    B = 2
     g = torch.Generator().manual_seed(3)
     x = torch.randn(B, L, generator=g)
     lo, band = O.sinc_init(C_, k, sr)
@@ -546,10 +550,12 @@ def test_sinc_fused_fwd_bwd(ops, dtype, C_, k, L):
     y, mean, rstd = ops.sinc_fused_fwd(cu(x), cu(filt), cu(lw), cu(lb), cu(pa), cu(pb), C_=C_, k=k, dtype=dtype)
     assert rel_err(y[..., :C_].float().transpose(1, 2), ref) < tol(dtype)
     assert float(y[..., C_:].float().abs().max()) == 0.0
-    dycl = torch.zeros(B, L, 128)
+    Cp = ops.sinc_out_channels(C_, k)
+    assert y.shape[-1] == Cp == (128 if (C_ <= 128 and k <= 63) else 320)
+    dycl = torch.zeros(B, L, Cp)
     dycl[..., :C_] = dyr.transpose(1, 2)
     dfilt = torch.zeros(C_, k, device="cuda")
-    dpar = torch.zeros(4, 128, device="cuda")
+    dpar = torch.zeros(4, Cp, device="cuda")
     ops.sinc_fused_bwd(cu(x), cu(filt), cu(lw), cu(lb), cu(pa), cu(pb), dev(dycl, dtype), mean, rstd, dfilt, dpar, C_=C_, k=k)
     assert rel_err(dfilt, filt.grad) < 2e-4
     for i, p in enumerate((lw, lb, pa, pb)):

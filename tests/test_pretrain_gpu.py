@@ -669,3 +669,50 @@ def test_long_sequence_pretrain_vs_oracle(dtype, tol_y, tol_g):
     assert abs(float(eng.stats[4 * cfg.embed_dim]) - ls) / ls < tol_y
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
     assert errs[0][0] < tol_g, errs[:8]
+
+
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 5e-2, 2.5e-1)])
+def test_config5_44k_frontend_vs_oracle(dtype, tol_y, tol_g):
+    """BASELINE config 5's front end: 44.1 kHz, 296 sinc filters x 149 taps (the spec SURVEY 8d derives from the YAML's
+    own rule k ~ sqrt(sr / 2)), through the blocked SincConv kernels (tap chunks of 64, 320-channel pitch, filter
+    gradient per (channel group, tap chunk)) and a 2960-wide first conv: the whole pretraining step against the oracle,
+    including the gradients of low_hz_ / band_hz_, the channel LayerNorm and PSwish."""
+    from animal2vec_amd.config import Data2VecMultiConfig, D2vAudioConfig, D2vDecoderConfig
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    layers = [(296, 149, 1), (64, 10, 5)] + [(64, 3, 2)] * 3 + [(64, 3, 1)] + [(64, 2, 1)] * 2
+    layers_str = "[(296, 149, 1), (64, 10, 5)] + [(64, 3, 2)] * 3 + [(64, 3, 1)] + [(64, 2, 1)] * 2"
+    dims = dict(embed_dim=128, num_heads=2, depth=2, prenet_depth=1, decoder_dim=64, decoder_layers=2, decoder_kernel=7,
+                decoder_groups=8, clone_batch=2, conv_pos_groups=8, average_top_k_layers=2, conv_feature_layers=layers,
+                sample_rate=44100)
+    ocfg = O.OracleConfig(**dims)
+    p = O.init_params(ocfg, seed=6)
+    g = torch.Generator().manual_seed(10)
+    for k in p:                                # move the band edges / PSwish / LN off their init values
+        if "low_hz_" in k or "band_hz_" in k:
+            p[k] = p[k] * (1 + 0.05 * torch.randn(p[k].shape, generator=g))
+        elif "p_swish" in k or "conv_layers.0.2.1" in k:
+            p[k] = p[k] + 0.1 * torch.randn(p[k].shape, generator=g)
+    ema = {k: v + torch.randn(v.shape, generator=g) * 0.002 for k, v in O.make_teacher(p).items()}
+    L = 22050                                  # 0.5 s
+    T = O.frame_counts(L, layers)[-1]
+    keep = max(8, round(0.07 * T))
+    src = torch.nn.functional.layer_norm(torch.randn(2, L, generator=g), (L,))
+    mask = O.seeded_mask(2 * ocfg.clone_batch, T, keep, 3)
+    noise = torch.randn(2 * ocfg.clone_batch, T - keep, ocfg.embed_dim, generator=g) * 0.01
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    res = O.pretrain_forward(po, ema, src, mask, noise, ocfg)
+    res["losses"]["AUDIO_regression"].sum().backward()
+    a = D2vAudioConfig(conv_pos_groups=8, prenet_depth=1, conv_feature_layers=layers_str, sample_rate=44100,
+                       decoder=D2vDecoderConfig(decoder_dim=64, decoder_groups=8, decoder_layers=2))
+    cfg = Data2VecMultiConfig(depth=2, embed_dim=128, num_heads=2, clone_batch=2, average_top_k_layers=2, audio=a)
+    store, eng = build(cfg, p, ema, dtype)
+    assert eng.sinc_cp == 320
+    dbg = run(eng, src, mask, noise)
+    assert rel_err(dbg["local_features"].float(), res["_dbg"]["local_features"]) < tol_y
+    assert rel_err(dbg["targets"], res["_dbg"]["targets"]) < tol_y
+    ls = float(res["losses"]["AUDIO_regression"].sum().detach())
+    assert abs(float(eng.stats[4 * cfg.embed_dim]) - ls) / ls < tol_y
+    errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
+    assert errs[0][0] < tol_g, errs[:8]
+    fe = [e for e in errs if "conv_layers.0." in e[1]]
+    assert len(fe) == 6, fe                    # low_hz_, band_hz_, LN weight / bias, PSwish alpha / beta
