@@ -634,9 +634,9 @@ def test_finetune_large_full_size_vs_oracle(dtype, tol_y, tol_g):
 def test_long_sequence_pretrain_vs_oracle(dtype, tol_y, tol_g):
     """BASELINE config 5's sequence shape (5 s @ 44.1 kHz: T = 5513 frames, K = round(0.07 T) = 386 kept) through the
     pretraining step with head_dim 64: teacher attention over 5513 keys, student attention at S = 386 (forward with two
-    query blocks, the two-pass backward in bf16), pos-conv / decoder slabs over ragged T.  The 44.1 kHz front-end spec
-    itself (296 filters x 149 taps, build-chosen in SURVEY 8d) is outside the fused SincConv kernel's limits
-    (C <= 128, k <= 63) and is not covered: the waveform here goes through the 127 x 63 front end."""
+    query blocks, the two-pass backward in bf16), pos-conv / decoder slabs over ragged T.  (The 44.1 kHz front-end spec itself, 296 filters x 149 taps, is covered by
+    test_config5_44k_frontend_vs_oracle; the waveform here goes through the 127 x 63 front end to keep the CPU oracle's run
+    short.)"""
     from animal2vec_amd.config import Data2VecMultiConfig, D2vAudioConfig, D2vDecoderConfig
     torch.set_num_threads(min(16, torch.get_num_threads()))
     dims = dict(embed_dim=128, num_heads=2, depth=2, prenet_depth=1, decoder_dim=64, decoder_layers=2,
