@@ -36,7 +36,7 @@ SIGNATURES = {
     "a2v_sinc_filters_fwd": [_p, _p, _p, _p, _p, _i, _i, _i, _f, _f, _f, _p],
     "a2v_sinc_filters_bwd": [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _f, _f, _p],
     "a2v_sinc_fused_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "a2v_sinc_fused_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
+    "a2v_sinc_fused_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p],
     "a2v_sinc_out_channels": [_i, _i],
     "a2v_gather_tokens": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _u, _p],
     "a2v_scatter_tokens": [_i, _p, _p, _p, _i, _i, _i, _i, _p],

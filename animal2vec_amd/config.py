@@ -135,6 +135,15 @@ def large_config(**kw) -> Data2VecMultiConfig:
     return Data2VecMultiConfig(**kw)
 
 
+def large_44k_config(**kw) -> Data2VecMultiConfig:
+    """BASELINE config 5 (NIPS4Bplus-shaped, 44.1 kHz): the large model behind the front-end spec SURVEY 8d derives from
+    the YAML's own rule k ~ sqrt(sr / 2): 296 sinc filters x 149 taps (the reference ships no 44.1 kHz YAML)."""
+    layers = "[(296, 149, 1)] + [(512, 10, 5)] + [(512, 3, 2)] * 3 + [(512, 3, 1)] + [(512, 2, 1)] * 2"
+    d = dict(audio=D2vAudioConfig(conv_feature_layers=layers, sample_rate=44100))
+    d.update(kw)
+    return Data2VecMultiConfig(**d)
+
+
 def base_star_config(**kw) -> Data2VecMultiConfig:
     """Build-defined 'animal2vec-base' (the reference ships only the large YAML)."""
     a = D2vAudioConfig(prenet_depth=4, decoder=D2vDecoderConfig(decoder_dim=384, decoder_layers=4))

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void mixup_apply_kernel(const float* __restric
 // the reference's hann window and linear-power A-weighting table.
 extern "C" int a2v_mixup_gain(const float* x, const float* window, const float* aweight, float* gain_db, int B, int L,
                               int n_fft, int hop, float floor_, hipStream_t st) {
-  if (B <= 0 || n_fft <= 0 || n_fft > 1024 || hop <= 0 || L < n_fft) return A2V_ERR_ARG;
+  if (B <= 0 || n_fft <= 0 || n_fft > 4096 || hop <= 0 || L < n_fft) return A2V_ERR_ARG;      // 3 n_fft floats of LDS (<= 48 KB)
   const int nframes = (L - n_fft) / hop + 1;
   hipLaunchKernelGGL(mixup_gain_kernel, dim3(nframes, B), dim3(256), 3 * n_fft * sizeof(float), st, x, window, aweight,
                      gain_db, L, n_fft, hop, nframes, floor_);

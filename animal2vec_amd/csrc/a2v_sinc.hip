@@ -368,11 +368,11 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
 // result goes out straight from registers (8 / 16 B per lane).  Backward: a workgroup recomputes the whole conv tile
 // (all channels, all taps -- the LayerNorm backward needs every channel) but reduces the filter gradient only for
 // its (channel group, tap chunk) = blockIdx.y, so dW fits in registers; the per-channel parameter gradients are
-// accumulated in LDS by the blockIdx.y = 0 workgroups.
+// accumulated in LDS.  [superseded for the backward: see sinc_dconv_gen_kernel / sinc_dw_gen_kernel below]
 #define SINC_GEN_NJC 20                 // channels padded to 320
 #define SINC_GEN_CP (16 * SINC_GEN_NJC)
 #define SINC_GEN_MAXCH 4                // tap chunks of 64: k <= 255
-#define SINC_GEN_CGB 4                  // channel blocks (of 16) per backward channel group
+#define SINC_GEN_CGB 5                  // channel blocks (of 16) per dW workgroup
 
 template <typename T, int NJC>
 __global__ __launch_bounds__(256) void sinc_fused_fwd_gen_kernel(const float* __restrict__ x, const float* __restrict__ filt,
@@ -470,27 +470,27 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_gen_kernel(const float* __
   }
 }
 
-template <typename T, int NJC, int CGB>
-__global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __restrict__ x, const float* __restrict__ filt,
-                                                                 const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-                                                                 const float* __restrict__ ps_a, const float* __restrict__ ps_b,
-                                                                 const T* __restrict__ dy, const float* __restrict__ mean_in,
-                                                                 const float* __restrict__ rstd_in, float* __restrict__ dfilt,
-                                                                 float* __restrict__ dpar, int B, int L, int C, int k,
-                                                                 int tiles_per_blk, int nchunks) {
+// K1: dconv[t][c] (fp32, channel pitch CP) for every channel of every tile -> scratch, plus the per-channel parameter
+// gradients (LDS atomics, flushed once per workgroup).
+template <typename T, int NJC>
+__global__ __launch_bounds__(256) void sinc_dconv_gen_kernel(const float* __restrict__ x, const float* __restrict__ filt,
+                                                             const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                             const float* __restrict__ ps_a, const float* __restrict__ ps_b,
+                                                             const T* __restrict__ dy, const float* __restrict__ mean_in,
+                                                             const float* __restrict__ rstd_in, float* __restrict__ dconv,
+                                                             float* __restrict__ dpar, int B, int L, int C, int k,
+                                                             int tiles_per_blk, int nchunks) {
   constexpr int CP = 16 * NJC;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sF = (float*)smem;                         // [CP][SINC_FP]
   float* sPar = sF + CP * SINC_FP;                  // [4][CP] parameters
-  float* sG = sPar + 4 * CP;                        // [4][CP] parameter gradients (blockIdx.y == 0)
+  float* sG = sPar + 4 * CP;                        // [4][CP] parameter gradients
   float* sX = sG + 4 * CP;                          // [64 + 64 nchunks]
   float* sMean = sX + 64 + 64 * SINC_GEN_MAXCH;     // [64]
   float* sRstd = sMean + 64;                        // [64]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int half = k / 2;
-  const int tg = blockIdx.y % nchunks, cg = blockIdx.y / nchunks;     // this workgroup's tap chunk / channel group for dW
-  const bool grads = blockIdx.y == 0;
   for (int i = tid; i < CP; i += 256) {
     const bool ok = i < C;
     sPar[i] = ok ? ln_w[i] : 0.f;
@@ -499,11 +499,6 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __
     sPar[3 * CP + i] = ok ? ps_b[i] : 0.f;
     sG[i] = 0.f; sG[CP + i] = 0.f; sG[2 * CP + i] = 0.f; sG[3 * CP + i] = 0.f;
   }
-  f32x4 dW[CGB][4];                                 // rows c = 16 (cg CGB + jl) + 4g + r, cols tap = 64 tg + 16 jt + fr
-#pragma unroll
-  for (int jl = 0; jl < CGB; ++jl)
-#pragma unroll
-    for (int jt = 0; jt < 4; ++jt) dW[jl][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int tiles_per_clip = (L + 63) / 64;
   const long long ntiles = (long long)B * tiles_per_clip;
   const float invC = 1.f / (float)C;
@@ -542,7 +537,8 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __
         }
       }
     }
-    // pass 1 over all channels: LayerNorm-backward row sums (+ parameter gradients in the y == 0 workgroups)
+    // pass 1: d = dL/dh per element (kept in acc's place: h is recomputable from the statistics only with the conv
+    // value, so keep both: h in acc, d in dh), LayerNorm-backward row sums, parameter gradients
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     float mrow[4], rrow[4];
     bool tok[4];
@@ -551,6 +547,7 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __
       const int tl = wid * 16 + 4 * g + r;
       mrow[r] = sMean[tl]; rrow[r] = sRstd[tl]; tok[r] = t0 + tl < L;
     }
+    f32x4 dh[NJC];
 #pragma unroll
     for (int jc = 0; jc < NJC; ++jc) {
       const int c = fr + 16 * jc;
@@ -563,24 +560,24 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __
         const float h = (acc[jc][r] - mrow[r]) * rrow[r];
         const float yl = h * pw + pb_;
         const float sg = 1.f / (1.f + __expf(-pbs * yl));
-        float dz = (cok && tok[r]) ? Cvt<T>::to(dy[((long long)b * L + t0 + tl) * CP + c]) : 0.f;
+        const float dz = (cok && tok[r]) ? Cvt<T>::to(dy[((long long)b * L + t0 + tl) * CP + c]) : 0.f;
         const float dyl = dz * pa * (sg + yl * pbs * sg * (1.f - sg));
         ga += dz * yl * sg;
         gbs += dz * yl * pa * sg * (1.f - sg) * yl;
         gw += dyl * h;
         gb += dyl;
         const float d = dyl * pw;
+        acc[jc][r] = cok ? h : 0.f;
+        dh[jc][r] = d;
         s1[r] += d;
         s2[r] += cok ? d * h : 0.f;
       }
-      if (grads) {
-        gw += __shfl_xor(gw, 16, 64); gw += __shfl_xor(gw, 32, 64);
-        gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
-        ga += __shfl_xor(ga, 16, 64); ga += __shfl_xor(ga, 32, 64);
-        gbs += __shfl_xor(gbs, 16, 64); gbs += __shfl_xor(gbs, 32, 64);
-        if (g == 0 && cok) {
-          atomicAdd(sG + c, gw); atomicAdd(sG + CP + c, gb); atomicAdd(sG + 2 * CP + c, ga); atomicAdd(sG + 3 * CP + c, gbs);
-        }
+      gw += __shfl_xor(gw, 16, 64); gw += __shfl_xor(gw, 32, 64);
+      gb += __shfl_xor(gb, 16, 64); gb += __shfl_xor(gb, 32, 64);
+      ga += __shfl_xor(ga, 16, 64); ga += __shfl_xor(ga, 32, 64);
+      gbs += __shfl_xor(gbs, 16, 64); gbs += __shfl_xor(gbs, 32, 64);
+      if (g == 0 && cok) {
+        atomicAdd(sG + c, gw); atomicAdd(sG + CP + c, gb); atomicAdd(sG + 2 * CP + c, ga); atomicAdd(sG + 3 * CP + c, gbs);
       }
     }
 #pragma unroll
@@ -589,39 +586,69 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __
       for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
       s1[r] *= invC; s2[r] *= invC;
     }
-    // pass 2 over this workgroup's channel group: dconv, then dW[c][tap] += sum_t dconv[t][c] * xpad[t + tap]
-    f32x4 dh[CGB];
+    // pass 2: dconv[t][c] = rstd * (d - mean(d) - h * mean(d h)) -> scratch (zero for padded channels / time)
 #pragma unroll
-    for (int jl = 0; jl < CGB; ++jl) {
-      const int jc = cg * CGB + jl;
+    for (int jc = 0; jc < NJC; ++jc) {
       const int c = fr + 16 * jc;
-      const bool cok = jc < NJC && c < C;
-      const int cc = cok ? c : 0;
-      const float pw = sPar[cc], pb_ = sPar[CP + cc], pa = sPar[2 * CP + cc], pbs = sPar[3 * CP + cc];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tl = wid * 16 + 4 * g + r;
-        float a_ = 0.f;
-#pragma unroll
-        for (int j2 = 0; j2 < NJC; ++j2) a_ = (j2 == jc) ? acc[j2][r] : a_;       // select without dynamic indexing
-        const float h = (a_ - mrow[r]) * rrow[r];
-        const float yl = h * pw + pb_;
-        const float sg = 1.f / (1.f + __expf(-pbs * yl));
-        const float dz = (cok && tok[r]) ? Cvt<T>::to(dy[((long long)b * L + t0 + tl) * CP + cc]) : 0.f;
-        const float d = dz * pa * (sg + yl * pbs * sg * (1.f - sg)) * pw;
-        const float v = rrow[r] * (d - s1[r] - h * s2[r]);
-        dh[jl][r] = (cok && tok[r]) ? v : 0.f;
+        if (tok[r]) {
+          const float v = rrow[r] * (dh[jc][r] - s1[r] - acc[jc][r] * s2[r]);
+          dconv[((long long)b * L + t0 + tl) * CP + c] = c < C ? v : 0.f;
+        }
       }
     }
+  }
+  __syncthreads();
+  for (int i = tid; i < 4 * CP; i += 256) {
+    const int c = i % CP;
+    if (c < C && sG[i] != 0.f) atomicAdd(dpar + i, sG[i]);
+  }
+}
+
+// K2: dW[c][tap] += sum_t dconv[t][c] * xpad[t + tap] for this workgroup's (channel group, tap chunk) = blockIdx.y
+template <int NJC, int CGB>
+__global__ __launch_bounds__(256) void sinc_dw_gen_kernel(const float* __restrict__ x, const float* __restrict__ dconv,
+                                                          float* __restrict__ dfilt, int B, int L, int C, int k,
+                                                          int tiles_per_blk, int nchunks) {
+  constexpr int CP = 16 * NJC;
+  __shared__ float sX[64 + 64 + 16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int half = k / 2;
+  const int tg = blockIdx.y % nchunks, cg = blockIdx.y / nchunks;
+  f32x4 dW[CGB][4];                                 // rows c = 16 (cg CGB + jl) + 4g + r, cols tap = 64 tg + 16 jt + fr
+#pragma unroll
+  for (int jl = 0; jl < CGB; ++jl)
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) dW[jl][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int tiles_per_clip = (L + 63) / 64;
+  const long long ntiles = (long long)B * tiles_per_clip;
+  for (int it = 0; it < tiles_per_blk; ++it) {
+    const long long tile = (long long)blockIdx.x * tiles_per_blk + it;
+    if (tile >= ntiles) break;
+    const int b = (int)(tile / tiles_per_clip);
+    const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
+    __syncthreads();
+    if (tid < 128) sX[tid] = x[(long long)b * L + reflect_idx(t0 - half + tg * 64 + tid, L)];     // samples t0 + tl + tap - half
+    __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int tl = wid * 16 + 4 * g + r;
+      const bool tok = t0 + tl < L;
+      float dh[CGB];
+#pragma unroll
+      for (int jl = 0; jl < CGB; ++jl) {
+        const int c = 16 * (cg * CGB + jl) + fr;
+        dh[jl] = (tok && c < C) ? dconv[((long long)b * L + t0 + tl) * CP + c] : 0.f;
+      }
 #pragma unroll
       for (int jt = 0; jt < 4; ++jt) {
-        const float xb = sX[tl + tg * 64 + 16 * jt + fr];
+        const float xb = sX[tl + 16 * jt + fr];
 #pragma unroll
         for (int jl = 0; jl < CGB; ++jl)
-          dW[jl][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[jl][r], xb, dW[jl][jt], 0, 0, 0);
+          dW[jl][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[jl], xb, dW[jl][jt], 0, 0, 0);
       }
     }
   }
@@ -637,13 +664,6 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_gen_kernel(const float* __
         if (tap < k) atomicAdd(dfilt + (long long)c * k + tap, dW[jl][jt][r]);
       }
     }
-  if (grads) {
-    __syncthreads();
-    for (int i = tid; i < 4 * CP; i += 256) {
-      const int c = i % CP;
-      if (c < C && sG[i] != 0.f) atomicAdd(dpar + i, sG[i]);
-    }
-  }
 }
 
 // =============================================================================================
@@ -720,28 +740,31 @@ extern "C" int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, 
 // dfilt (C rows used, k) and dpar (4 x 128) are ACCUMULATED (atomics): zero them first.
 extern "C" int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
                                   const float* ps_alpha, const float* ps_beta, const void* dy, const float* mean,
-                                  const float* rstd, float* dfilt, float* dpar, int B, int L, int C, int k,
+                                  const float* rstd, float* dfilt, float* dpar, float* scratch, int B, int L, int C, int k,
                                   hipStream_t st) {
   if (B <= 0 || L < 128 || C <= 0 || !(k & 1)) return A2V_ERR_ARG;
   if (C > SINC_CP || k > 63) {                       // general shapes: dy is (B, L, 320), dpar is (4, 320)
     const int nch = (k + 63) / 64;
-    if (C > SINC_GEN_CP || nch > SINC_GEN_MAXCH || L < 64 + 64 * nch) return A2V_ERR_ARG;
+    if (C > SINC_GEN_CP || nch > SINC_GEN_MAXCH || L < 64 + 64 * nch || !scratch) return A2V_ERR_ARG;
     const long long nt = (long long)B * ((L + 63) / 64);
-    int tpbg = (int)((nt + 511) / 512);
-    if (tpbg < 1) tpbg = 1;
-    const int ncg = (SINC_GEN_NJC + SINC_GEN_CGB - 1) / SINC_GEN_CGB;
-    const dim3 gridg((unsigned)((nt + tpbg - 1) / tpbg), (unsigned)(ncg * nch));
+    const int tpbg = sinc_tiles_per_block(nt);
+    const int gridg = (int)((nt + tpbg - 1) / tpbg);
     const int ldsg = (SINC_GEN_CP * SINC_FP + 8 * SINC_GEN_CP + 64 + 64 * SINC_GEN_MAXCH + 128) * 4;
     if (dtype == A2V_BF16) {
-      (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_gen_kernel<bf16, SINC_GEN_NJC, SINC_GEN_CGB>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
-      hipLaunchKernelGGL((sinc_fused_bwd_gen_kernel<bf16, SINC_GEN_NJC, SINC_GEN_CGB>), gridg, dim3(256), ldsg, st, x, filt, ln_w, ln_b,
-                         ps_alpha, ps_beta, (const bf16*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpbg, nch);
+      (void)hipFuncSetAttribute((const void*)sinc_dconv_gen_kernel<bf16, SINC_GEN_NJC>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
+      hipLaunchKernelGGL((sinc_dconv_gen_kernel<bf16, SINC_GEN_NJC>), dim3(gridg), dim3(256), ldsg, st, x, filt, ln_w, ln_b,
+                         ps_alpha, ps_beta, (const bf16*)dy, mean, rstd, scratch, dpar, B, L, C, k, tpbg, nch);
     } else if (dtype == A2V_F32) {
-      (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_gen_kernel<float, SINC_GEN_NJC, SINC_GEN_CGB>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
-      hipLaunchKernelGGL((sinc_fused_bwd_gen_kernel<float, SINC_GEN_NJC, SINC_GEN_CGB>), gridg, dim3(256), ldsg, st, x, filt, ln_w, ln_b,
-                         ps_alpha, ps_beta, (const float*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpbg, nch);
+      (void)hipFuncSetAttribute((const void*)sinc_dconv_gen_kernel<float, SINC_GEN_NJC>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsg);
+      hipLaunchKernelGGL((sinc_dconv_gen_kernel<float, SINC_GEN_NJC>), dim3(gridg), dim3(256), ldsg, st, x, filt, ln_w, ln_b,
+                         ps_alpha, ps_beta, (const float*)dy, mean, rstd, scratch, dpar, B, L, C, k, tpbg, nch);
     } else
       return A2V_ERR_DTYPE;
+    int tpb2 = (int)((nt + 255) / 256);
+    if (tpb2 < 1) tpb2 = 1;
+    const int ncg = (SINC_GEN_NJC + SINC_GEN_CGB - 1) / SINC_GEN_CGB;
+    hipLaunchKernelGGL((sinc_dw_gen_kernel<SINC_GEN_NJC, SINC_GEN_CGB>), dim3((unsigned)((nt + tpb2 - 1) / tpb2), (unsigned)(ncg * nch)),
+                       dim3(256), 0, st, x, scratch, dfilt, B, L, C, k, tpb2, nch);
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }

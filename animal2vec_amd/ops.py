@@ -312,8 +312,10 @@ def sinc_fused_fwd(x, filt, ln_w, ln_b, ps_a, ps_b, *, C_, k, dtype, eps=1e-5, s
 
 def sinc_fused_bwd(x, filt, ln_w, ln_b, ps_a, ps_b, dy, mean, rstd, dfilt, dpar, *, C_, k):
     B, L = x.shape
+    cp = sinc_out_channels(C_, k)
+    scratch = torch.empty(B, L, cp, dtype=torch.float32, device=x.device) if cp != 128 else None     # blocked kernels: dconv
     rc = _L().a2v_sinc_fused_bwd(dt(dy), ptr(x), ptr(filt), ptr(ln_w), ptr(ln_b), ptr(ps_a), ptr(ps_b), ptr(dy), ptr(mean),
-                                 ptr(rstd), ptr(dfilt), ptr(dpar), B, L, C_, k, stream())
+                                 ptr(rstd), ptr(dfilt), ptr(dpar), ptr(scratch), B, L, C_, k, stream())
     check(rc, "a2v_sinc_fused_bwd")
 
 

@@ -179,7 +179,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--model", default="large", choices=["large", "base"])
+    ap.add_argument("--model", default="large", choices=["large", "base", "large44k"],
+                    help="large44k: BASELINE config 5 (296x149 front end @ 44.1 kHz; use --samples 220500 --keep 386)")
     ap.add_argument("--global-batch", type=int, default=64, help="clips per optimizer step over all GPUs")
     ap.add_argument("--micro-batch", type=int, default=8, help="clips per fwd/bwd launch sequence per GPU")
     ap.add_argument("--samples", type=int, default=80000)
@@ -208,10 +209,10 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from animal2vec_amd import ops
-    from animal2vec_amd.config import base_star_config, large_config
+    from animal2vec_amd.config import base_star_config, large_44k_config, large_config
     from animal2vec_amd.trainer import PretrainTrainer
 
-    cfg = large_config() if args.model == "large" else base_star_config()
+    cfg = {"large": large_config, "base": base_star_config, "large44k": large_44k_config}.get(args.model, base_star_config)()
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     assert args.global_batch % (world * args.micro_batch) == 0, "global batch must split into micro-batches per rank"
     n_mb = args.global_batch // (world * args.micro_batch)
@@ -271,8 +272,9 @@ def main():
         value = audio_s * args.steps / dt
         gf_fwd, gf_fb = gflop_per_clip(cfg, L, K)
         line = {
-            "metric": "audio-seconds/s pretrain (10s@8kHz, large model)" if args.model == "large" else
-                      "audio-seconds/s pretrain (10s@8kHz, base* model)",
+            "metric": {"large": "audio-seconds/s pretrain (10s@8kHz, large model)",
+                       "base": "audio-seconds/s pretrain (10s@8kHz, base* model)",
+                       "large44k": "audio-seconds/s pretrain (44.1 kHz, large model, BASELINE config 5)"}[args.model],
             "value": round(value, 2), "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

@@ -139,10 +139,13 @@ int a2v_sinc_filters_bwd(const float* low_hz, const float* band_hz, const float*
 int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
                        const float* ps_alpha, const float* ps_beta, void* y, float* mean, float* rstd, int B, int L,
                        int C, int k, float eps, a2v_stream_t stream);
-/* dfilt (C,k) and dpar (4,128: d ln_w, d ln_b, d ps_alpha, d ps_beta) are accumulated: zero first. */
+/* dfilt (C,k) and dpar (4, pitch: d ln_w, d ln_b, d ps_alpha, d ps_beta) are accumulated: zero first.  pitch =
+ * a2v_sinc_out_channels(C, k); when it is 320 (blocked kernels) `scratch` must hold B*L*320 floats (the conv-output
+ * gradient, formed once and then reduced into dfilt by a second kernel); it may be NULL for the 128-pitch specs. */
 int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
                        const float* ps_alpha, const float* ps_beta, const void* dy, const float* mean,
-                       const float* rstd, float* dfilt, float* dpar, int B, int L, int C, int k, a2v_stream_t stream);
+                       const float* rstd, float* dfilt, float* dpar, float* scratch, int B, int L, int C, int k,
+                       a2v_stream_t stream);
 /* Channel pitch of y / dy and row length of dpar for a (filters C, taps k) front-end spec: 128 for C <= 128, k <= 63
  * (the shipped 8 kHz spec 127 x 63), 320 for the blocked kernels (C <= 320, k <= 255: e.g. 296 x 149 at 44.1 kHz),
  * -1 if unsupported. */
