@@ -473,6 +473,38 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
   }
 }
 
+// d loss / d alibi_scale_h: every workgroup of a backward launch contributes to one of only H addresses -- as plain
+// atomics that is thousands of same-address read-modify-writes in a row, which the L2 serialises (60 us of a 160 us
+// launch at N*H = 1536 workgroups; a "last workgroup folds" counter has the same problem).  Each workgroup instead
+// stores its partial sum to its own slot of a device scratch and a one-block-per-head kernel folds them afterwards:
+// no contention, and the sum order is fixed (deterministic gradient).
+#define A2V_DAL_PART_MAX 65536
+__device__ float g_dal_part[A2V_DAL_PART_MAX];
+__device__ __forceinline__ void dalibi_finish(float dal_wave, float* dalibi, int h, int use_part, float slope, float asc) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  if (!use_part) {                                      // too many workgroups for the scratch: direct atomics
+    if ((tid & 63) == 0 && dalibi && asc >= 0.f) atomicAdd(dalibi + h, dal_wave * slope);
+    return;
+  }
+  if ((tid & 63) == 0) red[tid >> 6] = dal_wave;
+  __syncthreads();
+  if (tid == 0) {
+    const float v = asc >= 0.f ? (red[0] + red[1] + red[2] + red[3]) * slope : 0.f;
+    g_dal_part[((long long)h * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = v;      // blockIdx.y = head
+  }
+}
+__global__ __launch_bounds__(256) void dalibi_fold_kernel(float* __restrict__ dalibi, int per_head) {
+  __shared__ float red[4];
+  const int h = blockIdx.x, tid = threadIdx.x;
+  float s = 0.f;
+  for (int i = tid; i < per_head; i += 256) s += g_dal_part[(long long)h * per_head + i];
+  s = wave_sum(s);
+  if ((tid & 63) == 0) red[tid >> 6] = s;
+  __syncthreads();
+  if (tid == 0) dalibi[h] += red[0] + red[1] + red[2] + red[3];
+}
+
 struct AttnBwdArgs {
   const void* qkv; const void* d_out; const float* lse; const float* delta;
   void* dqkv;               // (N,S,3,H,HD): k and v slots written here
@@ -482,6 +514,7 @@ struct AttnBwdArgs {
   int N, S, H;
   float scale;
   Drop drop;
+  int dal_part;             // 1: per-workgroup partial sums of d alibi_scale go to g_dal_part (folded by dalibi_fold_kernel)
 };
 
 // NT = 0: one workgroup per 64-key block, dQ summed across key blocks with fp32 atomics into dq32 (any S).
@@ -794,7 +827,7 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
   }
   // ---- d alibi_scale_h = slope_h * [scale_h >= 0] * sum dS * (-dist)
   dal = wave_sum(dal);
-  if (lane == 0 && a.dalibi && asc >= 0.f) atomicAdd(a.dalibi + h, dal * slope);
+  dalibi_finish(dal, a.dalibi, h, a.dal_part, slope, asc);
 }
 
 // =============================================================================================
@@ -1062,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
       }
     }
   dal = wave_sum(dal);
-  if (lane == 0 && a.dalibi && asc >= 0.f) atomicAdd(a.dalibi + h, dal * slope);
+  dalibi_finish(dal, a.dalibi, h, a.dal_part, slope, asc);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1325,7 +1358,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
   }
   if (MODE == 0) {
     dal = wave_sum(dal);
-    if (lane == 0 && a.dalibi && asc >= 0.f) atomicAdd(a.dalibi + h, dal * slope);
+    dalibi_finish(dal, a.dalibi, h, a.dal_part, slope, asc);
   }
 }
 
@@ -1334,7 +1367,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
 int g_a2v_attn_long = 1;     // a2v_debug_set(8, v): two-pass long-sequence backward on / off (off: tiled kernel + dQ atomics)
 
 template <typename T, int HD>
-static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, hipStream_t st) {
+static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delta, hipStream_t st) {
+  AttnBwdArgs a = a_in;
+  // d alibi_scale: per-workgroup partials + fold kernel whenever the launch's workgroups fit the scratch
+  auto set_part = [&](const dim3& grid) {
+    a.dal_part = (a.dalibi && (long long)grid.x * grid.y * grid.z <= A2V_DAL_PART_MAX) ? 1 : 0;
+  };
+  auto fold = [&](const dim3& grid) {
+    if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(a.H), dim3(256), 0, st, a.dalibi, (int)(grid.x * grid.z));
+  };
   const long long total = (long long)a.N * a.S * a.H;
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
@@ -1348,6 +1389,7 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
     if ((a.S > ABS_ROWS && g_a2v_attn_long) || g_a2v_attn_long == 2) {       // long sequences: dK/dV pass + dQ pass, no atomics (2: every S, experiments)
       const bool dr = a.drop.thresh != 0;
       const dim3 grid((a.S + 127) / 128, a.H, a.N);
+      set_part(grid);
       if (dr) {
         hipLaunchKernelGGL((attn_bwd_long_kernel<0, true>), grid, dim3(256), ABL_LDS, st, a);
         hipLaunchKernelGGL((attn_bwd_long_kernel<1, true>), grid, dim3(256), ABL_LDS, st, a);
@@ -1355,6 +1397,7 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
         hipLaunchKernelGGL((attn_bwd_long_kernel<0, false>), grid, dim3(256), ABL_LDS, st, a);
         hipLaunchKernelGGL((attn_bwd_long_kernel<1, false>), grid, dim3(256), ABL_LDS, st, a);
       }
+      fold(grid);
       A2V_CHECK_LAUNCH();
       return A2V_OK;
     }
@@ -1362,19 +1405,28 @@ static int attn_bwd_launch(const AttnBwdArgs& a, const void* out, float* delta, 
       const bool dr = a.drop.thresh != 0;
       (void)hipFuncSetAttribute((const void*)attn_bwd_seq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ABS_LDS);
       (void)hipFuncSetAttribute((const void*)attn_bwd_seq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ABS_LDS);
-      if (dr) hipLaunchKernelGGL((attn_bwd_seq_kernel<true>), dim3(1, a.H, a.N), dim3(256), ABS_LDS, st, a, (const bf16*)out);
-      else hipLaunchKernelGGL((attn_bwd_seq_kernel<false>), dim3(1, a.H, a.N), dim3(256), ABS_LDS, st, a, (const bf16*)out);
+      const dim3 grid(1, a.H, a.N);
+      set_part(grid);
+      if (dr) hipLaunchKernelGGL((attn_bwd_seq_kernel<true>), grid, dim3(256), ABS_LDS, st, a, (const bf16*)out);
+      else hipLaunchKernelGGL((attn_bwd_seq_kernel<false>), grid, dim3(256), ABS_LDS, st, a, (const bf16*)out);
+      fold(grid);
       A2V_CHECK_LAUNCH();
       return A2V_OK;
     }
   }
   if (BF && a.S <= 64 * A2V_ATTN_SEQ_TILES) {
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD, BF ? A2V_ATTN_SEQ_TILES : 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, BF ? A2V_ATTN_SEQ_TILES : 0>), dim3(1, a.H, a.N), dim3(256), LDS, st, a);
+    const dim3 grid(1, a.H, a.N);
+    set_part(grid);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, BF ? A2V_ATTN_SEQ_TILES : 0>), grid, dim3(256), LDS, st, a);
+    fold(grid);
   } else {
     if (!a.dq32) return A2V_ERR_ARG;
     (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T, HD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, 0>), dim3((a.S + 63) / 64, a.H, a.N), dim3(256), LDS, st, a);
+    const dim3 grid((a.S + 63) / 64, a.H, a.N);
+    set_part(grid);
+    hipLaunchKernelGGL((attn_bwd_kernel<T, HD, 0>), grid, dim3(256), LDS, st, a);
+    fold(grid);
   }
   A2V_CHECK_LAUNCH();
   return A2V_OK;
@@ -1397,7 +1449,7 @@ extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, co
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || drop_p < 0.f || drop_p >= 1.f)
     return A2V_ERR_ARG;
   AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale,
-                make_drop(drop_p, drop_seed)};
+                make_drop(drop_p, drop_seed), 0};
   if (dtype == A2V_BF16) {
     if (HD == 64) return attn_bwd_launch<bf16, 64>(a, out, delta, stream);
     if (HD == 32) return attn_bwd_launch<bf16, 32>(a, out, delta, stream);

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void d2v_loss_kernel(const T* __restrict__ x, 
   const long long row0 = ((long long)blockIdx.x * 4 + wid) * rows_per_wave;
   const long long rows = (long long)N * Tn;
   const int nch = (D + 511) / 512;
+  float ls_tot = 0.f, cnt_tot = 0.f;
   for (int c = 0; c < nch; ++c) {
     const int col = (c * 64 + lane) * 8;
     float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sxx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -176,11 +177,20 @@ __global__ __launch_bounds__(256) void d2v_loss_kernel(const T* __restrict__ x, 
         atomicAdd(stats + which * D + gc, (double)v);
       }
     }
-    ls = wave_sum(ls);
-    if (lane == 0) {
-      atomicAdd(stats + 4 * D, (double)ls);
-      if (c == 0) atomicAdd(stats + 4 * D + 1, (double)cnt);
-    }
+    ls_tot += ls;
+    cnt_tot += cnt;
+  }
+  // loss and count: ONE double atomic per workgroup each (same-address atomics are serialised by the L2 at tens of
+  // nanoseconds apiece: one per wave and column chunk was a 4096-long chain on a single address)
+  __shared__ float red2[2][4];
+  ls_tot = wave_sum(ls_tot);
+  cnt_tot = wave_sum(cnt_tot);
+  if (lane == 0) { red2[0][wid] = ls_tot; red2[1][wid] = cnt_tot; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(stats + 4 * D, (double)red2[0][0] + (double)red2[0][1] + (double)red2[0][2] + (double)red2[0][3]);
+    const float cn = red2[1][0] + red2[1][1] + red2[1][2] + red2[1][3];
+    if (cn != 0.f) atomicAdd(stats + 4 * D + 1, (double)cn);
   }
 }
 

@@ -769,7 +769,7 @@ extern "C" int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, 
     return A2V_OK;
   }
   const long long ntiles = (long long)B * ((L + 63) / 64);
-  int tpb = (int)((ntiles + 1023) / 1024);
+  int tpb = (int)((ntiles + 511) / 512);        // ~2 workgroups per CU: every workgroup flushes its dW / parameter sums with atomics once
   if (tpb < 1) tpb = 1;
   const int grid = (int)((ntiles + tpb - 1) / tpb);
   const int esz = dtype == A2V_BF16 ? 2 : 4;
