@@ -214,7 +214,12 @@ int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, unsigned dr
  * 16 bits per element): keep-mask of rows x cols with rows = (n*H + h)*S + q, cols = key index. */
 int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop_p, unsigned drop_seed, a2v_stream_t stream);
 
-/* A/B knob for kernel variants (key 0: bf16 NT GEMM, 0 = register-staged, 1 = LDS-DMA staged) */
+/* A/B knobs for kernel variants (tests and tools/ only; defaults are the production paths):
+ *   0 bf16 NT GEMM staging (0 register-staged, 1 LDS-DMA)      1 persistent 256x256 NT kernel on / off
+ *   2 grouped-conv weight-gradient slab kernel on / off         3 grouped-conv slab kernel on / off
+ *   4 persistent 256x256 TN kernel on / off                     5 force the NT tile height (2 / 3 / 4 = 192 / 224 / 256 rows)
+ *   6 wave-group stagger (0 off, 1 by shape, 2 always)          7 tile hand-out (0 static, 1 dynamic after the first tile, 2 all dynamic)
+ *   8 long-sequence attention backward (0 tiled kernel + dQ atomics, 1 two-pass, 2 two-pass for every S) */
 int a2v_debug_set(int key, int value);
 
 /* library version / build info */
