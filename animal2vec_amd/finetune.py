@@ -143,19 +143,27 @@ def layer_lr_scales(n_blocks: int, layer_decay: float) -> List[float]:
     return [scales[i + 1] for i in range(n_blocks)]
 
 
+def _to_device(arr: np.ndarray, device) -> torch.Tensor:
+    """host array -> device through pinned memory (a pageable copy would synchronise the host with the stream)"""
+    t = torch.from_numpy(arr)
+    if torch.device(device).type != "cuda":
+        return t
+    return t.pin_memory().to(device, non_blocking=True)
+
+
 def make_aug(fcfg: FinetuneConfig, B: int, T: int, D: int, n_prenet: int, n_blocks: int, rng: np.random.Generator,
              noise_std: float, device="cuda", train_dropout: bool = True) -> dict:
     """The per-micro-batch random draws of the train form (what Engine.finetune_forward takes as `aug`)."""
     aug: Dict[str, object] = {}
     if fcfg.apply_mask and fcfg.mask_prob > 0:
         m = compute_mask_indices((B, T), fcfg.mask_prob, fcfg.mask_length, rng, min_masks=1, require_same_masks=True)
-        aug["mask_t"] = torch.from_numpy(m.astype(np.uint8)).to(device)
+        aug["mask_t"] = _to_device(m.astype(np.uint8), device)
         aug["noise_std"] = 0.0 if fcfg.zero_mask else noise_std
         aug["noise_seed"] = int(rng.integers(0, 2 ** 31))
     if fcfg.apply_mask and fcfg.mask_channel_prob > 0:
         mc = compute_mask_indices((B, D), fcfg.mask_channel_prob, fcfg.mask_channel_length, rng, min_masks=0,
                                   require_same_masks=True)
-        aug["mask_c"] = torch.from_numpy(mc.astype(np.uint8)).to(device)
+        aug["mask_c"] = _to_device(mc.astype(np.uint8), device)
     aug["active"] = [bool(fcfg.layerdrop == 0 or rng.random() > fcfg.layerdrop) for _ in range(n_blocks)]
     if not any(aug["active"][n_prenet:]):          # the reference divides by zero layer results here; keep one block
         aug["active"][-1] = True
@@ -189,6 +197,8 @@ class FinetuneTrainer:
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.num_updates = 0
         self.rng = np.random.default_rng(seed * 1000 + 17 + self.rank)
+        self._perm_gen = torch.Generator(device=dev)            # device-side permutations: no pageable H2D copy per micro-batch
+        self._perm_gen.manual_seed(seed * 7919 + 29 + self.rank)
         self.mixup = ops.Mixup(model_cfg.audio.sample_rate, self.fcfg.mixing_window_length, dev) \
             if self.fcfg.source_mixup >= 0 and self.fcfg.mixup_prob > 0 else None
         assert self.fcfg.mixup_prob in (0.0, 1.0), "partial mixup (mixup_prob < 1) is not on the shipped configs' path"
@@ -244,13 +254,13 @@ class FinetuneTrainer:
             return src, tgt
         B = src.shape[0]
         r = float(self.rng.uniform(max(1e-6, f.source_mixup), 1.0))
-        perm = torch.from_numpy(self.rng.permutation(B).astype("int32")).to(src.device)
+        perm = torch.rand(B, device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
         src = self.mixup(src, perm, r)
         if f.target_mixup:
             tgt = tgt * r + (1 - r) * tgt[perm.long()]
         if f.inner_source_mixup and self.cfg.source_mixup >= 0 and self.cfg.mixup_prob > 0:
             r2 = float(self.rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
-            perm2 = torch.from_numpy(self.rng.permutation(B).astype("int32")).to(src.device)
+            perm2 = torch.rand(B, device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
             src = self.mixup(src, perm2, r2)
         return src, tgt
 

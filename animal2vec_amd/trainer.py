@@ -57,6 +57,10 @@ class PretrainTrainer:
             if (cfg.source_mixup >= 0 and cfg.mixup_prob > 0 and mixup) else None
         self._np_rng = __import__("numpy").random.default_rng(seed + 17)
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        # device-side permutations: a pageable host->device copy per micro-batch would make the host wait for the
+        # stream to drain (ROCm stages such copies synchronously) and leave the GPU idle while it catches up again
+        self._perm_gen = torch.Generator(device=self.store.device)
+        self._perm_gen.manual_seed(seed * 7919 + 17 + self.rank)
         self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
         self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device
@@ -107,7 +111,7 @@ class PretrainTrainer:
             src = mb["source"]
             if self.mixup is not None:        # BC-learning mixup, train only (data2vec2.py:536-598)
                 r = float(self._np_rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
-                perm = torch.from_numpy(self._np_rng.permutation(src.shape[0]).astype("int32")).to(src.device, non_blocking=True)
+                perm = torch.rand(src.shape[0], device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
                 src = self.mixup(src, perm, r)
             eng.forward_backward(src, mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise, dropout_seed=dseed)
         self.sync.arm(False)
