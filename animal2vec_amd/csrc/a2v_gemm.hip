@@ -592,12 +592,14 @@ extern int g_a2v_p8_ih;
 extern int g_a2v_p8_stagger;
 extern int g_a2v_p8_dynamic;
 extern int g_a2v_attn_long;
+extern int g_a2v_p8_slot;
 extern "C" int a2v_debug_set(int key, int value) {
   if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
   if (key == 1) { g_a2v_gemm_p8 = value; return A2V_OK; }     // 256x256 8-phase kernel on / off
   if (key == 2) { g_a2v_wgrad_slab = value; return A2V_OK; }  // slab weight-gradient kernel on / off
   if (key == 3) { g_a2v_conv_slab = value; return A2V_OK; }   // slab grouped-conv kernel on / off
   if (key == 4) { g_a2v_tn_p8 = value; return A2V_OK; }       // 256x256 TN weight-gradient kernel on / off
+  if (key == 9) { if (value < 0 || value > 3) return A2V_ERR_ARG; g_a2v_p8_slot = value; return A2V_OK; }   // tile-counter set for the stream about to be used
   if (key == 8) { g_a2v_attn_long = value; return A2V_OK; }        // long-sequence attention backward: two-pass kernel on / off
   if (key == 7) { g_a2v_p8_dynamic = value; return A2V_OK; }  // persistent kernels: dynamic tile hand-out on / off
   if (key == 6) { g_a2v_p8_stagger = value; return A2V_OK; }  // 8-phase kernels: stagger the two wave groups on / off

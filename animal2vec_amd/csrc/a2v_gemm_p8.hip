@@ -42,7 +42,8 @@ __device__ __forceinline__ void p8_glds16(const char* gsrc, char* lds_dst) {
 // workgroups finished (the last one resets all, so the next launch on the stream starts from zero).  A workgroup that starts late -- its CU held by
 // another kernel, e.g. RCCL's all-reduce overlapping the backward pass -- then simply takes fewer tiles instead of
 // stretching the launch by a whole extra round of its statically assigned ones.
-__device__ unsigned g_p8_ctr[9];
+#define P8_CTR_SLOTS 4     // one counter set per concurrently used stream (a2v_debug_set(9, slot) before launching on it)
+__device__ unsigned g_p8_ctr_all[P8_CTR_SLOTS][9];
 
 struct P8Tile {      // byte offsets (from the A / B base of the group) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
@@ -53,7 +54,8 @@ struct P8Tile {      // byte offsets (from the A / B base of the group) of the 1
 // M = 13440 (96 clips x 140 kept frames) is 60 x 224: with BM = 224 the student's Linears fill 240 of 256 CUs per
 // round with no M tail, 12.5 % less work per round than 53 ragged 256-row tiles.
 template <int IH>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles) {
+__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot) {
+  unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
   constexpr int BM = 128 + 32 * IH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
 }
 
+int g_a2v_p8_slot = 0;      // a2v_debug_set(9, v): tile-counter set of the persistent NT kernel (one per concurrent stream)
 int g_a2v_p8_dynamic = 2;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent NT kernel (2: first tile too)
 int g_a2v_p8_stagger = 1;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
@@ -406,8 +409,8 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   // costs a few per cent at K = 1024, where the epilogue dominates (g_a2v_p8_stagger: 0 off, 1 by shape, 2 always)
   const int stagger = g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048);
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
-  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic);
-  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic);
-  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic);
+  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot);
+  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot);
+  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot);
   return true;
 }

@@ -14,6 +14,8 @@ backward still runs (`on_grad_ready` callback).
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -38,6 +40,8 @@ class Engine:
         c0 = self.layers[0][0]
         k0 = self.layers[0][1]
         self.dfilt = torch.zeros(c0, k0, dtype=torch.float32, device=dev)
+        # A2V_TEACHER_STREAM=1: run the EMA teacher's forward on a side stream, concurrently with the student's forward
+        self.tstream = torch.cuda.Stream(dev) if (os.environ.get("A2V_TEACHER_STREAM", "0") == "1" and dev.type == "cuda") else None
         self.sinc_cp = ops.sinc_out_channels(c0, k0)      # channel pitch of the SincConv output (128, or 320 for the blocked kernels)
         self.dpar = torch.zeros(4, self.sinc_cp, dtype=torch.float32, device=dev)
 
@@ -545,8 +549,26 @@ class Engine:
         B, T, _ = feats.shape
         N, K = ids_keep.shape
         asc = p[P + "alibi_scale"].view(-1)
-        # ---- teacher targets from the student's local features (data2vec2.py:811-818)
-        y = self.teacher_targets(feats)
+        # ---- teacher targets from the student's local features (data2vec2.py:811-818): no gradient, independent of the
+        # student until the loss -> on a side stream, so its kernels fill the CUs the student's kernels leave idle
+        # (single-round GEMMs occupy 240 of 256 CUs, every kernel has a ramp and a tail) and vice versa
+        if self.tstream is not None:
+            main = torch.cuda.current_stream()
+            fork = torch.cuda.Event()
+            fork.record(main)
+            with torch.cuda.stream(self.tstream):
+                self.tstream.wait_event(fork)
+                ops.debug_set(9, 1)                 # the teacher's persistent GEMMs use their own tile counters
+                try:
+                    y = self.teacher_targets(feats)
+                finally:
+                    ops.debug_set(9, 0)
+                join = torch.cuda.Event()
+                join.record(self.tstream)
+            y.record_stream(main)
+        else:
+            join = None
+            y = self.teacher_targets(feats)
         # ---- student context encoder (base.py:215-344)
         # kept frames as flat rows n*T + t: the last pos-conv layer is only evaluated there (compact), with the
         # gathered local features added in its LayerNorm kernel
@@ -575,6 +597,8 @@ class Engine:
         dec_in = ops.decoder_input(x, noise, ids_restore, drop=d_dec)          # (N,T,D)
         dec_out = self.decoder_fwd(dec_in, save=save)
         loss_rows = torch.empty(N, T, D, dtype=torch.float32, device=x.device) if keep_debug else None
+        if join is not None:
+            torch.cuda.current_stream().wait_event(join)
         dx = ops.d2v_loss(dec_out, y, mask_u8, cb, stats=self.stats, want_dx=save, gscale=1.0, loss_rows=loss_rows)
         if keep_debug:
             dbg.update(local_features=feats, targets=y, x_pos=x_pos, decoder_in=dec_in, decoder_out=dec_out,

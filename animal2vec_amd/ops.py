@@ -501,3 +501,7 @@ def mask_frames(x, mask_t=None, mask_c=None, *, noise_std=0.0, seed=0, backward=
                               int(seed) & 0xFFFFFFFF, 1 if backward else 0, stream())
     check(rc, "a2v_mask_frames")
     return out
+
+
+def debug_set(key: int, value: int):
+    check(_L().a2v_debug_set(int(key), int(value)), "a2v_debug_set")

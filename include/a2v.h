@@ -219,7 +219,9 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   2 grouped-conv weight-gradient slab kernel on / off         3 grouped-conv slab kernel on / off
  *   4 persistent 256x256 TN kernel on / off                     5 force the NT tile height (2 / 3 / 4 = 192 / 224 / 256 rows)
  *   6 wave-group stagger (0 off, 1 by shape, 2 always)          7 tile hand-out (0 static, 1 dynamic after the first tile, 2 all dynamic)
- *   8 long-sequence attention backward (0 tiled kernel + dQ atomics, 1 two-pass, 2 two-pass for every S) */
+ *   8 long-sequence attention backward (0 tiled kernel + dQ atomics, 1 two-pass, 2 two-pass for every S)
+ * and one piece of launch state: 9 = tile-counter set (0..3) of the persistent NT GEMM -- kernels launched on streams that
+ * may run concurrently must use different sets (the engine sets 1 around the teacher's side-stream section). */
 int a2v_debug_set(int key, int value);
 
 /* library version / build info */
