@@ -60,7 +60,26 @@ def build(force: bool = False, verbose: bool = True) -> str:
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             raise RuntimeError(f"link failed:\n{r.stderr}")
+    build_abi_client(force=force or bool(jobs), verbose=verbose)
     return LIB
+
+
+def build_abi_client(force: bool = False, verbose: bool = True) -> str:
+    """tests/abi_client: a torch-free C++ program against include/a2v.h + liba2v_hip.so (run by the GPU tests)."""
+    root = os.path.dirname(HERE)
+    src = os.path.join(root, "tests", "abi_client", "abi_client.cpp")
+    out = os.path.join(root, "tests", "abi_client", "abi_client.bin")
+    if not os.path.exists(src):
+        return ""
+    if force or _stale(out, [src, os.path.join(root, "include", "a2v.h"), LIB]):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(root, "include"), src, "-o", out,
+               "-L", HERE, "-la2v_hip", "-Wl,-rpath,$ORIGIN/../../animal2vec_amd"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(f"abi client build failed:\n{r.stderr}")
+    return out
 
 
 if __name__ == "__main__":

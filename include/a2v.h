@@ -14,7 +14,10 @@
  *  - activations are channels-last: (batch, time, channels) row-major.
  *  - ownership: the caller owns every buffer (incl. workspaces and tensors saved for backward);
  *    kernels never allocate, free or retain pointers.
- *  - every call is asynchronous on `stream`, re-entrant and graph-capturable (no sync, no alloc).
+ *  - every call is asynchronous on `stream` and graph-capturable (no sync, no alloc).  Calls on ONE stream may be
+ *    issued back to back freely.  Two library-owned device scratch areas make concurrent use from several streams
+ *    conditional: the persistent NT GEMM's tile counters (pick a different set per stream, a2v_debug_set(9, slot))
+ *    and the d alibi_scale partial sums of a2v_attention_bwd (do not overlap two attention backward launches).
  *  - return value: 0 on success, <0 on error (-1 bad argument, -2 bad dtype, -(1000+hipError_t) on a
  *    launch failure).  No exceptions cross the ABI.
  */
