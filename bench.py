@@ -91,9 +91,44 @@ class GemmRecorder:
             return r
 
         ops.conv_gemm, ops.conv_wgrad = cg, wg
+        # HBM-bound families: algorithmic bytes = every tensor element the call must read or write, once
+        self._hbm_orig = {}
+        self.hbm = []
+
+        def timed(name, nbytes_of):
+            orig = getattr(ops, name)
+            rec._hbm_orig[name] = orig
+
+            def f(*a, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = orig(*a, **kw)
+                e1.record()
+                rec.hbm.append((name, float(nbytes_of(a, kw, r)), e0, e1))
+                return r
+            setattr(ops, name, f)
+
+        nb = lambda t: 0 if t is None else t.numel() * t.element_size()
+        timed("layernorm_fwd", lambda a, kw, r: nb(a[0]) * (2 + (kw.get("res") is not None) + (kw.get("sum_out") is not None)
+                                                            + (kw.get("post") is not None)))
+        timed("layernorm_bwd", lambda a, kw, r: nb(a[0]) * (3 + (2 if kw.get("drop_mode", 0) == 2 and kw.get("drop") else 0)))
+        timed("sinc_fused_fwd", lambda a, kw, r: nb(a[0]) + nb(r[0]))
+        timed("sinc_fused_bwd", lambda a, kw, r: nb(a[0]) + nb(a[6]))
 
     def unwrap(self, ops):
         ops.conv_gemm, ops.conv_wgrad = self._cg, self._wg
+        for name, orig in self._hbm_orig.items():
+            setattr(ops, name, orig)
+
+    def hbm_summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name in sorted({h[0] for h in self.hbm}):
+            rs = [(b, e0.elapsed_time(e1)) for n_, b, e0, e1 in self.hbm if n_ == name]
+            by, ms = sum(b for b, _ in rs), sum(t for _, t in rs)
+            out[name] = dict(launches=len(rs), avg_us=round(1e3 * ms / len(rs), 2), achieved_GBps=round(by / ms / 1e6, 1),
+                             frac_of_8TBps=round(by / ms / 1e6 / 8000.0, 3))
+        return out
 
     def table(self):
         torch.cuda.synchronize()
@@ -250,6 +285,7 @@ def main():
                                        torch.zeros(args.micro_batch * cfg.clone_batch, cfg.frame_counts(L)[-1] - K,
                                                    cfg.embed_dim, device=dev))
             s = rec.summary()
+            hbm = rec.hbm_summary()
             if args.gemm_table:
                 with open(args.gemm_table, "w") as f:
                     json.dump(rec.table(), f, indent=0)
@@ -263,7 +299,9 @@ def main():
                     traffic_source=traffic_src, algorithmic_bytes_per_launch=round(nt["alg_bytes"]),
                     launches_per_microbatch=nt["launches"], avg_launch_us=round(nt["avg_us"], 2),
                     wgrad_kernel=dict(tflops=round(s["tn"]["tflops"], 2), launches=s["tn"]["launches"],
-                                      avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None)
+                                      avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None,
+                    # the HBM-bound families of the same micro-batch (algorithmic bytes / HIP-event time, peak 8 TB/s)
+                    hbm_kernels=hbm)
     if use_dist:
         dist.barrier()
 
