@@ -40,8 +40,8 @@ class Engine:
         c0 = self.layers[0][0]
         k0 = self.layers[0][1]
         self.dfilt = torch.zeros(c0, k0, dtype=torch.float32, device=dev)
-        # A2V_TEACHER_STREAM=1: run the EMA teacher's forward on a side stream, concurrently with the student's forward
-        self.tstream = torch.cuda.Stream(dev) if (os.environ.get("A2V_TEACHER_STREAM", "0") == "1" and dev.type == "cuda") else None
+        # the EMA teacher's forward runs on a side stream, concurrently with the student's forward (A2V_TEACHER_STREAM=0: off)
+        self.tstream = torch.cuda.Stream(dev) if (os.environ.get("A2V_TEACHER_STREAM", "1") == "1" and dev.type == "cuda") else None
         self.sinc_cp = ops.sinc_out_channels(c0, k0)      # channel pitch of the SincConv output (128, or 320 for the blocked kernels)
         self.dpar = torch.zeros(4, self.sinc_cp, dtype=torch.float32, device=dev)
 
