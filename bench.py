@@ -279,6 +279,7 @@ def main():
     if not args.no_roofline and rank == 0:
         rec = GemmRecorder()
         rec.wrap(ops)
+        side, tr.engine.tstream = tr.engine.tstream, None     # per-kernel timing: one stream, nothing overlapping the timed launches
         try:
             tr.engine.stats.zero_()
             tr.engine.forward_backward(mbs[0]["source"], mbs[0]["mask_u8"], mbs[0]["ids_keep"], mbs[0]["ids_restore"],
@@ -291,6 +292,7 @@ def main():
                     json.dump(rec.table(), f, indent=0)
         finally:
             rec.unwrap(ops)
+            tr.engine.tstream = side
         nt = s["nt"]
         traffic, traffic_src = pmc_traffic("gemm_nt_bf16_p8_kernel") if dtype == torch.bfloat16 else (None, None)
         roof = dict(bound="mfma", kernel="gemm_nt_bf16_p8_kernel<*> + conv_nt_slab_kernel (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
