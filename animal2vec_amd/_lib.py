@@ -53,7 +53,7 @@ SIGNATURES = {
     "a2v_col2im": [_i, _p, _p, _i, _i, _i, _i, _i, _i, _i, _ll, _ll, _p],
     "a2v_cast2d": [_i, _i, _p, _p, _ll, _i, _ll, _ll, _p],
     "a2v_mixup_gain": [_p, _p, _p, _p, _i, _i, _i, _i, _f, _p],
-    "a2v_mixup_apply": [_p, _p, _p, _p, _i, _i, _i, _f, _p],
+    "a2v_mixup_apply": [_p, _p, _p, _p, _i, _i, _i, _f, _p, _p],
     "a2v_dropout_mask": [_p, _ll, _f, _u, _p],
     "a2v_dropout_mask2d": [_p, _ll, _i, _f, _u, _p],
     "a2v_debug_set": [_i, _i],

@@ -46,9 +46,19 @@ __global__ __launch_bounds__(256) void mixup_gain_kernel(const float* __restrict
 
 __global__ __launch_bounds__(256) void mixup_apply_kernel(const float* __restrict__ x, const int* __restrict__ perm,
                                                           const float* __restrict__ gain_db, float* __restrict__ out,
-                                                          int B, int L, int nframes, float r) {
+                                                          int B, int L, int nframes, float r,
+                                                          const unsigned char* __restrict__ mix_mask) {
   __shared__ float sp[2];
   const int b = blockIdx.y;
+  if (mix_mask && !mix_mask[b]) {          // mixup_prob < 1: this clip stays as it is (data2vec2.py:540-547,584-589)
+    const float* s1 = x + (long long)b * L;
+    float* o = out + (long long)b * L;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4; i < L; i += gridDim.x * blockDim.x * 4) {
+      if (i + 3 < L) *(f32x4*)(o + i) = *(const f32x4*)(s1 + i);
+      else for (int j = i; j < L; ++j) o[j] = s1[j];
+    }
+    return;
+  }
   const int b2 = perm[b];
   if (threadIdx.x < 64) {           // wave 0: max over frames of both clips
     float g1 = -INFINITY, g2 = -INFINITY;
@@ -92,11 +102,11 @@ extern "C" int a2v_mixup_gain(const float* x, const float* window, const float* 
 
 // out may not alias x (clips read their mixing partner).  L % 4 == 0 and 16-B aligned rows give vector access.
 extern "C" int a2v_mixup_apply(const float* x, const int* perm, const float* gain_db, float* out, int B, int L, int nframes,
-                               float r, hipStream_t st) {
+                               float r, const unsigned char* mix_mask, hipStream_t st) {
   if (B <= 0 || L <= 0 || nframes <= 0 || !(r > 0.f && r <= 1.f) || x == out || (L & 3)) return A2V_ERR_ARG;
   int gx = (L / 4 + 255) / 256;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(mixup_apply_kernel, dim3(gx, B), dim3(256), 0, st, x, perm, gain_db, out, B, L, nframes, r);
+  hipLaunchKernelGGL(mixup_apply_kernel, dim3(gx, B), dim3(256), 0, st, x, perm, gain_db, out, B, L, nframes, r, mix_mask);
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }

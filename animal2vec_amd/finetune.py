@@ -103,7 +103,7 @@ class FinetuneConfig:
     layer_decay: float = 1.0               # wav2vec2.py:214-236
     target_mixup: bool = True
     source_mixup: float = 0.5
-    mixup_prob: float = 1.0                # only 1.0 (every clip mixed) is implemented, as shipped
+    mixup_prob: float = 1.0                # < 1: bernoulli per clip (wav2vec2.py:366-373)
     same_mixup: bool = True
     mixing_window_length: float = 0.05
     # The wrapped pretraining model keeps ITS OWN source_mixup / mixup_prob (they are not in arg_overrides,
@@ -201,7 +201,6 @@ class FinetuneTrainer:
         self._perm_gen.manual_seed(seed * 7919 + 29 + self.rank)
         self.mixup = ops.Mixup(model_cfg.audio.sample_rate, self.fcfg.mixing_window_length, dev) \
             if self.fcfg.source_mixup >= 0 and self.fcfg.mixup_prob > 0 else None
-        assert self.fcfg.mixup_prob in (0.0, 1.0), "partial mixup (mixup_prob < 1) is not on the shipped configs' path"
         # trainable slice of the flat buffer: transformer blocks .. project_features (the decoder is removed and the
         # conv feature extractor frozen, wav2vec2.py:176, finetune_mixup_100.yaml:85)
         by = self.store.by_name
@@ -255,13 +254,20 @@ class FinetuneTrainer:
         B = src.shape[0]
         r = float(self.rng.uniform(max(1e-6, f.source_mixup), 1.0))
         perm = torch.rand(B, device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
-        src = self.mixup(src, perm, r)
+        mm = None
+        if f.mixup_prob < 1:                  # bernoulli(mixup_prob) per clip (wav2vec2.py:366-373)
+            mm = (torch.rand(B, device=src.device, generator=self._perm_gen) < f.mixup_prob).to(torch.uint8)
+        src = self.mixup(src, perm, r, mm)
         if f.target_mixup:
-            tgt = tgt * r + (1 - r) * tgt[perm.long()]
+            mixed_t = tgt * r + (1 - r) * tgt[perm.long()]
+            tgt = mixed_t if mm is None else torch.where(mm.bool().view(-1, 1, 1), mixed_t, tgt)
         if f.inner_source_mixup and self.cfg.source_mixup >= 0 and self.cfg.mixup_prob > 0:
             r2 = float(self.rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
             perm2 = torch.rand(B, device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
-            src = self.mixup(src, perm2, r2)
+            mm2 = None
+            if self.cfg.mixup_prob < 1:
+                mm2 = (torch.rand(B, device=src.device, generator=self._perm_gen) < self.cfg.mixup_prob).to(torch.uint8)
+            src = self.mixup(src, perm2, r2, mm2)
         return src, tgt
 
     def train_step(self, micro_batches: Sequence[dict]) -> None:

@@ -400,11 +400,14 @@ class Mixup:
         check(rc, "a2v_mixup_gain")
         return g
 
-    def __call__(self, x, perm, r: float):
-        """x (B,L) fp32, perm (B) int32 device tensor, r in (0,1] -> mixed (B,L)"""
+    def __call__(self, x, perm, r: float, mix_mask=None):
+        """x (B,L) fp32, perm (B) int32 device tensor, r in (0,1] -> mixed (B,L); mix_mask (B) uint8: only those clips
+        are mixed (mixup_prob < 1), None = all"""
         g = self.gain_db(x)
         out = torch.empty_like(x)
-        rc = _L().a2v_mixup_apply(ptr(x), ptr(perm), ptr(g), ptr(out), x.shape[0], x.shape[1], g.shape[1], float(r), stream())
+        assert mix_mask is None or (mix_mask.dtype == torch.uint8 and mix_mask.numel() == x.shape[0])
+        rc = _L().a2v_mixup_apply(ptr(x), ptr(perm), ptr(g), ptr(out), x.shape[0], x.shape[1], g.shape[1], float(r),
+                                  ptr(mix_mask), stream())
         check(rc, "a2v_mixup_apply")
         return out
 

@@ -112,7 +112,10 @@ class PretrainTrainer:
             if self.mixup is not None:        # BC-learning mixup, train only (data2vec2.py:536-598)
                 r = float(self._np_rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
                 perm = torch.rand(src.shape[0], device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
-                src = self.mixup(src, perm, r)
+                mm = None
+                if self.cfg.mixup_prob < 1:            # bernoulli(mixup_prob) per clip (data2vec2.py:540-545)
+                    mm = (torch.rand(src.shape[0], device=src.device, generator=self._perm_gen) < self.cfg.mixup_prob).to(torch.uint8)
+                src = self.mixup(src, perm, r, mm)
             eng.forward_backward(src, mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise, dropout_seed=dseed)
         self.sync.arm(False)
         D = self.cfg.embed_dim

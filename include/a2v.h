@@ -179,8 +179,10 @@ int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsigned char* 
  * mixup block (:536-598, same_mixup, mixup_prob 1): out[b] = (p x[b] + (1-p) x[perm[b]]) / sqrt(p^2+(1-p)^2). */
 int a2v_mixup_gain(const float* x, const float* window, const float* aweight, float* gain_db, int B, int L, int n_fft,
                    int hop, float floor_, a2v_stream_t stream);
+/* mix_mask (B) uint8 or NULL: with mixup_prob < 1 only the clips whose byte is set are mixed (with x[perm[b]]), the
+ * others are copied through (data2vec2.py:540-547,584-589). */
 int a2v_mixup_apply(const float* x, const int* perm, const float* gain_db, float* out, int B, int L, int nframes,
-                    float r, a2v_stream_t stream);
+                    float r, const unsigned char* mix_mask, a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- optimizer side
  * EMA teacher: fairseq EMAModule.step driven from data2vec2.py:386-410, flat fp32 buffers. */

@@ -787,6 +787,24 @@ def test_mixup_golden(ops):
     assert rel_err(out, mx["mixed"]) < 1e-4
 
 
+def test_mixup_partial(ops):
+    """mixup_prob < 1 (data2vec2.py:540-547,584-589): only the flagged clips are mixed -- each with x[perm[b]], gains
+    taken over the whole batch -- the others pass through unchanged."""
+    g = torch.Generator().manual_seed(4)
+    B, L = 6, 8000
+    x = torch.nn.functional.layer_norm(torch.randn(B, L, generator=g), (L,)) * (0.5 + torch.rand(B, 1, generator=g))
+    perm = torch.randperm(B, generator=g)
+    mm = torch.tensor([1, 0, 1, 1, 0, 1], dtype=torch.uint8)
+    r = 0.7
+    ref_all = O.bc_mixup(x, perm, r)
+    ref = torch.where(mm.bool().view(-1, 1), ref_all, x)
+    m = ops.Mixup(8000, 0.05, "cuda")
+    out = m(x.cuda(), perm.int().cuda(), r, mm.cuda())
+    assert rel_err(out, ref) < 1e-4
+    assert torch.equal(out[1].cpu(), x[1]) and torch.equal(out[4].cpu(), x[4])
+    assert rel_err(m(x.cuda(), perm.int().cuda(), r), ref_all) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_mask_frames(ops, dtype):
     """apply_mask (base.py:457-485): replaced frames ~ N(0, std), zeroed channels, untouched elsewhere; the backward
