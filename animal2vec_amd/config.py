@@ -85,6 +85,7 @@ class Data2VecMultiConfig:
     clone_batch: int = 12
     encoder_dropout: float = 0.1
     post_mlp_drop: float = 0.1
+    dropout_input: float = 0.0             # data2vec2.py:273,646-647: on the encoder input of the main blocks
     attention_dropout: float = 0.1
     average_top_k_layers: int = 16
     instance_norm_target_layer: bool = True

@@ -342,6 +342,7 @@ class Engine:
                                                       pos-conv, which therefore sees the masked input (base.py:268-298)
           noise_std, noise_seed (device hash noise) or replacement ((num_masked, D) explicit rows, for reproducibility)
           active: list of bool, prenet blocks then main blocks -- layerdrop outcome (modules.py:89-94, data2vec2.py:651-655)
+          p_in / p_final                                   -- dropout_input (before the main blocks), final_dropout (before the head)
           drop_seed (int or None), p_drop / p_act / p_att  -- cfg.dropout (prenet, proj, post-mlp), activation_dropout
                                                       (the Mlp's two dropouts), attention_dropout (wav2vec2.py:94-128)"""
         cfg, st, sp = self.cfg, self.store, self.sp
@@ -382,6 +383,13 @@ class Engine:
             if active[i]:
                 x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, None, asc, H, save=f"fpb{i}" if save else None,
                                       drop_base=db, site=i, dp=dp)
+        d_in = d_fin = None
+        if aug is not None and db is not None:
+            if aug.get("p_in", 0.0) > 0:
+                d_in = (aug["p_in"], self._site(db, 9002))
+                x = ops.add_drop(None, x, drop=d_in)          # dropout_input (data2vec2.py:646-647)
+            if aug.get("p_final", 0.0) > 0:
+                d_fin = (aug["p_final"], self._site(db, 9003))
         ts = []
         for i in range(cfg.depth):
             if active[a.prenet_depth + i]:
@@ -391,10 +399,12 @@ class Engine:
         sel = ts[-top_k:]
         assert sel, "layerdrop removed every block"
         xm = ops.mean_layers([t for _, t in sel]).view(B * T, D)
+        if d_fin is not None:
+            xm = ops.add_drop(None, xm, drop=d_fin)                             # final_dropout (wav2vec2.py:467)
         logits = ops.linear(xm, head.w_op, head.b_op)                           # (B*T, Cp), Cp = classes padded to 16
         if save:
             self.sv["ft"] = dict(xm=xm, tok=tok, st=(m0, r0), B=B, T=T, sel=[i for i, _ in sel], active=active, masks=masks,
-                                 d_pre=d_pre)
+                                 d_pre=d_pre, d_in=d_in, d_fin=d_fin)
         return logits
 
     def finetune_backward(self, dlog, head, *, head_only=False):
@@ -416,6 +426,8 @@ class Engine:
             self.sv.clear()
             return
         dxm = ops.linear(dlog, head.wt_op)                                       # (B*T, D)
+        if c.get("d_fin") is not None:
+            dxm = ops.add_drop(None, dxm, drop=c["d_fin"])
         sel, active = c["sel"], c["active"]
         dt = ops.mean_layers([dxm], scale=1.0 / len(sel)).view(B, T, D)
         # ---- blocks: the last executed block's output x feeds nothing; every selected block receives dt at its FFN output
@@ -424,6 +436,8 @@ class Engine:
             if active[a.prenet_depth + i]:
                 dxe = self.block_bwd(dxe, f"blocks.{i}.", None, asc, H, f"fmb{i}", dt=dt if i in sel else None)
             self._ready(f"block{i}")
+        if c.get("d_in") is not None:
+            dxe = ops.add_drop(None, dxe.contiguous(), drop=c["d_in"])
         for i in reversed(range(a.prenet_depth)):
             if active[i]:
                 dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", None, asc, H, f"fpb{i}")
@@ -588,6 +602,9 @@ class Engine:
                                   save=f"pb{i}" if save else None, drop_base=db, site=i)
         if keep_debug:
             dbg["prenet_out"] = x
+        d_in = (cfg.dropout_input, self._site(db, 9002)) if db is not None and cfg.dropout_input > 0 else None
+        if d_in is not None:                               # data2vec2.py:646-647
+            x = ops.add_drop(None, x, drop=d_in)
         for i in range(cfg.depth):
             x, _ = self.block_fwd(x, f"blocks.{i}.", sp, p, ids_keep, asc, H, save=f"mb{i}" if save else None,
                                   drop_base=db, site=a.prenet_depth + i)
@@ -605,7 +622,7 @@ class Engine:
                        loss_rows=loss_rows)
         if save:
             self.sv["ctx"] = dict(dx=dx, mask_u8=mask_u8, ids_keep=ids_keep, ids_restore=ids_restore, T=T, d_pre=d_pre,
-                                  d_dec=d_dec, rows=rows)
+                                  d_dec=d_dec, rows=rows, d_in=d_in)
         return dbg
 
     def backward(self, gscale: float = 1.0):
@@ -624,6 +641,8 @@ class Engine:
         for i in reversed(range(cfg.depth)):
             dxe = self.block_bwd(dxe, f"blocks.{i}.", ids_keep, asc, H, f"mb{i}")
             self._ready(f"block{i}")
+        if c.get("d_in") is not None:
+            dxe = ops.add_drop(None, dxe.contiguous(), drop=c["d_in"])
         for i in reversed(range(a.prenet_depth)):
             dxe = self.block_bwd(dxe, P + f"context_encoder.blocks.{i}.", ids_keep, asc, H, f"pb{i}")
             self._ready(f"prenet{i}")

@@ -98,6 +98,8 @@ class FinetuneConfig:
     dropout: float = 0.1                   # -> encoder_dropout, prenet_dropout, post_mlp_drop (wav2vec2.py:116-126)
     activation_dropout: float = 0.1
     attention_dropout: float = 0.2
+    dropout_input: float = 0.0
+    final_dropout: float = 0.0
     layerdrop: float = 0.1                 # -> layerdrop and prenet_layerdrop
     freeze_finetune_updates: int = 10000
     layer_decay: float = 1.0               # wav2vec2.py:214-236
@@ -167,9 +169,10 @@ def make_aug(fcfg: FinetuneConfig, B: int, T: int, D: int, n_prenet: int, n_bloc
     aug["active"] = [bool(fcfg.layerdrop == 0 or rng.random() > fcfg.layerdrop) for _ in range(n_blocks)]
     if not any(aug["active"][n_prenet:]):          # the reference divides by zero layer results here; keep one block
         aug["active"][-1] = True
-    if train_dropout and (fcfg.dropout > 0 or fcfg.activation_dropout > 0 or fcfg.attention_dropout > 0):
+    if train_dropout and max(fcfg.dropout, fcfg.activation_dropout, fcfg.attention_dropout, fcfg.dropout_input,
+                             fcfg.final_dropout) > 0:
         aug.update(drop_seed=int(rng.integers(0, 2 ** 31)), p_drop=fcfg.dropout, p_act=fcfg.activation_dropout,
-                   p_att=fcfg.attention_dropout)
+                   p_att=fcfg.attention_dropout, p_in=fcfg.dropout_input, p_final=fcfg.final_dropout)
     return aug
 
 

@@ -173,6 +173,7 @@ def test_dropout_gradients_by_finite_differences(tiny_golden):
     fx = tiny_golden
     p, ema, _ = split_golden(fx)
     cfg = tiny_config()
+    cfg.dropout_input = 0.15             # 0.0 in the shipped YAML; exercised here (data2vec2.py:646-647)
     store, eng = build(cfg, p, ema, torch.float32)
     m, keep, restore = make_maskinfo(fx["mask"].cuda())
     src, noise = fx["source"].cuda(), fx["noise"].cuda()
@@ -427,7 +428,7 @@ def test_finetune_train_form_dropout_by_finite_differences(tiny_golden):
     head.load(ft["head_w"].cuda(), ft["head_b"].cuda())
     src, tgt = ft["source"].cuda(), ft["target"].cuda()
     aug = dict(mask_t=ft["mask_t"].cuda(), mask_c=ft["mask_c"].cuda(), noise_std=0.5, noise_seed=77,
-               active=[True, True, True], drop_seed=991, p_drop=0.1, p_act=0.1, p_att=0.2)
+               active=[True, True, True], drop_seed=991, p_drop=0.1, p_act=0.1, p_att=0.2, p_in=0.15, p_final=0.1)
 
     def loss():
         eng.sp.refresh()
