@@ -442,15 +442,44 @@ def sigmoid_focal_loss(inputs, targets, alpha: float = 0.25, gamma: float = 2, r
     return loss.mean() if reduction == "mean" else (loss.sum() if reduction == "sum" else loss)
 
 
+def label_smoothed_nll_loss(lprobs, target, epsilon: float, ignore_index=None, reduce=True):
+    """fairseq.criterions.label_smoothed_cross_entropy.label_smoothed_nll_loss (third party, restated): lprobs (M, C)
+    log-probabilities, target (M,) class indices; eps_i = eps / (C - 1); loss = (1 - eps - eps_i) nll + eps_i smooth."""
+    if target.dim() == lprobs.dim() - 1:
+        target = target.unsqueeze(-1)
+    nll = -lprobs.gather(dim=-1, index=target)
+    smooth = -lprobs.sum(dim=-1, keepdim=True)
+    if ignore_index is not None:
+        pad = target.eq(ignore_index)
+        nll = nll.masked_fill(pad, 0.0)
+        smooth = smooth.masked_fill(pad, 0.0)
+    else:
+        nll, smooth = nll.squeeze(-1), smooth.squeeze(-1)
+    if reduce:
+        nll, smooth = nll.sum(), smooth.sum()
+    eps_i = epsilon / (lprobs.size(-1) - 1)
+    return (1.0 - epsilon - eps_i) * nll + eps_i * smooth, nll
+
+
+def confusion(preds, target):
+    """tp, fp, tn, fn counts of binary predictions against binary targets (nn/utils.py confusion, as logged by
+    criterions.py:219-231)"""
+    p, t = preds.bool(), target.bool()
+    return (int((p & t).sum()), int((p & ~t).sum()), int((~p & ~t).sum()), int((~p & t).sum()))
+
+
 @register_criterion("finetunecriterion")
 class FinetuneCrossEntropyCriterion:
-    """The focal-loss branch of the reference criterion (criterions.py:137-277, use_focal_loss: true in every shipped
-    finetune config): loss = sum of sigmoid_focal_loss(logits, target); sample_size = ntokens (sentence_avg false)."""
+    """The reference criterion (criterions.py:137-277) on the autograd surface: with use_focal_loss (every shipped
+    finetune config) loss = sum of sigmoid_focal_loss(logits, multi-hot target); otherwise fairseq's label-smoothed
+    cross entropy over single-label targets.  sample_size = ntokens (sentence_avg false).  With report_accuracy the
+    logging output carries accuracy and confusion counts at metric_threshold (segment-level scores are evaluation
+    tooling and not rebuilt)."""
 
-    def __init__(self, task=None, use_focal_loss=True, sentence_avg=False, metric_threshold=0.5, report_accuracy=False):
-        if not use_focal_loss:
-            raise NotImplementedError("label-smoothed cross entropy branch (single-label) is not on the shipped configs' path")
+    def __init__(self, task=None, use_focal_loss=True, sentence_avg=False, metric_threshold=0.5, report_accuracy=False,
+                 label_smoothing=0.0, padding_idx=None):
         self.task, self.sentence_avg, self.metric_threshold, self.report_accuracy = task, sentence_avg, metric_threshold, report_accuracy
+        self.use_focal_loss, self.eps, self.padding_idx = use_focal_loss, label_smoothing, padding_idx
 
     def __call__(self, model, sample, reduce=True):
         return self.forward(model, sample, reduce)
@@ -459,12 +488,30 @@ class FinetuneCrossEntropyCriterion:
         net_output = model(**sample["net_input"])
         logits = model.get_logits(net_output)
         target = model.get_targets(sample, net_output).to(logits.device)
-        loss = sigmoid_focal_loss(logits, target, reduction="sum" if reduce else "none")
+        if self.use_focal_loss:
+            loss = sigmoid_focal_loss(logits, target, reduction="sum" if reduce else "none")
+            nll_loss = torch.tensor(0.0)
+        else:
+            lprobs = torch.log_softmax(logits.float(), dim=-1)
+            loss, nll_loss = label_smoothed_nll_loss(lprobs, target.reshape(-1).long(), self.eps, ignore_index=self.padding_idx,
+                                                     reduce=reduce)
         sample_size = sample["target"].size(0) if self.sentence_avg else sample.get("ntokens", target.shape[0])
-        logging_output = {"loss": loss.data, "nll_loss": torch.tensor(0.0), "ntokens": sample.get("ntokens", target.shape[0]),
+        logging_output = {"loss": loss.data, "nll_loss": nll_loss.data, "ntokens": sample.get("ntokens", target.shape[0]),
                           "nsentences": sample["target"].size(0), "sample_size": sample_size}
         if self.report_accuracy:
-            preds = (torch.sigmoid(logits) >= self.metric_threshold).to(target.dtype)
-            logging_output["finetune/n_correct"] = float((preds == (target >= 0.5).to(target.dtype)).sum())
-            logging_output["finetune/total"] = float(target.numel())
+            with torch.no_grad():
+                if self.use_focal_loss:
+                    preds = (torch.sigmoid(logits) >= self.metric_threshold)
+                    tgt = target >= 0.5
+                    logging_output["finetune/n_correct"] = float((preds == tgt).sum())
+                    logging_output["finetune/total"] = float(target.numel())
+                else:
+                    t1 = target.reshape(-1).long()
+                    keep = t1.ne(self.padding_idx) if self.padding_idx is not None else torch.ones_like(t1, dtype=torch.bool)
+                    logging_output["finetune/n_correct"] = float((logits.argmax(-1)[keep] == t1[keep]).sum())
+                    logging_output["finetune/total"] = float(keep.sum())
+                    preds = torch.softmax(logits.float(), -1) >= self.metric_threshold
+                    tgt = torch.nn.functional.one_hot(t1, logits.size(-1)).bool()
+                tp, fp, tn, fn = confusion(preds, tgt)
+                logging_output.update({"finetune/tp": tp, "finetune/fp": fp, "finetune/tn": tn, "finetune/fn": fn})
         return loss, sample_size, logging_output

@@ -265,3 +265,36 @@ def test_checkpoint_with_foreign_config_objects(tmp_path):
     got = ck.load_checkpoint(path)
     assert torch.equal(got["model"]["blocks.0.norm1.weight"], torch.arange(4.0))
     assert ck.config_to_dict(got["cfg"]) == {"model": {"_name": "data2vec_multi", "depth": 16}}
+
+
+def test_finetune_criterion_label_smoothed_branch():
+    """criterions.py:245-247 with use_focal_loss false: fairseq's label-smoothed NLL (eps_i = eps / (C - 1)), accuracy
+    and confusion counts, on a stand-in model (the criterion only needs get_logits / get_targets)."""
+    import torch
+    from animal2vec_amd.finetune import FinetuneCrossEntropyCriterion, label_smoothed_nll_loss
+
+    class M:
+        def __call__(self, source):
+            return {"encoder_out": source, "target": None}
+
+        def get_logits(self, out, reshape=True):
+            return out["encoder_out"].reshape(-1, out["encoder_out"].size(-1))
+
+        def get_targets(self, sample, out, reshape=True):
+            return sample["target"].reshape(-1)
+
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(2, 7, 5, generator=g, requires_grad=True)
+    target = torch.randint(0, 5, (2, 7), generator=g)
+    crit = FinetuneCrossEntropyCriterion(use_focal_loss=False, label_smoothing=0.1, report_accuracy=True)
+    loss, n, log = crit(M(), {"net_input": {"source": logits}, "target": target, "ntokens": 14})
+    lp = torch.log_softmax(logits.detach().reshape(-1, 5), -1)
+    nll = -lp[torch.arange(14), target.reshape(-1)].sum()
+    smooth = -lp.sum()
+    assert float(loss) == pytest.approx(float((1 - 0.1 - 0.1 / 4) * nll + 0.1 / 4 * smooth), rel=1e-6)
+    assert float(log["nll_loss"]) == pytest.approx(float(nll), rel=1e-6) and n == 14
+    loss.backward()
+    assert logits.grad is not None and float(logits.grad.abs().sum()) > 0
+    assert log["finetune/total"] == 14 and log["finetune/tp"] + log["finetune/fn"] == 14
+    l0, _ = label_smoothed_nll_loss(lp, target.reshape(-1), 0.0)
+    assert float(l0) == pytest.approx(float(nll), rel=1e-6)
