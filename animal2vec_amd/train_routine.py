@@ -74,6 +74,8 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
         tr.engine.refresh_student_packs()
         tr.engine.refresh_teacher_packs()
         tr.num_updates = int(state.get("optimizer_history", [{}])[-1].get("num_updates", 0))
+        if isinstance(state.get("last_optimizer_state"), dict) and "adam_m" in state["last_optimizer_state"]:
+            tr.load_optimizer_state(state["last_optimizer_state"])          # exact resume (moments, counters, RNG)
     rng = __import__("numpy").random.default_rng(cfg.seed + rank)
     real = None
     for u in range(updates):
@@ -105,7 +107,8 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
             log({"num_updates": tr.num_updates, "wall_s": round(time.perf_counter() - t0, 3), **{k: round(v, 5) for k, v in met.items()}})
     if save_path and rank == 0:
         from . import checkpoint as ck
-        ck.save_checkpoint(save_path, tr.store, cfg={"model": {"_name": "data2vec_multi"}}, num_updates=tr.num_updates)
+        ck.save_checkpoint(save_path, tr.store, cfg={"model": {"_name": "data2vec_multi"}}, num_updates=tr.num_updates,
+                           optimizer_state=tr.optimizer_state())
     return tr
 
 

@@ -137,6 +137,26 @@ class PretrainTrainer:
             eng.refresh_teacher_packs()
         self.last = dict(stats=eng.stats, gnorm=gnorm)
 
+    # ------------------------------------------------------------------ exact resume
+    def optimizer_state(self) -> dict:
+        """What fairseq keeps under "last_optimizer_state" (Adam moments, step count) plus this trainer's own counters;
+        written by checkpoint.save_checkpoint(optimizer_state=...)."""
+        st = self.store
+        return {"adam_m": st.adam_m.detach().cpu(), "adam_v": st.adam_v.detach().cpu(), "num_updates": self.num_updates,
+                "ema_decay": self.ema_decay, "perm_rng": self._perm_gen.get_state().cpu(),
+                "np_rng": self._np_rng.bit_generator.state}
+
+    def load_optimizer_state(self, state: dict) -> None:
+        st = self.store
+        st.adam_m.copy_(state["adam_m"].to(st.device))
+        st.adam_v.copy_(state["adam_v"].to(st.device))
+        self.num_updates = int(state["num_updates"])
+        self.ema_decay = float(state.get("ema_decay", self.ema_decay))
+        if "perm_rng" in state:
+            self._perm_gen.set_state(state["perm_rng"].cpu())
+        if "np_rng" in state:
+            self._np_rng.bit_generator.state = state["np_rng"]
+
     # ------------------------------------------------------------------ logging-side scalars (sync)
     def metrics(self) -> Dict[str, float]:
         """loss / sample_size, pred_var, target_var (data2vec2.py:956-970,1095-1110) -- host sync."""

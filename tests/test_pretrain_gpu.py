@@ -753,3 +753,43 @@ def test_training_loop_learns(dtype):
     assert pvar[-1] > 0.01
     assert float((tr.store.teacher - teacher0).abs().max()) > 0
     assert tr.num_updates == 40
+
+
+def test_exact_resume_from_checkpoint(tmp_path):
+    """Stop after two updates, write the fairseq-style checkpoint with the optimizer state, resume in a fresh trainer and
+    take two more: same parameters / teacher as four updates in one go (dropout seeds derive from num_updates, the mixup
+    generators are restored), up to the atomics' summation order."""
+    from animal2vec_amd import checkpoint as ck
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.masking import make_maskinfo, seeded_keep_mask
+    from animal2vec_amd.trainer import OptimConfig, PretrainTrainer
+    cfg = tiny_config()
+    oc = OptimConfig(lr=1e-3, warmup_updates=2, max_update=20)
+    L = 3200
+    T = cfg.frame_counts(L)[-1]
+    g = torch.Generator().manual_seed(2)
+    src = torch.randn(4, L, generator=g).cuda()
+    m, keep, restore = make_maskinfo(seeded_keep_mask(4 * cfg.clone_batch, T, T // 4, 5, device="cuda"))
+    noise = torch.randn(4 * cfg.clone_batch, T - T // 4, cfg.embed_dim, generator=g).cuda() * 0.01
+    mbs = [dict(source=src, mask_u8=m, ids_keep=keep, ids_restore=restore, noise=noise)]
+    a = PretrainTrainer(cfg, oc, dtype=torch.float32, seed=4)
+    for _ in range(4):
+        a.train_step(mbs)
+    b = PretrainTrainer(cfg, oc, dtype=torch.float32, seed=4)
+    for _ in range(2):
+        b.train_step(mbs)
+    path = tmp_path / "checkpoint_2.pt"
+    ck.save_checkpoint(path, b.store, num_updates=b.num_updates, optimizer_state=b.optimizer_state())
+    c = PretrainTrainer(cfg, oc, dtype=torch.float32, seed=99)          # different init: everything must come from the file
+    state = ck.load_checkpoint(path)
+    ck.load_pretrained(c.store, state)
+    c.engine.refresh_student_packs()
+    c.engine.refresh_teacher_packs()
+    c.load_optimizer_state(state["last_optimizer_state"])
+    assert c.num_updates == 2
+    for _ in range(2):
+        c.train_step(mbs)
+    torch.cuda.synchronize()
+    assert float((a.store.flat - c.store.flat).abs().max()) < 5e-6
+    assert float((a.store.teacher - c.store.teacher).abs().max()) < 5e-6
+    assert float((a.store.adam_v - c.store.adam_v).abs().max()) < 1e-6
