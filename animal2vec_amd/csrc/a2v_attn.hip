@@ -900,9 +900,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
   const float asc = a.alibi_scale[h];
   const float coef = -slope * fmaxf(asc, 0.f);
 
-  // ---- stage Q and dO (zero padded), delta, lse, pos
+  // ---- one round trip for everything the first key block needs: Q / dO (all rows, zero padded), this thread's O row
+  // (delta), lse / pos, and key block 0's K / V fragments and K tile; later key blocks are fetched one block ahead,
+  // under the previous block's math (the kernel used to sit through three dependent global round trips before its
+  // first MFMA and two more per key block, with only two workgroups per CU to hide them)
+  const int ntile = (S + 63) / 64;
+  bf16x8 kf_n[2], vf_n[2];
+  uint4 kt_n[2];
+  float pos_n;
+#define ABS_FETCH_KB(kb_)                                                                                      \
+  {                                                                                                             \
+    const int kvn_ = (kb_) * 64 + wid * 16 + fr;                                                                \
+    const int kvc_ = kvn_ < S ? kvn_ : S - 1;                                                                   \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                          \
+      kf_n[ks] = *(const bf16x8*)(qkv + (long long)kvc_ * rowstride + (long long)H * HD + ks * 32 + g * 8);     \
+      vf_n[ks] = *(const bf16x8*)(qkv + (long long)kvc_ * rowstride + 2LL * H * HD + ks * 32 + g * 8);          \
+    }                                                                                                           \
+    pos_n = a.pos ? (float)a.pos[(long long)n * S + kvc_] : (float)kvc_;                                        \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
+      const int c = tid + 256 * u, r = c >> 3, ch = c & 7;                                                      \
+      kt_n[u] = make_uint4(0u, 0u, 0u, 0u);                                                                     \
+      if ((kb_) * 64 + r < S) kt_n[u] = *(const uint4*)(qkv + (long long)((kb_) * 64 + r) * rowstride + (long long)H * HD + ch * 8); \
+    }                                                                                                           \
+  }
   {
-    uint4 qz[ABS_ROWS * 8 / 256], dz[ABS_ROWS * 8 / 256];      // all 12 loads in flight before the first LDS write
+    uint4 qz[ABS_ROWS * 8 / 256], dz[ABS_ROWS * 8 / 256];      // all loads in flight before the first LDS write
+    uint4 oz[8];
 #pragma unroll
     for (int u = 0; u < ABS_ROWS * 8 / 256; ++u) {
       const int c = tid + 256 * u, r = c >> 3, ch = c & 7;
@@ -913,36 +936,41 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
         dz[u] = *(const uint4*)(dO + (long long)r * orow + ch * 8);
       }
     }
+    const bool rok = tid < S;                       // thread tid < ABS_ROWS owns query row tid for delta / lse / pos
+#pragma unroll
+    for (int u = 0; u < 8; ++u) oz[u] = rok ? *(const uint4*)(Of + (long long)tid * orow + u * 8) : make_uint4(0u, 0u, 0u, 0u);
+    float lse_r = INFINITY, pos_r = 0.f;            // exp(x - inf) = 0: padded queries vanish
+    if (rok) {
+      lse_r = a.lse[((long long)n * H + h) * S + tid];
+      pos_r = a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid;
+    }
+    ABS_FETCH_KB(0)
 #pragma unroll
     for (int u = 0; u < ABS_ROWS * 8 / 256; ++u) {
       const int c = tid + 256 * u, r = c >> 3, ch = c & 7;
       *(uint4*)(sQ + dual_off(r, ch)) = qz[u];
       *(uint4*)(sDO + dual_off(r, ch)) = dz[u];
     }
-  }
-  if (tid < ABS_ROWS) {
-    const bool ok = tid < S;
-    float dl = 0.f;
-    if (ok) {
+    __syncthreads();                                // dO image complete: delta reads row tid from it
+    if (tid < ABS_ROWS) {
+      float dl = 0.f;
 #pragma unroll
-      for (int d = 0; d < HD; d += 8) {
-        float x[8], y[8];
-        Vec8<bf16>::load(Of + (long long)tid * orow + d, x);
-        Vec8<bf16>::load(dO + (long long)tid * orow + d, y);
+      for (int u = 0; u < 8; ++u) {
+        const bf16x8 ov = *(const bf16x8*)&oz[u];
+        const bf16x8 dv_ = *(const bf16x8*)(sDO + dual_off(tid, u));
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dl += x[i] * y[i];
+        for (int i = 0; i < 8; ++i) dl += (float)ov[i] * (float)dv_[i];
       }
+      sDelta[tid] = dl;
+      sLse[tid] = lse_r;
+      sPosQ[tid] = pos_r;
     }
-    sDelta[tid] = dl;
-    sLse[tid] = ok ? a.lse[((long long)n * H + h) * S + tid] : INFINITY;     // exp(x - inf) = 0: padded queries vanish
-    sPosQ[tid] = ok ? (a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid) : 0.f;
   }
 
   f32x4 dq0[ND], dq1[ND], dq2[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) { dq0[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq1[i] = dq0[i]; dq2[i] = dq0[i]; }
   float dal = 0.f;
-  const int ntile = (S + 63) / 64;
   const int qq = (lane & 15) >> 2, pp = lane & 3;
 
 #pragma unroll 1
@@ -951,21 +979,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
     const int kv = kv0 + wid * 16 + fr;            // this lane's key column
     const int kvc = kv < S ? kv : S - 1;
     const bool kv_ok = kv < S;
-    const float pos_kv = a.pos ? (float)a.pos[(long long)n * S + kvc] : (float)kvc;
+    const float pos_kv = pos_n;
     bf16x8 kf_b[2], vf_b[2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      kf_b[ks] = *(const bf16x8*)(qkv + (long long)kvc * rowstride + (long long)H * HD + ks * 32 + g * 8);
-      vf_b[ks] = *(const bf16x8*)(qkv + (long long)kvc * rowstride + 2LL * H * HD + ks * 32 + g * 8);
-    }
+    for (int ks = 0; ks < 2; ++ks) { kf_b[ks] = kf_n[ks]; vf_b[ks] = vf_n[ks]; }
     __syncthreads();                               // previous key block's dQ products are done with sKt
-    for (int c = tid; c < 64 * 8; c += 256) {
-      const int r = c >> 3, ch = c & 7;
-      uint4 kz = {0u, 0u, 0u, 0u};
-      if (kv0 + r < S) kz = *(const uint4*)(qkv + (long long)(kv0 + r) * rowstride + (long long)H * HD + ch * 8);
-      *(uint4*)(sKt + trimg_off<HD>(r, ch * 8)) = kz;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 256 * u, r = c >> 3, ch = c & 7;
+      *(uint4*)(sKt + trimg_off<HD>(r, ch * 8)) = kt_n[u];
     }
-    __syncthreads();                               // (first pass: also publishes Q / dO / delta / lse / pos)
+    __syncthreads();                               // (first pass: also publishes delta / lse / pos)
+    if (kb + 1 < ntile) ABS_FETCH_KB(kb + 1)        // next key block's operands arrive under this block's math
 
     f32x4 dk[ND], dv[ND];
 #pragma unroll
