@@ -486,13 +486,16 @@ __global__ __launch_bounds__(256) void pack_weight_batch_kernel(const long long*
 }
 
 // gw[(g*N+n)][ci][j] += packed[g][n][j*Cgp + ci]     (fp32 both)
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const float* __restrict__ packed, float* __restrict__ gw,
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ packed, float* __restrict__ gw,
                                                            int Cg, int k, int Cgp, long long total) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int j = (int)(i % k);
     const int ci = (int)((i / k) % Cg);
     const long long gn = i / ((long long)k * Cg);
-    gw[i] += packed[(gn * k + j) * Cgp + ci];
+    const long long src = (gn * k + j) * Cgp + ci;
+    gw[i] += packed[src];
+    packed[src] = 0.f;          // leave the packed accumulator clear for the next micro-batch (saves a fill launch per use;
+                                // the tap-padding entries ci >= Cg never receive anything: their A operand is zero)
   }
 }
 
@@ -710,7 +713,7 @@ extern "C" int a2v_pack_weight_batch(int dtype, const long long* desc_dev, int n
   return A2V_OK;
 }
 
-extern "C" int a2v_unpack_wgrad(const float* packed, float* gw, int GN, int Cg, int k, int Cgp, hipStream_t st) {
+extern "C" int a2v_unpack_wgrad(float* packed, float* gw, int GN, int Cg, int k, int Cgp, hipStream_t st) {
   if (GN <= 0 || Cg <= 0 || k <= 0 || Cgp < Cg) return A2V_ERR_ARG;
   const long long total = (long long)GN * Cg * k;
   hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(grid_for(total)), dim3(256), 0, st, packed, gw, Cg, k, Cgp, total);

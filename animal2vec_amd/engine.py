@@ -121,8 +121,7 @@ class Engine:
             T_in, T_out = x_in.shape[1], dy.shape[1]
             dc = ops.layernorm_bwd(dy, sv[f"c{i}"], p[pre + f"{i}.2.1.weight"], p[pre + f"{i}.2.1.bias"], *sv[f"st{i}"],
                                    act=1, dgamma=g[pre + f"{i}.2.1.weight"], dbeta=g[pre + f"{i}.2.1.bias"])
-            gw = sp.gw[wname]
-            gw.zero_()
+            gw = sp.gw[wname]                      # cleared by the previous unpack_wgrad (zero at allocation)
             ops.conv1d_cl_wgrad(x_in, dc, gw, k=k, stride=s, pad=pl, groups=1, T_out=T_out, cv=m["Cgp"] if i == 1 else m["Cg"])
             ops.unpack_wgrad(gw, g[wname], GN=dim, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
             if s > 1:
@@ -295,8 +294,7 @@ class Engine:
             first, last = i == 1, i == depth
             dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1,
                                    dxsum=g[P + f"relative_positional_encoder.{i}.0.bias"])
-            gw = sp.gw[w]
-            gw.zero_()
+            gw = sp.gw[w]                          # cleared by the previous unpack_wgrad (zero at allocation)
             ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T,
                                 rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None,
                                 cv=m["Cg"], rowidx=rows if last else None)
@@ -323,8 +321,7 @@ class Engine:
             m = sp.meta[w]
             dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1,
                                    dxsum=g[P + f"relative_positional_encoder.{i}.0.bias"])
-            gw = sp.gw[w]
-            gw.zero_()
+            gw = sp.gw[w]                          # cleared by the previous unpack_wgrad (zero at allocation)
             ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, cv=m["Cg"])
             ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
             dy = ops.conv1d_cl(dc, sp.wt[w], None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D,
@@ -510,8 +507,7 @@ class Engine:
             w = P + f"decoder.blocks.{i}.0.weight"
             m = sp.meta[w]
             dc = ops.layernorm_bwd(dy, sv["c"], None, None, *sv["st"], act=1, dxsum=g[P + f"decoder.blocks.{i}.0.bias"])
-            gw = sp.gw[w]
-            gw.zero_()
+            gw = sp.gw[w]                          # cleared by the previous unpack_wgrad (zero at allocation)
             ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, cv=m["Cg"])
             ops.unpack_wgrad(gw, g[w], GN=Dd, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
             n_in = sv["x"].shape[-1]

@@ -207,7 +207,9 @@ int a2v_pack_weight(int dtype, const float* w, void* out, int G, int N, int Cg, 
  * image of a parameter set after the optimizer / EMA step (fairseq has no counterpart: its modules read the fp32
  * parameters directly). */
 int a2v_pack_weight_batch(int dtype, const long long* desc_dev, int n, a2v_stream_t stream);
-int a2v_unpack_wgrad(const float* packed, float* gw, int GN, int Cg, int k, int Cgp, a2v_stream_t stream);
+/* gw[(g*N+n)][ci][j] += packed[g][n][j*Cgp + ci], then the entries read are cleared: the packed fp32 accumulator of
+ * a2v_conv_wgrad is ready for the next micro-batch without a fill. */
+int a2v_unpack_wgrad(float* packed, float* gw, int GN, int Cg, int k, int Cgp, a2v_stream_t stream);
 int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, int C, int k, int s, int p,
                long long lda, long long ldo, a2v_stream_t stream);
 int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out, long long M, int C, long long ldi,

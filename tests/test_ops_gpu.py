@@ -324,11 +324,12 @@ def test_conv_slab_kernels_masked_long(ops):
         lib.a2v_debug_set(2, 1); lib.a2v_debug_set(3, 1)
     assert rel_err(y.float(), ref.detach()) < tol(dtype)
     assert rel_err(dx.float(), xm.grad) < tol(dtype, 2)
+    assert rel_err(gw, gw0) < 1e-4                              # fp32 atomics in a different order
     gw_un = torch.zeros(D, Cg, k, dtype=torch.float32, device="cuda")
     ops.unpack_wgrad(gw, gw_un, GN=D, Cg=Cg, k=k, Cgp=Cg)
     assert rel_err(gw_un, wr.grad) < tol(dtype, 2)
+    assert float(gw.abs().max()) == 0.0                         # unpack leaves the packed accumulator clear
     assert torch.equal(y, y0) and torch.equal(dx, dx0)        # same per-element accumulation order
-    assert rel_err(gw, gw0) < 1e-4                              # fp32 atomics in a different order
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
