@@ -515,6 +515,7 @@ struct AttnBwdArgs {
   float scale;
   Drop drop;
   int dal_part;             // 1: per-workgroup partial sums of d alibi_scale go to g_dal_part (folded by dalibi_fold_kernel)
+  float* bias_sum;          // (3, H, HD) fp32 or NULL: column sums of dqkv (the qkv Linear's bias gradient), whole-sequence kernel only
 };
 
 // NT = 0: one workgroup per 64-key block, dQ summed across key blocks with fp32 atomics into dq32 (any S).
@@ -873,7 +874,7 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
 __device__ __forceinline__ int dual_off(int r, int chunk) { return r * 128 + ((chunk ^ (r & 7)) << 4); }   // [rows][64] bf16
 
 #define ABS_ROWS 192
-#define ABS_LDS (2 * ABS_ROWS * 128 + 64 * 128 + 2 * 64 * 128 + 3 * ABS_ROWS * 4)
+#define ABS_LDS (2 * ABS_ROWS * 128 + 64 * 128 + 2 * 64 * 128 + 3 * ABS_ROWS * 4 + 3 * 64 * 4)
 
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, const bf16* __restrict__ o_fwd) {
@@ -886,6 +887,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
   float* const sLse = (float*)(sDS + 2 * 64 * 128);
   float* const sDelta = sLse + ABS_ROWS;
   float* const sPosQ = sDelta + ABS_ROWS;
+  float* const sBias = sPosQ + ABS_ROWS;                   // [3][64]: column sums of this (n, h)'s dQ / dK / dV (bias gradient)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -895,6 +897,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
   const long long orow = (long long)H * HD;
   const bf16* qkv = (const bf16*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
   const bf16* dO = (const bf16*)a.d_out + (long long)n * S * orow + (long long)h * HD;
+  if (a.bias_sum && tid < 192) sBias[tid] = 0.f;           // published by the barriers of the first key block
   const bf16* Of = o_fwd + (long long)n * S * orow + (long long)h * HD;
   const float slope = a.slopes[h];
   const float asc = a.alibi_scale[h];
@@ -1106,6 +1109,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
         Vec4<bf16>::store(dkv + 2LL * H * HD + 16 * i + 4 * g, dv[i]);
       }
     }
+    if (a.bias_sum) {          // column sums over this block's keys of what was stored (bf16-rounded), 16 key lanes -> 1
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sk = kv_ok ? (float)(bf16)(dk[i][r] * a.scale) : 0.f;
+          float sv_ = kv_ok ? (float)(bf16)dv[i][r] : 0.f;
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) { sk += __shfl_xor(sk, o, 64); sv_ += __shfl_xor(sv_, o, 64); }
+          if (fr == 0) {
+            atomicAdd(&sBias[64 + 16 * i + 4 * g + r], sk);
+            atomicAdd(&sBias[128 + 16 * i + 4 * g + r], sv_);
+          }
+        }
+    }
   }
   // ---- dQ into the q slot of dqkv: rows q = 64 t + 16 wid + 4g + r, col d = 16i + fr
 #pragma unroll
@@ -1119,6 +1137,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
         for (int i = 0; i < ND; ++i) dst[16 * i + fr] = (bf16)((t == 0 ? dq0[i][r] : (t == 1 ? dq1[i][r] : dq2[i][r])) * a.scale);
       }
     }
+  if (a.bias_sum) {            // dQ column sums: this lane's rows (t, r), then the 4 row groups g, then the 4 waves through LDS
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq2 = t * 64 + wid * 16 + 4 * g + r;
+          const float v = (t == 0 ? dq0[i][r] : (t == 1 ? dq1[i][r] : dq2[i][r])) * a.scale;
+          sq += qq2 < S ? (float)(bf16)v : 0.f;
+        }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (g == 0) atomicAdd(&sBias[16 * i + fr], sq);
+    }
+    __syncthreads();
+    if (tid < 192) atomicAdd(a.bias_sum + (long long)(tid >> 6) * H * HD + (long long)h * HD + (tid & 63), sBias[tid]);
+  }
   dal = wave_sum(dal);
   dalibi_finish(dal, a.dalibi, h, a.dal_part, slope, asc);
 }
@@ -1467,14 +1504,20 @@ extern "C" int a2v_attention_bwd_direct_dq(int dtype, int S, int HD) {
 
 // dq32 must be zero on entry; delta is (N,H,S) fp32 scratch.  dQ is left in dq32 (fp32, (N,S,H,HD));
 // the caller casts it into the q slot of dqkv (a2v_cast2d).
+// 1 when a2v_attention_bwd can also accumulate the column sums of dqkv (qkv_bias_grad) for this (dtype, S, HD)
+extern "C" int a2v_attention_bwd_fused_bias(int dtype, int S, int HD) {
+  return dtype == A2V_BF16 && HD == 64 && S <= ABS_ROWS && g_a2v_attn_long != 2 ? 1 : 0;
+}
+
 extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse,
-                                 float* delta, void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
-                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
-                                 unsigned drop_seed, hipStream_t stream) {
+                                 float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos,
+                                 const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
+                                 float drop_p, unsigned drop_seed, hipStream_t stream) {
+  if (qkv_bias_grad && !a2v_attention_bwd_fused_bias(dtype, S, HD)) return A2V_ERR_ARG;
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || drop_p < 0.f || drop_p >= 1.f)
     return A2V_ERR_ARG;
   AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale,
-                make_drop(drop_p, drop_seed), 0};
+                make_drop(drop_p, drop_seed), 0, qkv_bias_grad};
   if (dtype == A2V_BF16) {
     if (HD == 64) return attn_bwd_launch<bf16, 64>(a, out, delta, stream);
     if (HD == 32) return attn_bwd_launch<bf16, 32>(a, out, delta, stream);

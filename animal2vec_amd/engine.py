@@ -239,9 +239,9 @@ class Engine:
                                       dxsum=g[prefix + "attn.proj.bias"], drop=d_proj, drop_mode=2)
         datt = ops.linear(ds1d, sp.wt[prefix + "attn.proj.weight"])
         dqkv = ops.attention_bwd(sv["qkv"].view(N, S, 3 * D), sv["att"], datt.view(N, S, D), sv["lse"], pos,
-                                 st.alibi_slopes, alibi_scale, H, g[P + "alibi_scale"].view(-1), drop=d_att)
+                                 st.alibi_slopes, alibi_scale, H, g[P + "alibi_scale"].view(-1), drop=d_att,
+                                 bias_grad=g[prefix + "attn.qkv.bias"])
         dq2 = dqkv.view(N * S, 3 * D)
-        ops.colsum(dq2, g[prefix + "attn.qkv.bias"])
         ops.linear_wgrad_pair(sv["att"].view(N * S, D), ds1d, g[prefix + "attn.proj.weight"],
                               sv["x"], dq2, g[prefix + "attn.qkv.weight"])
         dxin = ops.linear(dq2, sp.wt[prefix + "attn.qkv.weight"], res=ds1)

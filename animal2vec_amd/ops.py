@@ -176,20 +176,25 @@ def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None)
     return out, lse
 
 
-def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, drop=None):
-    """-> dqkv (N,S,3*H*HD).  dalibi (H) fp32 is accumulated."""
+def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, drop=None, bias_grad=None):
+    """-> dqkv (N,S,3*H*HD).  dalibi (H) fp32 is accumulated; bias_grad (3*H*HD fp32, the qkv Linear's bias gradient =
+    column sums of dqkv) is accumulated too -- inside the kernel where it can (whole-sequence kernel), else by a pass
+    over dqkv."""
     N, S, W = qkv.shape
     HD = W // (3 * H)
     dqkv = torch.empty_like(qkv)
     direct = bool(_L().a2v_attention_bwd_direct_dq(dt(qkv), S, HD))
+    fused = bias_grad is not None and bool(_L().a2v_attention_bwd_fused_bias(dt(qkv), S, HD))
     dq32 = None if direct else torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
     delta = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
     rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(delta), ptr(dqkv), ptr(dq32),
-                                ptr(dalibi), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)),
-                                stream())
+                                ptr(dalibi), ptr(bias_grad) if fused else None, ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
+                                HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_bwd")
     if not direct:
         cast2d(dq32, dqkv.view(N * S, W)[:, : H * HD])
+    if bias_grad is not None and not fused:
+        colsum(dqkv.view(N * S, W), bias_grad)
     return dqkv
 
 

@@ -101,9 +101,13 @@ int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const i
  * otherwise dq32 (N,S,H,HD) fp32 must be zero on entry, receives dQ through atomics, and the caller casts it
  * into dqkv (a2v_cast2d). */
 int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse, float* delta,
-                      void* dqkv, float* dq32, float* dalibi, const int* pos, const float* slopes,
+                      void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos, const float* slopes,
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p, unsigned drop_seed,
                       a2v_stream_t stream);
+/* qkv_bias_grad (3*H*HD fp32, accumulated) or NULL: the column sums of dqkv -- the qkv Linear's bias gradient -- formed
+ * in the kernel instead of by a separate pass over dqkv; allowed only where a2v_attention_bwd_fused_bias() is 1 (the
+ * whole-sequence kernel: bf16, HD = 64, S <= 192). */
+int a2v_attention_bwd_fused_bias(int dtype, int S, int HD);
 int a2v_attention_bwd_direct_dq(int dtype, int S, int HD);
 
 /* ---------------------------------------------------------------- normalisation

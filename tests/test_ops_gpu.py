@@ -715,8 +715,11 @@ def test_attention_dropout(ops, dtype, hd):
     out, lse = ops.attention_fwd(qd, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, drop=(p_, seed))
     assert rel_err(out.float(), ref) < tol(dtype, 2)
     dal = torch.zeros(H, device="cuda")
-    dqkv = ops.attention_bwd(qd, out, dev(do, dtype), lse, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, dal, drop=(p_, seed))
+    bg = torch.zeros(3 * H * hd, device="cuda")
+    dqkv = ops.attention_bwd(qd, out, dev(do, dtype), lse, pos.cuda(), slopes.cuda(), sc.detach().cuda(), H, dal, drop=(p_, seed),
+                             bias_grad=bg)
     assert rel_err(dqkv.float(), qkv.grad) < tol(dtype, 3)
+    assert rel_err(bg, dqkv.float().sum((0, 1))) < 1e-4        # bias gradient = column sums of what was written
     assert rel_err(dal, sc.grad) < max(tol(dtype, 3), 5e-4)
 
 
