@@ -223,6 +223,8 @@ class ParamStore:
 
     def state_dict(self) -> Dict[str, torch.Tensor]:
         """Reference key names + '_ema' (data2vec2.py:412-418)."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)      # the teacher is updated on the trainer's side stream
         order = sorted(self.specs, key=lambda s: s.name)
         sd = {s.name: self.p[s.name].detach().clone() for s in order}
         sd["_ema"] = {n: v.detach().clone() for n, v in sorted(self.t.items())}

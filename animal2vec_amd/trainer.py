@@ -133,8 +133,19 @@ class PretrainTrainer:
         # EMA teacher (set_num_updates, data2vec2.py:386-410)
         self.ema_decay = self.ema_decay_at(self.num_updates)
         if self.ema_decay < 1:
-            ops.ema_update(st.teacher, st.flat[st.sh_lo:st.sh_hi], self.ema_decay)
-            eng.refresh_teacher_packs()
+            if eng.tstream is not None:
+                # the teacher's parameters and operand images are only read by the teacher forward, which runs on the
+                # side stream: update them there, under the next step's front end / student prelude on the main stream
+                main = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(eng.tstream):
+                    eng.tstream.wait_event(ev)
+                    ops.ema_update(st.teacher, st.flat[st.sh_lo:st.sh_hi], self.ema_decay)
+                    eng.refresh_teacher_packs()
+            else:
+                ops.ema_update(st.teacher, st.flat[st.sh_lo:st.sh_hi], self.ema_decay)
+                eng.refresh_teacher_packs()
         self.last = dict(stats=eng.stats, gnorm=gnorm)
 
     # ------------------------------------------------------------------ exact resume
