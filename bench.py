@@ -181,16 +181,15 @@ def make_microbatch(cfg, B, L, K, seed, device):
     return dict(source=src, mask_u8=m, ids_keep=keep, ids_restore=restore, noise=None)
 
 
-def cpu_baseline(model_name, L, K):
-    """The oracle (CPU restatement pinned to the reference) timed on this host: one clip, fwd+bwd."""
+def _cpu_leg(model_name, L, K, threads, budget_s):
+    """Child-process body of one cpu_baseline leg: the oracle (CPU restatement pinned to the reference), one clip,
+    forward + backward, `threads` torch threads: 1 untimed warm-up, then up to 3 timed runs (stops early once
+    `budget_s` of timed work is spent).  Prints one JSON object."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import a2v_oracle as O
-    dims = O.LARGE if model_name == "large" else O.BASE_STAR
+    dims = O.LARGE if model_name.startswith("large") else O.BASE_STAR
     cfg = O.OracleConfig(**dims)
-    # bounded: many-socket hosts run this small-op-dominated graph SLOWER with every core (608 s on 256 threads
-    # vs 52 s on 8), so cap the thread pool; `cores` reports what was actually used
-    ncores = min(os.cpu_count(), 16)
-    torch.set_num_threads(ncores)
+    torch.set_num_threads(threads)
     p = O.init_params(cfg, seed=0)
     ema = O.make_teacher(p)
     for v in p.values():
@@ -200,13 +199,143 @@ def cpu_baseline(model_name, L, K):
     src = torch.nn.functional.layer_norm(torch.randn(1, L, generator=g), (L,))
     mask = O.seeded_mask(cfg.clone_batch, T, K, 7)
     noise = torch.randn(cfg.clone_batch, T - K, cfg.embed_dim, generator=g) * 0.01
+
+    def one():
+        for v in p.values():
+            v.grad = None
+        t0 = time.perf_counter()
+        res = O.pretrain_forward(p, ema, src, mask, noise, cfg)
+        res["losses"]["AUDIO_regression"].sum().backward()
+        return time.perf_counter() - t0
+
+    warm = one()
+    times, spent = [], 0.0
+    while len(times) < 3 and (not times or spent + times[-1] <= budget_s):
+        times.append(one())
+        spent += times[-1]
+    print(json.dumps(dict(threads=threads, warmup_s=round(warm, 3), runs_s=[round(t, 3) for t in times])), flush=True)
+
+
+def cpu_baseline(model_name, L, K, sample_rate=8000):
+    """The oracle timed on this box's host cores (SURVEY 8d / BASELINE.md 4: 1 warm-up + median of 3, core count
+    stated).  Two legs, each in its own child process so torch's thread pool is sized before anything runs and the
+    leg can be bounded: (a) min(cores, 16) threads -- this small-op-dominated graph runs SLOWER on every core of a
+    many-socket host (608 s on 256 threads vs 52 s on 8 in round 1); (b) all cores, bounded by a timeout.  `value`
+    is the faster leg; both are reported."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    legs = []
+    for threads, timeout in ((min(ncpu, 16), 150), (ncpu, 100)):
+        if legs and threads == legs[0]["threads"]:
+            break
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--model", model_name,
+               "--samples", str(L), "--keep", str(K)]
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        try:
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+            rec = json.loads(out.stdout.strip().splitlines()[-1])
+            ts = sorted(rec["runs_s"])
+            med = ts[len(ts) // 2]
+            legs.append(dict(threads=threads, audio_s_per_s=round(L / sample_rate / med, 4), median_s=med,
+                             runs_s=rec["runs_s"], warmup_s=rec["warmup_s"]))
+        except subprocess.TimeoutExpired:
+            legs.append(dict(threads=threads, audio_s_per_s=None, note=f"no timed run finished within {timeout} s"))
+        except Exception as e:                                   # a failed leg must not lose the GPU measurement
+            legs.append(dict(threads=threads, audio_s_per_s=None, note=f"leg failed: {type(e).__name__}: {e}"))
+    ok = [l for l in legs if l.get("audio_s_per_s")]
+    if not ok:
+        return dict(value=None, unit="audio-s/s", cores=legs[0]["threads"], kind="port", sample="cpu legs failed", legs=legs)
+    best = max(ok, key=lambda l: l["audio_s_per_s"])
+    return dict(value=best["audio_s_per_s"], unit="audio-s/s", cores=best["threads"], kind="port", host_cores=ncpu,
+                sample=f"1 clip x {L / sample_rate:.1f}s, {model_name} model, fwd+bwd (teacher targets + student grads), fp32 "
+                       f"oracle on torch CPU; 1 warm-up + median of {len(best['runs_s'])} timed runs ({best['median_s']:.1f}s) on "
+                       f"{best['threads']} threads; legs = thread counts tried (min(cores,16) and all {ncpu} cores, bounded)",
+                legs=legs)
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks as children (torch.distributed.run, one process per
+    GPU, rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU -- the parent only waits and returns
+    the children's exit code; rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, world, rank):
+    """The bench's control flow on CPU tensors (no HIP kernel runs, nothing is measured): per step every rank fills
+    a tiny model's flat gradient buffer, GradSync all-reduces it bucket by bucket in backward order plus the packed
+    statistics; timing, barrier and the MAX over ranks are the real code path's."""
+    from animal2vec_amd import config as C
+    from animal2vec_amd.ddp import GradSync, make_buckets
+    from animal2vec_amd.params import bucket_starts, build_specs
+    use_dist = world > 1
+    if use_dist:
+        dist.init_process_group(args.backend if args.backend == "gloo" else "gloo")
+    cfg = C.tiny_config()
+    specs, _, total = build_specs(cfg)
+    buckets = make_buckets(bucket_starts(cfg, specs), total)
+    grad = torch.zeros(total)
+    stats = torch.zeros(6, dtype=torch.float64)
+    sync = GradSync(grad, buckets)
+    n_mb = max(1, args.global_batch // (world * args.micro_batch))
+
+    expect = float(n_mb * world * (world + 1) // 2)     # every rank adds (rank + 1) per micro-batch; SUM over ranks
+    okbox = [True]
+
+    def step():
+        grad.zero_()
+        for j in range(n_mb):
+            sync.arm(j == n_mb - 1)
+            grad.add_(float(rank + 1))
+            for ev in buckets:
+                sync.on_ready(ev)
+        sync.arm(False)
+        stats.fill_(1.0)
+        sync.finish(stats)
+        okbox[0] = okbox[0] and bool(torch.all(grad == expect)) and float(stats[0]) == float(world)
+
+    def sync_all():
+        if use_dist:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
     t0 = time.perf_counter()
-    res = O.pretrain_forward(p, ema, src, mask, noise, cfg)
-    res["losses"]["AUDIO_regression"].sum().backward()
-    dt = time.perf_counter() - t0
-    return dict(value=round(L / 8000.0 / dt, 4), unit="audio-s/s", cores=ncores, kind="port",
-                sample=f"1 clip x {L / 8000:.0f}s, {model_name} model, fwd+bwd (teacher targets + student grads), fp32, "
-                       f"torch CPU {ncores} threads, single untimed-warm-up-free run: {dt:.1f}s")
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    okt = torch.tensor([1.0 if okbox[0] else 0.0])
+    if use_dist:
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    ok = bool(okt[0] == 1.0)
+    if rank == 0:
+        dt = float(tmax)
+        audio_s = args.global_batch * args.samples / 8000.0
+        print(json.dumps({"metric": "audio-seconds/s pretrain (10s@8kHz, large model)", "value": round(audio_s * args.steps / dt, 2),
+                          "unit": "audio-s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "none", "data": "synthetic", "dry": True,
+                          "observed_world_size": dist.get_world_size() if use_dist else 1, "grad_sum_ok": ok,
+                          "config": {"workload": "DRY RUN: host-only stand-in, not a measurement", "global_batch": args.global_batch,
+                                     "micro_batch": args.micro_batch, "micro_batches_per_rank": n_mb, "parallelism": f"dp{world}"},
+                          "roofline": None, "cpu_baseline": None}), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+    return 0
 
 
 def main():
@@ -225,12 +354,25 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--debug-set", action="append", default=[], help="key=value for a2v_debug_set (A/B experiments)")
     ap.add_argument("--gemm-table", default=None, help="dump per-shape GEMM timings (json) from the roofline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (GPU runs); gloo only with --dry")
+    ap.add_argument("--dry", action="store_true",
+                    help="host-only stand-in step (tiny flat gradient buffer through the trainer's GradSync on CPU tensors): "
+                         "exercises spawn / rendezvous / barrier / max-over-ranks / the JSON line without a GPU")
+    ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)      # internal: one cpu_baseline leg
     args = ap.parse_args()
 
+    if args.cpu_leg:
+        _cpu_leg(args.model, args.samples, args.keep, args.cpu_leg, budget_s=45.0)
+        return 0
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry:
+        return dry_run(args, world, rank)
+    assert args.backend == "nccl", "the GPU path runs over RCCL; gloo is for --dry"
     torch.cuda.set_device(local)
     if args.debug_set:
         from animal2vec_amd import _lib
@@ -322,7 +464,10 @@ def main():
                                    f"all-reduce, clip+Adam, EMA) on {L}-sample clips @ {cfg.audio.sample_rate} Hz, "
                                    f"{K}/{cfg.frame_counts(L)[-1]} frames kept, clone_batch {cfg.clone_batch}",
                        "global_batch": args.global_batch, "micro_batch": args.micro_batch, "micro_batches_per_rank": n_mb,
-                       "parallelism": f"dp{world}", "dropout": "on (p=0.1, 5 sites)", "mixup": "on (BC, A-weighted gain)"},
+                       "parallelism": f"dp{world}", "dropout": "on (p=0.1, 5 sites)", "mixup": "on (BC, A-weighted gain)",
+                       "masks": "seeded keep-masks / gather ids precomputed once per micro-batch OUTSIDE the timed loop (SURVEY 8d); "
+                                "the reference samples them on the host every step (base.py:401-413)",
+                       "observed_world_size": dist.get_world_size() if use_dist else 1},
             "model_tflops_per_s": round(gf_fb * args.global_batch * args.steps / dt / 1e3, 2),
             "mfu_vs_bf16_dense_peak": round(gf_fb * args.global_batch * args.steps / dt / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "loss_per_sample": round(met["loss"], 5), "pred_var": round(met["pred_var"], 5),
@@ -330,7 +475,7 @@ def main():
             "roofline": roof,
         }
         if args.cpu_baseline == "auto" and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.model, L, K)
+            line["cpu_baseline"] = cpu_baseline(args.model, L, K, cfg.audio.sample_rate)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
@@ -339,4 +484,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

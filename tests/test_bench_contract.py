@@ -31,3 +31,65 @@ def test_default_bench_line_contract():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert j["value"] / c["value"] > 10          # the north-star's >= 10x the host-CPU path on one GPU
+
+
+def _run_bench(*argv, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in env_drop}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=env,
+                          timeout=300)
+
+
+def test_bench_spawns_its_own_ranks_gloo_dry():
+    """`python bench.py --gpus 2` with no launcher around it (the form the driver used at N = 1): the parent spawns two
+    ranks before touching any GPU, rank 0 prints ONE JSON line with n_gpus = 2 and the observed world size."""
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--steps", "3", "--warmup", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["observed_world_size"] == 2 and j["dry"] is True and j["grad_sum_ok"] is True
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["config"]["micro_batches_per_rank"] == 4
+    for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in j, k
+
+
+def test_bench_spawn_propagates_rank_failure():
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--micro-batch", "0")
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_world_size_mismatch_is_an_error():
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,
+                       env=env, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_cpu_baseline_median_and_best_leg(monkeypatch):
+    """cpu_baseline(): each leg = 1 warm-up + up to 3 timed runs in a child; value = the faster leg's median."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class R:
+        def __init__(self, out):
+            self.stdout, self.returncode = out, 0
+
+    def fake_run(cmd, **kw):
+        th = int(cmd[cmd.index("--cpu-leg") + 1])
+        if th > 16:
+            raise subprocess.TimeoutExpired(cmd, kw.get("timeout"))
+        return R(json.dumps(dict(threads=th, warmup_s=12.0, runs_s=[10.0, 8.0, 9.0])) + "\n")
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(os, "cpu_count", lambda: 64)
+    c = bench.cpu_baseline("large", 80000, 140)
+    assert c["cores"] == 16 and c["host_cores"] == 64 and c["kind"] == "port"
+    assert abs(c["value"] - 10.0 / 9.0) < 1e-3                      # median of (10, 8, 9) s for a 10 s clip
+    assert [l["threads"] for l in c["legs"]] == [16, 64] and c["legs"][1]["audio_s_per_s"] is None
