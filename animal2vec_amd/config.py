@@ -67,6 +67,9 @@ class D2vAudioConfig:
     mask_dropout: float = 0.0
     add_masks: bool = False
     encoder_zero_mask: bool = True
+    mask_channel_prob: float = 0.0         # base.py:52-53; the finetune recipe overrides them (wav2vec2.py:113-114)
+    mask_channel_length: int = 64
+    prenet_layerdrop: float = 0.0
     use_alibi_encoder: bool = True
     alibi_scale: float = 1.0
     learned_alibi_scale: bool = True
@@ -87,6 +90,7 @@ class Data2VecMultiConfig:
     post_mlp_drop: float = 0.1
     dropout_input: float = 0.0             # data2vec2.py:273,646-647: on the encoder input of the main blocks
     attention_dropout: float = 0.1
+    layerdrop: float = 0.0
     average_top_k_layers: int = 16
     instance_norm_target_layer: bool = True
     ema_decay: float = 0.9997

@@ -276,6 +276,8 @@ class DevicePrefetcher:
 
     def _work(self):
         try:
+            if self.stream is not None:
+                torch.cuda.set_device(self.device)      # pin_memory() in this thread must not open a context on GPU 0
             for b in self.batches:
                 col = self.ds.collater([self.ds[i] for i in b], self.rng)
                 src = col["net_input"]["source"]
@@ -309,5 +311,12 @@ class DevicePrefetcher:
             ev = item.pop("_ready", None)
             item.pop("_host", None)
             if ev is not None:
-                torch.cuda.current_stream(self.device).wait_event(ev)
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                # allocated on the prefetch stream, consumed on `cur`: without record_stream the caching allocator
+                # would hand the blocks back to the prefetch stream's pool as soon as the consumer drops them, and
+                # the worker's next H2D copy could overwrite them under kernels still queued on `cur`
+                for k in ("source", "target"):
+                    if item.get(k) is not None:
+                        item[k].record_stream(cur)
             yield item

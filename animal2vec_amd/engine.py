@@ -342,11 +342,30 @@ class Engine:
           p_in / p_final                                   -- dropout_input (before the main blocks), final_dropout (before the head)
           drop_seed (int or None), p_drop / p_act / p_att  -- cfg.dropout (prenet, proj, post-mlp), activation_dropout
                                                       (the Mlp's two dropouts), attention_dropout (wav2vec2.py:94-128)"""
+        cfg = self.cfg
+        D = cfg.embed_dim
+        top_k = cfg.average_top_k_layers if top_k is None else top_k
+        x, ts, ctx = self.encode_features(source, save=save, aug=aug)
+        B, T = ctx["B"], ctx["T"]
+        d_fin = ctx.pop("d_fin_spec")
+        sel = ts[-top_k:]
+        assert sel, "layerdrop removed every block"
+        xm = ops.mean_layers([t for _, t in sel]).view(B * T, D)
+        if d_fin is not None:
+            xm = ops.add_drop(None, xm, drop=d_fin)                             # final_dropout (wav2vec2.py:467)
+        logits = ops.linear(xm, head.w_op, head.b_op)                           # (B*T, Cp), Cp = classes padded to 16
+        if save:
+            self.sv["ft"] = dict(ctx, xm=xm, sel=[i for i, _ in sel], d_fin=d_fin)
+        return logits
+
+    def encode_features(self, source, *, save=False, aug=None):
+        """Data2VecMultiModel.forward(features_only=True, mask=aug has masks) (data2vec2.py:629-728): student weights, all T
+        frames (remove_masked False, clone_batch 1).  Returns (x (B,T,D), [(block index, FFN output t)], ctx) where ctx
+        holds what finetune_backward() needs besides the per-block saves.  `aug` as in finetune_forward."""
         cfg, st, sp = self.cfg, self.store, self.sp
         p = st.p
         H, D = cfg.num_heads, cfg.embed_dim
         a = cfg.audio
-        top_k = cfg.average_top_k_layers if top_k is None else top_k
         feats = self.frontend_fwd(source, save=save)
         B, T, _ = feats.shape
         asc = p[P + "alibi_scale"].view(-1)
@@ -369,9 +388,10 @@ class Engine:
                 assert len(active) == n_blocks
             db = aug.get("drop_seed")
             if db is not None:
-                dp = (aug.get("p_att", 0.0), aug.get("p_drop", 0.0), aug.get("p_drop", 0.0), aug.get("p_act", 0.0))
-                if aug.get("p_drop", 0.0) > 0:
-                    d_pre = (aug["p_drop"], self._site(db, 9000))
+                pd = aug.get("p_drop", 0.0)           # p_proj / p_mlp / p_pre: per-site overrides of cfg.dropout
+                dp = (aug.get("p_att", 0.0), aug.get("p_proj", pd), aug.get("p_mlp", pd), aug.get("p_act", 0.0))
+                if aug.get("p_pre", pd) > 0:
+                    d_pre = (aug.get("p_pre", pd), self._site(db, 9000))
         x_pos = self.posconv_fwd(feats, sp, p, None, 1, save=save)
         tok = torch.empty_like(feats) if save else None
         x, m0, r0 = ops.layernorm_fwd(feats, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
@@ -393,16 +413,8 @@ class Engine:
                 x, t = self.block_fwd(x, f"blocks.{i}.", sp, p, None, asc, H, save=f"fmb{i}" if save else None, want_t=True,
                                       drop_base=db, site=a.prenet_depth + i, dp=dp)
                 ts.append((i, t))
-        sel = ts[-top_k:]
-        assert sel, "layerdrop removed every block"
-        xm = ops.mean_layers([t for _, t in sel]).view(B * T, D)
-        if d_fin is not None:
-            xm = ops.add_drop(None, xm, drop=d_fin)                             # final_dropout (wav2vec2.py:467)
-        logits = ops.linear(xm, head.w_op, head.b_op)                           # (B*T, Cp), Cp = classes padded to 16
-        if save:
-            self.sv["ft"] = dict(xm=xm, tok=tok, st=(m0, r0), B=B, T=T, sel=[i for i, _ in sel], active=active, masks=masks,
-                                 d_pre=d_pre, d_in=d_in, d_fin=d_fin)
-        return logits
+        ctx = dict(tok=tok, st=(m0, r0), B=B, T=T, active=active, masks=masks, d_pre=d_pre, d_in=d_in, d_fin_spec=d_fin)
+        return x, ts, ctx
 
     def finetune_backward(self, dlog, head, *, head_only=False):
         """dlog (B*T, Cp): gradient of the loss wrt the padded logits (padded columns zero).  Accumulates encoder and
@@ -667,18 +679,5 @@ class Engine:
     def extract_features(self, source):
         """Data2VecMultiModel.forward(features_only=True, mask=False) (data2vec2.py:629-728, 1112-1123):
         student weights, all T frames, no token removal.  Returns (x, layer_results)."""
-        cfg, st, sp = self.cfg, self.store, self.sp
-        p = st.p
-        H = cfg.num_heads
-        feats = self.frontend_fwd(source, save=False)
-        asc = p[P + "alibi_scale"].view(-1)
-        x_pos = self.posconv_fwd(feats, sp, p, None, 1, save=False)
-        x, _, _ = ops.layernorm_fwd(feats, p[P + "context_encoder.norm.weight"], p[P + "context_encoder.norm.bias"],
-                                    cfg.norm_eps, res=x_pos, save_stats=False)
-        for i in range(cfg.audio.prenet_depth):
-            x, _ = self.block_fwd(x, P + f"context_encoder.blocks.{i}.", sp, p, None, asc, H, save=None)
-        layer_results = []
-        for i in range(cfg.depth):
-            x, t = self.block_fwd(x, f"blocks.{i}.", sp, p, None, asc, H, save=None, want_t=True)
-            layer_results.append(t)
-        return x, layer_results
+        x, ts, _ = self.encode_features(source, save=False, aug=None)
+        return x, [t for _, t in ts]

@@ -176,6 +176,31 @@ def make_aug(fcfg: FinetuneConfig, B: int, T: int, D: int, n_prenet: int, n_bloc
     return aug
 
 
+def bc_mix(mixup_op, f: "FinetuneConfig", model_cfg, src, tgt, rng: np.random.Generator, perm_gen):
+    """BC mixup of sources (wav2vec2.py:362-424) and, with target_mixup, of the targets (:426-432), then the
+    wrapped model's own second source mixup (see FinetuneConfig.inner_source_mixup)."""
+    if mixup_op is None:
+        return src, tgt
+    B = src.shape[0]
+    r = float(rng.uniform(max(1e-6, f.source_mixup), 1.0))
+    perm = torch.rand(B, device=src.device, generator=perm_gen).argsort().to(torch.int32)
+    mm = None
+    if f.mixup_prob < 1:                  # bernoulli(mixup_prob) per clip (wav2vec2.py:366-373)
+        mm = (torch.rand(B, device=src.device, generator=perm_gen) < f.mixup_prob).to(torch.uint8)
+    src = mixup_op(src, perm, r, mm)
+    if f.target_mixup and tgt is not None:
+        mixed_t = tgt * r + (1 - r) * tgt[perm.long()]
+        tgt = mixed_t if mm is None else torch.where(mm.bool().view(-1, 1, 1), mixed_t, tgt)
+    if f.inner_source_mixup and model_cfg.source_mixup >= 0 and model_cfg.mixup_prob > 0:
+        r2 = float(rng.uniform(max(1e-6, model_cfg.source_mixup), 1.0))
+        perm2 = torch.rand(B, device=src.device, generator=perm_gen).argsort().to(torch.int32)
+        mm2 = None
+        if model_cfg.mixup_prob < 1:
+            mm2 = (torch.rand(B, device=src.device, generator=perm_gen) < model_cfg.mixup_prob).to(torch.uint8)
+        src = mixup_op(src, perm2, r2, mm2)
+    return src, tgt
+
+
 class FinetuneTrainer:
     """Data-parallel finetune step on the native engine: train-form forward/backward per micro-batch (BC mixup of
     sources and targets, masking, layerdrop, dropouts), bucketed gradient all-reduce overlapped with backward, Adam
@@ -249,29 +274,7 @@ class FinetuneTrainer:
         return self.num_updates < self.fcfg.freeze_finetune_updates
 
     def _mix(self, src, tgt):
-        """BC mixup of sources (wav2vec2.py:362-424) and, with target_mixup, of the targets (:426-432), then the
-        wrapped model's own second source mixup (see FinetuneConfig.inner_source_mixup)."""
-        f = self.fcfg
-        if self.mixup is None:
-            return src, tgt
-        B = src.shape[0]
-        r = float(self.rng.uniform(max(1e-6, f.source_mixup), 1.0))
-        perm = torch.rand(B, device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
-        mm = None
-        if f.mixup_prob < 1:                  # bernoulli(mixup_prob) per clip (wav2vec2.py:366-373)
-            mm = (torch.rand(B, device=src.device, generator=self._perm_gen) < f.mixup_prob).to(torch.uint8)
-        src = self.mixup(src, perm, r, mm)
-        if f.target_mixup:
-            mixed_t = tgt * r + (1 - r) * tgt[perm.long()]
-            tgt = mixed_t if mm is None else torch.where(mm.bool().view(-1, 1, 1), mixed_t, tgt)
-        if f.inner_source_mixup and self.cfg.source_mixup >= 0 and self.cfg.mixup_prob > 0:
-            r2 = float(self.rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
-            perm2 = torch.rand(B, device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
-            mm2 = None
-            if self.cfg.mixup_prob < 1:
-                mm2 = (torch.rand(B, device=src.device, generator=self._perm_gen) < self.cfg.mixup_prob).to(torch.uint8)
-            src = self.mixup(src, perm2, r2, mm2)
-        return src, tgt
+        return bc_mix(self.mixup, self.fcfg, self.cfg, src, tgt, self.rng, self._perm_gen)
 
     def train_step(self, micro_batches: Sequence[dict]) -> None:
         """micro_batches: dicts with source (B,L) fp32 and target (B,T,C) fp32 multi-hot, on the device."""
@@ -293,7 +296,7 @@ class FinetuneTrainer:
         self.sync.arm(False)
         # ---- reduce: encoder buckets (already in flight), then the head and the scalars in one small call
         packed = torch.cat([head.gw.view(-1), head.gb.view(-1), head.loss_sum.float().view(-1),
-                            torch.tensor([float(ntok)], device=st.device)])
+                            torch.full((1,), float(ntok), dtype=torch.float32, device=st.device)])   # fill kernel, no H2D copy
         if self.sync.active:
             if not frozen:
                 self.sync.finish(None)
@@ -323,12 +326,12 @@ class FinetuneTrainer:
             enc_step = self.num_updates - f.freeze_finetune_updates
             ops.adam_step(st.flat[self.lo:self.hi], st.grad[self.lo:self.hi], st.adam_m[self.lo:self.hi],
                           st.adam_v[self.lo:self.hi], lr=lr, beta1=b1, beta2=b2, eps=f.adam_eps, weight_decay=f.weight_decay,
-                          step=max(1, enc_step), decay_mask=st.decay_mask[self.lo // ALIGN:self.hi // ALIGN],
-                          grad_scale_dev=scale, lr_scale=self.lr_scale)
+                          step=max(1, enc_step), decay_mask=None,     # plain fairseq `adam`: optim_overrides are ignored,
+                          grad_scale_dev=scale, lr_scale=self.lr_scale)   # weight_decay applies to every parameter
             eng.refresh_student_packs()
         for prm, gr, m, v in ((head.w, gw, self.head_m[0], self.head_v[0]), (head.b, gb, self.head_m[1], self.head_v[1])):
             ops.adam_step(prm.view(-1), gr.contiguous().view(-1), m.view(-1), v.view(-1), lr=lr, beta1=b1, beta2=b2,
-                          eps=f.adam_eps, weight_decay=0.0, step=self.num_updates)
+                          eps=f.adam_eps, weight_decay=f.weight_decay, step=self.num_updates)
         head.refresh()
         self.last = dict(loss_sum=loss_sum, sample_size=sample_size, lr=lr, gnorm=gnorm)
 
@@ -351,10 +354,10 @@ class _FinetuneLogits(torch.autograd.Function):
     buffer (encoder) and the head's gradient buffers."""
 
     @staticmethod
-    def forward(ctx, anchor, model, source):
-        ctx.model = model
+    def forward(ctx, anchor, model, source, aug=None, head_only=False):
+        ctx.model, ctx.head_only = model, head_only
         eng, head = model.encoder.engine, model.head
-        logits = eng.finetune_forward(source, head, save=True)
+        logits = eng.finetune_forward(source, head, save=True, aug=aug)
         B = source.shape[0]
         return logits.view(B, logits.shape[0] // B, -1)[..., : head.n_labels].float()
 
@@ -365,9 +368,11 @@ class _FinetuneLogits(torch.autograd.Function):
         B, T, C = dlogits.shape
         dl = torch.zeros(B * T, head.Cp, dtype=eng.dtype, device=dlogits.device)
         dl[:, :C] = dlogits.reshape(B * T, C).to(eng.dtype)
-        eng.finetune_backward(dl, head)
+        if not ctx.head_only:
+            model.encoder.attach_grads()                      # the optimizer may have set p.grad = None
+        eng.finetune_backward(dl, head, head_only=ctx.head_only)
         model._publish_head_grads()
-        return torch.zeros_like(model._anchor), None, None
+        return torch.zeros_like(model._anchor), None, None, None, None
 
 
 @register_model("wav2vec_ccas_finetune")
@@ -377,17 +382,36 @@ class Wav2VecCcasFinetune(tnn.Module):
     criterion uses them.  `encoder` is a Data2VecMultiModel of this package (its parameters' .grad are views of the
     flat gradient buffer); `proj.weight/.bias` mirror the head."""
 
-    def __init__(self, encoder, n_labels: int, seed: int = 0, use_focal_loss: bool = True):
+    def __init__(self, encoder, n_labels: int, seed: int = 0, use_focal_loss: bool = True, fcfg: Optional["FinetuneConfig"] = None):
+        """fcfg=None: deterministic form (no mixup, mask, layerdrop or dropout even in train mode; the parity tests use
+        it).  With a FinetuneConfig, train mode runs the reference's train form: BC mixup of sources and targets
+        (wav2vec2.py:362-432), apply_mask (mask = apply_mask and training, :433-437), layerdrop and dropouts pushed into
+        the encoder (:94-131), classifier-only gradients while num_updates < freeze_finetune_updates (:440-445)."""
         super().__init__()
         self.encoder = encoder
         self.cfg_use_focal_loss = use_focal_loss
+        self.fcfg = fcfg
+        self.num_updates = 0
         cfg = encoder.cfg
-        self.head = FinetuneHead(cfg.embed_dim, n_labels, dtype=encoder.engine.dtype, device=encoder.store.device, seed=seed)
-        self.proj = tnn.Linear(cfg.embed_dim, n_labels).to(encoder.store.device)
+        dev = encoder.store.device
+        self.head = FinetuneHead(cfg.embed_dim, n_labels, dtype=encoder.engine.dtype, device=dev, seed=seed)
+        self.proj = tnn.Linear(cfg.embed_dim, n_labels).to(dev)
         with torch.no_grad():
             self.proj.weight.copy_(self.head.w)
             self.proj.bias.copy_(self.head.b)
-        self._anchor = tnn.Parameter(torch.zeros(1, device=encoder.store.device))
+        self._anchor = tnn.Parameter(torch.zeros(1, device=dev))
+        self._rng = np.random.default_rng(seed * 1000 + 23)
+        self._perm_gen = None
+        self._mixup_op = None
+        if fcfg is not None and fcfg.source_mixup >= 0 and fcfg.mixup_prob > 0 and torch.device(dev).type == "cuda":
+            self._mixup_op = ops.Mixup(cfg.audio.sample_rate, fcfg.mixing_window_length, dev)
+
+    def set_num_updates(self, num_updates):
+        """wav2vec2.py:84-87 (fairseq calls it after every optimizer step): also the moment to rebuild the operand
+        images of whatever the optimizer just changed."""
+        self.num_updates = num_updates
+        self.sync_head()
+        self.encoder.engine.refresh_student_packs()
 
     def sync_head(self):
         """after an optimizer step on proj.*: rebuild the head's operand images"""
@@ -407,7 +431,20 @@ class Wav2VecCcasFinetune(tnn.Module):
             raise NotImplementedError("enable_padding is false in every shipped config")
         source = source.to(self.encoder.store.device, torch.float32).contiguous()
         if torch.is_grad_enabled() and self.training:
-            logits = _FinetuneLogits.apply(self._anchor, self, source)
+            aug, head_only, f = None, False, self.fcfg
+            if f is not None:
+                cfg = self.encoder.cfg
+                a = cfg.audio
+                if self._perm_gen is None:
+                    self._perm_gen = torch.Generator(device=source.device)
+                    self._perm_gen.manual_seed(cfg.seed * 7919 + 43)
+                tgt = target.to(source.device, torch.float32) if target is not None else None
+                source, target = bc_mix(self._mixup_op, f, cfg, source, tgt, self._rng, self._perm_gen)
+                T = cfg.frame_counts(source.shape[1])[-1]
+                aug = make_aug(f, source.shape[0], T, cfg.embed_dim, a.prenet_depth, a.prenet_depth + cfg.depth, self._rng,
+                               a.mask_noise_std, device=source.device)
+                head_only = self.num_updates < f.freeze_finetune_updates
+            logits = _FinetuneLogits.apply(self._anchor, self, source, aug, head_only)
         else:
             eng = self.encoder.engine
             lg = eng.finetune_forward(source, self.head, save=False)

@@ -4,6 +4,7 @@ signature, net_output keys, state-dict keys and EMA hooks as the reference's
 """
 from __future__ import annotations
 
+from collections import namedtuple
 from typing import Dict, Optional
 
 import numpy as np
@@ -17,6 +18,9 @@ from .masking import compute_mask_indices, make_maskinfo
 from .params import P, ParamStore
 from .registry import register_model
 from .trainer import get_annealed_rate
+
+
+MaskInfo = namedtuple("MaskInfo", ["x_unmasked", "mask", "ids_restore", "ids_keep"])      # base.py:26-27
 
 
 class _Node(tnn.Module):
@@ -46,6 +50,7 @@ class _PretrainLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         model = ctx.model
+        model.attach_grads()                                      # the optimizer may have set p.grad = None
         model.engine.backward(float(grad_out.reshape(-1)[0]))     # one host sync in drop-in mode only
         return None, None, None
 
@@ -60,14 +65,20 @@ class Data2VecMultiModel(tnn.Module):
         self.store = ParamStore(cfg, device=device, with_optimizer=False)
         self.store.init_reference(cfg.seed)
         self.engine = Engine(cfg, self.store, dtype=dtype)
+        self._by_name = {}
         for s in self.store.specs:
             prm = tnn.Parameter(self.store.p[s.name])
             prm.grad = self.store.g[s.name]
             if not s.decay:                                    # data2vec2.py:318-320
                 prm.optim_overrides = {"optimizer": {"weight_decay_scale": 0}}
             _attach(self, s.name, prm)
+            self._by_name[s.name] = prm
         self.skip_ema = skip_ema
         self.dropout = True          # train-mode dropout (set False for deterministic training-mode checks)
+        self.mixup = True            # train-mode BC mixup of the sources (data2vec2.py:536-598); False: deterministic checks
+        self._mixup_op = ops.Mixup(cfg.audio.sample_rate, cfg.mixing_window_length, self.store.device) \
+            if (cfg.source_mixup >= 0 and cfg.mixup_prob > 0 and torch.device(self.store.device).type == "cuda") else None
+        self._perm_gen = None
         self.num_updates = 0
         self.ema_decay = cfg.ema_decay
         self._rng = np.random.default_rng(cfg.seed)
@@ -78,6 +89,30 @@ class Data2VecMultiModel(tnn.Module):
     def build_model(cls, cfg: Data2VecMultiConfig, task=None, **kw):
         """Build a new model instance (data2vec2.py:500-514)."""
         return cls(cfg, task=task, **kw)
+
+    # ------------------------------------------------------------------ gradients live in the flat buffer
+    def attach_grads(self):
+        """Every parameter's .grad is a view of the flat gradient buffer the engine accumulates into.  torch's and
+        fairseq's zero_grad() set p.grad = None: a parameter found detached is re-attached with its slice cleared
+        (what "None" means to the optimizer), so `zero_grad(); loss.backward(); optimizer.step()` trains."""
+        st = self.store
+        lost = [n for n, prm in self._by_name.items() if prm.grad is None or prm.grad.data_ptr() != st.g[n].data_ptr()]
+        if not lost:
+            return
+        if len(lost) == len(self._by_name):
+            st.grad.zero_()
+        else:
+            for n in lost:
+                st.g[n].zero_()
+        for n in lost:
+            self._by_name[n].grad = st.g[n]
+
+    def zero_grad(self, set_to_none: bool = True):
+        """Clears the flat gradient buffer in one launch and keeps the views attached (set_to_none is accepted for
+        signature compatibility; a None gradient would make the optimizer skip the parameter)."""
+        self.store.grad.zero_()
+        for n, prm in self._by_name.items():
+            prm.grad = self.store.g[n]
 
     def state_dict(self, destination=None, prefix="", keep_vars=False):
         state = super().state_dict(destination=destination, prefix=prefix, keep_vars=keep_vars)
@@ -132,14 +167,14 @@ class Data2VecMultiModel(tnn.Module):
         anyway) unless ``unreduced_loss=True``."""
         if padding_mask is not None:
             raise NotImplementedError("enable_padding is false in every shipped config (and broken upstream, audio.py:168)")
+        if force_remove_masked:
+            raise NotImplementedError("force_remove_masked has no call site in the reference's audio path")
         source = source.to(self.store.device, torch.float32).contiguous()
         eng, cfg = self.engine, self.cfg
+        if self.training and self.mixup and self._mixup_op is not None:
+            source = self._mix_sources(source)                  # BC mixup, train mode only (data2vec2.py:536-598)
         if features_only:
-            if mask:
-                raise NotImplementedError("masked feature extraction (finetune path) is a 'next' row")
-            x, layer_results = eng.extract_features(source)
-            return {"x": x, "linear_eval_projection": None, "padding_mask": None, "layer_results": layer_results,
-                    "mask": None}
+            return self._features_only(source, mask, precomputed_mask)
         B, L = source.shape
         T = cfg.frame_counts(L)[-1]
         m = precomputed_mask if precomputed_mask is not None else self._make_mask(B, T, source.device)
@@ -179,6 +214,68 @@ class Data2VecMultiModel(tnn.Module):
             if float(result["pred_var"]) < cfg.min_pred_var:
                 raise Exception(f"pred_var is {float(result['pred_var'])} < {cfg.min_pred_var}, exiting (AUDIO)")
         return result
+
+    def _mix_sources(self, source):
+        """data2vec2.py:536-598 with same_mixup (one r per batch): r ~ U(max(1e-6, source_mixup), 1), a random partner
+        per clip, A-weighted gain ratio, optional bernoulli(mixup_prob) per clip.  The draws come from a device generator
+        (the reference's torch.FloatTensor().uniform_ / randperm streams are not reproducible anyway; the arithmetic is
+        pinned by tests/golden/mixup.npz).  Targets are not mixed here: target_mixup needs with_labels (linear-eval
+        during pretraining), which no shipped recipe switches on."""
+        cfg = self.cfg
+        if self._perm_gen is None:
+            self._perm_gen = torch.Generator(device=source.device)
+            self._perm_gen.manual_seed(cfg.seed * 7919 + 41)
+        B = source.shape[0]
+        r = float(self._rng.uniform(max(1e-6, cfg.source_mixup), 1.0))
+        perm = torch.rand(B, device=source.device, generator=self._perm_gen).argsort().to(torch.int32)
+        mm = None
+        if cfg.mixup_prob < 1:
+            mm = (torch.rand(B, device=source.device, generator=self._perm_gen) < cfg.mixup_prob).to(torch.uint8)
+        return self._mixup_op(source, perm, r, mm)
+
+    def _features_only(self, source, mask: bool, precomputed_mask):
+        """forward(features_only=True) (data2vec2.py:629-728): clone_batch 1, remove_masked False.  mask=True is how the
+        finetune model calls it in train mode (wav2vec2.py:433-445): span mask over frames (replaced by zeros with
+        encoder_zero_mask, else N(0, mask_noise_std)), channel mask, and -- in train mode -- layerdrop and the dropouts."""
+        eng, cfg = self.engine, self.cfg
+        a = cfg.audio
+        B, L = source.shape
+        T = cfg.frame_counts(L)[-1]
+        aug, minfo = {}, None
+        if mask:
+            if precomputed_mask is not None:
+                m = precomputed_mask.to(source.device).to(torch.uint8)
+            elif a.mask_prob > 0:
+                m = torch.from_numpy(compute_mask_indices((B, T), a.mask_prob, a.mask_length, self._rng, min_masks=1,
+                                                          require_same_masks=True, mask_dropout=a.mask_dropout)
+                                     .astype(np.uint8)).to(source.device)
+            else:
+                m = None
+            if m is not None:
+                mu8, keep, restore = make_maskinfo(m)
+                minfo = MaskInfo(x_unmasked=None, mask=mu8, ids_restore=restore, ids_keep=keep)
+                aug.update(mask_t=mu8, noise_std=0.0 if a.encoder_zero_mask else a.mask_noise_std,
+                           noise_seed=int(self._rng.integers(0, 2 ** 31)))
+            if a.mask_channel_prob > 0:                          # base.py:471-484
+                mc = compute_mask_indices((B, cfg.embed_dim), a.mask_channel_prob, a.mask_channel_length, self._rng,
+                                          min_masks=0, require_same_masks=True)
+                aug["mask_c"] = torch.from_numpy(mc.astype(np.uint8)).to(source.device)
+        if self.training:
+            nb = a.prenet_depth + cfg.depth
+            if cfg.layerdrop > 0 or a.prenet_layerdrop > 0:      # modules.py:89-94, data2vec2.py:651-655
+                act = [a.prenet_layerdrop == 0 or self._rng.random() > a.prenet_layerdrop for _ in range(a.prenet_depth)]
+                act += [cfg.layerdrop == 0 or self._rng.random() > cfg.layerdrop for _ in range(cfg.depth)]
+                aug["active"] = [bool(v) for v in act]
+                assert len(act) == nb
+            if self.dropout and max(cfg.encoder_dropout, cfg.attention_dropout, cfg.dropout_input, a.prenet_dropout) > 0:
+                self._fwd_count = getattr(self, "_fwd_count", 0) + 1
+                aug.update(drop_seed=(cfg.seed * 7919 + self._fwd_count) & 0x7FFFFFFF, p_drop=cfg.encoder_dropout,
+                           p_proj=cfg.encoder_dropout, p_mlp=cfg.post_mlp_drop, p_pre=a.prenet_dropout,
+                           p_att=cfg.attention_dropout, p_in=cfg.dropout_input, p_act=0.0, p_final=0.0)
+        with torch.no_grad():
+            x, ts, _ = eng.encode_features(source, save=False, aug=aug or None)
+        return {"x": x, "linear_eval_projection": None, "padding_mask": None, "layer_results": [t for _, t in ts],
+                "mask": minfo}
 
     def extract_features(self, source, mode=None, padding_mask=None, mask=False, remove_extra_tokens=True):
         """data2vec2.py:1112-1123"""

@@ -179,5 +179,14 @@ class PretrainTrainer:
             a, b = s[off:off + D], s[off + D:off + 2 * D]
             return float(torch.sqrt((b - a * a / n) / (n - 1) + 1e-6).mean())
 
-        return dict(loss=float(s[4 * D]) / n, sample_size=n, pred_var=var(0), target_var=var(2 * D),
-                    gnorm=float(self.last["gnorm"]), ema_decay=self.ema_decay * 1000)
+        out = dict(loss=float(s[4 * D]) / n, sample_size=n, pred_var=var(0), target_var=var(2 * D),
+                   gnorm=float(self.last["gnorm"]), ema_decay=self.ema_decay * 1000)
+        # representation-collapse guard (data2vec2.py:972-988); evaluated here because this is where the variances
+        # reach the host -- the step itself never synchronises
+        c = self.cfg
+        if self.num_updates > 5000:
+            if out["target_var"] < c.min_target_var:
+                raise Exception(f"target var is {out['target_var']} < {c.min_target_var}, exiting (AUDIO)")
+            if out["pred_var"] < c.min_pred_var:
+                raise Exception(f"pred_var is {out['pred_var']} < {c.min_pred_var}, exiting (AUDIO)")
+        return out

@@ -1,0 +1,177 @@
+"""GPU: the drop-in nn.Module surface behaves like the reference's under a stock training loop
+(zero_grad / backward / optimizer.step), applies the BC source mixup in train mode (data2vec2.py:536-598) and serves
+forward(features_only=True, mask=True) (data2vec2.py:1112-1124, called by wav2vec2.py:433-445)."""
+import numpy as np
+import pytest
+import torch
+
+import a2v_oracle as O
+from conftest import load_golden, rel_err, split_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(tiny_golden, dtype=torch.float32, **cfg_kw):
+    import nn
+    from animal2vec_amd.config import tiny_config
+    p, ema, g = split_golden(tiny_golden)
+    model = nn.Data2VecMultiModel.build_model(tiny_config(**cfg_kw), task=None, dtype=dtype)
+    sd = dict(p)
+    sd["_ema"] = ema
+    model.load_state_dict(sd)
+    return model, p, ema, g
+
+
+def test_stock_training_loop_default_zero_grad(tiny_golden):
+    """`optimizer.zero_grad()` (set_to_none=True since torch 2.0, and what fairseq's optimizer does) detaches p.grad from the
+    flat gradient buffer; the next backward must re-attach it with a CLEARED slice: parameters keep training and the
+    second step's gradient is the gradient at the new parameters, not an accumulation."""
+    fx = tiny_golden
+    model, p, ema, g = _model(fx)
+    model.train()
+    model.dropout = model.mixup = False
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    kw = dict(precomputed_mask=fx["mask"], noise=fx["noise"].cuda())
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    for step in range(3):
+        opt.zero_grad()                                  # default: set_to_none=True
+        assert all(q.grad is None for q in model.parameters())
+        loss = model(fx["source"], **kw)["losses"]["AUDIO_regression"].float().sum()
+        loss.backward()
+        grads = {k: q.grad for k, q in model.named_parameters()}
+        assert all(v is not None for v in grads.values())
+        if step == 0:
+            assert max(rel_err(grads[k], g[k]) for k in g) < 1e-3
+        if step == 2:
+            # a fresh model at the current parameters gives the same gradient (no stale accumulation)
+            fresh, *_ = _model(fx)
+            sd = {k: v.detach().clone() for k, v in model.named_parameters()}
+            sd["_ema"] = ema
+            fresh.load_state_dict(sd)
+            fresh.train()
+            fresh.dropout = fresh.mixup = False
+            fresh(fx["source"], **kw)["losses"]["AUDIO_regression"].float().sum().backward()
+            fg = {k: q.grad for k, q in fresh.named_parameters()}
+            assert max(rel_err(grads[k], fg[k]) for k in fg) < 1e-5
+        opt.step()
+        model.set_num_updates(step + 1)                  # re-packs the operand images (and steps the EMA teacher)
+    after = dict(model.named_parameters())
+    moved = [k for k in before if not torch.equal(before[k], after[k].detach())]
+    assert len(moved) == len(before), sorted(set(before) - set(moved))[:5]
+    # Module.zero_grad() keeps the views attached and clears the buffer in one launch
+    model.zero_grad()
+    assert all(q.grad is not None and float(q.grad.abs().sum()) == 0.0 for q in model.parameters())
+    assert float(model.store.grad.abs().sum()) == 0.0
+
+
+def test_forward_mixes_sources_in_train_mode(tiny_golden):
+    """train(): the sources that reach the engine are the BC mixture of the batch (one r, a partner per clip, A-weighted
+    gains), eval(): untouched.  The draws are reproduced from the model's seeds; the arithmetic is the oracle's."""
+    fx = tiny_golden
+    model, *_ = _model(fx)
+    cfg = model.cfg
+    g = torch.Generator().manual_seed(9)
+    B, L = 4, fx["source"].shape[1]
+    src = torch.nn.functional.layer_norm(torch.randn(B, L, generator=g), (L,)) * (0.5 + torch.rand(B, 1, generator=g))
+    T = cfg.frame_counts(L)[-1]
+    mask = O.seeded_mask(B * cfg.clone_batch, T, 16, 3)
+    seen = {}
+    orig = model.engine.forward
+
+    def spy(source, *a, **kw):
+        seen["src"] = source.detach().clone()
+        return orig(source, *a, **kw)
+
+    model.engine.forward = spy
+    model.train()
+    model.dropout = False
+    with torch.no_grad():
+        model(src, precomputed_mask=mask)
+    r = float(np.random.default_rng(cfg.seed).uniform(max(1e-6, cfg.source_mixup), 1.0))
+    pg = torch.Generator(device="cuda")
+    pg.manual_seed(cfg.seed * 7919 + 41)
+    perm = torch.rand(B, device="cuda", generator=pg).argsort().cpu()
+    want = O.bc_mixup(src, perm, r, fs=cfg.audio.sample_rate, wl=cfg.mixing_window_length)
+    assert rel_err(seen["src"], want) < 1e-4
+    assert rel_err(seen["src"], src) > 1e-2
+    model.eval()
+    with torch.no_grad():
+        model(src, precomputed_mask=mask)
+    assert torch.equal(seen["src"].cpu(), src)
+    model.train()
+    model.mixup = False
+    with torch.no_grad():
+        model(src, precomputed_mask=mask)
+    assert torch.equal(seen["src"].cpu(), src)
+
+
+def test_features_only_with_mask(tiny_golden):
+    """forward(features_only=True, mask=True): clone_batch 1, masked frames replaced (zeros with encoder_zero_mask, the
+    pretraining default), nothing removed -- equal to the oracle's finetune-form encoder on the same mask; the train-form
+    golden from the live reference (noise replacement + channel mask) is covered through the same engine call in
+    test_pretrain_gpu.py::test_finetune_train_form_fp32_vs_reference_golden."""
+    fx = tiny_golden
+    model, p, ema, _ = _model(fx)
+    cfg = model.cfg
+    model.eval()
+    src = fx["source"]
+    B, L = src.shape
+    T = cfg.frame_counts(L)[-1]
+    g = torch.Generator().manual_seed(3)
+    m = (torch.rand(B, T, generator=g) < 0.4)
+    m[1] = m[0].roll(5)                       # equal count per row (the reference assumes it)
+    res = model(src, features_only=True, mask=True, precomputed_mask=m)
+    assert res["mask"] is not None and torch.equal(res["mask"].mask.cpu().bool(), m)
+    assert res["x"].shape == (B, T, cfg.embed_dim) and len(res["layer_results"]) == cfg.depth
+    # oracle: same masked features through the unmasked encoder
+    from test_pretrain_gpu import TINY_LAYERS
+    ocfg = O.OracleConfig(embed_dim=64, num_heads=4, depth=2, prenet_depth=1, decoder_dim=32, decoder_layers=2, decoder_kernel=7,
+                          decoder_groups=4, clone_batch=2, conv_pos_groups=4, average_top_k_layers=2,
+                          conv_feature_layers=TINY_LAYERS)
+    # an identity "head" makes the oracle's logits the mean of the layer results
+    want = O.finetune_forward(p, torch.eye(64), torch.zeros(64), src, ocfg, mask_t=m.to(torch.uint8), replacement=None)
+    lm = sum(t.float() for t in res["layer_results"]) / len(res["layer_results"])
+    assert rel_err(lm.cpu(), want) < 1e-3
+    # mask=False: identical to extract_features
+    a = model(src, features_only=True, mask=False)
+    b = model.extract_features(src)
+    assert torch.equal(a["x"], b["x"]) and a["mask"] is None
+    # train mode + dropout: still runs, differs from eval
+    model.train()
+    model.mixup = False
+    c = model(src, features_only=True, mask=True, precomputed_mask=m)
+    assert rel_err(c["x"], res["x"]) > 1e-3
+
+
+def test_finetune_model_train_form_runs_and_freezes(tiny_golden):
+    """nn.Wav2VecCcasFinetune with a FinetuneConfig: train mode applies mixup / masks / layerdrop / dropouts; while
+    num_updates < freeze_finetune_updates only the classifier receives gradients (wav2vec2.py:440-445)."""
+    import nn
+    fx = tiny_golden
+    enc, p, ema, _ = _model(fx)
+    f = nn.FinetuneConfig(n_labels=3, freeze_finetune_updates=2, mask_prob=0.3, mask_length=2, mask_channel_prob=0.2,
+                          mask_channel_length=4, layerdrop=0.0)
+    model = nn.Wav2VecCcasFinetune(enc, n_labels=3, fcfg=f)
+    crit = nn.FinetuneCrossEntropyCriterion(task=None)
+    src = fx["source"]
+    B, L = src.shape
+    T = enc.cfg.frame_counts(L)[-1]
+    g = torch.Generator().manual_seed(1)
+    tgt = (torch.rand(B, T, 3, generator=g) < 0.2).float()
+    sample = {"net_input": {"source": src, "target": tgt}, "target": tgt, "ntokens": B * T}
+    model.train()
+    opt = torch.optim.SGD([q for q in model.parameters()], lr=1e-2)
+    enc_before = enc.store.flat.clone()
+    for step in range(4):
+        opt.zero_grad()
+        loss, n, log = crit(model, sample)
+        loss.backward()
+        assert model.proj.weight.grad is not None and float(model.proj.weight.grad.abs().sum()) > 0
+        frozen = step < 2
+        gsum = float(enc.store.grad.abs().sum())
+        assert (gsum == 0.0) == frozen, (step, gsum)
+        opt.step()
+        model.set_num_updates(step + 1)
+        if step == 1:
+            assert torch.equal(enc.store.flat, enc_before)
+    assert not torch.equal(enc.store.flat, enc_before)

@@ -118,7 +118,7 @@ def test_model_surface_dropin(tiny_golden):
     assert set(got) == set(p) | {"_ema"} and set(got["_ema"]) == set(ema)
     assert all(torch.equal(got[k].cpu(), p[k]) for k in p)
     model.train()
-    model.dropout = False        # the reference vectors were produced in eval mode
+    model.dropout = model.mixup = False        # the reference vectors were produced in eval mode
     model.store.grad.zero_()
     out = model(fx["source"], precomputed_mask=fx["mask"], noise=fx["noise"].cuda())
     assert set(out) >= {"losses", "sample_size", "masked_pct", "pred_var", "target_var", "ema_decay"}
