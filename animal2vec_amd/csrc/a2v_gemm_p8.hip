@@ -29,11 +29,27 @@ __device__ __forceinline__ void p8_glds16(const char* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((p8_gbl_cvoid_t*)gsrc, (p8_lds_void_t*)lds_dst, 16, 0, 0);
 }
 
-#define P8_BUF 65536                  // one K-tile: A_lo, A_hi, B_lo, B_hi (16 KiB half-tiles)
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+#define P8_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+  P8_DPP_ADD(0xB1);     // quad_perm [1,0,3,2]
+  P8_DPP_ADD(0x4E);     // quad_perm [2,3,0,1]
+  P8_DPP_ADD(0x141);    // row_half_mirror
+  P8_DPP_ADD(0x140);    // row_mirror
+#undef P8_DPP_ADD
+  return v;
+}
+
+// LDS map (16 KiB half-tiles): [A_lo0 A_hi0 A_lo1 A_hi1 | B_lo0 B_hi0 B_lo1 B_hi1]: the A region and the B region are
+// 64 KiB each, so every fragment read is ONE address register (a_off / b_off, plus its ^64 twin) + a 16-bit immediate
+// (buffer, half and row-tile offsets all fold into ds_read's offset field, which stops at 65535) -- with the two K-tile
+// buffers 64 KiB apart the +buffer variants were four more address registers per operand.
+#define P8_BUF 32768                  // K-tile buffer 1 relative to buffer 0, inside either region
 #define P8_ALO 0
 #define P8_AHI 16384
-#define P8_BLO 32768
-#define P8_BHI 49152
+#define P8_BLO 65536
+#define P8_BHI 81920
+#define P8_BREG 65536                 // start of the B region (folded into b_off)
 #define P8_STG 131072                 // epilogue staging: 8 waves x 16 rows x 64 fp32
 #define P8_LDS (131072 + 8 * 4096)    // = 160 KiB
 
@@ -64,15 +80,23 @@ __global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__
 #define P8_CTR_SLOTS 4     // one counter set per concurrently used stream (a2v_debug_set(9, slot) before launching on it)
 __device__ unsigned g_p8_ctr_all[P8_CTR_SLOTS][9];
 
-struct P8Tile {      // byte offsets (from the A / B base of the group) of the 16-B chunks this thread stages
+struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
-  int m0, n0;
-};
+  int m0, n0;        // first output row / column of the tile
+  int mc;            // DS: first row actually staged = min(m0, M - BM): the last m-tile is shifted up instead of
+};                   // clamping rows, its epilogue skips the rows below m0
 
 // IH = 16-row MFMA tiles per wave in the upper A half: the workgroup tile is BM = 128 + 32 IH rows (256 / 224 / 192).
 // M = 13440 (96 clips x 140 kept frames) is 60 x 224: with BM = 224 the student's Linears fill 240 of 256 CUs per
 // round with no M tail, 12.5 % less work per round than 53 ragged 256-row tiles.
-template <int IH>
+// DS ("direct store") = the epilogue writes the accumulators straight to global memory, no LDS staging: the MFMA
+// operands are swapped (D = W_frag x X_frag, so a lane holds 4 consecutive output COLUMNS of one row instead of 4 rows
+// of one column) and the rows of every 32-row group of the B half-tiles are permuted when they are staged (LDS row
+// 16 j + f of a group holds weight row 8 (f >> 2) + 4 j + (f & 3); the per-lane DMA source address makes that free), so
+// the two column blocks j = 0, 1 of a wave give each lane 8 consecutive columns = one 16-B bf16 store; the four lanes
+// with the same MFMA column cover 64 contiguous bytes of an output row.  Replaces 128 ds_write_b32 + 32 ds_read_b128 +
+// 16 wave barriers per wave and tile (LDS-store bound: 4 KiB per wave and pass at 64 B/clk/CU).
+template <int IH, bool DS>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot, int cs_part) {
   unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
   constexpr int BM = 128 + 32 * IH;
@@ -97,7 +121,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     tile_coords(id, tiles_m, tiles_n, tm, tn);
     t.m0 = tm * BM;
     t.n0 = tn * 256;
+    t.mc = t.m0;
     unsigned ao[4], bo[4];
+    if constexpr (DS) {
+      // rows of A are contiguous (launcher): address = row * pitch, so the offsets of one tile are those of another
+      // plus a uniform delta -- the tile seam adds that delta in place (next_tile below): no second set of offsets, no
+      // division at the seam.
+      t.mc = t.m0 + BM <= g.M ? t.m0 : g.M - BM;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int slab = wid + 8 * (q & 1);
+        if ((q >> 1) && slab >= IH * 4) slab = wid & 3;
+        ao[q] = (unsigned)(((long long)(t.mc + (q >> 1) * 128 + slab * 8 + lr) * a.pitch + P8_SRC_CHUNK(slab) * 8) * 2);
+        const int bslab = wid + 8 * (q & 1);
+        int brow = bslab * 8 + lr;
+        brow = (brow & ~31) + 8 * ((brow & 15) >> 2) + 4 * ((brow >> 4) & 1) + (brow & 3);
+        bo[q] = (unsigned)(((long long)(t.n0 + (q >> 1) * 128 + brow) * g.ldb + P8_SRC_CHUNK(bslab) * 8) * 2);
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {          // q = half * 2 + i: rows half*128 + (wid + 8 i) * 8 + lr
       int slab = wid + 8 * (q & 1);
@@ -110,6 +151,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       const int n = t.n0 + (q >> 1) * 128 + bslab * 8 + lr;
       bo[q] = (unsigned)(((long long)n * g.ldb + P8_SRC_CHUNK(bslab) * 8) * 2);
     }
+    }
     t.al0 = ao[0]; t.al1 = ao[1]; t.ah0 = ao[2]; t.ah1 = ao[3];
     t.bl0 = bo[0]; t.bl1 = bo[1]; t.bh0 = bo[2]; t.bh1 = bo[3];
     return t;
@@ -118,6 +160,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   const int ah_second = (wid + 8 < IH * 4) ? 8192 : ((wid & 3) - wid) * 1024;   // A_hi: second DMA's slab relative to dst0
 
   const int nk = g.K / 64;
+  const unsigned d64a = (unsigned)(a.pitch * 128), d64b = (unsigned)(g.ldb * 128);   // bytes of 64 rows of A / of B
   // stage one half-tile: 2 LDS-DMA per thread
 #define P8_STAGE2(base, o0, o1, kt, lds_off, second)            \
   {                                                            \
@@ -133,7 +176,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   const int lds0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;   // LDS address of smem[0]
   const int a_off = lds0 + (wr * 64 + fr) * 128 + ((fq ^ sw) << 4);       // + i * 2048
   const int ah_off = lds0 + (wr * IH * 16 + fr) * 128 + ((fq ^ sw) << 4);  // upper half: IH row tiles per wave
-  const int b_off = lds0 + (wc * 32 + fr) * 128 + ((fq ^ sw) << 4);       // + j * 2048
+  const int b_off = lds0 + P8_BREG + (wc * 32 + fr) * 128 + ((fq ^ sw) << 4);       // + j * 2048
 
   f32x4 acc[4 + IH][4];
   bf16x8 fa[4][2], fbl[2][2], fbh[2][2];
@@ -145,25 +188,25 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #define P8_DSR(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define P8_READ_A(cur, half_off)                                                                       \
   {                                                                                                    \
-    const int a0_ = (cur) ? a_off + P8_BUF : a_off, a1_ = (cur) ? (a_off ^ 64) + P8_BUF : (a_off ^ 64); \
-    P8_DSR(fa[0][0], a0_, (half_off)); P8_DSR(fa[0][1], a1_, (half_off));                              \
-    P8_DSR(fa[1][0], a0_, (half_off) + 2048); P8_DSR(fa[1][1], a1_, (half_off) + 2048);                \
-    P8_DSR(fa[2][0], a0_, (half_off) + 4096); P8_DSR(fa[2][1], a1_, (half_off) + 4096);                \
-    P8_DSR(fa[3][0], a0_, (half_off) + 6144); P8_DSR(fa[3][1], a1_, (half_off) + 6144);                \
+    const int a0_ = a_off, a1_ = a_off ^ 64;                                                           \
+    P8_DSR(fa[0][0], a0_, (cur) + (half_off)); P8_DSR(fa[0][1], a1_, (cur) + (half_off));              \
+    P8_DSR(fa[1][0], a0_, (cur) + (half_off) + 2048); P8_DSR(fa[1][1], a1_, (cur) + (half_off) + 2048); \
+    P8_DSR(fa[2][0], a0_, (cur) + (half_off) + 4096); P8_DSR(fa[2][1], a1_, (cur) + (half_off) + 4096); \
+    P8_DSR(fa[3][0], a0_, (cur) + (half_off) + 6144); P8_DSR(fa[3][1], a1_, (cur) + (half_off) + 6144); \
   }
 #define P8_READ_AH(cur)                                                                                 \
   {                                                                                                    \
-    const int a0_ = (cur) ? ah_off + P8_BUF : ah_off, a1_ = (cur) ? (ah_off ^ 64) + P8_BUF : (ah_off ^ 64); \
-    P8_DSR(fa[0][0], a0_, P8_AHI); P8_DSR(fa[0][1], a1_, P8_AHI);                                      \
-    P8_DSR(fa[1][0], a0_, P8_AHI + 2048); P8_DSR(fa[1][1], a1_, P8_AHI + 2048);                        \
-    if (IH > 2) { P8_DSR(fa[2][0], a0_, P8_AHI + 4096); P8_DSR(fa[2][1], a1_, P8_AHI + 4096); }        \
-    if (IH > 3) { P8_DSR(fa[3][0], a0_, P8_AHI + 6144); P8_DSR(fa[3][1], a1_, P8_AHI + 6144); }        \
+    const int a0_ = ah_off, a1_ = ah_off ^ 64;                                                         \
+    P8_DSR(fa[0][0], a0_, (cur) + P8_AHI); P8_DSR(fa[0][1], a1_, (cur) + P8_AHI);                      \
+    P8_DSR(fa[1][0], a0_, (cur) + P8_AHI + 2048); P8_DSR(fa[1][1], a1_, (cur) + P8_AHI + 2048);        \
+    if (IH > 2) { P8_DSR(fa[2][0], a0_, (cur) + P8_AHI + 4096); P8_DSR(fa[2][1], a1_, (cur) + P8_AHI + 4096); } \
+    if (IH > 3) { P8_DSR(fa[3][0], a0_, (cur) + P8_AHI + 6144); P8_DSR(fa[3][1], a1_, (cur) + P8_AHI + 6144); } \
   }
 #define P8_READ_B(fb, cur, half_off)                                                                   \
   {                                                                                                    \
-    const int b0_ = (cur) ? b_off + P8_BUF : b_off, b1_ = (cur) ? (b_off ^ 64) + P8_BUF : (b_off ^ 64); \
-    P8_DSR(fb[0][0], b0_, (half_off)); P8_DSR(fb[0][1], b1_, (half_off));                              \
-    P8_DSR(fb[1][0], b0_, (half_off) + 2048); P8_DSR(fb[1][1], b1_, (half_off) + 2048);                \
+    const int b0_ = b_off, b1_ = b_off ^ 64;          /* b_off includes P8_BREG */                     \
+    P8_DSR(fb[0][0], b0_, (cur) + (half_off) - P8_BREG); P8_DSR(fb[0][1], b1_, (cur) + (half_off) - P8_BREG); \
+    P8_DSR(fb[1][0], b0_, (cur) + (half_off) - P8_BREG + 2048); P8_DSR(fb[1][1], b1_, (cur) + (half_off) - P8_BREG + 2048); \
   }
 #define P8_TIE4(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1])
 #define P8_LGKM0                                                                                        \
@@ -176,30 +219,40 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
   _Pragma("unroll") for (int i = 0; i < (NI); ++i)                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-    acc[(ibase) + i][(jbase) + j] =                                                                    \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
+    acc[(ibase) + i][(jbase) + j] = DS                                                                 \
+        ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0) \
+        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                       \
   __builtin_amdgcn_s_barrier();
 
   // one K-tile held in buffer `cur`; T1 / k1 = tile and K index of the K-tile after it (A_hi goes to `oth`),
   // T2 / k2 = of the one after that (A_lo, B_lo, B_hi re-stage `cur`)
+// DS: the second chunk of a half-tile is 64 rows below the first = a uniform byte delta (d64a / d64b), added on the
+// scalar side of the address, so only the first chunk's offset lives in a VGPR (opaque copies: hoisted out of the K loop
+// the sums would be VGPRs again).  The short upper half (IH < 4) re-fetches a slab, its second offset stays a register.
+#define P8_AL1(T_) (DS ? T_.al0 + d64a_ : T_.al1)
+#define P8_AH1(T_) ((DS && IH == 4) ? T_.ah0 + d64a_ : T_.ah1)
+#define P8_BL1(T_) (DS ? T_.bl0 + d64b_ : T_.bl1)
+#define P8_BH1(T_) (DS ? T_.bh0 + d64b_ : T_.bh1)
 #define P8_KTILE(cur, oth, T1, k1, T2, k2)                                                             \
+  unsigned d64a_ = d64a, d64b_ = d64b;                                                                 \
+  asm volatile("" : "+s"(d64a_), "+s"(d64b_));                                                         \
   /* phase 1: quadrant lo/lo */                                                                        \
   P8_READ_B(fbl, cur, P8_BLO)                                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                                   \
   P8_READ_A(cur, P8_ALO)                                                                               \
-  P8_STAGE2(abase, T1.ah0, T1.ah1, k1, (oth) + P8_AHI, ah_second)                                      \
+  P8_STAGE2(abase, T1.ah0, P8_AH1(T1), k1, (oth) + P8_AHI, ah_second)                                      \
   P8_MFMA(0, 0, fbl, 4)                                                                                  \
   /* phase 2: lo/hi */                                                                                 \
   P8_READ_B(fbh, cur, P8_BHI)                                                                          \
-  P8_STAGE(abase, T2.al0, T2.al1, k2, (cur) + P8_ALO)                                                  \
+  P8_STAGE(abase, T2.al0, P8_AL1(T2), k2, (cur) + P8_ALO)                                                  \
   P8_MFMA(0, 2, fbh, 4)                                                                                  \
   /* phase 3: hi/hi */                                                                                 \
   P8_READ_AH(cur)                                                                                      \
-  P8_STAGE(bbase, T2.bl0, T2.bl1, k2, (cur) + P8_BLO)                                                  \
+  P8_STAGE(bbase, T2.bl0, P8_BL1(T2), k2, (cur) + P8_BLO)                                                  \
   P8_MFMA(4, 2, fbh, IH)                                                                                  \
   /* phase 4: hi/lo (B_lo fragments kept from phase 1) */                                              \
-  P8_STAGE(bbase, T2.bh0, T2.bh1, k2, (cur) + P8_BHI)                                                  \
+  P8_STAGE(bbase, T2.bh0, P8_BH1(T2), k2, (cur) + P8_BHI)                                                  \
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                     \
   P8_MFMA(4, 0, fbl, IH)
 
@@ -234,13 +287,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   }
   P8Tile T = make_tile(seq);
   // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
-  P8_STAGE(abase, T.al0, T.al1, 0, P8_ALO)
-  P8_STAGE(bbase, T.bl0, T.bl1, 0, P8_BLO)
-  P8_STAGE(bbase, T.bh0, T.bh1, 0, P8_BHI)
-  P8_STAGE2(abase, T.ah0, T.ah1, 0, P8_AHI, ah_second)
-  P8_STAGE(abase, T.al0, T.al1, 1, P8_BUF + P8_ALO)
-  P8_STAGE(bbase, T.bl0, T.bl1, 1, P8_BUF + P8_BLO)
-  P8_STAGE(bbase, T.bh0, T.bh1, 1, P8_BUF + P8_BHI)
+  {
+    const unsigned d64a_ = d64a, d64b_ = d64b;
+    P8_STAGE(abase, T.al0, P8_AL1(T), 0, P8_ALO)
+    P8_STAGE(bbase, T.bl0, P8_BL1(T), 0, P8_BLO)
+    P8_STAGE(bbase, T.bh0, P8_BH1(T), 0, P8_BHI)
+    P8_STAGE2(abase, T.ah0, P8_AH1(T), 0, P8_AHI, ah_second)
+    P8_STAGE(abase, T.al0, P8_AL1(T), 1, P8_BUF + P8_ALO)
+    P8_STAGE(bbase, T.bl0, P8_BL1(T), 1, P8_BUF + P8_BLO)
+    P8_STAGE(bbase, T.bh0, P8_BH1(T), 1, P8_BUF + P8_BHI)
+  }
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   // The two waves that share a SIMD (w and w + 4, i.e. wr = 0 / 1) run half a phase apart from here on: one extra
@@ -258,24 +314,160 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     for (int kt = 0; kt < nk - 2; kt += 2) {
-      P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2)
-      P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3)
+      { P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2) }
+      { P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3) }
     }
     // last two K-tiles: the stream continues with K-tiles 0 / 1 of the next tile (its offsets are formed here, not
     // at the top of the tile, so that they are not live -- and spilled -- across the main loop)
-    seq_next = dynamic ? (int)__builtin_amdgcn_readfirstlane(*(volatile unsigned*)slot) : seq + (int)gridDim.x;
+    // (an LDS-typed read: through a generic pointer this was a flat_load, whose s_waitcnt vmcnt(0) lgkmcnt(0) drained
+    // the three half-tiles in flight at every tile seam)
+    if (dynamic) {
+      unsigned nx;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(nx) : "v"(lds0 + P8_STG) : "memory");
+      seq_next = (int)__builtin_amdgcn_readfirstlane(nx);
+    } else {
+      seq_next = seq + (int)gridDim.x;
+    }
+    // Claim the tile after the next one now: an atomic written in C++ is rewritten by the compiler's atomic optimizer into
+    // a wave-wide form whose result it consumes at once, i.e. s_waitcnt vmcnt(0) -- every DMA in flight -- right where
+    // the atomic is issued.  As raw asm it simply returns under the next two K-tiles (their vmcnt(6) waits retire it).
+    if (dynamic && tid == 0) {
+      const unsigned one = 1u, zoff = 0u;
+      // s_nop 4: the pointer's SGPRs may have just been restored by v_readlane (SGPR spill); a VMEM instruction reading an
+      // SGPR written by VALU needs 5 wait states, which the compiler only inserts around instructions it can see
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zoff), "v"(one), "s"(&g_p8_ctr[xcd]) : "memory");
+    }
     const bool has_next = seq_next < ntiles;
-    const P8Tile Tn = has_next ? make_tile(seq_next) : T;
+    P8Tile Tn = T;
+    if constexpr (DS) {
+      if (has_next) {
+        // opaque copies: the divisions' reciprocals are formed here, not hoisted out of the tile loop into registers
+        // that live (and spill) across the K loop
+        int tm_ = tiles_m, tn_ = tiles_n;
+        asm volatile("" : "+s"(tm_), "+s"(tn_));
+        const int idn = xcd_remap(seq_next, tm_ * tn_);
+        int tmn, tnn;
+        tile_coords(idn, tm_, tn_, tmn, tnn);
+        Tn.m0 = tmn * BM;
+        Tn.n0 = tnn * 256;
+        Tn.mc = Tn.m0 + BM <= g.M ? Tn.m0 : g.M - BM;
+        const unsigned da = (unsigned)((Tn.mc - T.mc) * (int)a.pitch * 2), db = (unsigned)((Tn.n0 - T.n0) * (int)g.ldb * 2);
+        Tn.al0 += da; Tn.ah0 += da; Tn.ah1 += da;        // (al1, bl1, bh1 -- and ah1 at IH = 4 -- are derived, dead here)
+        Tn.bl0 += db; Tn.bh0 += db;
+      }
+    } else {
+      if (has_next) Tn = make_tile(seq_next);
+    }
     const int kn0 = has_next ? 0 : nk - 2, kn1 = has_next ? 1 : nk - 1;
-    P8_KTILE(0, P8_BUF, T, nk - 1, Tn, kn0)
-    P8_KTILE(P8_BUF, 0, Tn, kn0, Tn, kn1)
+    { P8_KTILE(0, P8_BUF, T, nk - 1, Tn, kn0) }
+    { P8_KTILE(P8_BUF, 0, Tn, kn0, Tn, kn1) }
+    // the "+v" ties of P8_LGKM0 make every fragment register look live from one phase to the next, and so across the
+    // epilogue into the next tile's first phase: redefine them (no instruction) so that the epilogue may use them
+#define P8_KILL4(x) "=v"(x[0][0]), "=v"(x[0][1]), "=v"(x[1][0]), "=v"(x[1][1])
+    asm volatile("" : P8_KILL4(fa), "=v"(fa[2][0]), "=v"(fa[2][1]), "=v"(fa[3][0]), "=v"(fa[3][1]), P8_KILL4(fbl), P8_KILL4(fbh));
+#undef P8_KILL4
 
     // ---- epilogue (overlaps the LDS-DMA already in flight for the next tile): 8 passes of 16 rows per wave
     // lane-derived values are re-formed from an opaque copy of the lane id: hoisted out of the tile loop they
     // would be live -- and spilled -- across the K loop, and a spill reload is a VMEM load whose wait drains the DMA
-    if (dynamic && tid == 0) fetched = id_base + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;   // returns under the epilogue
+    // `fetched` (claimed before the last two K-tiles, below) has been back since their counted waits; the opaque pass
+    // through keeps every use of it behind those waits
+    asm volatile("" : "+v"(fetched));
     int le = lane;
     asm volatile("" : "+v"(le));
+    bf16* const C = (bf16*)g.C;
+    bf16* const C2 = (bf16*)g.C2;
+    const bf16* const R = (const bf16*)g.R;
+    const bool need_r = (g.flags & (F_RES | F_GELU_BWD)) != 0;
+    if constexpr (DS) {
+      // lane (fq, fr) holds, for row block i and column half hb: row i*16 + fr, columns hb*128 + wc*32 + 8 fq + [0, 8).
+      // Addresses: a uniform 64-bit tile base (SGPRs) + a 32-bit per-lane element offset inside the tile's rows.
+      const int fre = le & 15, fqe = le >> 4;
+      const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
+      bf16* const Ct = C + tile_off;
+      bf16* const C2t = C2 + tile_off;
+      const bf16* const Rt = R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0);
+      const int rskip = T.m0 - T.mc;                        // the shifted last m-tile: rows below m0 belong to its neighbour
+      const int rlo = wr * 64 + fre, rhi = 128 + wr * IH * 16 + fre;
+      // Residual / pre-activation rows are fetched RQ row blocks ahead of their use.  Loads, stores and the
+      // LDS-DMA share one in-order counter (vmcnt): a load issued after a store cannot be waited for without waiting for
+      // that store's acknowledgement too, which serialised the staged epilogue on memory latency (one round trip per
+      // 16-row pass).  Stores are unconditional: the rows a shifted last m-tile shares with its neighbour are computed
+      // from the same operands in the same order, so both write the same bits (the launcher refuses C overlapping R).
+      constexpr int RQ = IH == 4 ? 2 : 4;    // residual row blocks in flight (4 VGPRs each; the 256-row tile has fewer to spare)
+      Raw8<bf16> rq[RQ];
+#define P8_DROW(i_) ((i_) < 4 ? rlo + (i_) * 16 : rhi + ((i_) - 4) * 16)
+#pragma unroll
+      for (int hb = 0; hb < 2; ++hb) {
+        const int cl = hb * 128 + wc * 32 + fqe * 8;          // column inside the tile
+        if (need_r) {
+#pragma unroll
+          for (int i = 0; i < RQ; ++i) rq[i].load(Rt + (unsigned)(P8_DROW(i) * (int)g.ldr + cl));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (g.flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + T.n0 + cl, bias8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(bias8[i]));     // consumed here (see the staged form below)
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 4 + IH; ++i) {
+          const int row = P8_DROW(i);
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * hb][r]; v[4 + r] = acc[i][2 * hb + 1][r]; }
+          const unsigned eo = (unsigned)(row * (int)g.ldc + cl);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] += bias8[q];
+          if (g.flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
+          if (g.flags & F_GELU) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
+          }
+          if (g.flags & F_DROPOUT) {
+            const unsigned long long e0 = (unsigned long long)(T.mc + row) * g.ldc + (unsigned long long)((long long)grp * g.c_goff + T.n0 + cl);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = drop_apply(g.drop, e0 + q, v[q]);
+          }
+          if (need_r) {
+            float h[8];
+            rq[i % RQ].unpack(h);
+            if (i + RQ < 4 + IH) rq[i % RQ].load(Rt + (unsigned)(P8_DROW(i + RQ) * (int)g.ldr + cl));   // RQ blocks ahead
+            if (g.flags & F_RES) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] += h[q];
+            }
+            if (g.flags & F_GELU_BWD) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_f(h[q]);
+            }
+          }
+          Vec8<bf16>::store(Ct + eo, v);
+          if (g.flags & F_COLSUM) {
+            const float own = row >= rskip ? 1.f : 0.f;        // rows of the shifted tile's neighbour are summed there
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs[q] = fmaf(own, Cvt<bf16>::to(Cvt<bf16>::from(v[q])), cs[q]);
+          }
+          __builtin_amdgcn_sched_barrier(0);       // one row block at a time: interleaved, the blocks' temporaries spill
+        }
+        if (g.flags & F_COLSUM) {                // rows live in fr (the 16 lanes of a DPP row) and in i (in-lane)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) cs[q] = row16_sum(cs[q]);
+          if (fre == 0) {
+            const int ncol = T.n0 + cl;
+            if (cs_part) {                                   // own row of the scratch: plain stores, folded after the launch
+              float* const dst = g_p8_cs_part + ((long long)(T.m0 / BM) * 2 + wr) * g.N + ncol;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) dst[q] = cs[q];
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) atomicAdd(g.colsum + (long long)grp * g.N + ncol + q, cs[q]);
+            }
+          }
+        }
+      }
+#undef P8_DROW
+    } else {
     const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
     const int er = le >> 3, ec = (le & 7) * 8;           // read-out: 8 rows x 8 lanes, 8 columns (16 B of bf16) per lane
     float* const stg = (float*)(smem + P8_STG) + wid * 1024;
@@ -288,11 +480,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #pragma unroll
     for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(bias8[i]));
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bf16* const C = (bf16*)g.C;
-    bf16* const C2 = (bf16*)g.C2;
-    const bf16* const R = (const bf16*)g.R;
     // residual / pre-activation rows are fetched one pass (16 rows) ahead of their use
-    const bool need_r = (g.flags & (F_RES | F_GELU_BWD)) != 0;
     Raw8<bf16> rq[2][2];
 #define P8_RLOAD(ps_, slot)                                                                           \
   if (need_r) {                                                                                       \
@@ -381,7 +569,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       }
     }
 #undef P8_RLOAD
-    if (dynamic && tid == 0) *slot = fetched;     // read by every wave at the next tile's tail, many barriers later
+    }
+    if (dynamic && tid == 0) *slot = id_base + 8u * fetched + xcd;     // read by every wave at the next tile's tail, many barriers later
     T = Tn;
   }
   if (dynamic && tid == 0) {
@@ -397,12 +586,19 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 int g_a2v_p8_slot = 0;      // a2v_debug_set(9, v): tile-counter set of the persistent NT kernel (one per concurrent stream)
 int g_a2v_p8_dynamic = 2;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent NT kernel (2: first tile too)
 int g_a2v_p8_stagger = 1;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels)
+int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swapped MFMA operands, permuted B rows) on / off
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
   const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
                      a.Cv == a.Cg;
   if (!plain || g.K % 128 != 0 || g.K < 256 || g.N % 256 != 0 || g.M < 1024) return false;
+  // the direct-store form addresses A rows as row * pitch (contiguous batch items); anything else takes the staged form
+  const bool contiguous = a.bdiv == 1 && (a.T_out >= g.M || a.bstride == (long long)a.T_out * a.pitch);
+  const char *c0 = (const char*)g.C, *c1 = c0 + ((long long)(g.M - 1) * g.ldc + g.N) * 2;
+  const char *r0 = (const char*)g.R, *r1 = r0 + ((long long)(g.M - 1) * g.ldr + g.N) * 2;
+  const bool c_r_overlap = g.R != nullptr && r0 < c1 && c0 < r1;
+  const bool direct = g_a2v_p8_direct && contiguous && !c_r_overlap && g.G == 1 && (long long)256 * g.ldc * 2 < (1LL << 31) && (long long)256 * g.ldr * 2 < (1LL << 31);
   // 32-bit byte offsets inside one group's operands
   const long long a_span = ((long long)((g.M - 1) / a.T_out / a.bdiv) * a.bstride + (long long)a.T_out * a.pitch + g.K) * 2;
   const long long b_span = ((long long)g.N * g.ldb + g.K) * 2;
@@ -414,9 +610,9 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     (void)hipGetDevice(&dev);
     (void)hipGetDeviceProperties(&p, dev);
     cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+#define P8_ATTR(IH_, DS_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<IH_, DS_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    P8_ATTR(4, true) P8_ATTR(3, true) P8_ATTR(2, true) P8_ATTR(4, false) P8_ATTR(3, false) P8_ATTR(2, false)
+#undef P8_ATTR
   }
   // tile height: rounds x rows per round is what one CU executes; ties go to the taller tile
   int best_ih = 4;
@@ -436,9 +632,13 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);
   const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX && g_a2v_p8_slot == 0) ? 1 : 0;
-  if (best_ih == 4) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<4>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot, cs_part);
-  else if (best_ih == 3) hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<3>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot, cs_part);
-  else hipLaunchKernelGGL(gemm_nt_bf16_p8_kernel<2>, grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot, cs_part);
+#define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot, cs_part)
+  if (direct) {
+    if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);
+  } else {
+    if (best_ih == 4) P8_GO(4, false); else if (best_ih == 3) P8_GO(3, false); else P8_GO(2, false);
+  }
+#undef P8_GO
   if (cs_part) hipLaunchKernelGGL(p8_colsum_fold_kernel, dim3(cdiv(g.N, 256), 16), dim3(256), 0, stream, g.colsum, g.N, parts);
   return true;
 }

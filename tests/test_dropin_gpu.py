@@ -46,7 +46,7 @@ def test_stock_training_loop_default_zero_grad(tiny_golden):
             # a fresh model at the current parameters gives the same gradient (no stale accumulation)
             fresh, *_ = _model(fx)
             sd = {k: v.detach().clone() for k, v in model.named_parameters()}
-            sd["_ema"] = ema
+            sd["_ema"] = model.state_dict()["_ema"]       # set_num_updates has stepped the EMA teacher twice by now
             fresh.load_state_dict(sd)
             fresh.train()
             fresh.dropout = fresh.mixup = False

@@ -96,11 +96,13 @@ def test_linear_p8_tile_handout_modes(ops, M, N, K):
     assert rel_err(outs[2].float(), F.gelu(xd.float() @ wd.float().t() + bd)) < tol(dtype)
 
 
+@pytest.mark.parametrize("direct", [1, 0])
 @pytest.mark.parametrize("ih", [0, 2, 3, 4])
-@pytest.mark.parametrize("M,N,K", [(1100, 512, 256), (1024, 256, 384), (2049, 768, 1024)])
-def test_linear_p8_kernel(ops, M, N, K, ih):
+@pytest.mark.parametrize("M,N,K", [(1100, 512, 256), (1024, 256, 384), (2049, 768, 1024), (13440 + 100, 1024, 512)])
+def test_linear_p8_kernel(ops, M, N, K, ih, direct):
     """Shapes eligible for the 256x256 8-phase bf16 kernel (N % 256 == 0, K % 128 == 0, M >= 1024): M tails,
-    every epilogue, against fp32 torch and against the 128x128 kernel (a2v_debug_set(1, 0))."""
+    every epilogue, against fp32 torch and against the 128x128 kernel (a2v_debug_set(1, 0)); direct = 1: the
+    direct-store epilogue (swapped MFMA operands, permuted B rows, shifted last m-tile), 0: the LDS-staged one."""
     from animal2vec_amd import _lib
     dtype = torch.bfloat16
     x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
@@ -123,10 +125,15 @@ def test_linear_p8_kernel(ops, M, N, K, ih):
         return out
 
     _lib.load().a2v_debug_set(5, ih)          # tile height 192 / 224 / 256 rows, 0 = the launcher's choice
+    _lib.load().a2v_debug_set(10, direct)
     try:
         new = run_all()
+        again = run_all()                     # several multi-tile launches back to back (tile counters, scratch reuse)
     finally:
         _lib.load().a2v_debug_set(5, 0)
+        _lib.load().a2v_debug_set(10, 1)
+    for k in new:
+        assert torch.equal(new[k], again[k]) or (k == "cs" and rel_err(new[k], again[k]) < 1e-5), k
     _lib.load().a2v_debug_set(1, 0)
     try:
         old = run_all()

@@ -793,3 +793,72 @@ def test_exact_resume_from_checkpoint(tmp_path):
     assert float((a.store.flat - c.store.flat).abs().max()) < 5e-6
     assert float((a.store.teacher - c.store.teacher).abs().max()) < 5e-6
     assert float((a.store.adam_v - c.store.adam_v).abs().max()) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs 1 and 2 (base*)
+def _base_star_setup(seed=0):
+    ocfg = O.OracleConfig(**O.BASE_STAR)
+    p = O.init_params(ocfg, seed=seed)
+    g = torch.Generator().manual_seed(21)
+    for k in p:                      # off the init: biases / alibi / p-swish matter too
+        if "alibi_scale" in k:
+            p[k] = p[k] + torch.rand(p[k].shape, generator=g) * 0.3
+        elif k.endswith(".bias"):
+            p[k] = p[k] + torch.randn(p[k].shape, generator=g) * 0.01
+    ema = {k: v + torch.randn(v.shape, generator=g) * 0.002 for k, v in O.make_teacher(p).items()}
+    return ocfg, p, ema, g
+
+
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
+def test_base_star_pretrain_vs_oracle(dtype, tol_y, tol_g):
+    """BASELINE config 2's model (base*: D 768, 12 heads, 4 + 12 blocks, decoder 4 x 384, clone_batch 8) on one 10 s clip
+    @ 8 kHz with 140 of 2000 frames kept: targets, decoder output, loss and every gradient against the oracle on this
+    box's CPU.  bf16 gradient bound: profiles/r02_bf16_parity.json (per-tensor table of the same comparison)."""
+    from animal2vec_amd.config import base_star_config
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ocfg, p, ema, g = _base_star_setup()
+    L, keep = 80000, 140
+    T = O.frame_counts(L, ocfg.conv_feature_layers)[-1]
+    src = torch.nn.functional.layer_norm(torch.randn(1, L, generator=g), (L,))
+    mask = O.seeded_mask(ocfg.clone_batch, T, keep, 13)
+    noise = torch.randn(ocfg.clone_batch, T - keep, ocfg.embed_dim, generator=g) * 0.01
+    po = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    res = O.pretrain_forward(po, ema, src, mask, noise, ocfg)
+    res["losses"]["AUDIO_regression"].sum().backward()
+    cfg = base_star_config()
+    store, eng = build(cfg, p, ema, dtype)
+    dbg = run(eng, src, mask, noise)
+    assert rel_err(dbg["local_features"].float(), res["_dbg"]["local_features"]) < tol_y
+    assert rel_err(dbg["targets"], res["_dbg"]["targets"]) < tol_y
+    assert rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]) < tol_y
+    D = cfg.embed_dim
+    ls = float(res["losses"]["AUDIO_regression"].sum())
+    assert abs(float(eng.stats[4 * D]) - ls) / ls < tol_y
+    assert int(eng.stats[4 * D + 1]) == int(res["sample_size"])
+    errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
+    assert errs[0][0] < tol_g, errs[:8]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
+def test_base_star_extract_features_4x10s(dtype, tol):
+    """BASELINE config 1's workload (base*, forward only, 4 x 10 s @ 8 kHz) through the drop-in surface
+    (nn.Data2VecMultiModel.extract_features) against the oracle; head_dim 64, so the bf16 leg runs the MFMA attention
+    forward over all 2000 frames."""
+    import nn
+    from animal2vec_amd.config import base_star_config
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    ocfg, p, ema, g = _base_star_setup(seed=1)
+    B, L = 4, 80000
+    src = torch.nn.functional.layer_norm(torch.randn(B, L, generator=g), (L,))
+    with torch.no_grad():
+        x_ref, lrs_ref = O.features_only_forward(p, src, ocfg)
+    model = nn.Data2VecMultiModel.build_model(base_star_config(), dtype=dtype)
+    sd = dict(p)
+    sd["_ema"] = ema
+    model.load_state_dict(sd)
+    model.eval()
+    res = model.extract_features(src)
+    assert res["x"].shape == x_ref.shape and len(res["layer_results"]) == len(lrs_ref)
+    assert rel_err(res["x"].float(), x_ref) < tol
+    worst = max(rel_err(a.float(), b) for a, b in zip(res["layer_results"], lrs_ref))
+    assert worst < tol, worst
