@@ -114,6 +114,11 @@ def read_labels(path: str) -> Dict[str, np.ndarray]:
     if path.endswith(".npz"):
         z = np.load(path)
         return {k: np.asarray(z[k]) for k in keys if k in z}
+    with open(path, "rb") as f:
+        magic = f.read(4)
+    if magic[:2] == b"PK":                        # an .npz container under the .h5 name (test corpora, converted labels)
+        z = np.load(path)
+        return {k: np.asarray(z[k]) for k in keys if k in z}
     try:
         import h5py
     except ImportError as e:                      # pragma: no cover - h5py is not in this image
@@ -172,9 +177,14 @@ class AudioLabelDataset:
     def __init__(self, manifest_path: str, *, sample_rate: int, conv_feature_layers, unique_labels: Optional[Sequence[str]] = None,
                  return_labels: bool = True, normalize: bool = True, max_sample_size: Optional[int] = None,
                  min_sample_size: Optional[int] = 0, min_label_size: int = 0, use_focal_loss: bool = True,
-                 do_focal_prediction: bool = True):
+                 do_focal_prediction: bool = True, require_label_files: Optional[bool] = None, crop: str = "aligned"):
+        """require_label_files: the reference drops every manifest entry without a label file larger than
+        min_label_size bytes even when labels are not returned (audio_tasks.py:253-262); None = only when labels are
+        returned (label-free pretraining corpora).  crop: see collater()."""
         self.m = read_manifest(manifest_path, min_sample_size=min_sample_size, min_label_size=min_label_size,
-                               require_labels=return_labels)
+                               require_labels=return_labels if require_label_files is None else require_label_files)
+        assert crop in ("aligned", "reference")
+        self.crop = crop
         self.sample_rate, self.normalize = sample_rate, normalize
         self.conv_feature_layers = [tuple(x) for x in conv_feature_layers]
         self.unique_labels = list(unique_labels or [])
@@ -203,18 +213,22 @@ class AudioLabelDataset:
 
     # ------------------------------------------------------------------ collate (audio_tasks.py:388-465, pad = False)
     def collater(self, samples: List[dict], rng: Optional[np.random.Generator] = None) -> dict:
-        """Crop every clip to the shortest one (and to max_sample_size).  The reference crops sources at a random
-        offset and then every label column at its OWN random offset (collate_samples -> crop_to_max_size per column),
-        which misaligns labels whenever clips differ in length; here one offset per clip is drawn and the labels are
-        cropped at the matching frame.  Equal-length chunks (the shipped MeerKAT layout) take the diff == 0 branch in
-        both."""
+        """Crop every clip to the shortest one (and to max_sample_size).  Equal-length chunks (the shipped MeerKAT
+        layout) are copied as they are.  When clips differ in length the reference crops the sources at a random offset
+        and then every label COLUMN of every longer clip at its OWN random offset (collate_samples ->
+        crop_to_max_size per column, audio_tasks.py:388-431), which misaligns labels and audio:
+          crop="aligned" (default): one offset per clip, labels cropped at the matching frame;
+          crop="reference": the reference's draws, call for call, from numpy's global RNG (np.random.seed decides) --
+                            bit-equal to FileAudioLabelDataset.collater (tests/golden/data_pipeline.npz)."""
         samples = [s for s in samples if s.get("source") is not None]
         if not samples:
             return {}
-        rng = rng or np.random.default_rng()
         sizes = [len(s["source"]) for s in samples]
         tsz = min(min(sizes), self.max_sample_size)
         src = torch.zeros(len(samples), tsz)
+        if self.crop == "reference":
+            return self._collate_reference(samples, sizes, tsz, src)
+        rng = rng or np.random.default_rng()
         starts = []
         for i, (s, size) in enumerate(zip(samples, sizes)):
             st = int(rng.integers(0, size - tsz + 1)) if size > tsz else 0
@@ -229,6 +243,34 @@ class AudioLabelDataset:
                 f0 = int(round(starts[i] * tl[i] / sizes[i]))
                 f0 = min(f0, tl[i] - tt)
                 tgt[i] = torch.from_numpy(s["target"][f0:f0 + tt])
+            out["net_input"]["target"] = tgt
+            out["target"] = tgt
+            out["ntokens"] = int(tgt.shape[0] * tgt.shape[1])
+        return out
+
+    def _collate_reference(self, samples, sizes, tsz, src):
+        def crop(t, target_size):                 # fairseq RawAudioDataset.crop_to_max_size (numpy global RNG)
+            diff = t.shape[0] - target_size
+            if diff <= 0:
+                return t
+            start = np.random.randint(0, diff + 1)
+            return t[start:t.shape[0] - diff + start]
+
+        for i, (s, size) in enumerate(zip(samples, sizes)):
+            src[i] = s["source"] if size == tsz else crop(s["source"], tsz)
+        out = {"id": torch.tensor([s["id"] for s in samples], dtype=torch.long), "net_input": {"source": src}}
+        if self.return_labels:
+            tg = [torch.as_tensor(s["target"]) for s in samples]
+            tl = [t.shape[0] for t in tg]
+            tt = min(min(tl), self.max_sample_size)
+            tgt = torch.zeros((len(samples), tt) + tuple(tg[0].shape[1:]), dtype=torch.long)
+            for i, t in enumerate(tg):
+                if tl[i] == tt:
+                    tgt[i] = t
+                elif t.dim() > 1:
+                    tgt[i] = torch.stack([crop(col, tt) for col in t.t()], dim=1)
+                else:
+                    tgt[i] = crop(t, tt)
             out["net_input"]["target"] = tgt
             out["target"] = tgt
             out["ntokens"] = int(tgt.shape[0] * tgt.shape[1])

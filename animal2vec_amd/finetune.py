@@ -552,3 +552,34 @@ class FinetuneCrossEntropyCriterion:
                 tp, fp, tn, fn = confusion(preds, tgt)
                 logging_output.update({"finetune/tp": tp, "finetune/fp": fp, "finetune/tn": tn, "finetune/fn": fn})
         return loss, sample_size, logging_output
+
+    @classmethod
+    def reduce_metrics(cls, logging_outputs) -> None:
+        """criterions.py:279-380: loss in bits per sample, nll / perplexity, every other logged key as the mean over the
+        logging outputs, and -- when accuracy counts were logged -- the derived accuracy / precision / recall / F1."""
+        from . import metrics
+        from .criterion import _log_prf
+        item = lambda v: float(v.item()) if hasattr(v, "item") else float(v)
+        tot = lambda key: item(sum(log.get(key, 0) for log in logging_outputs))
+        loss_sum, nll_sum, ntokens, sample_size, nsentences = tot("loss"), tot("nll_loss"), tot("ntokens"), tot("sample_size"), tot("nsentences")
+        metrics.log_scalar("misc/ntokens", ntokens)
+        metrics.log_scalar("misc/nsentences", nsentences)
+        metrics.log_scalar("misc/sample_size", sample_size)
+        metrics.log_scalar("loss", loss_sum / sample_size / math.log(2), sample_size, round=3)
+        metrics.log_scalar("misc/nll_loss", nll_sum / ntokens / math.log(2), ntokens, round=3)
+        metrics.log_derived("misc/perplexity", lambda m: metrics.safe_round(2 ** min(m["misc/nll_loss"].avg, 100.0), 2))
+        metrics.log_scalar("finetune/total", tot("count"))
+        builtin = {"loss", "nll_loss", "ntokens", "nsentences", "sample_size", "total"}
+        for k in logging_outputs[0]:
+            if k in builtin or k.startswith("_"):
+                continue
+            val = tot(k)
+            if k.startswith("loss"):
+                metrics.log_scalar("individual_losses/" + k, val / (sample_size or 1) / math.log(2), sample_size, round=3)
+            else:
+                metrics.log_scalar(k, val / len(logging_outputs), round=3)
+        if tot("finetune/total") > 0:
+            _log_prf(metrics, "finetune")
+
+    def logging_outputs_can_be_summed(self) -> bool:
+        return True

@@ -40,6 +40,60 @@ def config_from_yaml(path: str):
     return cfg, oc, run
 
 
+def finetune_config_from_yaml(path: str):
+    """Map a reference finetune recipe (configs/MeerKAT/finetune_mixup_{001,025,100}.yaml) onto FinetuneConfig plus the
+    run-level settings around it.  Every `model:` / `optimization:` / `optimizer:` / `lr_scheduler:` field the finetune
+    hot path reads is taken from the file (wav2vec2.py:94-131 push the model fields into the encoder config); fields of
+    the reference's control plane (checkpoint policy, validation cadence, tensorboard) are returned untouched under
+    run["yaml"] for whoever drives the loop."""
+    from .finetune import FinetuneConfig
+    y = yaml.safe_load(open(path))
+    m, t, o = y.get("model", {}), y.get("task", {}), y.get("optimization", {})
+    opt, sch, crit = y.get("optimizer", {}), y.get("lr_scheduler", {}), y.get("criterion", {})
+    labels = t.get("unique_labels", "[]")
+    labels = list(__import__("ast").literal_eval(labels)) if isinstance(labels, str) else list(labels)
+    betas = opt.get("adam_betas", (0.9, 0.98))
+    if isinstance(betas, str):
+        betas = tuple(float(v) for v in betas.strip("()[] ").split(","))
+    d = FinetuneConfig()
+    pick = lambda src, k, cast, default: cast(src[k]) if k in src and src[k] is not None else default
+    f = FinetuneConfig(
+        n_labels=len(labels) or d.n_labels,
+        apply_mask=pick(m, "apply_mask", bool, d.apply_mask), mask_prob=pick(m, "mask_prob", float, d.mask_prob),
+        mask_length=pick(m, "mask_length", int, d.mask_length),
+        mask_channel_prob=pick(m, "mask_channel_prob", float, d.mask_channel_prob),
+        mask_channel_length=pick(m, "mask_channel_length", int, d.mask_channel_length),
+        zero_mask=pick(m, "zero_mask", bool, d.zero_mask), dropout=pick(m, "dropout", float, d.dropout),
+        activation_dropout=pick(m, "activation_dropout", float, d.activation_dropout),
+        attention_dropout=pick(m, "attention_dropout", float, d.attention_dropout),
+        dropout_input=pick(m, "dropout_input", float, d.dropout_input), final_dropout=pick(m, "final_dropout", float, d.final_dropout),
+        layerdrop=pick(m, "layerdrop", float, d.layerdrop),
+        freeze_finetune_updates=pick(m, "freeze_finetune_updates", int, d.freeze_finetune_updates),
+        layer_decay=pick(m, "layer_decay", float, d.layer_decay), target_mixup=pick(m, "target_mixup", bool, d.target_mixup),
+        source_mixup=pick(m, "source_mixup", float, d.source_mixup), mixup_prob=pick(m, "mixup_prob", float, d.mixup_prob),
+        same_mixup=pick(m, "same_mixup", bool, d.same_mixup),
+        mixing_window_length=pick(m, "mixing_window_length", float, d.mixing_window_length),
+        lr=float((o.get("lr") or [d.lr])[0]), adam_betas=tuple(betas), adam_eps=float(opt.get("adam_eps", d.adam_eps)),
+        weight_decay=float(opt.get("weight_decay", d.weight_decay)), clip_norm=float(o.get("clip_norm", d.clip_norm)),
+        warmup_updates=pick(sch, "warmup_updates", int, d.warmup_updates),
+        warmup_init_lr=pick(sch, "warmup_init_lr", float, d.warmup_init_lr), min_lr=pick(sch, "min_lr", float, d.min_lr),
+        max_update=pick(o, "max_update", int, d.max_update))
+    if not f.same_mixup:
+        raise NotImplementedError("same_mixup: false (one mixing strength per clip) is not used by any shipped recipe")
+    if m.get("gain_mode", "A_weighting") != "A_weighting":
+        raise NotImplementedError(f"gain_mode {m.get('gain_mode')!r}: only A_weighting (every shipped recipe) is built")
+    if float(m.get("feature_grad_mult", 0.0)) != 0.0:
+        raise NotImplementedError("feature_grad_mult != 0: the finetune path keeps the conv feature extractor frozen")
+    run = dict(unique_labels=labels, max_tokens=int(y.get("dataset", {}).get("max_tokens", 426_667)),
+               update_freq=int((o.get("update_freq") or [1])[0]), sample_rate=int(t.get("sample_rate", 8000)),
+               average_top_k_layers=m.get("average_top_k_layers"), min_label_size=int(t.get("min_label_size", 0)),
+               min_sample_size=int(t.get("min_sample_size", 0)), max_sample_size=t.get("max_sample_size"),
+               train_subset=y.get("dataset", {}).get("train_subset", "train"),
+               metric_threshold=float(crit.get("metric_threshold", 0.5)), use_focal_loss=bool(crit.get("use_focal_loss", True)),
+               conv_feature_layers=t.get("conv_feature_layers"), yaml=y)
+    return f, run
+
+
 def _dist_setup():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -26,17 +26,33 @@ def cli_main():
     ap.add_argument("--labels", default=None, help="unique labels, e.g. \"['beep','cc','focal']\" (task.unique_labels)")
     a = ap.parse_args()
     import nn
+    import yaml
     from animal2vec_amd.train_routine import config_from_yaml
     path = os.path.join(a.config_dir, a.config_name if a.config_name.endswith(".yaml") else a.config_name + ".yaml")
+    is_ft_recipe = (yaml.safe_load(open(path)).get("model", {}) or {}).get("_name") == "wav2vec_ccas_finetune"
+    if a.finetune or is_ft_recipe:
+        import ast
+        from animal2vec_amd.config import large_config
+        from animal2vec_amd.train_routine import animal2vec_finetune_main, finetune_config_from_yaml
+        assert a.data, "finetuning needs --data <labelled manifest.tsv>"
+        if is_ft_recipe:
+            # the recipe's model / optimization / optimizer / lr_scheduler blocks -> FinetuneConfig; the encoder's own
+            # dimensions come with the pretrained checkpoint in the reference (w2v_args) -- here the large model
+            fcfg, run = finetune_config_from_yaml(path)
+            cfg = large_config()
+            if run["average_top_k_layers"]:
+                cfg.average_top_k_layers = int(run["average_top_k_layers"])
+            labels = list(ast.literal_eval(a.labels)) if a.labels else run["unique_labels"]
+            fcfg.n_labels = len(labels)
+        else:
+            cfg, _, run = config_from_yaml(path)
+            assert a.labels, "--finetune on a pretraining recipe needs --labels"
+            labels, fcfg = list(ast.literal_eval(a.labels)), None
+        animal2vec_finetune_main(cfg, fcfg, data=a.data, unique_labels=labels, pretrained=a.pretrained, updates=a.updates,
+                                 update_freq=run["update_freq"], max_tokens=run["max_tokens"], save_path=a.save)
+        return
     cfg, optim, run = config_from_yaml(path)
     clips = max(1, run["max_tokens"] // 80000)
-    if a.finetune:
-        import ast
-        from animal2vec_amd.train_routine import animal2vec_finetune_main
-        assert a.data and a.labels, "--finetune needs --data and --labels"
-        animal2vec_finetune_main(cfg, data=a.data, unique_labels=list(ast.literal_eval(a.labels)), pretrained=a.pretrained,
-                                 updates=a.updates, update_freq=run["update_freq"], max_tokens=run["max_tokens"], save_path=a.save)
-        return
     nn.animal2vec_audio_main(cfg, optim, updates=a.updates, clips_per_micro_batch=clips, update_freq=run["update_freq"],
                              data=a.data, max_tokens=run["max_tokens"], restore_file=a.restore_file, save_path=a.save)
 

@@ -422,6 +422,87 @@ def finetune_train_fixture(refnn, model, cfg, seed=33, n_labels=12, tol=2e-5):
     return fx
 
 
+def make_corpus(root, spec, seed):
+    """Synthetic labelled corpus in the reference's on-disk layout: <root>/wav/<name>.wav (PCM16), <root>/lbl/<name>.h5
+    (the four label arrays, stored as an .npz container: h5py is absent in this image and read through a stand-in),
+    <root>/<split>.tsv.  spec: list of (name, n_samples, n_channels, n_events or None = no label file).
+    Returns the raw arrays, so that a test can rebuild the same corpus from the fixture alone."""
+    import wave
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "wav"), exist_ok=True)
+    os.makedirs(os.path.join(root, "lbl"), exist_ok=True)
+    raw = {}
+    lines = [root]           # manifest root = the parent of wav/ and lbl/, entries "wav/<name>.wav" (a root that itself ends
+                             # in wav/ cannot be served by the reference: __getitem__ then looks for <parent>/<name>.wav)
+    for name, n, ch, nev in spec:
+        x = (rs.randn(n, ch) * 3000).clip(-32768, 32767).astype("<i2")
+        with wave.open(os.path.join(root, "wav", name + ".wav"), "wb") as w:
+            w.setnchannels(ch)
+            w.setsampwidth(2)
+            w.setframerate(8000)
+            w.writeframes(x.tobytes())
+        raw[f"wav.{name}"] = x
+        lines.append(f"wav/{name}.wav\t{n}")
+        if nev is None:
+            continue
+        st = np.sort(rs.randint(0, n - 400, size=nev)).astype(np.int64)
+        en = (st + rs.randint(100, 2500, size=nev)).clip(max=n).astype(np.int64)
+        cat = rs.randint(0, 3, size=nev).astype(np.int64)
+        foc = rs.randint(0, 2, size=nev).astype(np.int64)
+        with open(os.path.join(root, "lbl", name + ".h5"), "wb") as f:
+            np.savez(f, start_frame_lbl=st, end_frame_lbl=en, lbl_cat=cat, foc=foc)
+        raw.update({f"lbl.{name}.start": st, f"lbl.{name}.end": en, f"lbl.{name}.cat": cat, f"lbl.{name}.foc": foc})
+    return raw, lines
+
+
+DATA_SPECS = {
+    # equal-length chunks (the shipped MeerKAT layout), one stereo file, one entry without labels, one too short
+    "equal": [("a0", 8000, 1, 5), ("a1", 8000, 2, 7), ("a2", 8000, 1, 0), ("nolabel", 8000, 1, None), ("short", 900, 1, 2)],
+    # clips of different lengths: the collater's random crops (numpy global RNG, seeded below)
+    "ragged": [("b0", 8000, 1, 6), ("b1", 9000, 1, 6), ("b2", 7200, 1, 4)],
+}
+DATA_LABELS = ["a", "b", "c", "focal"]
+
+
+def data_pipeline_fixture(refnn):
+    """G17: FileAudioLabelDataset (audio_tasks.py:196-465) on a synthetic corpus -- manifest
+    filtering, __getitem__ (PCM16 -> float32, channel mean, whole-clip layer norm, event list -> frame targets through
+    interp1d) and collater (equal lengths: copy; different lengths: per-clip and per-label-column random crops).
+    Third-party pieces behind it (RawAudioDataset.postprocess / crop_to_max_size, soundfile, h5py) are stand-ins
+    (ref_shims.py): what is pinned is the reference's own arithmetic and control flow in audio_tasks.py."""
+    import tempfile
+
+    from nn.audio_tasks import FileAudioLabelDataset
+    fx = {"labels": np.array(DATA_LABELS), "layers": np.array(ref_shims.LARGE_LAYERS)}
+    with tempfile.TemporaryDirectory() as tmp:
+        for split, spec in DATA_SPECS.items():
+            root = os.path.join(tmp, split)
+            raw, lines = make_corpus(root, spec, seed=len(split))
+            with open(os.path.join(root, "train.tsv"), "w") as f:
+                f.write("\n".join(lines) + "\n")
+            ds = FileAudioLabelDataset(os.path.join(root, "train.tsv"), sample_rate=8000, max_sample_size=None,
+                                       min_sample_size=1000, pad=False, normalize=True, unique_labels=DATA_LABELS,
+                                       use_focal_loss=True, return_labels=True, conv_feature_layers=ref_shims.LARGE_LAYERS,
+                                       min_label_size=0, do_focal_prediction=True)
+            fx.update({f"{split}.{k}": v for k, v in raw.items()})
+            fx[f"{split}.manifest"] = np.array(lines[1:])
+            names = [ds.fnames[i].as_py() if not isinstance(ds.fnames, list) else ds.fnames[i] for i in range(len(ds.fnames))]
+            fx[f"{split}.kept"] = np.array(names)
+            fx[f"{split}.sizes"] = ds.sizes
+            items = [ds[i] for i in range(len(names))]
+            for i, it in enumerate(items):
+                fx[f"{split}.item{i}.source"] = it["source"]
+                fx[f"{split}.item{i}.target"] = it["target"]
+            np.random.seed(123)
+            col = ds.collater(items)
+            fx[f"{split}.collate.id"] = col["id"]
+            fx[f"{split}.collate.source"] = col["net_input"]["source"]
+            fx[f"{split}.collate.target"] = col["target"]
+            fx[f"{split}.collate.ntokens"] = np.array(col["ntokens"])
+            check(f"G17 {split}: target is net_input.target", col["target"].float(), col["net_input"]["target"].float(), 0.0)
+    return fx
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also validate large dims at L=80000 (slow)")
@@ -442,7 +523,9 @@ def main():
     if args.full:
         run_pair(refnn, O.LARGE, O.LARGE_LAYERS, ref_shims.LARGE_LAYERS, B=1, L=80000, keep=140, seed=3,
                  tol=5e-5, grads=True)
+    dpx = data_pipeline_fixture(refnn)
     if not args.no_write:
+        save("data_pipeline.npz", dpx)
         save("sinc.npz", sx)
         save("tiny_pretrain.npz", fx)
         save("tiny_ema.npz", ex)
@@ -453,3 +536,19 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def finetune_recipes_fixture():
+    """tests/golden/finetune_recipes.json: the task / dataset / criterion / optimization / optimizer / lr_scheduler /
+    model sections of the three shipped finetune recipes (configs/MeerKAT/finetune_mixup_{001,025,100}.yaml) as parsed
+    data -- the inputs of tests/test_host_logic.py::test_finetune_yaml_mapping_shipped_recipes.
+    (run: python -c "import gen_golden as g; g.finetune_recipes_fixture()" from oracle/)"""
+    import json
+
+    import yaml
+    out = {}
+    for n in ("001", "025", "100"):
+        y = yaml.safe_load(open(f"/root/reference/configs/MeerKAT/finetune_mixup_{n}.yaml"))
+        out[f"finetune_mixup_{n}"] = {k: y[k] for k in ("task", "dataset", "criterion", "optimization", "optimizer", "lr_scheduler", "model")}
+    with open(os.path.join(GOLD, "finetune_recipes.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)

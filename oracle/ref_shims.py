@@ -308,6 +308,96 @@ class TextCompressionLevel(enum.Enum):
     high = 2
 
 
+class RawAudioDataset:
+    """fairseq.data.audio.raw_audio_dataset.RawAudioDataset @ 920a548, the parts FileAudioLabelDataset uses (third
+    party, restated from its published semantics: parity unpinned): field bookkeeping, `postprocess`
+    (channel mean, sample-rate check, whole-clip layer norm) and `crop_to_max_size` (numpy GLOBAL RNG)."""
+
+    def __init__(self, sample_rate, max_sample_size=None, min_sample_size=0, shuffle=True, pad=False, normalize=False,
+                 feature_encoder_spec=None, **_unused):
+        import sys as _sys
+        self.sample_rate = sample_rate
+        self.sizes = []
+        self.max_sample_size = max_sample_size if max_sample_size is not None else _sys.maxsize
+        self.min_sample_size = min_sample_size
+        self.pad, self.shuffle, self.normalize = pad, shuffle, normalize
+
+    def __len__(self):
+        return len(self.sizes)
+
+    def postprocess(self, feats, curr_sample_rate):
+        if feats.dim() == 2:
+            feats = feats.mean(-1)
+        if curr_sample_rate != self.sample_rate:
+            raise Exception(f"sample rate: {curr_sample_rate}, need {self.sample_rate}")
+        assert feats.dim() == 1, feats.dim()
+        if self.normalize:
+            with torch.no_grad():
+                feats = F.layer_norm(feats, feats.shape)
+        return feats
+
+    def crop_to_max_size(self, t, target_size, dim=0):
+        import numpy as _np
+        size = t.size(dim)
+        diff = size - target_size
+        if diff <= 0:
+            return t
+        start = _np.random.randint(0, diff + 1)
+        end = size - diff + start
+        slices = [slice(None)] * t.dim()
+        slices[dim] = slice(start, end)
+        return t[tuple(slices)]
+
+    def set_bucket_info(self, num_buckets):
+        self.num_buckets = num_buckets
+
+
+class TextCompressor:
+    def __init__(self, level=None, max_input_byte_length=2 ** 16):
+        self.level = level
+
+    def compress(self, text):
+        return text
+
+    def decompress(self, compressed):
+        return compressed
+
+
+def _sf_read(path_or_fp, dtype="float32"):
+    """soundfile.read(dtype="float32") for PCM16 wav files: int16 / 32768 (libsndfile's normalisation)."""
+    import wave as _wave
+
+    import numpy as _np
+    with _wave.open(path_or_fp, "rb") as w:
+        nch, width, sr, n = w.getnchannels(), w.getsampwidth(), w.getframerate(), w.getnframes()
+        raw = w.readframes(n)
+    assert width == 2, "the fixture corpus is PCM16"
+    x = _np.frombuffer(raw, dtype="<i2").astype(_np.float32) / 32768.0
+    return (x.reshape(-1, nch) if nch > 1 else x), sr
+
+
+class _H5File:
+    """h5py.File stand-in over an .npz container (the fixture corpus stores the four label arrays that way under the
+    .h5 name the reference looks for): `with h5py.File(p, "r") as f: list(f["start_frame_lbl"])`."""
+
+    def __init__(self, path, mode="r"):
+        import numpy as _np
+        self._z = _np.load(path)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self._z.close()
+        return False
+
+    def __getitem__(self, k):
+        return self._z[k]
+
+    def __contains__(self, k):
+        return k in self._z.files
+
+
 def install(reference_root="/root/reference"):
     """Install the shims and return the imported reference ``nn`` package."""
     if "nn" in sys.modules and getattr(sys.modules["nn"], "__file__", "").startswith(reference_root):
@@ -336,6 +426,14 @@ def install(reference_root="/root/reference"):
     mod("fairseq.dataclass").FairseqDataclass = FairseqDataclass
     mod("fairseq.logging.meters").Meter = Meter
     mod("fairseq.data.text_compressor").TextCompressionLevel = TextCompressionLevel
+    mod("fairseq.data.text_compressor").TextCompressor = TextCompressor
+    mod("fairseq.data.audio.raw_audio_dataset").RawAudioDataset = RawAudioDataset
+    au = mod("fairseq.data.audio.audio_utils")
+    au.parse_path = lambda p: (p, [])
+    au.read_from_stored_zip = _permissive
+    au.is_sf_audio_data = lambda b: True
+    mod("soundfile").read = _sf_read
+    mod("h5py").File = _H5File
     for path, names in {
         "fairseq.tasks.audio_pretraining": ["AudioPretrainingConfig"],
         "fairseq.criterions.model_criterion": ["ModelCriterionConfig"],

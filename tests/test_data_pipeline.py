@@ -135,3 +135,99 @@ def test_collate_crop_to_min_and_prefetch(corpus):
     assert len(got) == len(bs) and got[0]["target"].dtype == torch.float32 and got[0]["source"].dim() == 2
     with pytest.raises(IndexError):
         list(D.DevicePrefetcher(ds, [[99]], device=None))
+
+
+# ------------------------------------------------------------------------------------------ pinned against the reference
+def _rebuild_corpus(fx, split, root):
+    """Write the fixture's synthetic corpus (tests/golden/data_pipeline.npz, dumped by oracle/gen_golden.py from the
+    corpus it served through the LIVE reference's FileAudioLabelDataset) back to disk in the reference's layout."""
+    import wave
+    os.makedirs(os.path.join(root, "wav"), exist_ok=True)
+    os.makedirs(os.path.join(root, "lbl"), exist_ok=True)
+    names = sorted({k.split(".")[2] for k in fx if k.startswith(f"{split}.wav.")})
+    for name in names:
+        x = fx[f"{split}.wav.{name}"].numpy()
+        with wave.open(os.path.join(root, "wav", name + ".wav"), "wb") as w:
+            w.setnchannels(x.shape[1])
+            w.setsampwidth(2)
+            w.setframerate(8000)
+            w.writeframes(x.astype("<i2").tobytes())
+        if f"{split}.lbl.{name}.start" in fx:
+            with open(os.path.join(root, "lbl", name + ".h5"), "wb") as f:      # the reference's file name; an .npz container
+                np.savez(f, start_frame_lbl=fx[f"{split}.lbl.{name}.start"].numpy(), end_frame_lbl=fx[f"{split}.lbl.{name}.end"].numpy(),
+                         lbl_cat=fx[f"{split}.lbl.{name}.cat"].numpy(), foc=fx[f"{split}.lbl.{name}.foc"].numpy())
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_pipeline.npz"))
+    with open(os.path.join(root, "train.tsv"), "w") as f:
+        f.write(root + "\n" + "\n".join(str(l) for l in z[f"{split}.manifest"]) + "\n")
+
+
+def _task(root, crop):
+    import nn
+    from animal2vec_amd.config import LARGE_LAYERS_STR
+    cfg = nn.AudioConfigCCAS(data=root, sample_rate=8000, normalize=True, with_labels=True, min_sample_size=1000,
+                             max_sample_size=None, conv_feature_layers=LARGE_LAYERS_STR, unique_labels="['a', 'b', 'c', 'focal']",
+                             use_focal_loss=True, do_focal_prediction=True, collate_crop=crop)
+    return nn.AudioTaskCCAS.setup_task(cfg)
+
+
+@pytest.mark.parametrize("split", ["equal", "ragged"])
+def test_dataset_and_collater_match_the_reference(tmp_path, split):
+    """AudioTaskCCAS.load_dataset -> data.AudioLabelDataset against FileAudioLabelDataset's own outputs: which manifest
+    entries survive (no label file / shorter than min_sample_size are dropped), every item's waveform (PCM16 -> float,
+    stereo mean, whole-clip layer norm) and frame targets (event list -> multi-hot through the reference's interp1d
+    path), and the collated batch -- equal lengths: a copy; different lengths: the reference's per-clip and
+    per-label-column random crops reproduced draw for draw (collate_crop="reference", numpy global RNG seeded alike)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_pipeline.npz"))
+    fx = {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+    root = str(tmp_path / split)
+    _rebuild_corpus(fx, split, root)
+    task = _task(root, "reference")
+    ds = task.load_dataset("train")
+    assert task.dataset("train") is ds
+    kept = [str(k) for k in fx[f"{split}.kept"]]
+    assert ds.m.fnames == kept
+    assert np.array_equal(ds.sizes, fx[f"{split}.sizes"].numpy())
+    items = [ds[i] for i in range(len(ds))]
+    for i, it in enumerate(items):
+        assert torch.allclose(it["source"], fx[f"{split}.item{i}.source"], rtol=0, atol=1e-6), i
+        assert np.array_equal(it["target"], fx[f"{split}.item{i}.target"].numpy()), i
+    np.random.seed(123)
+    col = ds.collater(items)
+    assert torch.equal(col["id"], fx[f"{split}.collate.id"])
+    assert torch.allclose(col["net_input"]["source"], fx[f"{split}.collate.source"], rtol=0, atol=1e-6)
+    assert torch.equal(col["target"], fx[f"{split}.collate.target"]) and col["target"] is col["net_input"]["target"]
+    assert int(col["ntokens"]) == int(fx[f"{split}.collate.ntokens"])
+
+
+def test_aligned_collate_differs_from_the_reference_only_in_the_label_crop(tmp_path):
+    """collate_crop="aligned" (the default): one crop offset per clip and the labels cut at the matching frame -- each row
+    of the batch is a contiguous window of its item, and its labels are the item's labels of that window; the
+    reference's independent per-column offsets do not have that property on the same corpus (fixture)."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_pipeline.npz"))
+    fx = {k: (torch.from_numpy(z[k]) if z[k].dtype.kind in "fiu" else z[k]) for k in z.files}
+    root = str(tmp_path / "ragged")
+    _rebuild_corpus(fx, "ragged", root)
+    ds = _task(root, "aligned").load_dataset("train")
+    items = [ds[i] for i in range(len(ds))]
+    col = ds.collater(items, np.random.default_rng(5))
+    L = col["net_input"]["source"].shape[1]
+    assert L == 7200 and col["target"].shape[1] == 180
+
+    def window_start(row, full):
+        full = full.numpy() if torch.is_tensor(full) else full
+        row = row.numpy()
+        hits = [s for s in range(len(full) - len(row) + 1) if np.array_equal(full[s:s + len(row)], row)]
+        return hits
+
+    for i, it in enumerate(items):
+        s_hits = window_start(col["net_input"]["source"][i], it["source"])
+        assert len(s_hits) == 1
+        t_hits = window_start(col["target"][i], torch.from_numpy(it["target"]))
+        assert t_hits, i                                   # ALL label columns come from one window ...
+        f0 = int(round(s_hits[0] * it["target"].shape[0] / len(it["source"])))
+        assert min(f0, it["target"].shape[0] - 180) in t_hits          # ... the one under the audio crop
+    # the reference's batch on this corpus: at least one row whose label columns are NOT one window of the item
+    ref_t = fx["ragged.collate.target"]
+    broken = [i for i, it in enumerate(items)
+              if it["target"].shape[0] > 180 and not window_start(ref_t[i], torch.from_numpy(it["target"]))]
+    assert broken, "expected the reference's per-column crops to misalign at least one ragged row"

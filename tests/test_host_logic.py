@@ -298,3 +298,80 @@ def test_finetune_criterion_label_smoothed_branch():
     assert log["finetune/total"] == 14 and log["finetune/tp"] + log["finetune/fn"] == 14
     l0, _ = label_smoothed_nll_loss(lp, target.reshape(-1), 0.0)
     assert float(l0) == pytest.approx(float(nll), rel=1e-6)
+
+
+def test_finetune_yaml_mapping_shipped_recipes(tmp_path):
+    """configs/MeerKAT/finetune_mixup_{001,025,100}.yaml -> FinetuneConfig: the three recipes differ in lr, max_update,
+    mask_prob and mask_length (and in control-plane cadence); a trainer built from the 025 recipe must not run the 100
+    recipe's hyper-parameters.  Inputs: the recipes' parsed sections (tests/golden/finetune_recipes.json, dumped by
+    oracle/gen_golden.py::finetune_recipes_fixture)."""
+    import json
+    import yaml
+    from animal2vec_amd.finetune import cosine_lr
+    from animal2vec_amd.train_routine import finetune_config_from_yaml
+    from conftest import GOLD
+    recipes = json.load(open(os.path.join(GOLD, "finetune_recipes.json")))
+    want = {"finetune_mixup_100": dict(lr=3e-5, max_update=30000, mask_prob=0.825, mask_length=4, train_subset="train_0"),
+            "finetune_mixup_025": dict(lr=7.5e-5, max_update=18000, mask_prob=1.0, mask_length=3, train_subset="train_0_few_2"),
+            "finetune_mixup_001": dict(lr=1e-4, max_update=13000, mask_prob=1.1, mask_length=2, train_subset="train_0_few_0")}
+    for name, w in want.items():
+        p = tmp_path / (name + ".yaml")
+        p.write_text(yaml.safe_dump(recipes[name]))
+        f, run = finetune_config_from_yaml(str(p))
+        assert (f.lr, f.max_update, f.mask_prob, f.mask_length) == (w["lr"], w["max_update"], w["mask_prob"], w["mask_length"]), name
+        assert run["train_subset"] == w["train_subset"]
+        # common to the three (model / optimizer / scheduler blocks)
+        assert f.n_labels == 12 and run["unique_labels"][-1] == "focal" and len(run["unique_labels"]) == 12
+        assert (f.apply_mask, f.mask_channel_prob, f.mask_channel_length) == (True, 0.5, 64)
+        assert (f.dropout, f.activation_dropout, f.attention_dropout, f.dropout_input, f.final_dropout, f.layerdrop) == \
+            (0.1, 0.1, 0.2, 0.0, 0.0, 0.1)
+        assert f.freeze_finetune_updates == 10000 and f.target_mixup and f.source_mixup == 0.5 and f.mixup_prob == 1.0
+        assert f.adam_betas == (0.9, 0.98) and f.adam_eps == 1e-8 and f.weight_decay == 0.0 and f.clip_norm == 0.0
+        assert (f.warmup_updates, f.warmup_init_lr, f.min_lr) == (2000, 1e-10, 5e-6)
+        assert (run["max_tokens"], run["update_freq"], run["average_top_k_layers"]) == (426667, 9, 16)
+        assert run["min_label_size"] == 3032 and run["metric_threshold"] == 0.175 and run["use_focal_loss"] is True
+        assert abs(cosine_lr(f, f.warmup_updates) - f.lr) < 1e-12 and f.min_lr <= cosine_lr(f, f.max_update - 1) < f.min_lr * 1.001
+    ref_dir = "/root/reference/configs/MeerKAT"
+    if os.path.isdir(ref_dir):                       # in the build container: the files themselves
+        f, run = finetune_config_from_yaml(os.path.join(ref_dir, "finetune_mixup_025.yaml"))
+        assert (f.lr, f.max_update, f.mask_prob, f.mask_length) == (7.5e-5, 18000, 1.0, 3)
+
+
+def test_reduce_metrics_of_both_criterions_and_the_task():
+    """ExpandedModelCriterion.reduce_metrics (criterions.py:413-502), FinetuneCrossEntropyCriterion.reduce_metrics
+    (:279-380) and AudioTaskCCAS.reduce_metrics (audio_tasks.py:154-188) on two workers' logging outputs."""
+    import math
+    import nn
+    from animal2vec_amd import metrics
+    metrics.reset()
+    logs = [{"loss": torch.tensor(30.0), "ntokens": 10, "nsentences": 2, "sample_size": 10, "_world_size": 1, "pred_var": 0.5,
+             "loss_AUDIO_regression": torch.tensor(30.0), "ema_decay": 999.7},
+            {"loss": torch.tensor(10.0), "ntokens": 30, "nsentences": 6, "sample_size": 30, "_world_size": 1, "pred_var": 0.3,
+             "loss_AUDIO_regression": torch.tensor(10.0), "ema_decay": 999.7}]
+    crit = nn.ExpandedModelCriterion(None, None, ["pred_var", "ema_decay"])
+    task = nn.AudioTaskCCAS.setup_task(nn.AudioConfigCCAS())
+    task.reduce_metrics(logs, crit)
+    m = metrics.get_smoothed_values()
+    assert m["loss"] == 1.0 and m["loss_AUDIO_regression"] == 1.0 and m["sample_size"] == 40 and m["ntokens"] == 40
+    assert m["pred_var"] == 0.4 and m["ema_decay"] == 999.7            # mean over workers (/ sum of _world_size)
+    assert m["misc/wpb"] == 40 and m["misc/bsz"] == 8 and "misc/wps" in m
+    # a second call aggregates as fairseq's meters do: loss weighted by sample_size
+    task.reduce_metrics([{"loss": 120.0, "ntokens": 40, "nsentences": 8, "sample_size": 40, "_world_size": 1, "pred_var": 0.2,
+                          "loss_AUDIO_regression": 120.0, "ema_decay": 999.8}], crit)
+    assert metrics.get_smoothed_values()["loss"] == 2.0
+    # finetune criterion: bits, counts and the derived scores
+    metrics.reset()
+    flogs = [{"loss": 8.0 * math.log(2), "nll_loss": 0.0, "ntokens": 4, "nsentences": 1, "sample_size": 4, "finetune/n_correct": 30.0,
+              "finetune/total": 48.0, "finetune/tp": 6, "finetune/fp": 2, "finetune/tn": 36, "finetune/fn": 4},
+             {"loss": 4.0 * math.log(2), "nll_loss": 0.0, "ntokens": 4, "nsentences": 1, "sample_size": 4, "finetune/n_correct": 40.0,
+              "finetune/total": 48.0, "finetune/tp": 2, "finetune/fp": 2, "finetune/tn": 42, "finetune/fn": 2}]
+    nn.FinetuneCrossEntropyCriterion.reduce_metrics(flogs)
+    m = metrics.get_smoothed_values()
+    assert m["loss"] == 1.5 and m["misc/ntokens"] == 8 and m["misc/sample_size"] == 8
+    # (the reference logs the non-builtin keys as means over the logging outputs; the derived scores use meter SUMS)
+    assert m["finetune/tp"] == 4.0
+    # "finetune/total" is logged twice per call by the reference (the sum of the absent "count" key = 0, then the mean of
+    # the logged totals): its meter averages to 24 while its SUM -- what the derived scores read -- is 48
+    assert m["finetune/total"] == 24.0
+    assert m["metrics/finetune/accuracy"] == round(35.0 * 100 / 48.0, 3)
+    assert m["metrics/finetune/precision"] == round(4 * 100.0 / 6, 3) and m["metrics/finetune/recall"] == round(4 * 100.0 / 7, 3)

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import a2v_oracle as O
-from conftest import rel_err, split_golden
+from conftest import parity_report, rel_err, split_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -57,7 +57,7 @@ def test_tiny_fp32_vs_reference_golden(tiny_golden):
     assert worst[1] < TOL, worst
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 1.5e-1)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
 def test_hd64_vs_oracle(dtype, tol_y, tol_g):
     """Real front end (127x63 sinc, 512-wide convs), head_dim 64, D=128: HIP path vs oracle on the box's CPU."""
     from animal2vec_amd.config import Data2VecMultiConfig, D2vAudioConfig, D2vDecoderConfig
@@ -97,10 +97,14 @@ def test_hd64_vs_oracle(dtype, tol_y, tol_g):
     ls = float(res["losses"]["AUDIO_regression"].sum())
     assert abs(float(eng.stats[4 * D]) - ls) / ls < tol_y
     bad = []
+    allerr = []
     for k, v in po.items():
         e = rel_err(store.g[k], v.grad)
+        allerr.append((e, k))
         if e > tol_g:
             bad.append((k, e))
+    parity_report("hd64_vs_oracle", dtype, allerr, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
+                  decoder_out=rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]))
     assert not bad, bad[:8]
 
 
@@ -233,11 +237,20 @@ def test_batched_operand_packing_matches_single_launches(tiny_golden, dtype):
             assert torch.equal(got, v), (kind, k)
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 5e-2, 2.5e-1)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 4e-2)])
 def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     """BASELINE.json's configuration at full size (large model: D 1024, 16 heads, 8 + 16 blocks, decoder 4 x 768,
     clone_batch 12, one 10 s clip @ 8 kHz, 140 of 2000 frames kept): HIP path against the oracle run on this box's
-    CPU.  fp32 mode carries the north-star's 1e-3; the bf16 throughput mode is held to bf16-level bounds."""
+    CPU.  fp32 mode carries the north-star's 1e-3.  The bf16 bounds follow the measured per-tensor table of this very
+    comparison (profiles/r02_bf16_parity_large.json, tools/bf16_parity.py): local features 1.1e-2, decoder output
+    9.1e-3, loss 1.7e-4, 342 gradient tensors with median 1.1e-2 and 2.7e-2 for the worst ordinary one (the sinc
+    band edges) -> 2e-2 on activations, 4e-2 on every gradient, with two named exceptions that have a written cause:
+      * targets (4.4e-2 measured, bound 6e-2): the teacher runs 24 post-LN blocks over all 2000 frames in bf16, the
+        average of 16 layer outputs is instance-normalised over time, which divides out the signal's scale but not
+        the accumulated rounding; the reference's own bf16 autocast of the same forward is at 1.17e-1;
+      * d alibi_scale (5.4e-2 measured, bound 8e-2): 16 numbers, each the sum over 24 layers x 96 sequences x 140^2
+        score gradients times |i - j| with heavy cancellation (norm 3e-3 of a 1e3-norm gradient vector); formed from
+        bf16 probabilities.  The whole gradient vector is within 7.2e-3 (autocast oracle: 8.6e-3)."""
     from animal2vec_amd.config import large_config
     torch.set_num_threads(min(16, torch.get_num_threads()))
     ocfg = O.OracleConfig(**O.LARGE)
@@ -256,14 +269,21 @@ def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     cfg = large_config()
     store, eng = build(cfg, p, ema, dtype)
     dbg = run(eng, src, mask, noise)
+    bf = dtype == torch.bfloat16
     assert rel_err(dbg["local_features"].float(), res["_dbg"]["local_features"]) < tol_y
-    assert rel_err(dbg["targets"], res["_dbg"]["targets"]) < tol_y
+    assert rel_err(dbg["targets"], res["_dbg"]["targets"]) < (6e-2 if bf else tol_y)
     assert rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]) < tol_y
     D = cfg.embed_dim
     ls = float(res["losses"]["AUDIO_regression"].sum())
-    assert abs(float(eng.stats[4 * D]) - ls) / ls < tol_y
+    assert abs(float(eng.stats[4 * D]) - ls) / ls < (2e-3 if bf else tol_y)
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
-    assert errs[0][0] < tol_g, errs[:8]
+    named = {"modality_encoders.AUDIO.alibi_scale": 8e-2} if bf else {}
+    bad = [(e, k) for e, k in errs if e >= named.get(k, tol_g)]
+    assert not bad, bad[:8]
+    # the update direction as a whole (all 315.8 M gradient entries as one vector)
+    ga = torch.cat([store.g[k].detach().float().cpu().reshape(-1) for k in po])
+    gb = torch.cat([v.grad.reshape(-1) for v in po.values()])
+    assert rel_err(ga, gb) < (1.5e-2 if bf else 1e-4)
 
 
 # ------------------------------------------------------------------------------------------ finetune path (8f rank 1)
@@ -300,7 +320,7 @@ def test_finetune_tiny_fp32_vs_reference_golden(tiny_golden):
             assert float(store.g[k].abs().max()) == 0.0, k
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 1.5e-1)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
 def test_finetune_hd64_vs_oracle(dtype, tol_y, tol_g):
     """Real front end, head_dim 64, S = T = 400 (the attention backward with dQ atomics): HIP finetune step vs oracle."""
     from animal2vec_amd.config import Data2VecMultiConfig, D2vAudioConfig, D2vDecoderConfig
@@ -333,13 +353,17 @@ def test_finetune_hd64_vs_oracle(dtype, tol_y, tol_g):
     assert abs(loss - float(loss_o)) / float(loss_o) < tol_y
     assert rel_err(head.grad_w, ow.grad) < tol_g and rel_err(head.grad_b, ob.grad) < tol_g
     bad = []
+    allerr = []
     for k, v in po.items():
         if v.grad is None:
             assert float(store.g[k].abs().max()) == 0.0, k
             continue
         e = rel_err(store.g[k], v.grad)
+        allerr.append((e, k))
         if e > tol_g:
             bad.append((k, e))
+    parity_report("finetune_hd64_vs_oracle", dtype, allerr, logits=rel_err(logits.float(), logits_o.detach()),
+                  head_w=rel_err(head.grad_w, ow.grad), head_b=rel_err(head.grad_b, ob.grad))
     assert not bad, bad[:8]
 
 
@@ -585,7 +609,7 @@ def test_real_data_pretrain_checkpoint_finetune_end_to_end(tmp_path):
     assert torch.equal(a_, b_)
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 5e-2, 2.5e-1)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
 def test_finetune_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     """BASELINE config 4 at full size (large model, one 10 s clip, all 2000 frames, 12 labels), train form with
     explicit draws (time mask with noise replacement, channel mask, two dropped blocks): HIP path -- the two-pass
@@ -628,10 +652,12 @@ def test_finetune_large_full_size_vs_oracle(dtype, tol_y, tol_g):
             continue
         errs.append((rel_err(store.g[k], v.grad), k))
     errs.sort(reverse=True)
+    parity_report("finetune_large_full_size", dtype, errs, logits=rel_err(logits.float(), logits_o.detach()),
+                  head_w=rel_err(head.grad_w, ow.grad), head_b=rel_err(head.grad_b, ob.grad))
     assert len(errs) > 250 and errs[0][0] < tol_g, errs[:8]
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 5e-2, 2.5e-1)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 4e-2, 5e-2)])
 def test_long_sequence_pretrain_vs_oracle(dtype, tol_y, tol_g):
     """BASELINE config 5's sequence shape (5 s @ 44.1 kHz: T = 5513 frames, K = round(0.07 T) = 386 kept) through the
     pretraining step with head_dim 64: teacher attention over 5513 keys, student attention at S = 386 (forward with two
@@ -669,10 +695,12 @@ def test_long_sequence_pretrain_vs_oracle(dtype, tol_y, tol_g):
     ls = float(res["losses"]["AUDIO_regression"].sum())
     assert abs(float(eng.stats[4 * cfg.embed_dim]) - ls) / ls < tol_y
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
+    parity_report("long_sequence_pretrain", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
+                  decoder_out=rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]))
     assert errs[0][0] < tol_g, errs[:8]
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 5e-2, 2.5e-1)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 4e-2, 5e-2)])
 def test_config5_44k_frontend_vs_oracle(dtype, tol_y, tol_g):
     """BASELINE config 5's front end: 44.1 kHz, 296 sinc filters x 149 taps (the spec SURVEY 8d derives from the YAML's
     own rule k ~ sqrt(sr / 2)), through the blocked SincConv kernels (tap chunks of 64, 320-channel pitch, filter
@@ -714,6 +742,8 @@ def test_config5_44k_frontend_vs_oracle(dtype, tol_y, tol_g):
     ls = float(res["losses"]["AUDIO_regression"].sum().detach())
     assert abs(float(eng.stats[4 * cfg.embed_dim]) - ls) / ls < tol_y
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
+    parity_report("config5_44k_frontend", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
+                  local_features=rel_err(dbg["local_features"].float(), res["_dbg"]["local_features"]))
     assert errs[0][0] < tol_g, errs[:8]
     fe = [e for e in errs if "conv_layers.0." in e[1]]
     assert len(fe) == 6, fe                    # low_hz_, band_hz_, LN weight / bias, PSwish alpha / beta
@@ -836,7 +866,13 @@ def test_base_star_pretrain_vs_oracle(dtype, tol_y, tol_g):
     assert abs(float(eng.stats[4 * D]) - ls) / ls < tol_y
     assert int(eng.stats[4 * D + 1]) == int(res["sample_size"])
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
-    assert errs[0][0] < tol_g, errs[:8]
+    parity_report("base_star_pretrain", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
+                  decoder_out=rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]))
+    # d alibi_scale (12 numbers, sums with heavy cancellation; see test_large_full_size_vs_oracle) is the one tensor
+    # measured near the common bound (5.0e-2 here, profiles/r02_parity_report.jsonl)
+    named = {"modality_encoders.AUDIO.alibi_scale": 8e-2} if dtype == torch.bfloat16 else {}
+    bad = [(e, k) for e, k in errs if e >= named.get(k, tol_g)]
+    assert not bad, bad[:8]
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-3), (torch.bfloat16, 3e-2)])
