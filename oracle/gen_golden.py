@@ -524,8 +524,10 @@ def main():
         run_pair(refnn, O.LARGE, O.LARGE_LAYERS, ref_shims.LARGE_LAYERS, B=1, L=80000, keep=140, seed=3,
                  tol=5e-5, grads=True)
     dpx = data_pipeline_fixture(refnn)
+    inx = init_fixture(refnn)
     if not args.no_write:
         save("data_pipeline.npz", dpx)
+        save("init_stats.npz", inx)
         save("sinc.npz", sx)
         save("tiny_pretrain.npz", fx)
         save("tiny_ema.npz", ex)
@@ -536,6 +538,27 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def init_fixture(refnn):
+    """G18 (rows a1 / a21): initial parameter statistics of the LIVE reference model (mid dims: real 127 x 63 sinc + 512-wide
+    conv stack, D = 128) -- per parameter: numel, mean, std, abs-max, and the values themselves where the init is
+    deterministic (SincConv band edges, LayerNorm, PSwish, alibi_scale, zero biases).  Three seeds for the random laws."""
+    mid = dict(O.TINY, embed_dim=128, num_heads=8, conv_pos_groups=16, decoder_groups=16, decoder_dim=64)
+    fx = {}
+    for seed in (0, 1, 2):
+        kw = dict(mid)
+        model, _ = ref_shims.build_reference_model(refnn, conv_feature_layers=ref_shims.LARGE_LAYERS, seed=seed, **kw)
+        sd = {k: v for k, v in model.state_dict().items() if k != "_ema" and not k.startswith("_ema")}
+        for k, v in sd.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            v = v.detach().float()
+            fx[f"s{seed}.{k}.stats"] = np.array([v.numel(), float(v.mean()), float(v.std()) if v.numel() > 1 else 0.0, float(v.abs().max())])
+            deterministic = float(v.std()) == 0.0 if v.numel() > 1 else True
+            if seed == 0 and (deterministic or "low_hz_" in k or "band_hz_" in k):
+                fx[f"value.{k}"] = v.numpy()
+    return fx
 
 
 def finetune_recipes_fixture():

@@ -375,3 +375,56 @@ def test_reduce_metrics_of_both_criterions_and_the_task():
     assert m["finetune/total"] == 24.0
     assert m["metrics/finetune/accuracy"] == round(35.0 * 100 / 48.0, 3)
     assert m["metrics/finetune/precision"] == round(4 * 100.0 / 6, 3) and m["metrics/finetune/recall"] == round(4 * 100.0 / 7, 3)
+
+
+def test_init_laws_match_the_reference_model(tmp_path):
+    """Rows a1 / a21: ParamStore.init_reference against the LIVE reference model's initial state (mid dims: 127 x 63 sinc,
+    512-wide conv stack, D = 128; tests/golden/init_stats.npz from oracle/gen_golden.py::init_fixture).  Deterministic
+    inits (mel-spaced SincConv band edges, LayerNorm 1 / 0, PSwish 2 / 0, alibi_scale 1, zero biases) are equal value by
+    value; every random tensor follows the same law: same support for the uniform ones (abs-max), same standard
+    deviation and zero mean within sampling error -- for each of three seeds on both sides."""
+    from conftest import load_golden, rel_err
+    from animal2vec_amd.config import D2vAudioConfig, D2vDecoderConfig, Data2VecMultiConfig
+    from animal2vec_amd.params import ParamStore, sinc_mel_init
+    fx = load_golden("init_stats.npz")
+    a = D2vAudioConfig(conv_pos_groups=16, prenet_depth=1, decoder=D2vDecoderConfig(decoder_dim=64, decoder_groups=16, decoder_layers=2))
+    cfg = Data2VecMultiConfig(depth=2, embed_dim=128, num_heads=8, clone_batch=2, average_top_k_layers=2, audio=a)
+    names = sorted(k[3:-6] for k in fx if k.startswith("s0.") and k.endswith(".stats"))
+    st = ParamStore(cfg, device="cpu", with_optimizer=False)
+    assert sorted(s.name for s in st.specs) == names
+    for seed in (0, 1, 2):
+        st.init_reference(seed)
+        for n in names:
+            v = st.p[n].float()
+            numel, mean, std, amax = (float(x) for x in fx[f"s{seed}.{n}.stats"])
+            assert v.numel() == int(numel), n
+            if f"value.{n}" in fx:                                   # deterministic
+                assert torch.allclose(v.reshape(-1), fx[f"value.{n}"].reshape(-1), rtol=1e-6, atol=1e-6), n
+                continue
+            assert std > 0, n
+            se = 1.0 / math.sqrt(2 * numel)                          # relative standard error of a sample std
+            assert abs(float(v.std()) / std - 1) < 6 * math.sqrt(2) * se + 1e-3, (n, float(v.std()), std)
+            assert abs(float(v.mean()) - mean) < 6 * math.sqrt(2) * std / math.sqrt(numel), n
+            uniform = amax < 2.0 * std                               # a uniform law: abs-max = sqrt(3) std; a normal one: > 3 std
+            if uniform:
+                assert abs(float(v.abs().max()) / amax - 1) < 0.03, n
+            else:
+                assert float(v.abs().max()) > 2.5 * std, n
+    # a1 on the other front-end specs of tests/golden/sinc.npz (8 kHz tiny, 44.1 kHz, the blocked 296 x 149 one)
+    sx = load_golden("sinc.npz")
+    for spec in ("127_63_8000", "127_63_44100", "296_149_44100", "31_15_8000"):
+        c, k, sr = (int(x) for x in spec.split("_"))
+        lo, band = sinc_mel_init(c, k, sr)
+        assert torch.allclose(lo, sx[f"init.{spec}.low"], rtol=1e-6, atol=1e-4) and torch.allclose(band, sx[f"init.{spec}.band"], rtol=1e-6, atol=1e-4)
+    # window / time axis buffers (sinc.py:264-276): the init filters of the golden follow from them (sinc.py:181-223)
+    for spec, layers in (("127_63_8000", None), ("31_15_8000", "[(31, 15, 1)] + [(32, 10, 5)] + [(32, 3, 2)] * 3 + [(32, 3, 1)] + [(32, 2, 1)] * 2")):
+        c, k, sr = (int(x) for x in spec.split("_"))
+        cfg2 = cfg if layers is None else Data2VecMultiConfig(depth=2, embed_dim=128, num_heads=8, audio=D2vAudioConfig(
+            conv_feature_layers=layers, conv_pos_groups=16, prenet_depth=1, decoder=D2vDecoderConfig(decoder_dim=64, decoder_layers=2)))
+        s2 = ParamStore(cfg2, device="cpu", with_optimizer=False)
+        low = 50.0 + sx[f"init.{spec}.low"].abs()
+        high = torch.clamp(low + s2.sinc_min_band + sx[f"init.{spec}.band"].abs(), 50.0, sr / 2)
+        bandw = (high - low)[:, 0]
+        left = ((torch.sin(high * s2.sinc_n) - torch.sin(low * s2.sinc_n)) / (s2.sinc_n / 2)) * s2.sinc_window
+        filt = torch.cat([left, 2 * bandw.view(-1, 1), left.flip(1)], dim=1) / (2 * bandw[:, None])
+        assert rel_err(filt, sx[f"init.{spec}.filters"].view(c, k)) < 1e-5, spec
