@@ -58,6 +58,7 @@ SIGNATURES = {
     "a2v_dropout_mask": [_p, _ll, _f, _u, _p],
     "a2v_dropout_mask2d": [_p, _ll, _i, _f, _u, _p],
     "a2v_debug_set": [_i, _i],
+    "a2v_stream_release": [_p],
     "a2v_attention_bwd_direct_dq": [_i, _i, _i],
     "a2v_pack_weight_batch": [_i, _p, _i, _p],
     "a2v_focal_loss": [_i, _p, _p, _p, _p, _ll, _i, _i, _f, _f, _f, _p],

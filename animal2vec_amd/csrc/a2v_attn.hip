@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 // stores its partial sum to its own slot of a device scratch and a one-block-per-head kernel folds them afterwards:
 // no contention, and the sum order is fixed (deterministic gradient).
 #define A2V_DAL_PART_MAX 65536
-__device__ float g_dal_part[A2V_DAL_PART_MAX];
+__device__ float g_dal_part_all[A2V_MAX_STREAMS][A2V_DAL_PART_MAX];     // one set per stream (a2v_stream_slot)
 __device__ __forceinline__ void dalibi_finish(float dal_wave, float* dalibi, int h, int use_part, float slope, float asc) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
@@ -491,10 +491,11 @@ __device__ __forceinline__ void dalibi_finish(float dal_wave, float* dalibi, int
   __syncthreads();
   if (tid == 0) {
     const float v = asc >= 0.f ? (red[0] + red[1] + red[2] + red[3]) * slope : 0.f;
-    g_dal_part[((long long)h * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = v;      // blockIdx.y = head
+    g_dal_part_all[use_part - 1][((long long)h * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = v;      // blockIdx.y = head
   }
 }
-__global__ __launch_bounds__(256) void dalibi_fold_kernel(float* __restrict__ dalibi, int per_head) {
+__global__ __launch_bounds__(256) void dalibi_fold_kernel(float* __restrict__ dalibi, int per_head, int slot) {
+  const float* const g_dal_part = g_dal_part_all[slot];
   __shared__ float red[4];
   const int h = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
@@ -514,7 +515,7 @@ struct AttnBwdArgs {
   int N, S, H;
   float scale;
   Drop drop;
-  int dal_part;             // 1: per-workgroup partial sums of d alibi_scale go to g_dal_part (folded by dalibi_fold_kernel)
+  int dal_part;             // s + 1: per-workgroup partial sums of d alibi_scale go to the stream's scratch set s (folded by dalibi_fold_kernel); 0: atomics
   float* bias_sum;          // (3, H, HD) fp32 or NULL: column sums of dqkv (the qkv Linear's bias gradient), whole-sequence kernel only
 };
 
@@ -1432,11 +1433,12 @@ template <typename T, int HD>
 static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delta, hipStream_t st) {
   AttnBwdArgs a = a_in;
   // d alibi_scale: per-workgroup partials + fold kernel whenever the launch's workgroups fit the scratch
+  const int ws = a.dalibi ? a2v_stream_slot(st) : -1;     // (no set left for this stream: direct atomics)
   auto set_part = [&](const dim3& grid) {
-    a.dal_part = (a.dalibi && (long long)grid.x * grid.y * grid.z <= A2V_DAL_PART_MAX) ? 1 : 0;
+    a.dal_part = (a.dalibi && ws >= 0 && (long long)grid.x * grid.y * grid.z <= A2V_DAL_PART_MAX) ? ws + 1 : 0;
   };
   auto fold = [&](const dim3& grid) {
-    if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(a.H), dim3(256), 0, st, a.dalibi, (int)(grid.x * grid.z));
+    if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(a.H), dim3(256), 0, st, a.dalibi, (int)(grid.x * grid.z), ws);
   };
   const long long total = (long long)a.N * a.S * a.H;
   int g = (int)((total + 255) / 256);

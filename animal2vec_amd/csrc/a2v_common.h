@@ -223,3 +223,11 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Library-owned device scratch (tile counters of the persistent GEMM, column-sum partial rows, d alibi_scale partial
+// sums) exists once per STREAM: the stream argument every entry point takes selects the set, so launches on different
+// streams never share scratch (re-entrant across streams) while launches on one stream are ordered anyway.  Static device
+// arrays, assigned to streams in order of first use: nothing is allocated, ever.  a2v_stream_slot returns -1 when more
+// than A2V_MAX_STREAMS distinct streams are live (a2v_stream_release gives a set back).
+#define A2V_MAX_STREAMS 4
+int a2v_stream_slot(hipStream_t stream);

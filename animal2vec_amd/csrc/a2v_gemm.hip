@@ -586,13 +586,32 @@ extern "C" int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long
   return conv_wgrad_impl(nullptr, dtype, xb, ldb_, 0, 0, M, M, 1, 0, 1, Kb, 0, nullptr, 1, dyb, ldpb, 0, gwb, ldwb, 0, M, Nb, Kb, 1, stream);
 }
 
+// ---- per-stream scratch sets (a2v_common.h)
+#include <mutex>
+static std::mutex g_ws_mu;
+static hipStream_t g_ws_stream[A2V_MAX_STREAMS];
+static bool g_ws_used[A2V_MAX_STREAMS];
+int a2v_stream_slot(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 0; i < A2V_MAX_STREAMS; ++i)
+    if (g_ws_used[i] && g_ws_stream[i] == stream) return i;
+  for (int i = 0; i < A2V_MAX_STREAMS; ++i)
+    if (!g_ws_used[i]) { g_ws_used[i] = true; g_ws_stream[i] = stream; return i; }
+  return -1;
+}
+extern "C" int a2v_stream_release(hipStream_t stream) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  for (int i = 0; i < A2V_MAX_STREAMS; ++i)
+    if (g_ws_used[i] && g_ws_stream[i] == stream) { g_ws_used[i] = false; return A2V_OK; }
+  return A2V_ERR_ARG;
+}
+
 // debugging / A-B benchmarking knob: key 0 = bf16 NT kernel variant (0 register-staged, 1 LDS-DMA)
 extern int g_a2v_gemm_variant;
 extern int g_a2v_p8_ih;
 extern int g_a2v_p8_stagger;
 extern int g_a2v_p8_dynamic;
 extern int g_a2v_attn_long;
-extern int g_a2v_p8_slot;
 extern int g_a2v_p8_direct;
 extern "C" int a2v_debug_set(int key, int value) {
   if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
@@ -600,7 +619,6 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 2) { g_a2v_wgrad_slab = value; return A2V_OK; }  // slab weight-gradient kernel on / off
   if (key == 3) { g_a2v_conv_slab = value; return A2V_OK; }   // slab grouped-conv kernel on / off
   if (key == 4) { g_a2v_tn_p8 = value; return A2V_OK; }       // 256x256 TN weight-gradient kernel on / off
-  if (key == 9) { if (value < 0 || value > 3) return A2V_ERR_ARG; g_a2v_p8_slot = value; return A2V_OK; }   // tile-counter set for the stream about to be used
   if (key == 8) { g_a2v_attn_long = value; return A2V_OK; }        // long-sequence attention backward: two-pass kernel on / off
   if (key == 7) { g_a2v_p8_dynamic = value; return A2V_OK; }  // persistent kernels: dynamic tile hand-out on / off
   if (key == 6) { g_a2v_p8_stagger = value; return A2V_OK; }  // 8-phase kernels: stagger the two wave groups on / off

@@ -62,9 +62,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 // of this scratch and a small kernel folds them.  As atomics on the N addresses of the final buffer they sat in vmcnt
 // ahead of the next tile's first counted wait (stores and atomics share that counter on gfx9) and, contended 120-fold
 // per address, held the K loop back: +23 us on a 144 us GEMM.
-#define P8_CS_PART_MAX (1 << 20)
-__device__ float g_p8_cs_part[P8_CS_PART_MAX];
-__global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__ colsum, int N, int parts) {
+#define P8_CS_PART_MAX (1 << 22)
+__device__ float g_p8_cs_part_all[A2V_MAX_STREAMS][P8_CS_PART_MAX];     // one set per stream (a2v_stream_slot)
+__global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__ colsum, int N, int parts, int slot) {
+  const float* const g_p8_cs_part = g_p8_cs_part_all[slot];
   const int n = blockIdx.x * 256 + threadIdx.x;        // blockIdx.y: one of 16 interleaved slices of the partial rows
   if (n >= N) return;
   float s0 = 0.f, s1 = 0.f;
@@ -77,8 +78,7 @@ __global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__
   atomicAdd(colsum + n, s0 + s1);
 }
 
-#define P8_CTR_SLOTS 4     // one counter set per concurrently used stream (a2v_debug_set(9, slot) before launching on it)
-__device__ unsigned g_p8_ctr_all[P8_CTR_SLOTS][9];
+__device__ unsigned g_p8_ctr_all[A2V_MAX_STREAMS][9];      // one counter set per stream (a2v_stream_slot)
 
 struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
@@ -99,6 +99,7 @@ struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B ch
 template <int IH, bool DS>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot, int cs_part) {
   unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
+  float* const g_p8_cs_part = g_p8_cs_part_all[ctr_slot];
   constexpr int BM = 128 + 32 * IH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -583,7 +584,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
 }
 
-int g_a2v_p8_slot = 0;      // a2v_debug_set(9, v): tile-counter set of the persistent NT kernel (one per concurrent stream)
 int g_a2v_p8_dynamic = 2;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent NT kernel (2: first tile too)
 int g_a2v_p8_stagger = 1;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels)
 int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swapped MFMA operands, permuted B rows) on / off
@@ -631,14 +631,16 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const int stagger = g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048);
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);
-  const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX && g_a2v_p8_slot == 0) ? 1 : 0;
-#define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, g_a2v_p8_slot, cs_part)
+  const int ws = a2v_stream_slot(stream);
+  if (ws < 0) return false;                  // no scratch set left for this stream: the 128 x 128 kernel needs none
+  const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX) ? 1 : 0;
+#define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
   if (direct) {
     if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);
   } else {
     if (best_ih == 4) P8_GO(4, false); else if (best_ih == 3) P8_GO(3, false); else P8_GO(2, false);
   }
 #undef P8_GO
-  if (cs_part) hipLaunchKernelGGL(p8_colsum_fold_kernel, dim3(cdiv(g.N, 256), 16), dim3(256), 0, stream, g.colsum, g.N, parts);
+  if (cs_part) hipLaunchKernelGGL(p8_colsum_fold_kernel, dim3(cdiv(g.N, 256), 16), dim3(256), 0, stream, g.colsum, g.N, parts, ws);
   return true;
 }

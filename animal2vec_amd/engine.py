@@ -580,11 +580,7 @@ class Engine:
             fork.record(main)
             with torch.cuda.stream(self.tstream):
                 self.tstream.wait_event(fork)
-                ops.debug_set(9, 1)                 # the teacher's persistent GEMMs use their own tile counters
-                try:
-                    y = self.teacher_targets(feats)
-                finally:
-                    ops.debug_set(9, 0)
+                y = self.teacher_targets(feats)     # (the library keeps one scratch set per stream: include/a2v.h)
                 join = torch.cuda.Event()
                 join.record(self.tstream)
             y.record_stream(main)

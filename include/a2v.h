@@ -14,10 +14,11 @@
  *  - activations are channels-last: (batch, time, channels) row-major.
  *  - ownership: the caller owns every buffer (incl. workspaces and tensors saved for backward);
  *    kernels never allocate, free or retain pointers.
- *  - every call is asynchronous on `stream` and graph-capturable (no sync, no alloc).  Calls on ONE stream may be
- *    issued back to back freely.  Two library-owned device scratch areas make concurrent use from several streams
- *    conditional: the persistent NT GEMM's tile counters (pick a different set per stream, a2v_debug_set(9, slot))
- *    and the d alibi_scale partial sums of a2v_attention_bwd (do not overlap two attention backward launches).
+ *  - every call is asynchronous on `stream` and graph-capturable (no sync, no alloc) and re-entrant across streams:
+ *    the little device scratch the library owns itself (tile counters of the persistent GEMM, column-sum partial rows,
+ *    d alibi_scale partial sums) exists once per stream -- static device arrays, a set is bound to a stream the first
+ *    time the stream is passed in (at most 4 live streams; a2v_stream_release returns a set; a fifth stream still
+ *    works, through the kernels that need no scratch).  Calls on ONE stream are ordered by the stream as usual.
  *  - return value: 0 on success, <0 on error (-1 bad argument, -2 bad dtype, -(1000+hipError_t) on a
  *    launch failure).  No exceptions cross the ABI.
  */
@@ -231,9 +232,13 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   4 persistent 256x256 TN kernel on / off                     5 force the NT tile height (2 / 3 / 4 = 192 / 224 / 256 rows)
  *   6 wave-group stagger (0 off, 1 by shape, 2 always)          7 tile hand-out (0 static, 1 dynamic after the first tile, 2 all dynamic)
  *   8 long-sequence attention backward (0 tiled kernel + dQ atomics, 1 two-pass, 2 two-pass for every S)
- * and one piece of launch state: 9 = tile-counter set (0..3) of the persistent NT GEMM -- kernels launched on streams that
- * may run concurrently must use different sets (the engine sets 1 around the teacher's side-stream section). */
+ *   10 persistent NT kernel epilogue (1 direct stores, 0 staged through LDS)
+ * No launch state goes through here (ABI 5's key 9, the tile-counter set, is gone: the stream argument selects it). */
 int a2v_debug_set(int key, int value);
+
+/* Gives the per-stream scratch set bound to `stream` back to the pool (see "re-entrant across streams" above); only needed
+ * by hosts that create and destroy many streams.  -1 if the stream holds no set. */
+int a2v_stream_release(a2v_stream_t stream);
 
 /* library version / build info */
 /* ---------------------------------------------------------------- finetune path

@@ -50,13 +50,13 @@ def test_bench_spawns_its_own_ranks_gloo_dry():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["observed_world_size"] == 2 and j["dry"] is True and j["grad_sum_ok"] is True
-    assert j["steps"] == 3 and j["warmup"] == 1 and j["config"]["micro_batches_per_rank"] == 4
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["config"]["micro_batch"] == 32 and j["config"]["micro_batches_per_rank"] == 1
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in j, k
 
 
 def test_bench_spawn_propagates_rank_failure():
-    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--micro-batch", "0")
+    r = _run_bench("--gpus", "2", "--backend", "gloo", "--dry", "--global-batch", "7", "--micro-batch", "2")
     assert r.returncode != 0
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 

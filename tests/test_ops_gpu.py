@@ -895,3 +895,56 @@ def test_adam_lr_scale_table(ops):
     step_size = lr * math.sqrt(1 - b2) / (1 - b1)
     exp = p0 - wd * lr * lse * p0 - step_size * lse * m1 / (v1.sqrt() + eps)
     assert rel_err(p, exp) < 1e-5
+
+
+def test_streams_have_their_own_scratch(ops):
+    """Re-entrancy across streams (include/a2v.h): the persistent GEMM's tile counters, its column-sum partial rows and
+    the attention backward's d alibi_scale partials exist once per stream, so the same launches issued concurrently on
+    two streams give bit for bit what they give one after the other (a shared set loses tiles or mixes partial sums)."""
+    from animal2vec_amd import _lib
+    dtype = torch.bfloat16
+    shapes = [(13440, 1024, 512), (16000, 2048, 512)]
+
+    def gemm_work(seed, M, N, K):
+        x, w = dev(rnd(M, K, dtype=dtype, seed=seed), dtype), dev(rnd(N, K, dtype=dtype, seed=seed + 1, scale=K ** -0.5), dtype)
+        aux = dev(rnd(M, N, dtype=dtype, seed=seed + 2), dtype)
+        return x, w, aux
+
+    def attn_work(seed, N_=6, S=140, H=4):
+        qkv = dev(rnd(N_, S, 3 * H * 64, dtype=dtype, seed=seed, scale=0.5), dtype)
+        do = dev(rnd(N_, S, H * 64, dtype=dtype, seed=seed + 1), dtype)
+        pos = torch.arange(S, device="cuda", dtype=torch.int32).repeat(N_, 1).contiguous()
+        return qkv, do, pos, torch.rand(H, device="cuda") + 0.1, torch.ones(H, device="cuda"), H
+
+    works = [gemm_work(10 + 10 * i, *shapes[i]) for i in range(2)]
+    aws = [attn_work(50 + 10 * i) for i in range(2)]
+
+    def run(i, reps=6):
+        x, w, aux = works[i]
+        outs = []
+        for _ in range(reps):
+            cs = torch.zeros(w.shape[0], dtype=torch.float32, device="cuda")
+            y = ops.linear(x, w, None, gelu_bwd_aux=aux, colsum=cs)
+            outs.append((y, cs))
+        qkv, do, pos, slopes, asc, H = aws[i]
+        att, lse = ops.attention_fwd(qkv, pos, slopes, asc, H)
+        dal = torch.zeros(H, dtype=torch.float32, device="cuda")
+        dqkv = ops.attention_bwd(qkv, att, do, lse, pos, slopes, asc, H, dal)
+        return outs, dqkv, dal
+
+    serial = [run(0), run(1)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    conc = [None, None]
+    for rep in range(3):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                conc[i] = run(i)
+        torch.cuda.synchronize()
+        for i in (0, 1):
+            for (y, cs), (y0, cs0) in zip(conc[i][0], serial[i][0]):
+                assert torch.equal(y, y0) and torch.equal(cs, cs0), (rep, i)
+            assert torch.equal(conc[i][1], serial[i][1]) and torch.equal(conc[i][2], serial[i][2]), (rep, i)
+    for s_ in streams:
+        assert _lib.load().a2v_stream_release(s_.cuda_stream) == 0
+    assert _lib.load().a2v_stream_release(streams[0].cuda_stream) != 0       # already released
