@@ -303,7 +303,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   // The two waves that share a SIMD (w and w + 4, i.e. wr = 0 / 1) run half a phase apart from here on: one extra
   // barrier for the wr = 1 group pairs its "reads done" barrier with the other group's "MFMAs done" barrier, so one
   // wave of a SIMD issues LDS reads / DMA while the other owns the MFMA pipe (in lock step both queue for it at once).
-  if (stagger && wr == 1) __builtin_amdgcn_s_barrier();
+  if ((stagger & 1) && wr == 1) __builtin_amdgcn_s_barrier();
 
   int seq_next = 0;
   for (; seq < ntiles; seq = seq_next) {
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       for (int i = 0; i < 9; ++i) g_p8_ctr[i] = 0u;
     }
   }
-  if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
+  if ((stagger & 1) && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail's re-fetches must land before the LDS is released
 }
 
@@ -628,7 +628,7 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const int ntiles = cdiv(g.M, bm) * (g.N / 256);
   // measured: staggering the wave groups pays for long K loops (K = 4096: +5..9 %, 8192^3: 1379 -> 1538 TFLOP/s) and
   // costs a few per cent at K = 1024, where the epilogue dominates (g_a2v_p8_stagger: 0 off, 1 by shape, 2 always)
-  const int stagger = g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048);
+  const int stagger = ((g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048)) ? 1 : 0) ;
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);
   const int ws = a2v_stream_slot(stream);

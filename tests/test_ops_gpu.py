@@ -943,7 +943,7 @@ def test_streams_have_their_own_scratch(ops):
         torch.cuda.synchronize()
         for i in (0, 1):
             for (y, cs), (y0, cs0) in zip(conc[i][0], serial[i][0]):
-                assert torch.equal(y, y0) and torch.equal(cs, cs0), (rep, i)
+                assert torch.equal(y, y0) and rel_err(cs, cs0) < 1e-5, (rep, i)     # (the fold's 16 slices add atomically: order varies)
             assert torch.equal(conc[i][1], serial[i][1]) and torch.equal(conc[i][2], serial[i][2]), (rep, i)
     for s_ in streams:
         assert _lib.load().a2v_stream_release(s_.cuda_stream) == 0
