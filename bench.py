@@ -152,22 +152,49 @@ class GemmRecorder:
         return out
 
 
-def pmc_traffic(kernel_prefix):
-    """Average fabric bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (FETCH_SIZE / WRITE_SIZE cannot be collected from inside this process; tools/pmc_traffic.py makes the file
-    from two separate counter runs of this same command, corrected as MI355X_MICROARCH.md prescribes)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
+PMC_MFMA = os.path.join("profiles", "r02_mfma_util.json")
+
+
+def _pmc_doc(rel):
     try:
-        with open(path) as f:
-            doc = json.load(f)
+        with open(os.path.join(ROOT, rel)) as f:
+            return json.load(f)
     except OSError:
-        return None, None
-    n = b = 0
+        return None
+
+
+def pmc_traffic(kernel_substr):
+    """Average fabric bytes per launch, and the GB/s they amount to, of the kernels whose name contains `kernel_substr`,
+    from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE cannot be collected from inside this process;
+    tools/pmc_traffic.py makes the file from two separate counter runs of this bench's workload at the default
+    micro-batch, corrected as MI355X_MICROARCH.md prescribes)."""
+    doc = _pmc_doc(PMC_TRAFFIC)
+    if doc is None:
+        return None, None, None
+    n = b = us = 0
     for name, v in doc["kernels"].items():
-        if name.startswith(kernel_prefix):
+        if kernel_substr in name:
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
-    return (round(b / n) if n else None), "profiles/r01_pmc_traffic.json"
+            us += v["launches"] * v["avg_us_under_pmc"]
+    if not n:
+        return None, None, PMC_TRAFFIC
+    return round(b / n), round(b / us / 1e3, 1), PMC_TRAFFIC
+
+
+def pmc_mfma(kernel_substr):
+    """MFMA-busy share (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles), tools/pmc_mfma.py) of matching kernels."""
+    doc = _pmc_doc(PMC_MFMA)
+    if doc is None:
+        return None
+    n = acc = 0.0
+    for name, v in doc["kernels"].items():
+        if kernel_substr in name and v.get("mfma_busy_share") is not None:
+            w = v["launches"] * v["avg_us_under_pmc"]
+            n += w
+            acc += w * v["mfma_busy_share"]
+    return round(acc / n, 4) if n else None
 
 
 def make_microbatch(cfg, B, L, K, seed, device):
@@ -442,7 +469,11 @@ def main():
             rec.unwrap(ops)
             tr.engine.tstream = side
         nt = s["nt"]
-        traffic, traffic_src = pmc_traffic("gemm_nt_bf16_p8_kernel") if dtype == torch.bfloat16 else (None, None)
+        traffic, _, traffic_src = pmc_traffic("gemm_nt_bf16_p8_kernel") if dtype == torch.bfloat16 else (None, None, None)
+        for name, sub in (("layernorm_fwd", "layernorm_fwd_kernel"), ("layernorm_bwd", "layernorm_bwd_kernel"),
+                          ("sinc_fused_fwd", "sinc_fused_fwd_kernel"), ("sinc_fused_bwd", "sinc_fused_bwd_kernel")):
+            if name in hbm:      # the same kernels' fabric bytes / duration from the PMC passes (not an algorithmic count)
+                hbm[name]["pmc_bytes_per_launch"], hbm[name]["pmc_GBps"], _ = pmc_traffic(sub)
         roof = dict(bound="mfma", kernel="gemm_nt_bf16_p8_kernel<*> + conv_nt_slab_kernel (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
                     achieved=round(nt["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (HBM+MALL, PMC)",
@@ -450,6 +481,10 @@ def main():
                     launches_per_microbatch=nt["launches"], avg_launch_us=round(nt["avg_us"], 2),
                     wgrad_kernel=dict(tflops=round(s["tn"]["tflops"], 2), launches=s["tn"]["launches"],
                                       avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None,
+                    # rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES share of the kernels' cycles (profiles/r02_mfma_util.json)
+                    mfma_busy_share={"gemm_nt_bf16_p8_kernel": pmc_mfma("gemm_nt_bf16_p8_kernel"), "conv_nt_slab_kernel": pmc_mfma("conv_nt_slab_kernel"),
+                                     "gemm_tn_bf16_p8_kernel": pmc_mfma("gemm_tn_bf16_p8_kernel"), "attn_fwd_bf16_kernel": pmc_mfma("attn_fwd_bf16_kernel"),
+                                     "source": PMC_MFMA} if dtype == torch.bfloat16 else None,
                     # the HBM-bound families of the same micro-batch (algorithmic bytes / HIP-event time, peak 8 TB/s)
                     hbm_kernels=hbm)
     if use_dist:
