@@ -161,6 +161,7 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream);
 bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream);   // a2v_gemm_tn8.hip: 256x256 weight gradients of the Linears
 bool a2v_launch_tn_bf16_p8_pair(const WgradArgs* ga, const WgradArgs* gb, hipStream_t stream);   // two of them in one launch
 bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream);
+bool a2v_launch_conv_dec48(const GemmArgs& g, hipStream_t stream);     // a2v_conv_dec.hip: decoder grouped conv (48 channels per group, HBM-bound)
 bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream);      // a2v_conv_slab.hip: grouped-conv forward / input grads    // a2v_wgrad_slab.hip: grouped-conv weight grads     // a2v_gemm_p8.hip: 256x256 8-phase kernel
 bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream);
 int a2v_tn_bf16_tiles(int N, int K);

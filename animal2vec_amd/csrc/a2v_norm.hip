@@ -121,13 +121,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // (one uncontended atomic per column) and zeroes them again.
 #define SPREAD 64
 #define SPREAD_C 4096
+// one self-cleaning copy set per stream (a2v_stream_slot): static device memory, zero at load, nothing is allocated
+__device__ float g_spread_ws[A2V_MAX_STREAMS][SPREAD * 3 * SPREAD_C];
 static float* spread_ws(hipStream_t st) {
-  static float* ws = nullptr;
-  if (!ws) {
-    if (hipMalloc((void**)&ws, sizeof(float) * SPREAD * 3 * SPREAD_C) != hipSuccess) return nullptr;
-    (void)hipMemsetAsync(ws, 0, sizeof(float) * SPREAD * 3 * SPREAD_C, st);
-  }
-  return ws;
+  const int slot = a2v_stream_slot(st);
+  if (slot < 0) return nullptr;                 // no set left for this stream: direct atomics
+  static float* base = nullptr;                 // address of the device symbol: looked up once
+  if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_spread_ws)) != hipSuccess) return nullptr;
+  return base + (size_t)slot * SPREAD * 3 * SPREAD_C;
 }
 __global__ __launch_bounds__(256) void spread_fold_kernel(float* __restrict__ ws, float* __restrict__ d0,
                                                           float* __restrict__ d1, float* __restrict__ d2, int C) {

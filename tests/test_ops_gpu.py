@@ -948,3 +948,46 @@ def test_streams_have_their_own_scratch(ops):
     for s_ in streams:
         assert _lib.load().a2v_stream_release(s_.cuda_stream) == 0
     assert _lib.load().a2v_stream_release(streams[0].cuda_stream) != 0       # already released
+
+
+@pytest.mark.parametrize("B,T", [(3, 2000), (2, 1100), (5, 64), (1, 333)])
+def test_conv_decoder_kernel(ops, B, T):
+    """Decoder1d's grouped conv (768 -> 768, k 7, groups 16: 48 channels per group) through the HBM-bound all-groups kernel
+    (a2v_conv_dec.hip): forward with bias, input gradient with the residual add, clip edges, ragged row blocks; against
+    fp32 torch and against the slab / implicit-GEMM kernels (a2v_debug_set(13, 0))."""
+    from animal2vec_amd import _lib
+    dtype = torch.bfloat16
+    G, k, Cg, N = 16, 7, 48, 48
+    D = G * Cg
+    x = rnd(B, D, T, dtype=dtype, seed=1)
+    w = rnd(D, Cg, k, dtype=dtype, seed=2, scale=(Cg * k) ** -0.5)
+    bias = rnd(D, dtype=torch.float32, seed=3)
+    dy = rnd(B, D, T, dtype=dtype, seed=4)
+    res = rnd(B, T, D, dtype=dtype, seed=5)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv1d(xr, w, bias, padding=k // 2, groups=G)
+    ref.backward(dy)
+    xcl, dycl = to_cl(x, D, dtype), to_cl(dy, D, dtype)
+    wp = dev(pack_ref(w, G, 64), dtype)
+    wt = torch.empty(G, Cg, k * 64, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(w, torch.float32), wt, G=G, N=N, Cg=Cg, k=k, Np=64, mode=1)
+    rd = dev(res, dtype)
+
+    def run():
+        y = ops.conv1d_cl(xcl, wp, dev(bias, torch.float32), k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, cv=Cg)
+        dx = ops.conv1d_cl(dycl, wt, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D, cv=N, res=rd)
+        return y, dx
+
+    y, dx = run()
+    y2, dx2 = run()
+    assert torch.equal(y, y2) and torch.equal(dx, dx2)
+    lib = _lib.load()
+    lib.a2v_debug_set(13, 0)
+    try:
+        y0, dx0 = run()
+    finally:
+        lib.a2v_debug_set(13, 1)
+    assert rel_err(y.float().transpose(1, 2), ref.detach()) < tol(dtype)
+    assert rel_err(dx.float(), xr.grad.transpose(1, 2) + res) < tol(dtype, 2)
+    # K is accumulated as (tap, channel) here and as tap-major 64-wide steps there: same products, fp32 sums in another order
+    assert rel_err(y.float(), y0.float()) < 4e-3 and rel_err(dx.float(), dx0.float()) < 4e-3
