@@ -18,21 +18,35 @@
 //     channels of one row: 16-B + 8-B stores straight from the accumulators, no LDS staging.
 // Epilogues: bias and / or residual add (what Decoder1d's forward and its input gradient need); anything else, other
 // shapes, masks and row gathers stay with the slab / implicit-GEMM kernels.
+// Template <CI, CO, GPW>: input / output channels per group and groups per wave -- <48, 48, 2> the three 768 -> 768 layers
+// and their input gradients (a workgroup covers 8 groups), <64, 48, 1> the first layer (1024 -> 768) and <48, 64, 1> its
+// input gradient (4 groups per workgroup: the weight fragments of one group are 168 / 176 registers there).
 #include "a2v_gemm.h"
 
 #define CD_ROWS 64
 #define CD_TAPS 7
-#define CD_CG 48
-#define CD_GW 8                                   // groups per workgroup
 #define CD_SLAB_ROWS (CD_ROWS + CD_TAPS - 1)      // 70
-#define CD_PITCH (CD_GW * CD_CG * 2 + 16)         // 784 B: 16 consecutive rows start 4 banks apart (conflict-free b128 reads)
-#define CD_SLAB_BYTES (CD_SLAB_ROWS * CD_PITCH)
-#define CD_LDS (2 * CD_SLAB_BYTES)                // 109760
-#define CD_CHUNKS (CD_SLAB_ROWS * CD_GW * CD_CG / 8)   // 16-B chunks of a slab: 3360
-#define CD_NLD ((CD_CHUNKS + 255) / 256)          // per thread: 14
-#define CD_KSTEPS 11                              // 7 taps x 6 chunks of 8 channels = 42 chunks = 10.5 K-steps of 4 chunks
 
-__global__ __launch_bounds__(256) void conv_dec48_kernel(GemmArgs g, int blocks_per_wg) {
+template <int CI, int CO, int GPW>
+struct CdGeom {
+  static constexpr int GW = 4 * GPW;                       // groups per workgroup
+  static constexpr int RCH = GW * CI / 8;                  // 16-B chunks per slab row
+  static constexpr int PITCH = GW * CI * 2 + 16;           // 16 consecutive rows start on 16 different 4-bank groups
+  static constexpr int SLAB_BYTES = CD_SLAB_ROWS * PITCH;
+  static constexpr int LDS = 2 * SLAB_BYTES + GW * CO * 4;    // two slabs + the workgroup's bias values
+  static constexpr int CHUNKS = CD_SLAB_ROWS * RCH;
+  static constexpr int NLD = (CHUNKS + 255) / 256;
+  static constexpr int TCH = CI / 8;                       // K-chunks (8 channels) per tap
+  static constexpr int KCH = CD_TAPS * TCH;                // 42 / 56
+  static constexpr int KSTEPS = (KCH + 3) / 4;             // 11 / 14
+  static constexpr int NJ = CO / 16;                       // 3 / 4
+};
+
+template <int CI, int CO, int GPW>
+__global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_per_wg) {
+  using GM = CdGeom<CI, CO, GPW>;
+  constexpr int CD_GW = GM::GW, CD_PITCH = GM::PITCH, CD_SLAB_BYTES = GM::SLAB_BYTES, CD_CHUNKS = GM::CHUNKS, CD_NLD = GM::NLD;
+  constexpr int CD_KSTEPS = GM::KSTEPS, TCH = GM::TCH, KCH = GM::KCH, NJ = GM::NJ, RCH = GM::RCH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
@@ -49,21 +63,22 @@ __global__ __launch_bounds__(256) void conv_dec48_kernel(GemmArgs g, int blocks_
   // ---- weights of this wave's two groups as MFMA fragments.  K-chunk q = 4 s + fq of step s is channels [8 (q % 6), +8)
   // of tap q / 6 (chunks 42, 43 of the last step: zero); fragment row fr of column block j is output channel
   // 8 (fr >> 2) + 4 j + (fr & 3) (j < 2) or 32 + fr (j = 2): rows 4 fq + r of D are then channels 8 fq + 4 j + r / 32 + 4 fq + r
-  bf16x8 wf[2][CD_KSTEPS][3];
+  // (CO = 64: two column-block pairs, channels 32 p + 8 fq + 4 (j & 1) + r; CO = 48: one pair and the single block above)
+  bf16x8 wf[GPW][CD_KSTEPS][NJ];
 #pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
-    const bf16* wb = (const bf16*)g.B + (long long)(g0 + 2 * wid + gi) * g.b_gstride;
+  for (int gi = 0; gi < GPW; ++gi) {
+    const bf16* wb = (const bf16*)g.B + (long long)(g0 + GPW * wid + gi) * g.b_gstride;
 #pragma unroll
     for (int s = 0; s < CD_KSTEPS; ++s) {
       const int q = 4 * s + fq;
-      const int tap = q / 6, c0 = (q - 6 * tap) * 8;
+      const int tap = q / TCH, c0 = (q - TCH * tap) * 8;
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int n = j < 2 ? 8 * (fr >> 2) + 4 * j + (fr & 3) : 32 + fr;
+      for (int j = 0; j < NJ; ++j) {
+        const int n = (NJ == 3 && j == 2) ? 32 + fr : 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3);
         bf16x8 w;
 #pragma unroll
         for (int e = 0; e < 8; ++e) w[e] = (bf16)0.f;
-        if (q < 42) w = *(const bf16x8*)(wb + (long long)n * g.ldb + tap * 64 + c0);
+        if (q < KCH) w = *(const bf16x8*)(wb + (long long)n * g.ldb + tap * 64 + c0);
         wf[gi][s][j] = w;
       }
     }
@@ -73,19 +88,22 @@ __global__ __launch_bounds__(256) void conv_dec48_kernel(GemmArgs g, int blocks_
 #pragma unroll
   for (int s = 0; s < CD_KSTEPS; ++s) {
     int q = 4 * s + fq;
-    q = q < 42 ? q : 41;
-    const int tap = q / 6, c0 = (q - 6 * tap) * 8;
+    q = q < KCH ? q : KCH - 1;
+    const int tap = q / TCH, c0 = (q - TCH * tap) * 8;
     xoff[s] = (fr + tap) * CD_PITCH + c0 * 2;
   }
 
   const bf16* const xb = (const bf16*)a.ptr + (long long)(clip / a.bdiv) * a.bstride + (long long)g0 * a.goff;
   uint4 rg[CD_NLD];
-  auto fetch = [&](int blk) {                        // slab rows t_begin + 64 blk - pad + [0, 70): zero outside the clip
-    const int t0 = t_begin + blk * CD_ROWS - a.pad;
+  // Every block is a full 64 rows: the last one of a chunk starts at t_end - 64 and recomputes rows its predecessor (or the
+  // previous chunk's workgroup) also writes -- same operands, same order, same bits (the launcher refuses C overlapping R).
+  auto block_t0 = [&](int blk) { return min(t_begin + blk * CD_ROWS, t_end - CD_ROWS); };
+  auto fetch = [&](int blk) {                        // slab rows block_t0 - pad + [0, 70): zero outside the clip
+    const int t0 = block_t0(blk) - a.pad;
 #pragma unroll
     for (int u = 0; u < CD_NLD; ++u) {
       const int idx = tid + 256 * u;
-      const int row = idx / (CD_GW * CD_CG / 8), ch = idx - row * (CD_GW * CD_CG / 8);
+      const int row = idx / RCH, ch = idx - row * RCH;
       const int rs = t0 + row;
       rg[u] = make_uint4(0u, 0u, 0u, 0u);
       if (idx < CD_CHUNKS && (unsigned)rs < (unsigned)a.T_in) rg[u] = *(const uint4*)(xb + (long long)rs * a.pitch + ch * 8);
@@ -95,81 +113,89 @@ __global__ __launch_bounds__(256) void conv_dec48_kernel(GemmArgs g, int blocks_
 #pragma unroll
     for (int u = 0; u < CD_NLD; ++u) {
       const int idx = tid + 256 * u;
-      const int row = idx / (CD_GW * CD_CG / 8), ch = idx - row * (CD_GW * CD_CG / 8);
+      const int row = idx / RCH, ch = idx - row * RCH;
       if (idx < CD_CHUNKS) *(uint4*)(buf + row * CD_PITCH + ch * 16) = rg[u];
     }
   };
 
-  // bias of this lane's output channels (8 + 4 per group)
-  float b8[2][8], b4[2][4];
-#pragma unroll
-  for (int gi = 0; gi < 2; ++gi) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) b8[gi][e] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) b4[gi][e] = 0.f;
-    if (g.flags & F_BIAS) {
-      const float* bp = g.bias + (long long)(g0 + 2 * wid + gi) * g.N;
-      Vec8<float>::load(bp + 8 * fq, b8[gi]);
-      const f32x4 t4 = *(const f32x4*)(bp + 32 + 4 * fq);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) b4[gi][e] = t4[e];
-    }
-  }
+  // bias of the workgroup's GW x CO output channels in LDS (zeros without F_BIAS): held in registers it cost 24 of the 256
+  // arch VGPRs next to 264 weight registers (AGPRs), 56 of slab staging and 48 accumulators
+  float* const sBias = (float*)(smem + 2 * CD_SLAB_BYTES);
+  for (int i = tid; i < CD_GW * CO; i += 256) sBias[i] = (g.flags & F_BIAS) ? g.bias[(long long)g0 * g.N + i] : 0.f;
 
   fetch(0);
   stash(smem);
   __syncthreads();
   bf16* const C = (bf16*)g.C;
   const bf16* const R = (const bf16*)g.R;
+  // One block = fetch the next slab (registers) -> per group: residual rows (registers), MFMAs, stores -> stash the next slab.
+  // Loads, stores and their waits share ONE in-order counter (vmcnt): the residual rows of a group are all requested before
+  // its first store (a load issued behind a store cannot be waited for without that store's acknowledgement), and the stores
+  // of a full 64-row block are unconditional so that the compiler can count them -- behind a branch it has to assume none was
+  // issued and waits for vmcnt(0), i.e. for every store of the block, before the next slab may be written to LDS.
   for (int blk = 0; blk < nblk; ++blk) {
     const char* const cur = smem + (blk & 1) * CD_SLAB_BYTES;
     if (blk + 1 < nblk) fetch(blk + 1);               // in flight under this block's MFMAs
 #pragma unroll
-    for (int gi = 0; gi < 2; ++gi) {
-      f32x4 acc[4][3];
+    for (int gi = 0; gi < GPW; ++gi) {
+      const int grp = g0 + GPW * wid + gi;
+      const long long m0 = (long long)clip * T + block_t0(blk) + fr;       // row of i = 0
+      Raw8<bf16> h8[4][NJ / 2];
+      uint2 h4[4];
+      if (g.flags & F_RES) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const bf16* rp = R + (m0 + 16 * i) * g.ldr + (long long)grp * g.c_goff;
+#pragma unroll
+          for (int p = 0; p < NJ / 2; ++p) h8[i][p].load(rp + 32 * p + 8 * fq);
+          if (NJ == 3) h4[i] = *(const uint2*)(rp + 32 + 4 * fq);
+        }
+      }
+      f32x4 acc[4][NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const char* const xs = cur + (2 * wid + gi) * (CD_CG * 2);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const char* const xs = cur + (GPW * wid + gi) * (CI * 2);
 #pragma unroll
       for (int s = 0; s < CD_KSTEPS; ++s) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const bf16x8 xf = *(const bf16x8*)(xs + xoff[s] + i * 16 * CD_PITCH);
 #pragma unroll
-          for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gi][s][j], xf, acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gi][s][j], xf, acc[i][j], 0, 0, 0);
         }
       }
-      // ---- epilogue of (this block, group): lane (fq, fr) holds row 16 i + fr, channels 8 fq + [0, 8) and 32 + 4 fq + [0, 4)
-      const int grp = g0 + 2 * wid + gi;
+      // ---- epilogue of (this block, group): lane (fq, fr) holds row 16 i + fr, channels 32 p + 8 fq + [0, 8) per column-block
+      // pair p (and 32 + 4 fq + [0, 4) of the single block at CO = 48)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int t = t_begin + blk * CD_ROWS + i * 16 + fr;
-        if (t < t_end) {
-          const long long m = (long long)clip * T + t;
-          float v8[8], v4[4];
+        bf16* const cp = C + (m0 + 16 * i) * g.ldc + (long long)grp * g.c_goff;
+#pragma unroll
+        for (int p = 0; p < NJ / 2; ++p) {
+          float v8[8];
+          const float* bp = sBias + (GPW * wid + gi) * CO + 32 * p + 8 * fq;
+          const f32x4 ba = *(const f32x4*)bp, bb = *(const f32x4*)(bp + 4);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v8[r] = acc[i][0][r] + b8[gi][r];
-            v8[4 + r] = acc[i][1][r] + b8[gi][4 + r];
-            v4[r] = acc[i][2][r] + b4[gi][r];
+            v8[r] = acc[i][2 * p][r] + ba[r];
+            v8[4 + r] = acc[i][2 * p + 1][r] + bb[r];
           }
-          const long long co = m * g.ldc + (long long)grp * g.c_goff;
           if (g.flags & F_RES) {
-            const long long ro = m * g.ldr + (long long)grp * g.c_goff;
-            float h8[8];
-            Vec8<bf16>::load(R + ro + 8 * fq, h8);
-            const f32x4 h4 = Vec4<bf16>::load(R + ro + 32 + 4 * fq);
+            float hh[8];
+            h8[i][p].unpack(hh);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v8[e] += h8[e];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v4[e] += h4[e];
+            for (int e = 0; e < 8; ++e) v8[e] += hh[e];
           }
-          Vec8<bf16>::store(C + co + 8 * fq, v8);
-          const f32x4 o4 = {v4[0], v4[1], v4[2], v4[3]};
-          Vec4<bf16>::store(C + co + 32 + 4 * fq, o4);
+          Vec8<bf16>::store(cp + 32 * p + 8 * fq, v8);
+        }
+        if (NJ == 3) {
+          f32x4 o4 = acc[i][2] + *(const f32x4*)(sBias + (GPW * wid + gi) * CO + 32 + 4 * fq);
+          if (g.flags & F_RES) {
+            o4[0] += __uint_as_float(h4[i].x << 16); o4[1] += __uint_as_float(h4[i].x & 0xffff0000u);
+            o4[2] += __uint_as_float(h4[i].y << 16); o4[3] += __uint_as_float(h4[i].y & 0xffff0000u);
+          }
+          Vec4<bf16>::store(cp + 32 + 4 * fq, o4);
         }
       }
     }
@@ -179,24 +205,37 @@ __global__ __launch_bounds__(256) void conv_dec48_kernel(GemmArgs g, int blocks_
 }
 
 int g_a2v_conv_dec = 1;     // a2v_debug_set(13, v): decoder grouped conv through this kernel on / off
-bool a2v_launch_conv_dec48(const GemmArgs& g, hipStream_t stream) {
+template <int CI, int CO, int GPW>
+static void conv_dec_go(const GemmArgs& g, hipStream_t stream) {
+  using GM = CdGeom<CI, CO, GPW>;
   const ConvA& a = g.a;
-  if (!g_a2v_conv_dec) return false;
-  if (a.Cg != 64 || a.Cv != CD_CG || a.goff != CD_CG || g.N != CD_CG || g.c_goff != CD_CG || a.taps != CD_TAPS || a.stride != 1 ||
-      a.T_in != a.T_out || g.K != CD_TAPS * 64 || g.G % CD_GW || g.M % a.T_out != 0 || a.pad >= a.taps || a.T_out < CD_ROWS ||
-      a.rowmask || a.rowidx || a.bdiv != 1 || (g.flags & ~(F_BIAS | F_RES)) || a.pitch % 8 || g.ldc % 8 || (g.flags & F_RES && g.ldr % 8))
-    return false;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_dec48_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_dec_kernel<CI, CO, GPW>, hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS);
     attr = true;
   }
   const int nclips = g.M / a.T_out;
-  // rows per workgroup: long enough that the 2 x 33 KB of weights a wave loads are a small share of its traffic, short
+  // rows per workgroup: long enough that the weight fragments a wave loads are a small share of its traffic, short
   // enough for a few rounds over the CUs
   int bpw = 16;
-  while (bpw > 4 && (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS) * (g.G / CD_GW) < 512) bpw >>= 1;
-  dim3 grid(nclips * cdiv(a.T_out, bpw * CD_ROWS), g.G / CD_GW, 1);
-  hipLaunchKernelGGL(conv_dec48_kernel, grid, dim3(256), CD_LDS, stream, g, bpw);
-  return true;
+  while (bpw > 4 && (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS) * (g.G / GM::GW) < 512) bpw >>= 1;
+  dim3 grid(nclips * cdiv(a.T_out, bpw * CD_ROWS), g.G / GM::GW, 1);
+  hipLaunchKernelGGL((conv_dec_kernel<CI, CO, GPW>), grid, dim3(256), GM::LDS, stream, g, bpw);
+}
+bool a2v_launch_conv_dec48(const GemmArgs& g, hipStream_t stream) {
+  const ConvA& a = g.a;
+  if (!g_a2v_conv_dec) return false;
+  if (a.Cg != 64 || a.goff != a.Cv || g.c_goff != g.N || a.taps != CD_TAPS || a.stride != 1 || a.T_in != a.T_out ||
+      g.K != CD_TAPS * 64 || g.M % a.T_out != 0 || a.pad >= a.taps || a.T_out < CD_ROWS || a.rowmask || a.rowidx || a.bdiv != 1 ||
+      (g.flags & ~(F_BIAS | F_RES)) || a.pitch % 8 || g.ldc % 8 || ((g.flags & F_RES) && g.ldr % 8))
+    return false;
+  if (g.flags & F_RES) {                       // overlapping blocks write identical bits only if the residual is not the output
+    const char *c0 = (const char*)g.C, *c1 = c0 + ((long long)(g.M - 1) * g.ldc + (long long)g.G * g.c_goff) * 2;
+    const char *r0 = (const char*)g.R, *r1 = r0 + ((long long)(g.M - 1) * g.ldr + (long long)g.G * g.c_goff) * 2;
+    if (r0 < c1 && c0 < r1) return false;
+  }
+  if (a.Cv == 48 && g.N == 48 && g.G % 8 == 0) { conv_dec_go<48, 48, 2>(g, stream); return true; }
+  if (a.Cv == 64 && g.N == 48 && g.G % 4 == 0) { conv_dec_go<64, 48, 1>(g, stream); return true; }
+  if (a.Cv == 48 && g.N == 64 && g.G % 4 == 0) { conv_dec_go<48, 64, 1>(g, stream); return true; }
+  return false;
 }

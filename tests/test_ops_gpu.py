@@ -950,32 +950,34 @@ def test_streams_have_their_own_scratch(ops):
     assert _lib.load().a2v_stream_release(streams[0].cuda_stream) != 0       # already released
 
 
+@pytest.mark.parametrize("CI,CO", [(48, 48), (64, 48)])
 @pytest.mark.parametrize("B,T", [(3, 2000), (2, 1100), (5, 64), (1, 333)])
-def test_conv_decoder_kernel(ops, B, T):
-    """Decoder1d's grouped conv (768 -> 768, k 7, groups 16: 48 channels per group) through the HBM-bound all-groups kernel
-    (a2v_conv_dec.hip): forward with bias, input gradient with the residual add, clip edges, ragged row blocks; against
-    fp32 torch and against the slab / implicit-GEMM kernels (a2v_debug_set(13, 0))."""
+def test_conv_decoder_kernel(ops, B, T, CI, CO):
+    """Decoder1d's grouped convs (k 7, groups 16: 768 -> 768 with 48 channels per group, and the first layer 1024 -> 768)
+    through the HBM-bound all-groups kernel (a2v_conv_dec.hip): forward with bias, input gradient with the residual add
+    (48 -> 48, and 48 -> 64 for the first layer's), clip edges, ragged row blocks; against fp32 torch and against the slab
+    / implicit-GEMM kernels (a2v_debug_set(13, 0))."""
     from animal2vec_amd import _lib
     dtype = torch.bfloat16
-    G, k, Cg, N = 16, 7, 48, 48
-    D = G * Cg
-    x = rnd(B, D, T, dtype=dtype, seed=1)
-    w = rnd(D, Cg, k, dtype=dtype, seed=2, scale=(Cg * k) ** -0.5)
-    bias = rnd(D, dtype=torch.float32, seed=3)
-    dy = rnd(B, D, T, dtype=dtype, seed=4)
-    res = rnd(B, T, D, dtype=dtype, seed=5)
+    G, k = 16, 7
+    Din, Dout = G * CI, G * CO
+    x = rnd(B, Din, T, dtype=dtype, seed=1)
+    w = rnd(Dout, CI, k, dtype=dtype, seed=2, scale=(CI * k) ** -0.5)
+    bias = rnd(Dout, dtype=torch.float32, seed=3)
+    dy = rnd(B, Dout, T, dtype=dtype, seed=4)
+    res = rnd(B, T, Din, dtype=dtype, seed=5)
     xr = x.clone().requires_grad_(True)
     ref = F.conv1d(xr, w, bias, padding=k // 2, groups=G)
     ref.backward(dy)
-    xcl, dycl = to_cl(x, D, dtype), to_cl(dy, D, dtype)
+    xcl, dycl = to_cl(x, Din, dtype), to_cl(dy, Dout, dtype)
     wp = dev(pack_ref(w, G, 64), dtype)
-    wt = torch.empty(G, Cg, k * 64, dtype=dtype, device="cuda")
-    ops.pack_weight(dev(w, torch.float32), wt, G=G, N=N, Cg=Cg, k=k, Np=64, mode=1)
+    wt = torch.empty(G, CI, k * 64, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(w, torch.float32), wt, G=G, N=CO, Cg=CI, k=k, Np=64, mode=1)
     rd = dev(res, dtype)
 
     def run():
-        y = ops.conv1d_cl(xcl, wp, dev(bias, torch.float32), k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, cv=Cg)
-        dx = ops.conv1d_cl(dycl, wt, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D, cv=N, res=rd)
+        y = ops.conv1d_cl(xcl, wp, dev(bias, torch.float32), k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=Dout, cv=CI)
+        dx = ops.conv1d_cl(dycl, wt, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=Din, cv=CO, res=rd)
         return y, dx
 
     y, dx = run()

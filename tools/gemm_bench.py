@@ -110,6 +110,20 @@ def main():
             ms = timeit(lambda: ops.conv1d_cl(x, w, bias, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, out=out), a.reps)
         rows.append((name, B * T, Cg, k * Cg, G, ms, 2.0 * B * T * Cg * k * Cg * G / ms / 1e9))
 
+    def dec(name, B, T, CI, CO, res=False):
+        """decoder grouped conv (k 7, 16 groups, taps padded to 64 in the packed operand)"""
+        if a.only and a.only not in name:
+            return
+        G, k = 16, 7
+        x = rn(B, T, G * CI)
+        w = rn(G, CO, k * 64) * (k * CI) ** -0.5
+        bias = torch.randn(G * CO, device=dev)
+        r = rn(B, T, G * CO) if res else None
+        out = torch.empty(B, T, G * CO, device=dev, dtype=dt)
+        ms = timeit(lambda: ops.conv1d_cl(x, w, None if res else bias, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=G * CO, out=out,
+                                          cv=CI, res=r), a.reps)
+        rows.append((name, B * T, CO, k * CI, G, ms, 2.0 * B * T * CO * k * CI * G / ms / 1e9))
+
     for spec in a.lin:
         M_, N_, K_ = (int(v) for v in spec.split(","))
         lin(f"lin {spec}", M_, N_, K_)
@@ -127,6 +141,10 @@ def main():
     wgrad("wgrad fc1", 13440, 4096, 1024)
     wgrad("wgrad fc2", 13440, 1024, 4096)
     wgrad("wgrad proj", 13440, 1024, 1024)
+    dec("conv dec 48->48 bias", 384, 2000, 48, 48)
+    dec("conv dec 48->48 res", 384, 2000, 48, 48, res=True)
+    dec("conv dec 64->48 bias", 384, 2000, 64, 48)
+    dec("conv dec 48->64 res", 384, 2000, 48, 64, res=True)
     conv("posconv fwd", 96, 2000, 1024, 16, 19)
     conv("posconv wgrad", 96, 2000, 1024, 16, 19, wg=True)
     def attn(name, N, S, H=16, HD=64, drop=None):
