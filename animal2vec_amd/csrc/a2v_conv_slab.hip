@@ -117,6 +117,142 @@ __global__ __launch_bounds__(512) void conv_nt_slab_kernel(GemmArgs g) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Second form (64 outputs per group, bias / residual epilogues): 384-row slabs, TWO workgroups per CU.
+// The 1024-row form holds one 150 KB workgroup per CU, whose slab load (through registers, latency bound), 19 taps of
+// MFMAs and LDS-staged epilogue run strictly one after the other: the matrix pipe idles through the first and the last.
+// With 52 KB slabs two workgroups share a CU and one's load / store phases run under the other's MFMAs.  What makes the
+// small slab possible: no epilogue staging (the staged epilogue needs 17 KB per wave) -- swapped MFMA operands
+// (D = W_frag x X_frag) and a permuted weight-row order give each lane 2 x 8 consecutive output channels of one row, stored
+// straight from the accumulators -- and 48 accumulator registers per wave (3 x 4 tiles) instead of 128.
+#define CS2_BM 384
+#define CS2_SLAB_ROWS (CS2_BM + 24)
+#define CS2_SLAB_BYTES (CS2_SLAB_ROWS * 128)         // 52224
+#define CS2_LDS (CS2_SLAB_BYTES + 2 * CS_B_BYTES)    // 68608: two per CU
+#define CS2_NLD ((CS2_SLAB_ROWS * 8 + 511) / 512)    // 7
+
+__global__ __launch_bounds__(512, 2) void conv_nt_slab2_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sB = smem + CS2_SLAB_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const ConvA& a = g.a;
+  const int grp = blockIdx.y;
+  const int T = a.T_out;
+  const int bpc = (T + CS2_BM - 1) / CS2_BM;
+  const int clip = blockIdx.x / bpc;
+  const int t_base = (blockIdx.x - clip * bpc) * CS2_BM;
+  const int taps = a.taps;
+  const int rows_here = min(CS2_BM, T - t_base);
+  const int rows_needed = rows_here + taps - 1;
+
+  // ---- weight tile of tap 0 by LDS-DMA: LDS row p = 16 j + f holds output channel 32 (j >> 1) + 8 (f >> 2) + 4 (j & 1) + (f & 3)
+  const int lr = lane >> 3;
+  const int bp = wid * 8 + lr;                              // LDS row this lane feeds
+  const int bn = 32 * (bp >> 5) + 8 * ((bp & 15) >> 2) + 4 * ((bp >> 4) & 1) + (bp & 3);
+  const int bsrc_chunk = ((lane & 7) ^ ((bp >> 1) & 7)) & 7;
+  const char* const bsrc = (const char*)g.B + ((long long)grp * g.b_gstride + (long long)bn * g.ldb + bsrc_chunk * 8) * 2;
+  __builtin_amdgcn_global_load_lds((cs_gbl_cvoid_t*)bsrc, (cs_lds_void_t*)(sB + wid * 1024), 16, 0, 0);
+
+  {
+    const bf16* xb = (const bf16*)a.ptr + (long long)(clip / a.bdiv) * a.bstride + (long long)grp * a.goff;
+    const unsigned char* mk = a.rowmask ? a.rowmask + (long long)clip * a.T_in : nullptr;
+    uint4 rg[CS2_NLD];
+#pragma unroll
+    for (int u = 0; u < CS2_NLD; ++u) {
+      const int idx = tid + 512 * u;
+      const int row = idx >> 3, ch = idx & 7;
+      const int rs = t_base - a.pad + row;
+      rg[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (row < rows_needed && ch * 8 < a.Cv && (unsigned)rs < (unsigned)a.T_in && !(mk && mk[rs]))
+        rg[u] = *(const uint4*)(xb + (long long)rs * a.pitch + ch * 8);
+    }
+#pragma unroll
+    for (int u = 0; u < CS2_NLD; ++u) {
+      const int idx = tid + 512 * u;
+      const int row = idx >> 3, ch = idx & 7;
+      if (row < CS2_SLAB_ROWS) *(uint4*)(smem + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = rg[u];
+    }
+  }
+  __syncthreads();                                    // also drains the tap-0 weight DMA (vmcnt(0))
+
+  f32x4 acc[3][4];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fq = lane >> 4;
+  const int b_off = fr * 128 + ((fq ^ ((fr >> 1) & 7)) << 4);       // + j * 2048, ks flips chunk bit 2 (^ 64 B)
+  const int a_row0 = wid * 48 + fr;                                 // + i * 16 + tap
+  for (int tap = 0; tap < taps; ++tap) {
+    const int buf = tap & 1;
+    if (tap + 1 < taps)
+      __builtin_amdgcn_global_load_lds((cs_gbl_cvoid_t*)(bsrc + (tap + 1) * 128),
+                                       (cs_lds_void_t*)(sB + (buf ^ 1) * CS_B_BYTES + wid * 1024), 16, 0, 0);
+    const char* sb_ = sB + buf * CS_B_BYTES;
+    const int ar = a_row0 + tap;
+    const int a_off = ar * 128 + ((fq ^ ((ar >> 1) & 7)) << 4);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 fb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) fb[j] = *(const bf16x8*)(sb_ + (b_off ^ (ks << 6)) + j * 2048);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const bf16x8 fa = *(const bf16x8*)(smem + (a_off ^ (ks << 6)) + i * 2048);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                  // weight tile tap+1 landed (vmcnt(0)), tile `buf` free
+  }
+
+  // ---- epilogue: lane (fq, fr) holds row 48 wid + 16 i + fr, channels 32 p + 8 fq + [0, 8) for p = 0, 1
+  bf16* const C = (bf16*)g.C;
+  const bf16* const R = (const bf16*)g.R;
+  float b8[2][8];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) b8[p][e] = 0.f;
+    if (g.flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + 32 * p + 8 * fq, b8[p]);
+  }
+  Raw8<bf16> h8[3][2];
+  if (g.flags & F_RES) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int rl = wid * 48 + i * 16 + fr;
+      const long long m = (long long)clip * T + t_base + (rl < rows_here ? rl : 0);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) h8[i][p].load(R + m * g.ldr + (long long)grp * g.c_goff + 32 * p + 8 * fq);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int rl = wid * 48 + i * 16 + fr;
+    if (rl < rows_here) {
+      const long long m = (long long)clip * T + t_base + rl;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        float v8[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v8[r] = acc[i][2 * p][r] + b8[p][r];
+          v8[4 + r] = acc[i][2 * p + 1][r] + b8[p][4 + r];
+        }
+        if (g.flags & F_RES) {
+          float hh[8];
+          h8[i][p].unpack(hh);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v8[e] += hh[e];
+        }
+        Vec8<bf16>::store(C + m * g.ldc + (long long)grp * g.c_goff + 32 * p + 8 * fq, v8);
+      }
+    }
+  }
+}
+
+int g_a2v_conv_slab2 = 1;    // a2v_debug_set(14, v): 384-row two-per-CU form of the slab kernel on / off
 bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
   if (a.Cg != 64 || a.stride != 1 || a.T_in != a.T_out || a.taps < 2 || a.taps > 24 || g.N > 64 || g.N % 4 ||
@@ -125,9 +261,16 @@ bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_nt_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_nt_slab2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CS2_LDS);
     attr = true;
   }
   const int nclips = g.M / a.T_out;
+  if (g_a2v_conv_slab2 && g.N == 64 && !(g.flags & ~(F_BIAS | F_RES)) && g.ldc % 8 == 0 && g.c_goff % 8 == 0 &&
+      (!(g.flags & F_RES) || g.ldr % 8 == 0)) {
+    dim3 grid2(nclips * cdiv(a.T_out, CS2_BM), g.G, 1);
+    hipLaunchKernelGGL(conv_nt_slab2_kernel, grid2, dim3(512), CS2_LDS, stream, g);
+    return true;
+  }
   dim3 grid(nclips * cdiv(a.T_out, CS_BM), g.G, 1);
   hipLaunchKernelGGL(conv_nt_slab_kernel, grid, dim3(512), CS_LDS, stream, g);
   return true;

@@ -233,6 +233,7 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   6 wave-group stagger (0 off, 1 by shape, 2 always)          7 tile hand-out (0 static, 1 dynamic after the first tile, 2 all dynamic)
  *   8 long-sequence attention backward (0 tiled kernel + dQ atomics, 1 two-pass, 2 two-pass for every S)
  *   10 persistent NT kernel epilogue (1 direct stores, 0 staged through LDS)     13 decoder grouped-conv kernel on / off
+ *   14 grouped-conv slab kernel form (1: 384-row slabs, two workgroups per CU; 0: 1024-row slabs)
  * No launch state goes through here (ABI 5's key 9, the tile-counter set, is gone: the stream argument selects it). */
 int a2v_debug_set(int key, int value);
 
