@@ -89,18 +89,26 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
                                                              float* __restrict__ rstd_out, int B, int L, int C, int k,
                                                              float eps, int tiles_per_blk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* sF = (float*)smem;                         // [128][SINC_FP]
-  float* sPar = sF + SINC_CP * SINC_FP;             // [4][128]: ln_w, ln_b, ps_a, ps_b
+  float* sPar = (float*)smem;                       // [4][128]: ln_w, ln_b, ps_a, ps_b
   float* sX = sPar + 4 * SINC_CP;                   // [64 + 64] padded signal of the current tile
   T* sOut = (T*)(sX + 128);                         // [4 waves][16][SINC_CP + 8]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int half = k / 2;
 
-  for (int i = tid; i < SINC_CP * SINC_MAXK; i += 256) {
-    const int c = i >> 6, j = i & 63;
-    sF[c * SINC_FP + j] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
-  }
+  // A band-pass row is symmetric (sinc.py:204-218: [left, centre, flip(left)]; a2v_sinc_filters_fwd writes f[j] and
+  // f[k-1-j] from one value), so  sum_j W[c][j] x[t+j] = sum_{j<half} W[c][j] (x[t+j] + x[t+k-1-j]) + W[c][half] x[t+half]:
+  // the contraction runs over half + 1 <= 32 folded taps instead of 64 -- half the fp32 MFMA work, which is what bounds
+  // this kernel (exact fp32 matrix cores run at 1/16 of the bf16 rate) -- and the 8 x 8 folded filter values a lane needs
+  // fit in registers for the block's whole life (the LDS image of the filters cost one ds_read per MFMA).
+  float wa[8][8];
+#pragma unroll
+  for (int jc = 0; jc < 8; ++jc)
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int c = 16 * jc + fr, j = 4 * ks + g;
+      wa[jc][ks] = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+    }
   for (int i = tid; i < SINC_CP; i += 256) {
     const bool ok = i < C;
     sPar[i] = ok ? ln_w[i] : 0.f;
@@ -125,14 +133,15 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
 #pragma unroll
     for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tl = wid * 16 + fr;                     // local time of this lane
-#pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-      const float xb = sX[tl + ks * 4 + g];            // B[k=tap][col=t]
 #pragma unroll
-      for (int jc = 0; jc < 8; ++jc) {
-        const float wa = sF[(16 * jc + fr) * SINC_FP + ks * 4 + g];   // A[row=c][k=tap]
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xb, acc[jc], 0, 0, 0);
-      }
+    for (int ks = 0; ks < 8; ++ks) {
+      const int j = ks * 4 + g;                        // folded tap: B[k = j][col = t] = x[t+j] + x[t+k-1-j] (j < half), x[t+half]
+      const int jm = k - 1 - j;
+      const float xl = sX[tl + (j <= half ? j : half)];
+      const float xr = sX[tl + (jm >= 0 ? jm : 0)];
+      const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
+#pragma unroll
+      for (int jc = 0; jc < 8; ++jc) acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[jc][ks], xb, acc[jc], 0, 0, 0);
     }
     // acc[jc][r] = conv[c = 16jc+4g+r][t = t0+tl]
     float s = 0.f;
@@ -231,11 +240,14 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
   float gw[8], gb[8], ga[8], gbs[8];
 #pragma unroll
   for (int jc = 0; jc < 8; ++jc) { gw[jc] = 0.f; gb[jc] = 0.f; ga[jc] = 0.f; gbs[jc] = 0.f; }
-  f32x4 dW[8][4];                                   // [jc][jt]: rows c = 16jc+4g+r, cols tap = 16jt+fr
+  // symmetric band-pass rows (see the forward): taps are folded, j <-> k-1-j, so both the conv recompute and the filter
+  // gradient run over half + 1 <= 32 folded taps; dfilt[c][j] (j < half) receives d/dW[c][j] + d/dW[c][k-1-j] -- the one
+  // number a2v_sinc_filters_bwd reads (it sums the two mirrored entries) -- and the mirrored entries stay untouched
+  f32x4 dW[8][2];                                   // [jc][jt]: rows c = 16jc+4g+r, cols folded tap = 16jt+fr
 #pragma unroll
   for (int jc = 0; jc < 8; ++jc)
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) dW[jc][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jt = 0; jt < 2; ++jt) dW[jc][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int tiles_per_clip = (L + 63) / 64;
   const long long ntiles = (long long)B * tiles_per_clip;
@@ -266,11 +278,14 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
 #pragma unroll
     for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-    for (int ks = 0; ks < 16; ++ks) {
-      const float xa = sX[wid * 16 + fr + ks * 4 + g];
+    for (int ks = 0; ks < 8; ++ks) {
+      const int j = ks * 4 + g, jm = k - 1 - j;
+      const float xl = sX[wid * 16 + fr + (j <= half ? j : half)];
+      const float xr = sX[wid * 16 + fr + (jm >= 0 ? jm : 0)];
+      const float xa = j < half ? xl + xr : (j == half ? xl : 0.f);
 #pragma unroll
       for (int jc = 0; jc < 8; ++jc) {
-        const float wb = sF[(16 * jc + fr) * SINC_FP + ks * 4 + g];
+        const float wb = sF[(16 * jc + fr) * SINC_FP + j];                 // (columns j > half are multiplied by xa = 0)
         acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[jc], 0, 0, 0);
       }
     }
@@ -322,8 +337,11 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
     for (int r = 0; r < 4; ++r) {
       const int tl = wid * 16 + 4 * g + r;
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
-        const float xb = sX[tl + 16 * jt + fr];          // B[k=t][col=tap]
+      for (int jt = 0; jt < 2; ++jt) {
+        const int j = 16 * jt + fr, jm = k - 1 - j;      // B[k=t][col = folded tap j]
+        const float xl = sX[tl + (j <= half ? j : half)];
+        const float xr = sX[tl + (jm >= 0 ? jm : 0)];
+        const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
 #pragma unroll
         for (int jc = 0; jc < 8; ++jc)
           dW[jc][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[jc][r], xb, dW[jc][jt], 0, 0, 0);
@@ -338,9 +356,9 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
       const int c = 16 * jc + 4 * g + r;
       if (c >= C) continue;
 #pragma unroll
-      for (int jt = 0; jt < 4; ++jt) {
+      for (int jt = 0; jt < 2; ++jt) {
         const int tap = 16 * jt + fr;
-        if (tap < k) atomicAdd(dfilt + (long long)c * k + tap, dW[jc][jt][r]);
+        if (tap <= half) atomicAdd(dfilt + (long long)c * k + tap, dW[jc][jt][r]);
       }
     }
   // per-channel parameter grads: reduce over the 4 lane groups (same fr), then atomics
@@ -722,7 +740,7 @@ extern "C" int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, 
   const int tpb = sinc_tiles_per_block(ntiles);
   const int grid = (int)((ntiles + tpb - 1) / tpb);
   const int esz = dtype == A2V_BF16 ? 2 : 4;
-  const int lds = (SINC_CP * SINC_FP + 4 * SINC_CP + 128) * 4 + 4 * 16 * (SINC_CP + 8) * esz;
+  const int lds = (4 * SINC_CP + 128) * 4 + 4 * 16 * (SINC_CP + 8) * esz;
   if (dtype == A2V_BF16) {
     (void)hipFuncSetAttribute((const void*)sinc_fused_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(sinc_fused_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,

@@ -143,11 +143,15 @@ int a2v_sinc_filters_bwd(const float* low_hz, const float* band_hz, const float*
                          float min_band_hz, float sample_rate, a2v_stream_t stream);
 /* x (B,L) fp32 -> y (B,L,128) channels-last: reflect pad + conv1d + LayerNorm(C) + PSwish in one
  * pass -- SincConv.forward (sinc.py:107-159) + ConvFeatureExtractionModel block 0 tail
- * (nn/utils.py:1105-1117) + PSwish.forward (utils.py:1430-1431). mean/rstd (B,L) saved for backward. */
+ * (nn/utils.py:1105-1117) + PSwish.forward (utils.py:1430-1431). mean/rstd (B,L) saved for backward.
+ * `filt` must be what a2v_sinc_filters_fwd produces: band-pass rows are symmetric (filt[c][j] == filt[c][k-1-j],
+ * sinc.py:204-218) and the single-pass kernels (C <= 128, k <= 63) fold the mirrored taps (half the fp32 MFMA work). */
 int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
                        const float* ps_alpha, const float* ps_beta, void* y, float* mean, float* rstd, int B, int L,
                        int C, int k, float eps, a2v_stream_t stream);
-/* dfilt (C,k) and dpar (4, pitch: d ln_w, d ln_b, d ps_alpha, d ps_beta) are accumulated: zero first.  pitch =
+/* dfilt (C,k) and dpar (4, pitch: d ln_w, d ln_b, d ps_alpha, d ps_beta) are accumulated: zero first.  dfilt is the
+ * gradient with respect to the SYMMETRIC filter: what is defined is dfilt[c][j] + dfilt[c][k-1-j] for j < k/2 (and the centre
+ * tap) -- exactly what a2v_sinc_filters_bwd consumes; the single-pass kernels put the whole sum into entry j.  pitch =
  * a2v_sinc_out_channels(C, k); when it is 320 (blocked kernels) `scratch` must hold B*L*320 floats (the conv-output
  * gradient, formed once and then reduced into dfilt by a second kernel); it may be NULL for the 128-pitch specs. */
 int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, const float* ln_w, const float* ln_b,
