@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
                                                              float eps, int tiles_per_blk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sPar = (float*)smem;                       // [4][128]: ln_w, ln_b, ps_a, ps_b
-  float* sX = sPar + 4 * SINC_CP;                   // [64 + 64] padded signal of the current tile
-  T* sOut = (T*)(sX + 128);                         // [4 waves][16][SINC_CP + 8]
+  float* sX = sPar + 4 * SINC_CP;                   // 2 x [64 + 64] padded signal of the current / next tile
+  T* sOut = (T*)(sX + 256);                         // [4 waves][16][SINC_CP + 8]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int half = k / 2;
@@ -120,14 +120,25 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
   const long long ntiles = (long long)B * tiles_per_clip;
   T* myOut = sOut + wid * 16 * (SINC_CP + 8);
 
+  // the padded signal of tile it + 1 is requested before tile it is multiplied and lands in the other half of sX after it:
+  // one barrier per tile and no exposed global round trip (was: load -> barrier -> compute, twice a barrier per tile)
+  auto xsrc = [&](long long tile_) {
+    const int b_ = (int)(tile_ / tiles_per_clip);
+    const int t0_ = (int)(tile_ - (long long)b_ * tiles_per_clip) * 64;
+    return x[(long long)b_ * L + reflect_idx(t0_ - half + (tid & 127), L)];
+  };
+  const long long tile_first = (long long)blockIdx.x * tiles_per_blk;
+  if (tile_first < ntiles && tid < 128) sX[tid] = xsrc(tile_first);
+  __syncthreads();
   for (int it = 0; it < tiles_per_blk; ++it) {
-    const long long tile = (long long)blockIdx.x * tiles_per_blk + it;
+    const long long tile = tile_first + it;
     if (tile >= ntiles) break;
     const int b = (int)(tile / tiles_per_clip);
     const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
-    __syncthreads();
-    if (tid < 128) sX[tid] = x[(long long)b * L + reflect_idx(t0 - half + tid, L)];
-    __syncthreads();
+    const float* sXc = sX + (it & 1) * 128;
+    const bool more = it + 1 < tiles_per_blk && tile + 1 < ntiles;
+    float xnext = 0.f;
+    if (more && tid < 128) xnext = xsrc(tile + 1);
 
     f32x4 acc[8];
 #pragma unroll
@@ -137,8 +148,8 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
     for (int ks = 0; ks < 8; ++ks) {
       const int j = ks * 4 + g;                        // folded tap: B[k = j][col = t] = x[t+j] + x[t+k-1-j] (j < half), x[t+half]
       const int jm = k - 1 - j;
-      const float xl = sX[tl + (j <= half ? j : half)];
-      const float xr = sX[tl + (jm >= 0 ? jm : 0)];
+      const float xl = sXc[tl + (j <= half ? j : half)];
+      const float xr = sXc[tl + (jm >= 0 ? jm : 0)];
       const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
 #pragma unroll
       for (int jc = 0; jc < 8; ++jc) acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[jc][ks], xb, acc[jc], 0, 0, 0);
@@ -198,6 +209,8 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
         Vec8<T>::store(y + ((long long)b * L + tt) * SINC_CP + cc, v);
       }
     }
+    if (more && tid < 128) sX[((it + 1) & 1) * 128 + tid] = xnext;
+    __syncthreads();
   }
 }
 
@@ -216,10 +229,10 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
                                                              int tiles_per_blk) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* sF = (float*)smem;                         // [128][SINC_FP]
-  float* sX = sF + SINC_CP * SINC_FP;               // [128]
-  float* sMean = sX + 128;                          // [64]
-  float* sRstd = sMean + 64;                        // [64]
-  T* sDy = (T*)(sRstd + 64);                        // [64][SINC_CP + 8]
+  float* sX = sF + SINC_CP * SINC_FP;               // 2 x [128]
+  float* sMean = sX + 256;                          // 2 x [64]
+  float* sRstd = sMean + 128;                       // 2 x [64]
+  T* sDy = (T*)(sRstd + 128);                       // 2 x [64][SINC_CP + 8]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
   const int half = k / 2;
@@ -253,25 +266,56 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
   const long long ntiles = (long long)B * tiles_per_clip;
   const float invC = 1.f / (float)C;
 
+  // Staging of tile it + 1 (signal, LayerNorm statistics, the 64 x 128 dy tile) is requested before tile it is worked on
+  // and written to the other LDS buffers after it: one barrier per tile, no exposed global round trip (this kernel runs one
+  // workgroup per CU, so nothing else hides it).
+  constexpr int DYCH = 64 * (SINC_CP / 8) / 256;      // dy chunks (8 elements) per thread: 4
+  struct Stage { float xv, mv, rv; Raw8<T> dyv[DYCH]; };
+  auto stage_fetch = [&](long long tile_, Stage& st) {
+    const int b_ = (int)(tile_ / tiles_per_clip);
+    const int t0_ = (int)(tile_ - (long long)b_ * tiles_per_clip) * 64;
+    st.xv = tid < 128 ? x[(long long)b_ * L + reflect_idx(t0_ - half + tid, L)] : 0.f;
+    st.mv = 0.f; st.rv = 0.f;
+    if (tid < 64 && t0_ + tid < L) { st.mv = mean_in[(long long)b_ * L + t0_ + tid]; st.rv = rstd_in[(long long)b_ * L + t0_ + tid]; }
+#pragma unroll
+    for (int u = 0; u < DYCH; ++u) {
+      const int i = tid + 256 * u;
+      const int r = i / (SINC_CP / 8), cc = (i % (SINC_CP / 8)) * 8;
+      const int tt = t0_ + r < L ? t0_ + r : L - 1;                       // (rows past L are zeroed by the t0 + tl >= L test below)
+      st.dyv[u].load(dy + ((long long)b_ * L + tt) * SINC_CP + cc);
+    }
+  };
+  auto stage_store = [&](int buf, const Stage& st) {
+    if (tid < 128) sX[buf * 128 + tid] = st.xv;
+    if (tid < 64) { sMean[buf * 64 + tid] = st.mv; sRstd[buf * 64 + tid] = st.rv; }
+#pragma unroll
+    for (int u = 0; u < DYCH; ++u) {
+      const int i = tid + 256 * u;
+      const int r = i / (SINC_CP / 8), cc = (i % (SINC_CP / 8)) * 8;
+      float v[8];
+      st.dyv[u].unpack(v);
+      Vec8<T>::store(sDy + (size_t)buf * 64 * (SINC_CP + 8) + r * (SINC_CP + 8) + cc, v);
+    }
+  };
+  const long long tile_first = (long long)blockIdx.x * tiles_per_blk;
+  {
+    Stage st0;
+    if (tile_first < ntiles) { stage_fetch(tile_first, st0); stage_store(0, st0); }
+  }
+  __syncthreads();
   for (int it = 0; it < tiles_per_blk; ++it) {
-    const long long tile = (long long)blockIdx.x * tiles_per_blk + it;
+    const long long tile = tile_first + it;
     if (tile >= ntiles) break;
     const int b = (int)(tile / tiles_per_clip);
     const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
-    __syncthreads();
-    if (tid < 128) sX[tid] = x[(long long)b * L + reflect_idx(t0 - half + tid, L)];
-    if (tid < 64) {
-      const int t = t0 + tid;
-      sMean[tid] = t < L ? mean_in[(long long)b * L + t] : 0.f;
-      sRstd[tid] = t < L ? rstd_in[(long long)b * L + t] : 0.f;
-    }
-    for (int i = tid; i < 64 * (SINC_CP / 8); i += 256) {
-      const int r = i / (SINC_CP / 8), cc = (i % (SINC_CP / 8)) * 8;
-      float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (t0 + r < L) Vec8<T>::load(dy + ((long long)b * L + t0 + r) * SINC_CP + cc, v);
-      Vec8<T>::store(sDy + r * (SINC_CP + 8) + cc, v);
-    }
-    __syncthreads();
+    const int cb_ = it & 1;
+    const bool more = it + 1 < tiles_per_blk && tile + 1 < ntiles;
+    Stage stn;
+    if (more) stage_fetch(tile + 1, stn);
+    const float* const sXc = sX + cb_ * 128;
+    const float* const sMc = sMean + cb_ * 64;
+    const float* const sRc = sRstd + cb_ * 64;
+    const T* const sDc = sDy + (size_t)cb_ * 64 * (SINC_CP + 8);
 
     // conv recompute: D[row t = 4g+r][col c = fr+16jc]; A = X[t=fr][tap], B = filt[c][tap]
     f32x4 acc[8];
@@ -280,8 +324,8 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
 #pragma unroll 4
     for (int ks = 0; ks < 8; ++ks) {
       const int j = ks * 4 + g, jm = k - 1 - j;
-      const float xl = sX[wid * 16 + fr + (j <= half ? j : half)];
-      const float xr = sX[wid * 16 + fr + (jm >= 0 ? jm : 0)];
+      const float xl = sXc[wid * 16 + fr + (j <= half ? j : half)];
+      const float xr = sXc[wid * 16 + fr + (jm >= 0 ? jm : 0)];
       const float xa = j < half ? xl + xr : (j == half ? xl : 0.f);
 #pragma unroll
       for (int jc = 0; jc < 8; ++jc) {
@@ -298,10 +342,10 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tl = wid * 16 + 4 * g + r;
-        const float h = (acc[jc][r] - sMean[tl]) * sRstd[tl];
+        const float h = (acc[jc][r] - sMc[tl]) * sRc[tl];
         const float yl = h * pw[jc] + pb_[jc];
         const float sg = 1.f / (1.f + __expf(-pbs[jc] * yl));
-        float dz = cok ? Cvt<T>::to(sDy[tl * (SINC_CP + 8) + fr + 16 * jc]) : 0.f;
+        float dz = cok ? Cvt<T>::to(sDc[tl * (SINC_CP + 8) + fr + 16 * jc]) : 0.f;
         if (t0 + tl >= L) dz = 0.f;
         ga[jc] += dz * yl * sg;
         gbs[jc] += dz * yl * pa[jc] * sg * (1.f - sg) * yl;
@@ -328,7 +372,7 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int tl = wid * 16 + 4 * g + r;
-        const float v = sRstd[tl] * (dh[jc][r] - s1[r] - hh[jc][r] * s2[r]);
+        const float v = sRc[tl] * (dh[jc][r] - s1[r] - hh[jc][r] * s2[r]);
         dh[jc][r] = (cok && t0 + tl < L) ? v : 0.f;
       }
     }
@@ -339,14 +383,16 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         const int j = 16 * jt + fr, jm = k - 1 - j;      // B[k=t][col = folded tap j]
-        const float xl = sX[tl + (j <= half ? j : half)];
-        const float xr = sX[tl + (jm >= 0 ? jm : 0)];
+        const float xl = sXc[tl + (j <= half ? j : half)];
+        const float xr = sXc[tl + (jm >= 0 ? jm : 0)];
         const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
 #pragma unroll
         for (int jc = 0; jc < 8; ++jc)
           dW[jc][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[jc][r], xb, dW[jc][jt], 0, 0, 0);
       }
     }
+    if (more) stage_store(cb_ ^ 1, stn);
+    __syncthreads();
   }
   // flush: filter gradient rows c = 16jc+4g+r, cols tap = 16jt+fr
 #pragma unroll
@@ -740,7 +786,7 @@ extern "C" int a2v_sinc_fused_fwd(int dtype, const float* x, const float* filt, 
   const int tpb = sinc_tiles_per_block(ntiles);
   const int grid = (int)((ntiles + tpb - 1) / tpb);
   const int esz = dtype == A2V_BF16 ? 2 : 4;
-  const int lds = (4 * SINC_CP + 128) * 4 + 4 * 16 * (SINC_CP + 8) * esz;
+  const int lds = (4 * SINC_CP + 256) * 4 + 4 * 16 * (SINC_CP + 8) * esz;
   if (dtype == A2V_BF16) {
     (void)hipFuncSetAttribute((const void*)sinc_fused_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(sinc_fused_fwd_kernel<bf16>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
@@ -791,7 +837,7 @@ extern "C" int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, 
   if (tpb < 1) tpb = 1;
   const int grid = (int)((ntiles + tpb - 1) / tpb);
   const int esz = dtype == A2V_BF16 ? 2 : 4;
-  const int lds = (SINC_CP * SINC_FP + 128 + 128) * 4 + 64 * (SINC_CP + 8) * esz;
+  const int lds = (SINC_CP * SINC_FP + 256 + 256) * 4 + 2 * 64 * (SINC_CP + 8) * esz;
   if (dtype == A2V_BF16) {
     (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(sinc_fused_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
