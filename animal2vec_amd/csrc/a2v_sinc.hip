@@ -8,6 +8,7 @@
 //                              matrix cores; per-channel parameter gradients ride in registers.
 // The convolution runs on v_mfma_f32_16x16x4_f32 (exact fp32, like the reference's .float() conv).
 #include "a2v_common.h"
+#include <type_traits>
 
 #define SINC_FP 66          // LDS pitch (floats) of one filter row: conflict-free A/B reads
 #define SINC_MAXK 64        // taps padded to 64 (k <= 63)
@@ -101,14 +102,35 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
   // the contraction runs over half + 1 <= 32 folded taps instead of 64 -- half the fp32 MFMA work, which is what bounds
   // this kernel (exact fp32 matrix cores run at 1/16 of the bf16 rate) -- and the 8 x 8 folded filter values a lane needs
   // fit in registers for the block's whole life (the LDS image of the filters cost one ds_read per MFMA).
-  float wa[8][8];
+  // bf16 output mode: the (folded, K = 32) contraction runs on the bf16 matrix cores in split precision -- x = xh + xl,
+  // w = wh + wl with bf16 halves (16 mantissa bits each way), acc += wl xh + wh xl + wh xh in fp32: products exact to
+  // 2^-17, i.e. ~1e-5 on the conv output against 4e-3 of the bf16 store, at 3 x 16 cycles per 16 x 16 x 32 tile instead of
+  // 8 x 32 for the exact fp32 MFMA (which the fp32 parity mode keeps).
+  constexpr bool SPLIT = std::is_same<T, bf16>::value;
+  float wa[SPLIT ? 1 : 8][8];
+  bf16x8 wah[SPLIT ? 8 : 1], wal[SPLIT ? 8 : 1];
+  if constexpr (SPLIT) {
 #pragma unroll
-  for (int jc = 0; jc < 8; ++jc)
+    for (int jc = 0; jc < 8; ++jc) {
+      const int c = 16 * jc + fr;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int c = 16 * jc + fr, j = 4 * ks + g;
-      wa[jc][ks] = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const int j = 8 * g + e;
+        const float w = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+        const bf16 h = (bf16)w;
+        wah[jc][e] = h;
+        wal[jc][e] = (bf16)(w - (float)h);
+      }
     }
+  } else {
+#pragma unroll
+    for (int jc = 0; jc < 8; ++jc)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int c = 16 * jc + fr, j = 4 * ks + g;
+        wa[jc][ks] = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+      }
+  }
   for (int i = tid; i < SINC_CP; i += 256) {
     const bool ok = i < C;
     sPar[i] = ok ? ln_w[i] : 0.f;
@@ -144,15 +166,35 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
 #pragma unroll
     for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tl = wid * 16 + fr;                     // local time of this lane
+    if constexpr (SPLIT) {
+      bf16x8 xh, xl;                                   // B[k = 8g + e][col = t]: folded taps, split
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-      const int j = ks * 4 + g;                        // folded tap: B[k = j][col = t] = x[t+j] + x[t+k-1-j] (j < half), x[t+half]
-      const int jm = k - 1 - j;
-      const float xl = sXc[tl + (j <= half ? j : half)];
-      const float xr = sXc[tl + (jm >= 0 ? jm : 0)];
-      const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
+      for (int e = 0; e < 8; ++e) {
+        const int j = 8 * g + e, jm = k - 1 - j;
+        const float a_ = sXc[tl + (j <= half ? j : half)];
+        const float b_ = sXc[tl + (jm >= 0 ? jm : 0)];
+        const float xf = j < half ? a_ + b_ : (j == half ? a_ : 0.f);
+        const bf16 h = (bf16)xf;
+        xh[e] = h;
+        xl[e] = (bf16)(xf - (float)h);
+      }
 #pragma unroll
-      for (int jc = 0; jc < 8; ++jc) acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[jc][ks], xb, acc[jc], 0, 0, 0);
+      for (int jc = 0; jc < 8; ++jc) {
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wal[jc], xh, acc[jc], 0, 0, 0);
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wah[jc], xl, acc[jc], 0, 0, 0);
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wah[jc], xh, acc[jc], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int j = ks * 4 + g;                        // folded tap: B[k = j][col = t] = x[t+j] + x[t+k-1-j] (j < half), x[t+half]
+        const int jm = k - 1 - j;
+        const float xl = sXc[tl + (j <= half ? j : half)];
+        const float xr = sXc[tl + (jm >= 0 ? jm : 0)];
+        const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
+#pragma unroll
+        for (int jc = 0; jc < 8; ++jc) acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[jc][ks], xb, acc[jc], 0, 0, 0);
+      }
     }
     // acc[jc][r] = conv[c = 16jc+4g+r][t = t0+tl]
     float s = 0.f;
@@ -188,7 +230,7 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float yl = (acc[jc][r] - mean) * rstd * w[r] + bb[r];
-        const float sg = 1.f / (1.f + __expf(-pb[r] * yl));
+        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-pb[r] * yl));   // v_rcp_f32 (1 ulp), not the 10-instruction IEEE division
         o[r] = (c0 + r < C) ? yl * pa[r] * sg : 0.f;                    // utils.py:1431
       }
       Vec4<T>::store(myOut + fr * (SINC_CP + 8) + c0, o);
@@ -344,7 +386,7 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
         const int tl = wid * 16 + 4 * g + r;
         const float h = (acc[jc][r] - sMc[tl]) * sRc[tl];
         const float yl = h * pw[jc] + pb_[jc];
-        const float sg = 1.f / (1.f + __expf(-pbs[jc] * yl));
+        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-pbs[jc] * yl));
         float dz = cok ? Cvt<T>::to(sDc[tl * (SINC_CP + 8) + fr + 16 * jc]) : 0.f;
         if (t0 + tl >= L) dz = 0.f;
         ga[jc] += dz * yl * sg;
