@@ -474,7 +474,7 @@ def main():
                           ("sinc_fused_fwd", "sinc_fused_fwd_kernel"), ("sinc_fused_bwd", "sinc_fused_bwd_kernel")):
             if name in hbm:      # the same kernels' fabric bytes / duration from the PMC passes (not an algorithmic count)
                 hbm[name]["pmc_bytes_per_launch"], hbm[name]["pmc_GBps"], _ = pmc_traffic(sub)
-        roof = dict(bound="mfma", kernel="gemm_nt_bf16_p8_kernel<*> + conv_nt_slab_kernel (a2v_conv_gemm)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
+        roof = dict(bound="mfma", kernel="a2v_conv_gemm family: gemm_nt_bf16_p8_kernel<*> (Linears) + conv_nt_slab2_kernel / conv_dec_kernel (grouped convs) + gemm_nt_bf16_glds_kernel (front end)" if dtype == torch.bfloat16 else "gemm_nt_f32_kernel",
                     achieved=round(nt["tflops"], 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                     frac=round(nt["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic, traffic_unit="bytes/launch (HBM+MALL, PMC)",
                     traffic_source=traffic_src, algorithmic_bytes_per_launch=round(nt["alg_bytes"]),
@@ -482,7 +482,7 @@ def main():
                     wgrad_kernel=dict(tflops=round(s["tn"]["tflops"], 2), launches=s["tn"]["launches"],
                                       avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None,
                     # rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES share of the kernels' cycles (profiles/r02_mfma_util.json)
-                    mfma_busy_share={"gemm_nt_bf16_p8_kernel": pmc_mfma("gemm_nt_bf16_p8_kernel"), "conv_nt_slab_kernel": pmc_mfma("conv_nt_slab_kernel"),
+                    mfma_busy_share={"gemm_nt_bf16_p8_kernel": pmc_mfma("gemm_nt_bf16_p8_kernel"), "conv_nt_slab2_kernel": pmc_mfma("conv_nt_slab"), "conv_dec_kernel": pmc_mfma("conv_dec_kernel"),
                                      "gemm_tn_bf16_p8_kernel": pmc_mfma("gemm_tn_bf16_p8_kernel"), "attn_fwd_bf16_kernel": pmc_mfma("attn_fwd_bf16_kernel"),
                                      "source": PMC_MFMA} if dtype == torch.bfloat16 else None,
                     # the HBM-bound families of the same micro-batch (algorithmic bytes / HIP-event time, peak 8 TB/s)

@@ -1,5 +1,5 @@
-"""CPU: the committed default bench line (profiles/r01_bench_default.json, written by `python bench.py` on the GPU box)
-carries every field of the driver's contract, with consistent values."""
+"""CPU: the committed default bench line (profiles/r02_bench_default.json, written by `python bench.py` on the GPU box)
+carries every field of the driver's contract, with consistent values; bench.py spawns its own ranks."""
 import json
 import os
 
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_default_bench_line_contract():
-    with open(os.path.join(ROOT, "profiles", "r01_bench_default.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as f:
         j = json.load(f)
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)
@@ -26,10 +26,14 @@ def test_default_bench_line_contract():
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["traffic"] is None or r["traffic"] > 0
+    assert r["mfma_busy_share"]["gemm_nt_bf16_p8_kernel"] > 0.3 and "masks" in j["config"]
+    for fam in ("layernorm_fwd", "layernorm_bwd", "sinc_fused_fwd", "sinc_fused_bwd"):
+        assert r["hbm_kernels"][fam]["achieved_GBps"] > 0 and "pmc_GBps" in r["hbm_kernels"][fam]
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and len(c["legs"]) >= 1
+    assert "median" in c["sample"] and "warm-up" in c["sample"]
     assert j["value"] / c["value"] > 10          # the north-star's >= 10x the host-CPU path on one GPU
 
 
