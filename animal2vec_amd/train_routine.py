@@ -128,11 +128,18 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
         tr.engine.refresh_student_packs()
         tr.engine.refresh_teacher_packs()
         tr.num_updates = int(state.get("optimizer_history", [{}])[-1].get("num_updates", 0))
-        if isinstance(state.get("last_optimizer_state"), dict) and "adam_m" in state["last_optimizer_state"]:
-            tr.load_optimizer_state(state["last_optimizer_state"])          # exact resume (moments, counters, RNG)
     rng = __import__("numpy").random.default_rng(cfg.seed + rank)
+    u0 = 0
+    if restore_file:
+        los = state.get("last_optimizer_state")
+        if isinstance(los, dict) and "adam_m" in los:
+            tr.load_optimizer_state(los)                                     # exact resume: moments, counters, mixup / noise RNG
+            ex = los.get("extra") or {}
+            if "mask_rng" in ex:                                             # ... the span-mask stream and the loop position
+                rng.bit_generator.state = ex["mask_rng"]
+            u0 = int(ex.get("update_cursor", 0))
     real = None
-    for u in range(updates):
+    for u in range(u0, u0 + updates):
         mbs = []
         for j in range(update_freq):
             if data is not None:
@@ -161,8 +168,10 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
             log({"num_updates": tr.num_updates, "wall_s": round(time.perf_counter() - t0, 3), **{k: round(v, 5) for k, v in met.items()}})
     if save_path and rank == 0:
         from . import checkpoint as ck
+        # (synthetic batches are a function of the update index; a manifest epoch restarts at its first batch on resume)
         ck.save_checkpoint(save_path, tr.store, cfg={"model": {"_name": "data2vec_multi"}}, num_updates=tr.num_updates,
-                           optimizer_state=tr.optimizer_state())
+                           optimizer_state=tr.optimizer_state(extra={"mask_rng": rng.bit_generator.state,
+                                                                     "update_cursor": u0 + updates}))
     return tr
 
 

@@ -61,6 +61,10 @@ class PretrainTrainer:
         # stream to drain (ROCm stages such copies synchronously) and leave the GPU idle while it catches up again
         self._perm_gen = torch.Generator(device=self.store.device)
         self._perm_gen.manual_seed(seed * 7919 + 17 + self.rank)
+        # mask-token noise (base.py:172-176) from a trainer-owned generator, so that a resumed run draws what the
+        # uninterrupted one would have (the default CUDA generator is shared with everything else in the process)
+        self._noise_gen = torch.Generator(device=self.store.device)
+        self._noise_gen.manual_seed(seed * 7919 + 31 + self.rank)
         self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
         self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device
@@ -106,7 +110,7 @@ class PretrainTrainer:
                 N, K = mb["ids_keep"].shape
                 T = mb["ids_restore"].shape[1]
                 noise = torch.empty(N, T - K, self.cfg.embed_dim, dtype=torch.float32, device=st.device).normal_(
-                    0, self.cfg.audio.mask_noise_std)
+                    0, self.cfg.audio.mask_noise_std, generator=self._noise_gen)
             dseed = ((self.num_updates * 131 + j) * 257 + self.rank + 1) if self.dropout else None
             src = mb["source"]
             if self.mixup is not None:        # BC-learning mixup, train only (data2vec2.py:536-598)
@@ -149,13 +153,20 @@ class PretrainTrainer:
         self.last = dict(stats=eng.stats, gnorm=gnorm)
 
     # ------------------------------------------------------------------ exact resume
-    def optimizer_state(self) -> dict:
-        """What fairseq keeps under "last_optimizer_state" (Adam moments, step count) plus this trainer's own counters;
-        written by checkpoint.save_checkpoint(optimizer_state=...)."""
+    def optimizer_state(self, extra: Optional[dict] = None) -> dict:
+        """What fairseq keeps under "last_optimizer_state" (Adam moments, step count) plus this trainer's own counters and
+        every random stream a step draws from (mixup strength / permutation, mask-token noise); `extra` carries what the
+        caller owns (mask RNG state, data cursor: train_routine.py).  Layout note: this is NOT fairseq's
+        {"state": {param id: {exp_avg, exp_avg_sq, step}}, "param_groups"} dict -- the moments are the two flat fp32
+        buffers in the flat parameter order -- so the reference can load the MODEL from these files but must start its
+        optimizer afresh (`--reset-optimizer`)."""
         st = self.store
-        return {"adam_m": st.adam_m.detach().cpu(), "adam_v": st.adam_v.detach().cpu(), "num_updates": self.num_updates,
-                "ema_decay": self.ema_decay, "perm_rng": self._perm_gen.get_state().cpu(),
-                "np_rng": self._np_rng.bit_generator.state}
+        out = {"adam_m": st.adam_m.detach().cpu(), "adam_v": st.adam_v.detach().cpu(), "num_updates": self.num_updates,
+               "ema_decay": self.ema_decay, "perm_rng": self._perm_gen.get_state().cpu(),
+               "noise_rng": self._noise_gen.get_state().cpu(), "np_rng": self._np_rng.bit_generator.state}
+        if extra:
+            out["extra"] = dict(extra)
+        return out
 
     def load_optimizer_state(self, state: dict) -> None:
         st = self.store
@@ -165,6 +176,8 @@ class PretrainTrainer:
         self.ema_decay = float(state.get("ema_decay", self.ema_decay))
         if "perm_rng" in state:
             self._perm_gen.set_state(state["perm_rng"].cpu())
+        if "noise_rng" in state:
+            self._noise_gen.set_state(state["noise_rng"].cpu())
         if "np_rng" in state:
             self._np_rng.bit_generator.state = state["np_rng"]
 

@@ -908,3 +908,24 @@ def test_base_star_extract_features_4x10s(dtype, tol):
     assert rel_err(res["x"].float(), x_ref) < tol
     worst = max(rel_err(a.float(), b) for a, b in zip(res["layer_results"], lrs_ref))
     assert worst < tol, worst
+
+
+def test_training_routine_resumes_exactly_with_drawn_noise_and_masks(tmp_path):
+    """animal2vec_audio_main stopped after two updates and resumed for two more equals four updates in one go, with the
+    mask-token noise (noise=None: drawn from the trainer's generator), the span masks and the synthetic-batch cursor all
+    coming out of the checkpoint (the default CUDA generator / mask rng were not saved)."""
+    import nn
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.trainer import OptimConfig
+    cfg = tiny_config()
+    oc = OptimConfig(lr=1e-3, warmup_updates=2, max_update=20)
+    kw = dict(clip_samples=3200, clips_per_micro_batch=2, update_freq=2, dtype=torch.float32, log=lambda *_: None)
+    a = nn.animal2vec_audio_main(cfg, oc, updates=4, **kw)
+    path = str(tmp_path / "ck.pt")
+    nn.animal2vec_audio_main(cfg, oc, updates=2, save_path=path, **kw)
+    torch.manual_seed(12345)                       # whatever happened to the global generators in between must not matter
+    c = nn.animal2vec_audio_main(cfg, oc, updates=2, restore_file=path, **kw)
+    torch.cuda.synchronize()
+    assert c.num_updates == 4 == a.num_updates
+    assert float((a.store.flat - c.store.flat).abs().max()) < 5e-6
+    assert float((a.store.teacher - c.store.teacher).abs().max()) < 5e-6
