@@ -239,10 +239,27 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {   // no cano
   return d;
 }
 
+__device__ __forceinline__ float max2f(float a, float b) {
+  float d;
+  asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// max over the lanes l, l^16, l^32, l^48 (the four 16-lane rows that hold one query's keys) on the VALU:
+// v_permlane32_swap / v_permlane16_swap exchange half-waves / odd-even rows between two registers, no LDS round trip
+// (ds_bpermute: two dependent ~100-cycle LDS trips per query block and tile, in front of the whole softmax)
+__device__ __forceinline__ float rows_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float w = max2f(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  const unsigned x = __float_as_uint(w);
+  auto t = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return max2f(__uint_as_float(t[0]), __uint_as_float(t[1]));
+}
+
 // QB = 16-row query blocks per wave (workgroup = 64*QB query rows): with QB = 2 every K / V fragment read from
 // LDS feeds two MFMAs -- the QB = 1 kernel was LDS-bandwidth bound (16 KB of fragment reads per 16 MFMAs).
 template <int HD, bool DROP, int QB>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16_kernel(AttnArgs a) {
   typedef bf16 T;
   constexpr int ND = HD / 16;
   constexpr int NCH = HD / 8;                 // 16-B chunks per row
@@ -280,44 +297,97 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
     for (int i = 0; i < ND; ++i) o[b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  uint4 kreg[CPT], vreg[CPT];
-  float preg = 0.f;
-  const int ntile = (S + 63) / 64;
+  bf16x8 kreg[CPT], vreg[CPT];   // native vectors: an array of HIP uint4 structs that is not zero-initialised stays an alloca (scratch)
+  const int ntile = (S + 63) / 64, nfull = S / 64;
+
+  // ---- ALiBi without per-score arithmetic (positions = arange, the teacher).  For a key tile wholly BEFORE the workgroup's
+  // query rows |q - k| = q - k, wholly AFTER it k - q, so the bias splits into a per-row constant, which softmax does not see,
+  // and a per-key term that enters the QK MFMA as its C operand straight from LDS:
+  //   before:  t = acc + c(q - k) = [acc - c(k - qref)] + R      R = c (q - qref), c = c_rel (< 0), qref = q0
+  //   after :  t = acc + c(k - q) = [acc + c(k - qref)] - R
+  // Only the QB tiles that overlap the query rows take the |.| form (in true units t).  m_run lives in the units of the
+  // current phase and is shifted by R at the two phase changes (l and O are relative to it and do not move).  The producer of
+  // tile kt+1 writes what that tile's phase consumes into sPos: mul * pos + add.  Explicit positions (a.pos, the student's kept
+  // frames) are not assumed sorted: every tile is a |.| tile.
+  const bool sorted = a.pos == nullptr;
+  const int kd0 = sorted ? min(q0 / 64, ntile) : 0;             // tiles [kd0, kd1) overlap the query rows
+  const int kd1 = sorted ? min(q0 / 64 + QB, ntile) : ntile;
+  const float qref = (float)q0;
+  float pmul = 1.f, padd = 0.f;                                 // uniform: sPos = pmul * pos + padd for the tile being fetched
+  auto pos_form = [&](int kt_) {
+    if (kt_ < kd0) { pmul = -c_rel; padd = c_rel * qref; }
+    else if (kt_ < kd1) { pmul = 1.f; padd = 0.f; }
+    else { pmul = c_rel; padd = -c_rel * qref; }
+  };
+
+  // loop-invariant per-thread offsets of the tile copy (global elements, LDS bytes)
+  unsigned goff[CPT];
+  int kst[CPT], vst[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int c = tid + 256 * u;
+    const int r = c / NCH, ch = c % NCH;
+    goff[u] = (unsigned)(r * (int)rowstride + ch * 8);
+    kst[u] = rowimg_off<HD>(r, ch);
+    vst[u] = trimg_off<HD>(r, ch * 8);
+  }
+  // The fetch of tile kt+1 is ONLY loads into registers nothing else writes: no zero-initialised destination, no guard and no
+  // conversion of the loaded position -- each of those made hipcc put an s_waitcnt vmcnt(0) right behind the loads (a VALU write
+  // to a register a load of the previous trip may still target; a use of the loaded position), which parked every wave for the
+  // full global latency once per tile (SQ_WAIT_ANY 50 % of the wave cycles).  Rows past S re-read row S-1 (finite data); their
+  // scores are masked to -inf in the TAIL tile, so their V rows meet p = 0.
+  int praw = 0;
 #define AF_LOAD(kt_)                                                                              \
   {                                                                                               \
     const int kv0_ = (kt_) * 64;                                                                  \
     const T* tbase = qkv + (long long)kv0_ * rowstride;                                           \
-    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                             \
-      const int c = tid + 256 * u;                                                                \
-      const int r = c / NCH, ch = c % NCH;                                                        \
-      kreg[u] = make_uint4(0u, 0u, 0u, 0u);                                                       \
-      vreg[u] = kreg[u];                                                                          \
-      if (kv0_ + r < S) {                                                                         \
-        const T* base = tbase + (unsigned)(r * (int)rowstride + ch * 8);                          \
-        kreg[u] = *(const uint4*)(base + H * HD);                                                 \
-        vreg[u] = *(const uint4*)(base + 2 * H * HD);                                             \
+    unsigned go_[CPT];                                                                            \
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) go_[u] = goff[u];                             \
+    if ((kt_) >= nfull) {                            /* uniform, rare: ragged last tile */        \
+      _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                           \
+        const int c = tid + 256 * u;                                                              \
+        go_[u] = (unsigned)(min(c / NCH, S - 1 - kv0_) * (int)rowstride + (c % NCH) * 8);         \
       }                                                                                           \
     }                                                                                             \
-    if (tid < 64) {                                                                               \
-      const int kv = kv0_ + tid;                                                                  \
-      preg = kv < S ? (a.pos ? (float)a.pos[(long long)n * S + kv] : (float)kv) : 0.f;            \
-    }                                                                                             \
-  }
-#define AF_STORE(buf_)                                                                            \
-  {                                                                                               \
     _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                             \
-      const int c = tid + 256 * u;                                                                \
-      const int r = c / NCH, ch = c % NCH;                                                        \
-      *(uint4*)(sK[buf_] + rowimg_off<HD>(r, ch)) = kreg[u];                                      \
-      *(uint4*)(sV[buf_] + trimg_off<HD>(r, ch * 8)) = vreg[u];                                   \
+      kreg[u] = *(const bf16x8*)(tbase + go_[u] + H * HD);                                         \
+      vreg[u] = *(const bf16x8*)(tbase + go_[u] + 2 * H * HD);                                     \
     }                                                                                             \
-    if (tid < 64) sPos[buf_][tid] = preg;                                                         \
+    if (a.pos && tid < 64) praw = a.pos[(long long)n * S + min(kv0_ + tid, S - 1)];               \
+  }
+#define AF_STORE(kt_)                                                                             \
+  {                                                                                               \
+    const int buf_ = (kt_) & 1;                                                                   \
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                             \
+      *(bf16x8*)(sK[0] + buf_ * TILE_BYTES + kst[u]) = kreg[u];                                    \
+      *(bf16x8*)(sV[0] + buf_ * TILE_BYTES + vst[u]) = vreg[u];                                    \
+    }                                                                                             \
+    if (tid < 64) {                                                                               \
+      const int kv = (kt_) * 64 + tid;                                                            \
+      pos_form(kt_);                                                                              \
+      sPos[buf_][tid] = fmaf(a.pos ? (float)praw : (float)kv, pmul, padd);                        \
+    }                                                                                             \
   }
   AF_LOAD(0);
   AF_STORE(0);
   __syncthreads();
 
-  for (int kt = 0; kt < ntile; ++kt) {
+  // row sums of P on the matrix cores (dropout-free kernels): a ones fragment as the A operand of two more MFMAs per query
+  // block gives sum_k p[k][q] in every row of the accumulator -- 32 v_add per tile and the final cross-lane reduction leave
+  // the VALU, which is what bounds this kernel (SQ_ACTIVE_INST_VALU 83 % of the SIMD's cycles at 290 VALU per tile)
+  f32x4 lacc[QB];
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+  for (int b = 0; b < QB; ++b) lacc[b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // One key tile.  PH: 0 = |.| form, 1 = per-key term only (before / after the query rows).  TAIL (compile-time): the padded
+  // keys of a ragged last tile are masked to -inf -- as a run-time test inside one loop body the compiler if-converted it into
+  // 32 v_cndmask + 15 v_cmp executed for EVERY tile.
+  auto key_tile = [&](int kt, auto ph_tag, auto tail_tag) {
+    constexpr int PH = decltype(ph_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = kt & 1;
     const int kv0 = kt * 64;
     const bool more = kt + 1 < ntile;
@@ -335,14 +405,24 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
       const f32x4 pk = *(const f32x4*)(&sPos[buf][16 * j + 4 * g]);
 #pragma unroll
       for (int b = 0; b < QB; ++b) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (PH == 1) {
+          f32x4 acc = pk;                            // the bias IS the accumulator's initial value
 #pragma unroll
-        for (int ks = 0; ks < HD / 32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+          for (int ks = 0; ks < HD / 32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+          s[b][j] = acc;
+        } else {
+          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) s[b][j][r] = fmaf(fabsf(pos_q[b] - pk[r]), c_rel, acc[r]);
+          for (int ks = 0; ks < HD / 32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+          // acc + c_rel |pos_q - pos_k| = v_sub + one v_fma with the |.| source modifier.  This file is built with
+          // -fno-slp-vectorize: paired into v_pk_fma_f32 (no modifiers) the abs costs a separate v_and per element and the
+          // packed op more issue time next to MFMAs than two plain fmas (MI355X_MICROARCH.md cycle constants).
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[b][j][r] = __builtin_fmaf(__builtin_fabsf(pos_q[b] - pk[r]), c_rel, acc[r]);
+        }
       }
     }
-    if (kv0 + 64 > S) {   // last tile: padded keys -> -inf
+    if (TAIL) {   // last tile: padded keys -> -inf
 #pragma unroll
       for (int b = 0; b < QB; ++b)
 #pragma unroll
@@ -351,28 +431,36 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
           for (int r = 0; r < 4; ++r)
             if (kv0 + 16 * j + 4 * g + r >= S) s[b][j][r] = -INFINITY;
     }
+    float mx[QB];
+    bool grow = false;
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
-      float mx = max3f(s[b][0][0], s[b][0][1], s[b][0][2]);
-      mx = max3f(mx, s[b][0][3], s[b][1][0]);
-      mx = max3f(mx, s[b][1][1], s[b][1][2]);
-      mx = max3f(mx, s[b][1][3], s[b][2][0]);
-      mx = max3f(mx, s[b][2][1], s[b][2][2]);
-      mx = max3f(mx, s[b][2][3], s[b][3][0]);
-      mx = max3f(mx, s[b][3][1], s[b][3][2]);
-      mx = fmaxf(mx, s[b][3][3]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      // deferred maximum: rescale only when some row's maximum grew by more than 2^4 (p stays <= 16: harmless
-      // for fp32 sums and for bf16's scale-free relative precision); the decision is wave-uniform
-      if (__any(mx > m_run[b] + thr_acc)) {
-        const float m_new = fmaxf(m_run[b], mx);
+      float v = max3f(s[b][0][0], s[b][0][1], s[b][0][2]);
+      v = max3f(v, s[b][0][3], s[b][1][0]);
+      v = max3f(v, s[b][1][1], s[b][1][2]);
+      v = max3f(v, s[b][1][3], s[b][2][0]);
+      v = max3f(v, s[b][2][1], s[b][2][2]);
+      v = max3f(v, s[b][2][3], s[b][3][0]);
+      v = max3f(v, s[b][3][1], s[b][3][2]);
+      v = max2f(v, s[b][3][3]);
+      mx[b] = rows_max(v);
+      grow |= mx[b] > m_run[b] + thr_acc;
+    }
+    // deferred maximum: rescale only when some row's maximum grew by more than 2^4 (p stays <= 16: harmless
+    // for fp32 sums and for bf16's scale-free relative precision); ONE wave-uniform decision for all query blocks
+    if (__any(grow)) {
+#pragma unroll
+      for (int b = 0; b < QB; ++b) {
+        const float m_new = fmaxf(m_run[b], mx[b]);
         const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * scale2);
         m_run[b] = m_new;
-        l_run[b] *= alpha;
+        if constexpr (DROP) l_run[b] *= alpha; else lacc[b] *= alpha;
 #pragma unroll
         for (int i = 0; i < ND; ++i) o[b][i] *= alpha;
       }
+    }
+#pragma unroll
+    for (int b = 0; b < QB; ++b) {
       const float nm = -m_run[b] * scale2;
       float ps = 0.f;
 #pragma unroll
@@ -386,15 +474,15 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(fmaf(s[b][j][r], scale2, nm));
-          ps += p;                                  // the normaliser is dropout-free
           if (DROP) {
+            ps += p;                                // the normaliser is dropout-free
             const unsigned h16 = (r & 1) ? (hp[r >> 1] >> 16) : (hp[r >> 1] & 0xFFFFu);
             p = h16 >= (a.drop.thresh >> 16) ? p * a.drop.scale : 0.f;
           }
           s[b][j][r] = p;
         }
       }
-      l_run[b] += ps;
+      if (DROP) l_run[b] += ps;
     }
 
     // ---- O^T += V^T P^T
@@ -413,19 +501,48 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(AttnArgs a) {
 #pragma unroll
         for (int b = 0; b < QB; ++b) o[b][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b], o[b][i], 0, 0, 0);
       }
+      if constexpr (!DROP) {
+#pragma unroll
+        for (int b = 0; b < QB; ++b) lacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[b], lacc[b], 0, 0, 0);
+      }
     }
     // buffer buf^1 was last read in iteration kt-1; every wave has passed that iteration's barrier
-    if (more) AF_STORE(buf ^ 1);
+    if (more) AF_STORE(kt + 1);
     __syncthreads();
+  };
+  typedef std::integral_constant<int, 0> PhAbs;
+  typedef std::integral_constant<int, 1> PhKey;
+  {
+    int kt = 0;
+    for (; kt < kd0; ++kt) key_tile(kt, PhKey{}, std::false_type{});            // before the query rows: always whole tiles
+    if (kd0 > 0) {                                                               // units t' -> t
+#pragma unroll
+      for (int b = 0; b < QB; ++b) m_run[b] += c_rel * (pos_q[b] - qref);
+    }
+    for (; kt < min(kd1, nfull); ++kt) key_tile(kt, PhAbs{}, std::false_type{});
+    if (kt < kd1) { key_tile(kt, PhAbs{}, std::true_type{}); ++kt; }
+    if (kt < ntile) {                                                            // units t -> t''
+#pragma unroll
+      for (int b = 0; b < QB; ++b) m_run[b] += c_rel * (pos_q[b] - qref);
+      for (; kt < nfull; ++kt) key_tile(kt, PhKey{}, std::false_type{});
+      if (kt < ntile) key_tile(kt, PhKey{}, std::true_type{});
+#pragma unroll
+      for (int b = 0; b < QB; ++b) m_run[b] -= c_rel * (pos_q[b] - qref);        // back to true units for the LSE
+    }
   }
 #undef AF_LOAD
 #undef AF_STORE
   // ---- finish: O = O^T / l ; lse = ln2 * (m*scale2 + log2 l)  (natural-log LSE, as the backward expects)
 #pragma unroll
   for (int b = 0; b < QB; ++b) {
-    float l_tot = l_run[b];
-    l_tot += __shfl_xor(l_tot, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
+    float l_tot;
+    if constexpr (DROP) {
+      l_tot = l_run[b];
+      l_tot += __shfl_xor(l_tot, 16, 64);
+      l_tot += __shfl_xor(l_tot, 32, 64);
+    } else {
+      l_tot = lacc[b][0];                            // every accumulator row holds the whole row sum
+    }
     const float inv = 1.f / l_tot;
     if (q[b] < S) {
       T* orow = (T*)a.out + ((long long)n * S + q[b]) * ((long long)H * HD) + (long long)h * HD;

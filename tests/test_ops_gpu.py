@@ -453,16 +453,30 @@ def test_attention_fwd_bwd(ops, dtype, hd, S):
     assert rel_err(dal, sc.grad) < max(t, 2e-4)
 
 
+@pytest.mark.parametrize("S", [700, 64, 130, 257, 1000, 2000])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_teacher_arange_long(ops, dtype):
-    N, H, hd, S = 1, 2, 64, 700
+def test_attention_teacher_arange_long(ops, dtype, S):
+    """positions = arange (the teacher): the bf16 kernel takes the per-key ALiBi form off the diagonal (bias as the MFMA's
+    C operand, row constant dropped, running maximum re-based at the two phase changes) -- output AND log-sum-exp must come
+    out in true units whatever phase the last key tile was in (ragged last tile in either form: S = 700, 130, 257, 1000)."""
+    N, H, hd = 1, 2, 64
+    if dtype == torch.float32 and S > 1000:
+        pytest.skip("fp32 reference kernel: covered at S <= 1000")
     qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=4)
     slopes = torch.tensor(O.alibi_slopes(H))
     sc = torch.tensor([1.3, -0.2])          # negative learned scale is clamped to 0
     pos = torch.arange(S).unsqueeze(0).int()
     ref = attn_ref(qkv, pos, slopes, sc, H)
-    out, _ = ops.attention_fwd(dev(qkv, dtype), None, slopes.cuda(), sc.cuda(), H, need_lse=False)
+    out, lse = ops.attention_fwd(dev(qkv, dtype), None, slopes.cuda(), sc.cuda(), H, need_lse=True)
     assert rel_err(out.float(), ref) < tol(dtype, 2)
+    q, k, _ = qkv.float().view(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = O.alibi_bias_from_positions(pos.long(), H, sc.view(1, 1, H, 1, 1))
+    lse_ref = torch.logsumexp((q * hd ** -0.5) @ k.transpose(-2, -1) + bias, dim=-1)
+    assert (lse.cpu() - lse_ref.view_as(lse.cpu())).abs().max() < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+    # steep bias x long distances (a learned scale of 40-80: the per-key terms reach 1e4 accumulator units far from the diagonal)
+    sc2 = sc.abs() * 64
+    out2, _ = ops.attention_fwd(dev(qkv, dtype), None, slopes.cuda(), sc2.cuda(), H, need_lse=False)
+    assert rel_err(out2.float(), attn_ref(qkv, pos, slopes, sc2, H)) < tol(dtype, 2)
 
 
 # ------------------------------------------------------------------------------------------ norms
