@@ -607,7 +607,9 @@ __device__ __forceinline__ void dalibi_finish(float dal_wave, float* dalibi, int
   if ((tid & 63) == 0) red[tid >> 6] = dal_wave;
   __syncthreads();
   if (tid == 0) {
-    const float v = asc >= 0.f ? (red[0] + red[1] + red[2] + red[3]) * slope : 0.f;
+    float sum = 0.f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[w];
+    const float v = asc >= 0.f ? sum * slope : 0.f;
     g_dal_part_all[use_part - 1][((long long)h * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = v;      // blockIdx.y = head
   }
 }
@@ -1279,6 +1281,306 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16, HD = 64, S <= 144 (the student's 140 kept frames): the same whole-sequence backward on 48-row tiles and THREE
+// waves.  With 64-key blocks and four waves S = 140 is 2.19 blocks: in the third block one wave had keys and three sat
+// at the two barriers of each of its three query steps (SQ_WAIT_ANY 50 % of the wave cycles, MFMA busy 0.06).  Here a
+// key block is 48 keys (16 per wave; 140 = 2.92 blocks) and there is NO query-tile loop with barriers inside a key block:
+//   phase A  every wave walks ALL query rows (pairs of 16-row sub-blocks) against its 16 keys: S, P, dP, dS; dV^T / dK^T
+//            accumulate in registers; dS of all rows goes to LDS ([q][key], zero beyond key 48)
+//   barrier
+//   phase B  dQ: wave w owns the 16-row query groups w, w+3, w+6 (static accumulators, no select on a loop index) and
+//            multiplies their dS rows with the key block's K (transposed reads of the K tile)
+//   barrier
+// = 2 barriers per key block (6 per (n, h)) instead of 2 per (key block, query tile) step (18).  Per-row operands (lse in
+// log2 units, delta, position, dropout row term) are formed once into LDS and read as one 16-B vector per four rows.
+// The next key block's K / V fragments and K tile are fetched by loads NOTHING else touches until the block change (no
+// zero-initialised destinations, no guards: rows past S re-read row S-1 and are masked by kv_ok / zero dS columns).
+#define AB48_QROWS 160            // Q / dO images: 144 rows + one zero 16-row group (the odd ninth sub-block's partner)
+#define AB48_ROWS 144
+#define AB48_LDS (2 * AB48_QROWS * 128 + 64 * 128 + AB48_ROWS * 128 + 4 * AB48_ROWS * 4 + 3 * 64 * 4)
+
+template <bool DROP>
+__global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, const bf16* __restrict__ o_fwd) {
+  constexpr int HD = 64, ND = 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sQ = smem;                                   // [160][64] dual-use image
+  char* const sDO = sQ + AB48_QROWS * 128;
+  char* const sKt = sDO + AB48_QROWS * 128;                // [64][64] tr image of the key block's K (rows 48.. stay zero)
+  char* const sDS = sKt + 64 * 128;                        // [144 q][64 kv] row image (cols 48.. stay zero)
+  float* const sLse = (float*)(sDS + AB48_ROWS * 128);     // lse * log2(e); +inf on padded rows
+  float* const sDelta = sLse + AB48_ROWS;
+  float* const sPosQ = sDelta + AB48_ROWS;
+  unsigned* const sRowT = (unsigned*)(sPosQ + AB48_ROWS);  // dropout row terms
+  float* const sBias = (float*)(sRowT + AB48_ROWS);        // [3][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const long long orow = (long long)H * HD;
+  const bf16* qkv = (const bf16*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  const bf16* dO = (const bf16*)a.d_out + (long long)n * S * orow + (long long)h * HD;
+  const bf16* Of = o_fwd + (long long)n * S * orow + (long long)h * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float slope = a.slopes[h];
+  const float asc = a.alibi_scale[h];
+  const float coef2 = -slope * fmaxf(asc, 0.f) * LOG2E;
+  const float scale2 = a.scale * LOG2E;
+  const int nsub = (S + 15) >> 4;                  // 16-row query groups (<= 9)
+  const int npair = (nsub + 1) >> 1;
+  const int nkb = (S + 47) / 48;
+
+  bf16x8 kf_n[2], vf_n[2], kt_n[2];
+  int praw = 0;
+#define AB48_FETCH(kb_)                                                                                         \
+  {                                                                                                             \
+    const int kvc_ = min((kb_) * 48 + wid * 16 + fr, S - 1);                                                    \
+    const bf16* krow_ = qkv + (long long)kvc_ * rowstride + (long long)H * HD + g * 8;                          \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                          \
+      kf_n[ks] = *(const bf16x8*)(krow_ + ks * 32);                                                             \
+      vf_n[ks] = *(const bf16x8*)(krow_ + (long long)H * HD + ks * 32);                                         \
+    }                                                                                                           \
+    if (a.pos) praw = a.pos[(long long)n * S + kvc_];                                                           \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
+      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;                                                      \
+      kt_n[u] = *(const bf16x8*)(qkv + (long long)min((kb_) * 48 + r, S - 1) * rowstride + (long long)H * HD + ch * 8); \
+    }                                                                                                           \
+  }
+  {
+    constexpr int NQ = (AB48_QROWS * 8 + 191) / 192;       // 7 chunks of Q and of dO per thread
+    uint4 qz[NQ], dz[NQ], oz[8];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      qz[u] = make_uint4(0u, 0u, 0u, 0u);
+      dz[u] = qz[u];
+      if (r < S) {
+        qz[u] = *(const uint4*)(qkv + (long long)r * rowstride + ch * 8);
+        dz[u] = *(const uint4*)(dO + (long long)r * orow + ch * 8);
+      }
+    }
+    const bool rok = tid < S;                       // thread tid < 144 owns query row tid for delta / lse / pos / row term
+#pragma unroll
+    for (int u = 0; u < 8; ++u) oz[u] = rok ? *(const uint4*)(Of + (long long)tid * orow + u * 8) : make_uint4(0u, 0u, 0u, 0u);
+    float lse_r = INFINITY, pos_r = 0.f;            // exp2(x - inf) = 0: padded queries vanish
+    if (rok) {
+      lse_r = a.lse[((long long)n * H + h) * S + tid] * LOG2E;
+      pos_r = a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid;
+    }
+    AB48_FETCH(0)
+    if (a.bias_sum) sBias[tid] = 0.f;               // 192 threads = 3 x 64 sums
+    if (tid < 128) *(uint4*)(sKt + 48 * 128 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);         // key rows 48..63: zero for good
+#pragma unroll
+    for (int u = 0; u < AB48_ROWS * 8 / 192; ++u) *(uint4*)(sDS + (tid + 192 * u) * 16) = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      if (c < AB48_QROWS * 8) {
+        *(uint4*)(sQ + dual_off(r, ch)) = qz[u];
+        *(uint4*)(sDO + dual_off(r, ch)) = dz[u];
+      }
+    }
+    __syncthreads();                                // dO image complete: delta reads row tid from it
+    if (tid < AB48_ROWS) {
+      float dl = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bf16x8 ov = *(const bf16x8*)&oz[u];
+        const bf16x8 dv_ = *(const bf16x8*)(sDO + dual_off(tid, u));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dl += (float)ov[i] * (float)dv_[i];
+      }
+      sDelta[tid] = dl;
+      sLse[tid] = lse_r;
+      sPosQ[tid] = pos_r;
+      sRowT[tid] = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + min(tid, S - 1)));
+    }
+  }
+
+  f32x4 dq[3][ND];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dq[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dal = 0.f;
+  int ds_off[4];                                   // dS image: byte offset of (row 4g + r, column 16 wid + fr); + 128 * first row
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ql = 4 * g + r, col = wid * 16 + fr;
+    ds_off[r] = ql * 128 + ((((col >> 3) ^ ((ql >> 1) & 7)) & 7) << 4) + ((col & 7) << 1);
+  }
+
+#pragma unroll 1
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int kv = kb * 48 + wid * 16 + fr;        // this lane's key column
+    const bool kv_ok = kv < S;
+    const int kvc = kv_ok ? kv : S - 1;
+    const float pos_kv = a.pos ? (float)praw : (float)kvc;
+    bf16x8 kf_b[2], vf_b[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { kf_b[ks] = kf_n[ks]; vf_b[ks] = vf_n[ks]; }
+    // (the barrier that ended the previous key block's phase B -- or the prologue's -- protects sKt and sDS)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      *(bf16x8*)(sKt + trimg_off<HD>(r, ch * 8)) = kt_n[u];
+    }
+    if (kb + 1 < nkb) AB48_FETCH(kb + 1)           // next key block's operands arrive under this block's math
+    if (kb == 0) __syncthreads();                  // publishes delta / lse / pos / row terms (first block only)
+
+    f32x4 dk[ND], dv[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    // ---------------- phase A: all query rows against this wave's 16 keys, two 16-row groups per trip (one basic block:
+    // the second group's LDS reads and MFMAs interleave with the first group's VALU); an odd last group runs alone
+    auto rows16 = [&](int rb, f32x4& p_o, f32x4& ds_o) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 qa = *(const bf16x8*)(sQ + dual_off(rb + fr, ks * 4 + g));
+        const bf16x8 da = *(const bf16x8*)(sDO + dual_off(rb + fr, ks * 4 + g));
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf_b[ks], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf_b[ks], pacc, 0, 0, 0);
+      }
+      const f32x4 lse4 = *(const f32x4*)(sLse + rb + 4 * g);
+      const f32x4 del4 = *(const f32x4*)(sDelta + rb + 4 * g);
+      const f32x4 pq4 = *(const f32x4*)(sPosQ + rb + 4 * g);
+      const uint4 rt4 = *(const uint4*)(sRowT + rb + 4 * g);
+      const unsigned rts[4] = {rt4.x, rt4.y, rt4.z, rt4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dist = __builtin_fabsf(pq4[r] - pos_kv);
+        const float e2 = __builtin_fmaf(sacc[r], scale2, __builtin_fmaf(dist, coef2, -lse4[r]));
+        const float pv = kv_ok ? __builtin_amdgcn_exp2f(e2) : 0.f;
+        float mlt = 1.f;                             // dropout as ONE multiplier (0 or 1/(1-p)), same mask as the forward
+        if (DROP) mlt = drop_keep2(a.drop, rts[r], (unsigned)kvc) ? a.drop.scale : 0.f;
+        const float dsv = pv * __builtin_fmaf(pacc[r], mlt, -del4[r]);
+        p_o[r] = pv * mlt;
+        ds_o[r] = dsv;
+        dal = __builtin_fmaf(-dsv, dist, dal);
+        // dS -> LDS as [q][kv] (for dQ): row rb + 4g + r, column 16 wid + fr (per-lane offsets formed once, ds_off[])
+        *(bf16*)(sDS + rb * 128 + ds_off[r]) = (bf16)dsv;
+      }
+    };
+    auto pair_products = [&](int pr, const f32x4& p0, const f32x4& p1, const f32x4& d0, const f32x4& d1) {
+      // dV^T += dO^T P ; dK^T += Q^T dS      (k = q, permuted order shared by both operands)
+      bf16x8 pf, df;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pf[r] = (bf16)p0[r]; pf[4 + r] = (bf16)p1[r];
+        df[r] = (bf16)d0[r]; df[4 + r] = (bf16)d1[r];
+      }
+      const int r_lo = 32 * pr + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int chl = 2 * i + (pp >> 1), sub = (pp & 1) << 3;       // column 16 i + 4 pp: chunk, byte inside it
+        const bf16x8 dof = tr_frag(sDO + dual_off(r_lo, chl) + sub, sDO + dual_off(r_hi, chl) + sub);
+        const bf16x8 qf = tr_frag(sQ + dual_off(r_lo, chl) + sub, sQ + dual_off(r_hi, chl) + sub);
+        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, df, dk[i], 0, 0, 0);
+      }
+    };
+#pragma unroll 1
+    for (int pr = 0; pr < (nsub >> 1); ++pr) {
+      f32x4 p0, p1, d0, d1;
+      rows16(32 * pr, p0, d0);
+      rows16(32 * pr + 16, p1, d1);
+      pair_products(pr, p0, p1, d0, d1);
+    }
+    if (nsub & 1) {
+      f32x4 p0, d0;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rows16(16 * (nsub - 1), p0, d0);
+      pair_products(nsub >> 1, p0, z, d0, z);
+    }
+    // dK, dV of this key block: D rows d = 16i+4g+r, col kv = fr
+    if (kv_ok) {
+      bf16* dkv = (bf16*)a.dqkv + ((long long)n * S + kv) * rowstride + (long long)h * HD;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        f32x4 kk = dk[i] * a.scale;
+        Vec4<bf16>::store(dkv + (long long)H * HD + 16 * i + 4 * g, kk);
+        Vec4<bf16>::store(dkv + 2LL * H * HD + 16 * i + 4 * g, dv[i]);
+      }
+    }
+    if (a.bias_sum) {          // column sums over this block's keys of what was stored (bf16-rounded), 16 key lanes -> 1
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sk = kv_ok ? (float)(bf16)(dk[i][r] * a.scale) : 0.f;
+          float sv_ = kv_ok ? (float)(bf16)dv[i][r] : 0.f;
+          sk = row16_sum(sk);                        // DPP adds inside the 16-lane row (no LDS round trips)
+          sv_ = row16_sum(sv_);
+          if (fr == 0) {
+            atomicAdd(&sBias[64 + 16 * i + 4 * g + r], sk);
+            atomicAdd(&sBias[128 + 16 * i + 4 * g + r], sv_);
+          }
+        }
+    }
+    __syncthreads();           // dS of every row and the K tile are in LDS
+
+    // ---------------- phase B: dQ[q rows of groups wid, wid+3, wid+6][d] += dS K : A = dS rows, B = K (k = kv, col = d)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (kb * 48 + 32 * ks >= S) continue;        // no keys in this half (uniform)
+      const int r_lo = 32 * ks + 8 * g + qq, r_hi = r_lo + 4;
+      bf16x8 kfr[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+        kfr[i] = tr_frag(sKt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sKt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int qg = wid + 3 * t;
+        if (qg >= nsub) continue;                  // uniform
+        const int rq = 16 * qg + fr;
+        const int ch = ks * 4 + g;
+        const bf16x8 af = *(const bf16x8*)(sDS + rq * 128 + (((ch ^ ((rq >> 1) & 7)) & 7) << 4));
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kfr[i], dq[t][i], 0, 0, 0);
+      }
+    }
+    __syncthreads();           // the next key block overwrites sKt and sDS
+  }
+#undef AB48_FETCH
+  // ---- dQ into the q slot of dqkv: rows q = 16 (wid + 3t) + 4g + r, col d = 16i + fr
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qr = 16 * (wid + 3 * t) + 4 * g + r;
+      if (qr < S) {
+        bf16* dst = (bf16*)a.dqkv + ((long long)n * S + qr) * rowstride + (long long)h * HD;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dst[16 * i + fr] = (bf16)(dq[t][i][r] * a.scale);
+      }
+    }
+  if (a.bias_sum) {            // dQ column sums: this lane's rows (t, r), then the 4 row groups g, then the waves through LDS
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qr = 16 * (wid + 3 * t) + 4 * g + r;
+          sq += qr < S ? (float)(bf16)(dq[t][i][r] * a.scale) : 0.f;
+        }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (g == 0) atomicAdd(&sBias[16 * i + fr], sq);
+    }
+    __syncthreads();
+    atomicAdd(a.bias_sum + (long long)(tid >> 6) * H * HD + (long long)h * HD + (tid & 63), sBias[tid]);
+  }
+  dal = wave_sum(dal);
+  dalibi_finish(dal, a.dalibi, h, a.dal_part, slope, asc);
+}
+
+// ---------------------------------------------------------------------------------------------
 // bf16, HD = 64, long sequences (finetuning attends over all T = 2000 frames): two passes, no atomics, no fp32 dQ
 // scratch.  MODE 0 (dK, dV): a workgroup owns 128 keys (32 per wave, as B-operand fragments in registers) and
 // streams the queries; MODE 1 (dQ): it owns 128 queries and streams the keys.  The streamed side comes through LDS
@@ -1544,6 +1846,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
 
 #define A2V_ATTN_SEQ_TILES 3      // sequences up to 192 tokens take the atomic-free whole-sequence backward (bf16)
 
+int g_a2v_attn_seq48 = 1;    // a2v_debug_set(15, v): S <= 144 takes the 48-row / three-wave whole-sequence backward (0: the 64-row one)
 int g_a2v_attn_long = 1;     // a2v_debug_set(8, v): two-pass long-sequence backward on / off (off: tiled kernel + dQ atomics)
 
 template <typename T, int HD>
@@ -1578,6 +1881,18 @@ static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delt
         hipLaunchKernelGGL((attn_bwd_long_kernel<0, false>), grid, dim3(256), ABL_LDS, st, a);
         hipLaunchKernelGGL((attn_bwd_long_kernel<1, false>), grid, dim3(256), ABL_LDS, st, a);
       }
+      fold(grid);
+      A2V_CHECK_LAUNCH();
+      return A2V_OK;
+    }
+    if (a.S <= AB48_ROWS && g_a2v_attn_seq48) {
+      const bool dr = a.drop.thresh != 0;
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
+      const dim3 grid(1, a.H, a.N);
+      set_part(grid);
+      if (dr) hipLaunchKernelGGL((attn_bwd_seq48_kernel<true>), grid, dim3(192), AB48_LDS, st, a, (const bf16*)out);
+      else hipLaunchKernelGGL((attn_bwd_seq48_kernel<false>), grid, dim3(192), AB48_LDS, st, a, (const bf16*)out);
       fold(grid);
       A2V_CHECK_LAUNCH();
       return A2V_OK;

@@ -90,6 +90,17 @@ template <> struct Vec8<float> {
 // 64-lane sum, result in every lane.  DPP adds inside the 16-lane rows (quad_perm, row_half_mirror, row_mirror), then
 // row_bcast15 / row_bcast31 carry the row sums up to lane 63, which is broadcast through an SGPR: six VALU ops and
 // one v_readlane instead of six dependent ds_bpermute round trips through the LDS crossbar.
+// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+#define A2V_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+  A2V_DPP_ADD(0xB1);     // quad_perm [1,0,3,2]
+  A2V_DPP_ADD(0x4E);     // quad_perm [2,3,0,1]
+  A2V_DPP_ADD(0x141);    // row_half_mirror
+  A2V_DPP_ADD(0x140);    // row_mirror
+#undef A2V_DPP_ADD
+  return v;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #define A2V_DPP_ADD(ctrl, rmask, bctrl) \
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, bctrl))

@@ -29,17 +29,6 @@ __device__ __forceinline__ void p8_glds16(const char* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((p8_gbl_cvoid_t*)gsrc, (p8_lds_void_t*)lds_dst, 16, 0, 0);
 }
 
-// sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane of the row
-__device__ __forceinline__ float row16_sum(float v) {
-#define P8_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
-  P8_DPP_ADD(0xB1);     // quad_perm [1,0,3,2]
-  P8_DPP_ADD(0x4E);     // quad_perm [2,3,0,1]
-  P8_DPP_ADD(0x141);    // row_half_mirror
-  P8_DPP_ADD(0x140);    // row_mirror
-#undef P8_DPP_ADD
-  return v;
-}
-
 // LDS map (16 KiB half-tiles): [A_lo0 A_hi0 A_lo1 A_hi1 | B_lo0 B_hi0 B_lo1 B_hi1]: the A region and the B region are
 // 64 KiB each, so every fragment read is ONE address register (a_off / b_off, plus its ^64 twin) + a 16-bit immediate
 // (buffer, half and row-tile offsets all fold into ds_read's offset field, which stops at 65535) -- with the two K-tile

@@ -238,6 +238,7 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   8 long-sequence attention backward (0 tiled kernel + dQ atomics, 1 two-pass, 2 two-pass for every S)
  *   10 persistent NT kernel epilogue (1 direct stores, 0 staged through LDS)     13 decoder grouped-conv kernel on / off
  *   14 grouped-conv slab kernel form (1: 384-row slabs, two workgroups per CU; 0: 1024-row slabs)
+ *   15 whole-sequence attention backward for S <= 144 (1: 48-row tiles on three waves; 0: 64-row tiles on four)
  * No launch state goes through here (ABI 5's key 9, the tile-counter set, is gone: the stream argument selects it). */
 int a2v_debug_set(int key, int value);
 

@@ -3,7 +3,7 @@
 over them is seconds, not a whole bench:
 
   teacher forward : N=32 clips, S=2000 frames (positions = arange), H=16, hd=64   -> attn_fwd_bf16_kernel<64,false,2>
-  student forward : N=96 clone-batch rows, S=140 kept frames, dropout on          -> attn_fwd_bf16_kernel<64,true,1>
+  student forward : N=384 clone-batch rows, S=140 kept frames, dropout on          -> attn_fwd_bf16_kernel<64,true,1>
   student backward: same rows                                                     -> attn_bwd_seq_kernel<true>
 
     python tools/attn_bench.py [--iters 10] [--which teacher,student]
@@ -35,8 +35,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--which", default="teacher,student")
+    ap.add_argument("--student-rows", type=int, default=384, help="32 clips x 12 clones at micro-batch 32")
+    ap.add_argument("--no-drop", action="store_true")
+    ap.add_argument("--debug-set", action="append", default=[], help="key=value for a2v_debug_set (A/B experiments)")
     a = ap.parse_args()
     H, hd = 16, 64
+    for kv in a.debug_set:
+        k, v = kv.split("=")
+        ops.debug_set(int(k), int(v))
     slopes = torch.tensor([2.0 ** (-8.0 * (i + 1) / H) for i in range(H)], device="cuda")
     sc = torch.ones(H, device="cuda")
     out = {}
@@ -47,11 +53,11 @@ def main():
         fl = 4.0 * S * S * hd * H * N
         out["teacher_fwd"] = dict(us=round(us, 1), tflops=round(fl / us / 1e6, 1), frac_of_2p5pf=round(fl / us / 1e6 / 2500, 4))
     if "student" in a.which:
-        N, S = 96, 140
+        N, S = a.student_rows, 140
         g = torch.Generator().manual_seed(1)
         pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int().cuda()
         qkv = torch.randn(N, S, 3 * H * hd, device="cuda").bfloat16()
-        drop = (0.1, 1234)
+        drop = None if a.no_drop else (0.1, 1234)
         o, lse = ops.attention_fwd(qkv, pos, slopes, sc, H, drop=drop)
         us = timed(lambda: ops.attention_fwd(qkv, pos, slopes, sc, H, drop=drop), a.iters)
         out["student_fwd"] = dict(us=round(us, 1))
