@@ -557,8 +557,195 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bf16, HD = 64, S <= 144 (the student's 140 kept frames): whole-sequence forward.  One workgroup of THREE waves per (n, h);
+// K and V of all S keys are staged once (the tiled kernel above re-fetched them for each of its three 64-row query blocks
+// and padded 140 to 192 on both axes), each wave owns 48 query rows (three 16-row blocks) against every key, and the whole
+// score row is in registers: ONE pass of softmax (no running maximum, no rescale), one barrier in the kernel.
+#define AF48_ROWS 160             // K / V images: 144 rows + one zero 16-row group (the odd ninth key group's MFMA partner)
+#define AF48_LDS (2 * AF48_ROWS * 128 + AF48_ROWS * 4)
+__device__ __forceinline__ float rows_sum(float v) {    // sum over the lanes l, l^16, l^32, l^48 (see rows_max)
+  const unsigned u = __float_as_uint(v);
+  auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  const float w = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  const unsigned x = __float_as_uint(w);
+  auto t = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+  return __uint_as_float(t[0]) + __uint_as_float(t[1]);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
+  typedef bf16 T;
+  constexpr int HD = 64, ND = 4, QB = 3, NKG = 9;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sK = smem;                                   // [160][64] row image
+  char* const sV = sK + AF48_ROWS * 128;                   // [160][64] tr image
+  float* const sPos = (float*)(sV + AF48_ROWS * 128);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const T* qkv = (const T*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = a.scale * LOG2E;
+  const float c_rel = -a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f) / a.scale;       // ALiBi slope in accumulator units
+  const int nkg = (S + 15) >> 4;                           // 16-key groups with keys (<= 9)
+
+  // ---- every global load of the kernel first: K / V rows (zero past S), positions, this wave's Q fragments
+  {
+    constexpr int NQ = (AF48_ROWS * 8 + 191) / 192;
+    uint4 kz[NQ], vz[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      kz[u] = make_uint4(0u, 0u, 0u, 0u);
+      vz[u] = kz[u];
+      if (r < S) {
+        const T* base = qkv + (long long)r * rowstride + ch * 8;
+        kz[u] = *(const uint4*)(base + H * HD);
+        vz[u] = *(const uint4*)(base + 2 * H * HD);
+      }
+    }
+    if (tid < AF48_ROWS) sPos[tid] = tid < S ? (a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid) : 0.f;
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      if (c < AF48_ROWS * 8) {
+        *(uint4*)(sK + rowimg_off<HD>(r, ch)) = kz[u];
+        *(uint4*)(sV + trimg_off<HD>(r, ch * 8)) = vz[u];
+      }
+    }
+  }
+  int q[QB], qc[QB];
+  float pos_q[QB];
+  bf16x8 qf[QB][2];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    q[b] = (wid * QB + b) * 16 + fr;
+    qc[b] = q[b] < S ? q[b] : S - 1;
+    pos_q[b] = a.pos ? (float)a.pos[(long long)n * S + qc[b]] : (float)qc[b];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[b][ks] = *(const bf16x8*)(qkv + (long long)qc[b] * rowstride + ks * 32 + g * 8);
+  }
+  __syncthreads();
+  if (wid * 48 >= S) return;                               // (S <= 96: a wave without query rows; no barrier follows)
+
+  // ---- S^T in accumulator units: s[b][j][r] for key 16j + 4g + r, query block b
+  f32x4 s[QB][NKG];
+#pragma unroll
+  for (int j = 0; j < NKG; ++j) {
+    if (j < nkg) {                                         // uniform
+      bf16x8 kf[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kf[ks] = *(const bf16x8*)(sK + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
+      const f32x4 pk = *(const f32x4*)(sPos + 16 * j + 4 * g);
+#pragma unroll
+      for (int b = 0; b < QB; ++b) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = __builtin_fmaf(__builtin_fabsf(pos_q[b] - pk[r]), c_rel, acc[r]);
+          s[b][j][r] = (16 * j + 4 * g + r < S) ? v : -INFINITY;       // only the last group has keys past S
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < QB; ++b) s[b][j] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    }
+  }
+  // ---- softmax over the whole row, dropout, P -> bf16 in place
+  float m_row[QB], l_row[QB];
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    float mx = max3f(s[b][0][0], s[b][0][1], s[b][0][2]);
+    mx = max2f(mx, s[b][0][3]);
+#pragma unroll
+    for (int j = 1; j < NKG; ++j) {
+      mx = max3f(mx, s[b][j][0], s[b][j][1]);
+      mx = max3f(mx, s[b][j][2], s[b][j][3]);
+    }
+    mx = rows_max(mx);
+    m_row[b] = mx;
+    const float nm = -mx * scale2;
+    const unsigned rt = DROP ? drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc[b])) : 0u;
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < NKG; ++j) {
+      unsigned hp[2] = {0u, 0u};
+      if (DROP) {                                   // keys 16 j + 4 g + {0,1} and + {2,3}: one hash per pair
+        hp[0] = drop_hash_pair(rt, (unsigned)(16 * j + 4 * g));
+        hp[1] = drop_hash_pair(rt, (unsigned)(16 * j + 4 * g + 2));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][j][r], scale2, nm));
+        ps += p;                                    // the normaliser is dropout-free
+        if (DROP) {
+          const unsigned h16 = (r & 1) ? (hp[r >> 1] >> 16) : (hp[r >> 1] & 0xFFFFu);
+          p = h16 >= (a.drop.thresh >> 16) ? p * a.drop.scale : 0.f;
+        }
+        s[b][j][r] = p;
+      }
+    }
+    l_row[b] = rows_sum(ps);
+  }
+  // ---- O^T = V^T P^T over 32-key chunks (the tenth key group is the zero rows 144..159 against p = 0)
+  f32x4 o[QB][ND];
+#pragma unroll
+  for (int b = 0; b < QB; ++b)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[b][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+#pragma unroll
+  for (int st = 0; st < 5; ++st) {
+    if (32 * st < S) {                                     // uniform
+      bf16x8 pf[QB];
+#pragma unroll
+      for (int b = 0; b < QB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          pf[b][r] = (bf16)s[b][2 * st][r];
+          pf[b][4 + r] = 2 * st + 1 < NKG ? (bf16)s[b][2 * st + 1 < NKG ? 2 * st + 1 : 0][r] : (bf16)0.f;
+        }
+      const int r_lo = 32 * st + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const bf16x8 vf = tr_frag(sV + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sV + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+#pragma unroll
+        for (int b = 0; b < QB; ++b) o[b][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b], o[b][i], 0, 0, 0);
+      }
+    }
+  }
+  // ---- finish: O = O^T / l ; lse = ln2 * (m*scale2 + log2 l)  (natural-log LSE, as the backward expects)
+#pragma unroll
+  for (int b = 0; b < QB; ++b) {
+    const float inv = 1.f / l_row[b];
+    if (q[b] < S) {
+      T* orow = (T*)a.out + ((long long)n * S + q[b]) * ((long long)H * HD) + (long long)h * HD;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        f32x4 v = o[b][i] * inv;
+        Vec4<T>::store(orow + 16 * i + 4 * g, v);
+      }
+      if (g == 0 && a.lse)
+        a.lse[((long long)n * H + h) * S + q[b]] = (m_row[b] * scale2 + __builtin_amdgcn_logf(l_row[b])) * 0.6931471805599453f;
+    }
+  }
+}
+
+int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 template <int HD, bool DROP>
 static void attn_fwd_bf16_launch(const AttnArgs& a, hipStream_t st) {
+  if constexpr (HD == 64) {
+    if (a.S <= 144 && g_a2v_attn_fwd48) {
+      hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP>), dim3(1, a.H, a.N), dim3(192), AF48_LDS, st, a);
+      return;
+    }
+  }
   if (a.S >= 512) {   // long sequences (the teacher's 2000 frames): 128 query rows per workgroup
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2>), dim3((a.S + 127) / 128, a.H, a.N), dim3(256), 0, st, a);
   } else {
