@@ -47,6 +47,7 @@ struct AttnArgs {
   int N, S, H;
   float scale;
   Drop drop;                      // attention dropout on the softmax probabilities (modules.py:405)
+  int xcd_order;                  // 1: 1-D launch, query blocks of one (n, h) share an XCD (attn_fwd_bf16_kernel)
 };
 
 #define FP32_PITCH(HD) ((HD) + 4)
@@ -271,8 +272,22 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
-  const int q0 = blockIdx.x * (64 * QB), h = blockIdx.y, n = blockIdx.z;
   const int S = a.S, H = a.H;
+  int q0, h, n;
+  if (a.xcd_order) {
+    // 1-D launch, XCD-aware: workgroup ids go round-robin over the 8 XCDs, so ids with equal (id & 7) share an L2.  All query
+    // blocks of one (n, h) get ids of one residue class: its K / V (512 KB at S = 2000) are fetched into ONE L2 instead of eight
+    // (fabric reads per launch 2.26 GB -> see profiles/, 23 x the 98 MB of qkv before).
+    const int nqb = (S + 64 * QB - 1) / (64 * QB);
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int hl = (k / nqb) * 8 + xcd;
+    if (hl >= a.N * H) return;
+    q0 = (k % nqb) * (64 * QB);
+    h = hl % H;
+    n = hl / H;
+  } else {
+    q0 = blockIdx.x * (64 * QB); h = blockIdx.y; n = blockIdx.z;
+  }
   const long long rowstride = 3LL * H * HD;
   const T* qkv = (const T*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
   constexpr float LOG2E = 1.4426950408889634f;
@@ -737,9 +752,12 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
   }
 }
 
+int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 template <int HD, bool DROP>
-static void attn_fwd_bf16_launch(const AttnArgs& a, hipStream_t st) {
+static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
+  AttnArgs a = a_in;
+  a.xcd_order = 0;
   if constexpr (HD == 64) {
     if (a.S <= 144 && g_a2v_attn_fwd48) {
       hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP>), dim3(1, a.H, a.N), dim3(192), AF48_LDS, st, a);
@@ -747,7 +765,13 @@ static void attn_fwd_bf16_launch(const AttnArgs& a, hipStream_t st) {
     }
   }
   if (a.S >= 512) {   // long sequences (the teacher's 2000 frames): 128 query rows per workgroup
-    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2>), dim3((a.S + 127) / 128, a.H, a.N), dim3(256), 0, st, a);
+    const long long nqb = (a.S + 127) / 128, heads8 = ((long long)a.N * a.H + 7) / 8 * 8;
+    if (g_a2v_attn_xcd && heads8 * nqb < (1ll << 31)) {
+      a.xcd_order = 1;
+      hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2>), dim3((unsigned)(heads8 * nqb)), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2>), dim3((a.S + 127) / 128, a.H, a.N), dim3(256), 0, st, a);
+    }
   } else {
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 1>), dim3((a.S + 63) / 64, a.H, a.N), dim3(256), 0, st, a);
   }
@@ -1151,7 +1175,7 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
                                  const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
                                  unsigned drop_seed, hipStream_t stream) {
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
-  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed)};
+  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0};
   if (dtype == A2V_BF16) {
     const bool dr = a.drop.thresh != 0;
     if (HD == 64 && dr) attn_fwd_bf16_launch<64, true>(a, stream);
