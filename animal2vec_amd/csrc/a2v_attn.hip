@@ -259,9 +259,13 @@ __device__ __forceinline__ float rows_max(float v) {
 
 // QB = 16-row query blocks per wave (workgroup = 64*QB query rows): with QB = 2 every K / V fragment read from
 // LDS feeds two MFMAs -- the QB = 1 kernel was LDS-bandwidth bound (16 KB of fragment reads per 16 MFMAs).
-template <int HD, bool DROP, int QB>
+template <int HD, bool DROP, int QB, bool MSUM = false>
 __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16_kernel(AttnArgs a) {
   typedef bf16 T;
+  // MSUM (experiment, a2v_debug_set(18, 1), forward-only calls): row sums of P by a ones-MFMA over the bf16 P, -4 % time.
+  // Default: fp32 sums of the fp32 P on the VALU, as the reference's softmax -- normalised by the bf16 sums, d alibi_scale (a sum
+  // dominated by cancellation) of the 10 s / 44.1 kHz student moved from 0.16 to 0.26-0.28 relative error against the oracle.
+  constexpr bool VSUM = DROP || !MSUM;
   constexpr int ND = HD / 16;
   constexpr int NCH = HD / 8;                 // 16-B chunks per row
   constexpr int TILE_BYTES = 64 * HD * 2;
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
   AF_STORE(0);
   __syncthreads();
 
-  // row sums of P on the matrix cores (dropout-free kernels): a ones fragment as the A operand of two more MFMAs per query
+  // row sums of P on the matrix cores (MSUM kernels): a ones fragment as the A operand of two more MFMAs per query
   // block gives sum_k p[k][q] in every row of the accumulator -- 32 v_add per tile and the final cross-lane reduction leave
   // the VALU, which is what bounds this kernel (SQ_ACTIVE_INST_VALU 83 % of the SIMD's cycles at 290 VALU per tile)
   f32x4 lacc[QB];
@@ -437,6 +441,14 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
         }
       }
     }
+    if constexpr (PH == 1) {
+      // The scores of this form are MFMA results read DIRECTLY by the inline-asm v_max3 / v_max below.  hipcc inserts the wait
+      // states an XDL write needs before a VALU read (11 for this 8-pass MFMA) only in front of instructions it can see into,
+      // not inline asm: depending on the schedule the row maximum was formed from registers the last MFMAs had not written yet
+      // (garbage running maxima -> p underflow -> 0/0 with steep slopes; a build with two more live variables was correct).
+      // The pad is tied to the results of the last four MFMAs; every earlier one is > 16 issue cycles behind.
+      asm volatile("s_nop 7\n\ts_nop 4" : "+v"(s[0][3]), "+v"(s[QB - 1][3]), "+v"(s[0][2]), "+v"(s[QB - 1][2]));
+    }
     if (TAIL) {   // last tile: padded keys -> -inf
 #pragma unroll
       for (int b = 0; b < QB; ++b)
@@ -469,7 +481,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
         const float m_new = fmaxf(m_run[b], mx[b]);
         const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * scale2);
         m_run[b] = m_new;
-        if constexpr (DROP) l_run[b] *= alpha; else lacc[b] *= alpha;
+        if constexpr (VSUM) l_run[b] *= alpha; else lacc[b] *= alpha;
 #pragma unroll
         for (int i = 0; i < ND; ++i) o[b][i] *= alpha;
       }
@@ -489,15 +501,15 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(fmaf(s[b][j][r], scale2, nm));
+          if (VSUM) ps += p;                        // the normaliser is dropout-free
           if (DROP) {
-            ps += p;                                // the normaliser is dropout-free
             const unsigned h16 = (r & 1) ? (hp[r >> 1] >> 16) : (hp[r >> 1] & 0xFFFFu);
             p = h16 >= (a.drop.thresh >> 16) ? p * a.drop.scale : 0.f;
           }
           s[b][j][r] = p;
         }
       }
-      if (DROP) l_run[b] += ps;
+      if (VSUM) l_run[b] += ps;
     }
 
     // ---- O^T += V^T P^T
@@ -516,7 +528,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
 #pragma unroll
         for (int b = 0; b < QB; ++b) o[b][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b], o[b][i], 0, 0, 0);
       }
-      if constexpr (!DROP) {
+      if constexpr (!VSUM) {
 #pragma unroll
         for (int b = 0; b < QB; ++b) lacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[b], lacc[b], 0, 0, 0);
       }
@@ -551,7 +563,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
 #pragma unroll
   for (int b = 0; b < QB; ++b) {
     float l_tot;
-    if constexpr (DROP) {
+    if constexpr (VSUM) {
       l_tot = l_run[b];
       l_tot += __shfl_xor(l_tot, 16, 64);
       l_tot += __shfl_xor(l_tot, 32, 64);
@@ -752,6 +764,7 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
   }
 }
 
+int g_a2v_attn_msum = 0;     // a2v_debug_set(18, v): forward-only long-sequence calls sum P on the matrix cores (bf16 P; -4 % time, off: fp32 sums as the reference)
 int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 template <int HD, bool DROP>
@@ -766,12 +779,11 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   }
   if (a.S >= 512) {   // long sequences (the teacher's 2000 frames): 128 query rows per workgroup
     const long long nqb = (a.S + 127) / 128, heads8 = ((long long)a.N * a.H + 7) / 8 * 8;
-    if (g_a2v_attn_xcd && heads8 * nqb < (1ll << 31)) {
-      a.xcd_order = 1;
-      hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2>), dim3((unsigned)(heads8 * nqb)), dim3(256), 0, st, a);
-    } else {
-      hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2>), dim3((a.S + 127) / 128, a.H, a.N), dim3(256), 0, st, a);
-    }
+    const bool xo = g_a2v_attn_xcd && heads8 * nqb < (1ll << 31);
+    a.xcd_order = xo ? 1 : 0;
+    const dim3 grid = xo ? dim3((unsigned)(heads8 * nqb)) : dim3((a.S + 127) / 128, a.H, a.N);
+    if (!DROP && !a.lse && g_a2v_attn_msum) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, !DROP>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, false>), grid, dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 1>), dim3((a.S + 63) / 64, a.H, a.N), dim3(256), 0, st, a);
   }

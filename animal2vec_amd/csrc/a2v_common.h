@@ -87,9 +87,6 @@ template <> struct Vec8<float> {
   }
 };
 
-// 64-lane sum, result in every lane.  DPP adds inside the 16-lane rows (quad_perm, row_half_mirror, row_mirror), then
-// row_bcast15 / row_bcast31 carry the row sums up to lane 63, which is broadcast through an SGPR: six VALU ops and
-// one v_readlane instead of six dependent ds_bpermute round trips through the LDS crossbar.
 // sum over the 16 lanes of a DPP row (lanes that share lane >> 4), result in every lane of the row
 __device__ __forceinline__ float row16_sum(float v) {
 #define A2V_DPP_ADD(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
@@ -101,6 +98,9 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 
+// 64-lane sum, result in every lane.  DPP adds inside the 16-lane rows (quad_perm, row_half_mirror, row_mirror), then
+// row_bcast15 / row_bcast31 carry the row sums up to lane 63, which is broadcast through an SGPR: six VALU ops and
+// one v_readlane instead of six dependent ds_bpermute round trips through the LDS crossbar.
 __device__ __forceinline__ float wave_sum(float v) {
 #define A2V_DPP_ADD(ctrl, rmask, bctrl) \
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, bctrl))
@@ -145,32 +145,53 @@ __device__ __forceinline__ float wave_max(float v) {
 // libm's branchy erff, which made GELU epilogues as expensive as a K=1024 main loop.
 // gelu_parts: cdf = Phi(x) = 0.5 (1 + erf(x / sqrt 2)) and e = exp(-x^2 / 2) (shared by the pdf of the gradient);
 // v_rcp_f32 (1 ulp) instead of __frcp_rn, whose correctly-rounded expansion is an 11-instruction division.
-__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+// gelu_half: q = Phi(|x|) - 1/2 (in [0, 1/2)) and e = exp(-x^2 / 2).  gelu(x) = x Phi(x) = x/2 + |x| q needs no sign select;
+// Phi(x) = 1/2 + copysign(q, x).
+// FAST (bf16 epilogues of the persistent GEMM only, where the result is rounded to 8 bits): A-S 7.1.25, three terms,
+// |abs err of erf| <= 2.5e-5 -- two FMAs fewer per element in an epilogue that is VALU-bound (112 elements per lane and tile).
+template <bool FAST = false>
+__device__ __forceinline__ void gelu_half(float x, float& q, float& e) {
   const float ax = fabsf(x) * 0.70710678118654752f;
-  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);       // polynomial pre-scaled by 1/2
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
+  float p;
+  float t;
+  if (FAST) {
+    t = __builtin_amdgcn_rcpf(fmaf(0.47047f, ax, 1.f));
+    p = fmaf(0.5f * 0.7478556f, t, 0.5f * -0.0958798f);                // polynomial pre-scaled by 1/2
+    p = fmaf(p, t, 0.5f * 0.3480242f);
+  } else {
+    t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    p = fmaf(p, t, 0.5f * 1.421413741f);
+    p = fmaf(p, t, 0.5f * -0.284496736f);
+    p = fmaf(p, t, 0.5f * 0.254829592f);
+  }
   e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170f);          // exp(-x^2/2) = 2^(-x^2 log2(e) / 2)
-  const float h = p * t * e;                                          // (1 - erf(|x|/sqrt2)) / 2
-  cdf = x >= 0.f ? 1.f - h : h;
+  q = fmaf(-(p * t), e, 0.5f);                                        // 1/2 - (1 - erf(|x|/sqrt2)) / 2
+}
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+  float q;
+  gelu_half<false>(x, q, e);
+  cdf = 0.5f + copysignf(q, x);
 }
 __device__ __forceinline__ float erf_fast(float x) {
   float cdf, e;
   gelu_parts(x * 1.41421356237309505f, cdf, e);
   return 2.f * cdf - 1.f;
 }
-__device__ __forceinline__ float gelu_f(float x) {
-  float cdf, e;
-  gelu_parts(x, cdf, e);
-  return x * cdf;
+template <bool FAST = false>
+__device__ __forceinline__ float gelu_t(float x) {
+  float q, e;
+  gelu_half<FAST>(x, q, e);
+  return fmaf(fabsf(x), q, 0.5f * x);
 }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-  float cdf, e;
-  gelu_parts(x, cdf, e);
-  return fmaf(x * 0.39894228040143268f, e, cdf);
+template <bool FAST = false>
+__device__ __forceinline__ float gelu_grad_t(float x) {
+  float q, e;
+  gelu_half<FAST>(x, q, e);
+  return fmaf(x * 0.39894228040143268f, e, 0.5f + copysignf(q, x));
 }
+__device__ __forceinline__ float gelu_f(float x) { return gelu_t<false>(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<false>(x); }
 
 // Counter-based dropout (no mask tensor is ever stored): keep(seed, idx) is a pure function of a per-site
 // seed and the element's linear index, so the backward kernels regenerate exactly the forward mask.
@@ -184,8 +205,33 @@ __device__ __forceinline__ unsigned drop_hash(unsigned seed, unsigned long long 
   u ^= u >> 16; u *= 0x7FEB352Du; u ^= u >> 15; u *= 0x846CA68Bu; u ^= u >> 16;
   return u;
 }
+// One 32-bit hash decides TWO neighbouring elements (16 bits each, as the attention sites do): the mask of element idx is
+//   keep(idx) = half(idx & 1) of drop_hash(seed, idx >> 1)  >=  thresh >> 16.
+// The hash is two v_mul_lo_u32 (quarter rate) + 6 more instructions -- per element it cost as much as a GELU in the GEMM epilogues
+// (proj + residual + dropout: 163 us against 105 us for the plain product at 53760 x 1024 x 1024).
+__device__ __forceinline__ bool drop_keep(const Drop& d, unsigned long long idx) {
+  const unsigned h = drop_hash(d.seed, idx >> 1);
+  return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) >= (d.thresh >> 16);
+}
 __device__ __forceinline__ float drop_apply(const Drop& d, unsigned long long idx, float v) {
-  return drop_hash(d.seed, idx) < d.thresh ? 0.f : v * d.scale;
+  return drop_keep(d, idx) ? v * d.scale : 0.f;
+}
+// N (even) consecutive elements from e0: N/2 hashes when e0 is even (every caller's case: rows of even length, 4- or 8-element
+// groups); an odd e0 takes the per-element form of the same mask.
+template <int N>
+__device__ __forceinline__ void drop_apply_n(const Drop& d, unsigned long long e0, float* v) {
+  if (e0 & 1) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = drop_apply(d, e0 + i, v[i]);
+    return;
+  }
+  const unsigned t16 = d.thresh >> 16;
+#pragma unroll
+  for (int k = 0; k < N / 2; ++k) {
+    const unsigned h = drop_hash(d.seed, (e0 >> 1) + k);
+    v[2 * k] = (h & 0xFFFFu) >= t16 ? v[2 * k] * d.scale : 0.f;
+    v[2 * k + 1] = (h >> 16) >= t16 ? v[2 * k + 1] * d.scale : 0.f;
+  }
 }
 // Attention probabilities (N*H*S*S elements per layer, the one site where the hash itself shows up in the profile):
 // 2-D form, one hash per PAIR of adjacent key columns of a (n, h, q) row -- 16 bits per element, compared with the

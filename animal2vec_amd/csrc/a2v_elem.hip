@@ -28,8 +28,7 @@ __global__ __launch_bounds__(256) void gather_tokens_kernel(const T* __restrict_
       for (int j = 0; j < 8; ++j) x[j] += y[j];
     }
     if (drop.thresh) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) x[j] = drop_apply(drop, (unsigned long long)nk * D + v * 8 + j, x[j]);
+      drop_apply_n<8>(drop, (unsigned long long)nk * D + v * 8, x);
     }
     Vec8<T>::store(out + nk * D + v * 8, x);
   }
@@ -101,8 +100,7 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict_
     if (r < K) {
       Vec8<T>::load(x + ((long long)n * K + r) * D + v * 8, o);
       if (drop.thresh) {           // decoder input_dropout on the encoder tokens (base.py:163-165)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = drop_apply(drop, ((unsigned long long)n * K + r) * D + v * 8 + j, o[j]);
+        drop_apply_n<8>(drop, ((unsigned long long)n * K + r) * D + v * 8, o);
       }
     } else
       Vec8<float>::load(noise + ((long long)n * (Tn - K) + (r - K)) * D + v * 8, o);
@@ -266,8 +264,7 @@ __global__ __launch_bounds__(256) void add_drop_kernel(const T* __restrict__ a, 
       for (int j = 0; j < 8; ++j) vb[j] += vc[j];
     }
     if (d.thresh) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) vb[j] = drop_apply(d, (unsigned long long)(i * 8 + j), vb[j]);
+      drop_apply_n<8>(d, (unsigned long long)i * 8, vb);
     }
     if (a) {
       Vec8<T>::load(a + i * 8, va);
@@ -754,7 +751,7 @@ extern "C" int a2v_cast2d(int in_dtype, int out_dtype, const void* in, void* out
 // materialise the dropout keep-mask of linear indices [0, n) for a (p, seed) site: test / debugging aid
 __global__ void dropout_mask_kernel(unsigned char* out, long long n, Drop d) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
-    out[i] = drop_hash(d.seed, (unsigned long long)i) < d.thresh ? 0 : 1;
+    out[i] = drop_keep(d, (unsigned long long)i) ? 1 : 0;
 }
 extern "C" int a2v_dropout_mask(unsigned char* keep, long long n, float drop_p, unsigned drop_seed, hipStream_t st) {
   if (n <= 0 || !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;

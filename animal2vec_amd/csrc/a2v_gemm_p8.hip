@@ -416,8 +416,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           }
           if (g.flags & F_DROPOUT) {
             const unsigned long long e0 = (unsigned long long)(T.mc + row) * g.ldc + (unsigned long long)((long long)grp * g.c_goff + T.n0 + cl);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = drop_apply(g.drop, e0 + q, v[q]);
+            drop_apply_n<8>(g.drop, e0, v);
           }
           if (need_r) {
             float h[8];
@@ -513,7 +512,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           }
           if (g.flags & F_DROPOUT) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);   // (pair form: 10 spills at IH = 4 here)
           }
           if (need_r) {
             float h[8];
@@ -574,7 +573,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 }
 
 int g_a2v_p8_dynamic = 2;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent NT kernel (2: first tile too)
-int g_a2v_p8_stagger = 1;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels)
+int g_a2v_p8_stagger = 2;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels): 0 off, 1 only K >= 2048 (NT), 2 always
 int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swapped MFMA operands, permuted B rows) on / off
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
@@ -615,8 +614,9 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   }
   const int bm = 128 + 32 * best_ih;
   const int ntiles = cdiv(g.M, bm) * (g.N / 256);
-  // measured: staggering the wave groups pays for long K loops (K = 4096: +5..9 %, 8192^3: 1379 -> 1538 TFLOP/s) and
-  // costs a few per cent at K = 1024, where the epilogue dominates (g_a2v_p8_stagger: 0 off, 1 by shape, 2 always)
+  // staggering the wave groups: one group's epilogue (conversions, GELU, stores) runs under the other group's MFMAs.  With the
+  // LDS-staged epilogue of round 1 it cost a few per cent at K = 1024; with the direct-store epilogue it pays on every shape
+  // (53760 x 4096 x 1024: 430 -> 395 us, 13440 x 4096 x 1024: 117 -> 104 us, K = 4096 unchanged; weight gradients 407 -> 371 us)
   const int stagger = ((g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048)) ? 1 : 0) ;
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);

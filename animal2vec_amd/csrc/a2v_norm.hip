@@ -236,8 +236,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
         Vec8<T>::store(dx + row * ldx + col, o);
         if (DM == 2) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o[i] = drop_apply(drop, (unsigned long long)row * C + col + i, o[i]);
+          drop_apply_n<8>(drop, (unsigned long long)row * C + col, o);
           Vec8<T>::store(dx_drop + row * ldx + col, o);
         }
         if (dxsum) {

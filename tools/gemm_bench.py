@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--lin", action="append", default=[], help="extra plain linear shape M,N,K (repeatable)")
     ap.add_argument("--dyn", type=int, default=None, help="persistent NT kernel tile hand-out mode 0/1/2")
     ap.add_argument("--debug-set", action="append", default=[], help="key=value for a2v_debug_set")
+    ap.add_argument("--mscale", type=int, default=1, help="multiply the rows of the default Linear / wgrad shapes (4 = micro-batch 32)")
     ap.add_argument("--attn", action="append", default=[], help="extra attention shape N,S (repeatable)")
     a = ap.parse_args()
     for kv in a.debug_set:
@@ -67,6 +68,8 @@ def main():
     def lin(name, M, N, K, **kw):
         if a.only and a.only not in name:
             return
+        if not name.startswith("lin ") and not name.startswith("big"):
+            M *= a.mscale
         x, w = rn(M, K), rn(N, K) * K ** -0.5
         bias = torch.randn(N, device=dev)
         extra = {}
@@ -89,6 +92,7 @@ def main():
     def wgrad(name, M, N, K):
         if a.only and a.only not in name:
             return
+        M *= a.mscale
         x, dy = rn(M, K), rn(M, N)
         gw = torch.zeros(N, K, device=dev)
         ms = timeit(lambda: ops.linear_wgrad(x, dy, gw), a.reps)
