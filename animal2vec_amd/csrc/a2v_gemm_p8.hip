@@ -78,6 +78,13 @@ struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B ch
 // IH = 16-row MFMA tiles per wave in the upper A half: the workgroup tile is BM = 128 + 32 IH rows (256 / 224 / 192).
 // M = 13440 (96 clips x 140 kept frames) is 60 x 224: with BM = 224 the student's Linears fill 240 of 256 CUs per
 // round with no M tail, 12.5 % less work per round than 53 ragged 256-row tiles.
+// loads + stores issued in row blocks [b0, b1) of the direct-store epilogue after a given residual load: each block issues the
+// load RQ blocks ahead (while one exists) and one store
+__host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, int NT) {
+  int n = 0;
+  for (int b = b0; b < b1; ++b) n += (b + RQ < NT ? 1 : 0) + 1;
+  return n;
+}
 // DS ("direct store") = the epilogue writes the accumulators straight to global memory, no LDS staging: the MFMA
 // operands are swapped (D = W_frag x X_frag, so a lane holds 4 consecutive output COLUMNS of one row instead of 4 rows
 // of one column) and the rows of every 32-row group of the B half-tiles are permuted when they are staged (LDS row
@@ -318,15 +325,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     } else {
       seq_next = seq + (int)gridDim.x;
     }
-    // Claim the tile after the next one now: an atomic written in C++ is rewritten by the compiler's atomic optimizer into
-    // a wave-wide form whose result it consumes at once, i.e. s_waitcnt vmcnt(0) -- every DMA in flight -- right where
-    // the atomic is issued.  As raw asm it simply returns under the next two K-tiles (their vmcnt(6) waits retire it).
-    if (dynamic && tid == 0) {
-      const unsigned one = 1u, zoff = 0u;
-      // s_nop 4: the pointer's SGPRs may have just been restored by v_readlane (SGPR spill); a VMEM instruction reading an
-      // SGPR written by VALU needs 5 wait states, which the compiler only inserts around instructions it can see
-      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zoff), "v"(one), "s"(&g_p8_ctr[xcd]) : "memory");
-    }
     const bool has_next = seq_next < ntiles;
     P8Tile Tn = T;
     if constexpr (DS) {
@@ -360,9 +358,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     // ---- epilogue (overlaps the LDS-DMA already in flight for the next tile): 8 passes of 16 rows per wave
     // lane-derived values are re-formed from an opaque copy of the lane id: hoisted out of the tile loop they
     // would be live -- and spilled -- across the K loop, and a spill reload is a VMEM load whose wait drains the DMA
-    // `fetched` (claimed before the last two K-tiles, below) has been back since their counted waits; the opaque pass
-    // through keeps every use of it behind those waits
-    asm volatile("" : "+v"(fetched));
+    // Claim the tile after the next one HERE, at the top of the epilogue, as a raw-asm returning atomic (written in C++ the
+    // compiler's atomic optimizer turns it into a wave-wide form whose result it consumes at once: s_waitcnt vmcnt(0), every DMA
+    // in flight, right where it is issued).  Its result lands in `fetched` asynchronously; the counted wait in front of the slot
+    // publication at the end of the epilogue (at least 9 vector-memory operations later: the tile's stores) retires it.  It used to
+    // be issued two K-tiles earlier so that the K loop's own waits retired it -- but then the register had to survive the most
+    // register-starved stretch of the kernel untouched, and hipcc once split its live range there (a v_mov read it before the
+    // atomic had returned, the stale copy came back afterwards: repeating tile ids, a launch that never ends).  In the epilogue the
+    // 64 fragment registers are free; tests/test_abi.py still checks in the ISA that nothing touches the register in between.
+    if (dynamic && tid == 0) {
+      const unsigned one = 1u, zoff = 0u;
+      // s_nop 4: the pointer's SGPRs may have just been restored by v_readlane (SGPR spill); a VMEM instruction reading an
+      // SGPR written by VALU needs 5 wait states, which the compiler only inserts around instructions it can see
+      asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zoff), "v"(one), "s"(&g_p8_ctr[xcd]) : "memory");
+    }
     int le = lane;
     asm volatile("" : "+v"(le));
     bf16* const C = (bf16*)g.C;
@@ -379,24 +388,50 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       const bf16* const Rt = R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0);
       const int rskip = T.m0 - T.mc;                        // the shifted last m-tile: rows below m0 belong to its neighbour
       const int rlo = wr * 64 + fre, rhi = 128 + wr * IH * 16 + fre;
-      // Residual / pre-activation rows are fetched RQ row blocks ahead of their use.  Loads, stores and the
-      // LDS-DMA share one in-order counter (vmcnt): a load issued after a store cannot be waited for without waiting for
-      // that store's acknowledgement too, which serialised the staged epilogue on memory latency (one round trip per
-      // 16-row pass).  Stores are unconditional: the rows a shifted last m-tile shares with its neighbour are computed
-      // from the same operands in the same order, so both write the same bits (the launcher refuses C overlapping R).
+      // Residual / pre-activation rows are fetched RQ row blocks ahead of their use, across both column halves (2 NB row blocks
+      // form one sequence).  Loads, stores, atomics and the LDS-DMA share ONE in-order counter (vmcnt): the data of a load issued
+      // behind a store is only there once that store is acknowledged.  hipcc, which must assume the two kinds complete out of
+      // order, waits with vmcnt(0) wherever both are pending -- that sat out the acknowledgement of the store issued just before
+      // (and, at the top of the epilogue, the next tile's LDS-DMA) in front of every residual row block: +6 us on a 20 us K = 1024
+      // tile.  The residual loads are therefore raw asm (invisible to the compiler's bookkeeping) with hand-counted waits:
+      // vmcnt(P8_RN(k)) = the number of vector-memory operations certainly issued after load k (later residual loads + one store
+      // per finished row block; anything more -- the pre-activation store, column sums -- only makes the wait stronger than needed).
+      // Both halves' bias vectors are read before the first store for the same reason.  Stores are unconditional: the rows a
+      // shifted last m-tile shares with its neighbour are computed from the same operands in the same order, so both write the
+      // same bits (the launcher refuses C overlapping R).
       constexpr int RQ = IH == 4 ? 2 : 4;    // residual row blocks in flight (4 VGPRs each; the 256-row tile has fewer to spare)
-      Raw8<bf16> rq[RQ];
+      constexpr int NB = 4 + IH, NT = 2 * NB;
+      typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
+      p8_u32x4 rq[RQ];                       // (a native vector: asm operands cannot be members of the HIP uint4 struct)
 #define P8_DROW(i_) ((i_) < 4 ? rlo + (i_) * 16 : rhi + ((i_) - 4) * 16)
+      // (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, as the compiler's own loads here; s_nop: the base may have
+      //  just been written by v_readfirstlane / v_readlane, and a VMEM instruction reading such an SGPR needs 5 wait states)
+#define P8_ROFF(k_) ((unsigned)(P8_DROW((k_) % NB) * (int)g.ldr + ((k_) / NB) * 128 + wc * 32 + fqe * 8) * 2u)
+#define P8_RLOAD(k_) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(rq[(k_) % RQ]) : "v"(P8_ROFF(k_)), "s"(Rt) : "memory")
+      // operations issued after residual load k and before its use in row block k (see above)
+#define P8_RN(k_) ((k_) < RQ ? (RQ - 1 - (k_)) + p8_later((k_) , 0, (k_), RQ, NT) : 1 + p8_later((k_), (k_) - RQ + 1, (k_), RQ, NT))
+      if (need_r) {
+#pragma unroll
+        for (int k = 0; k < RQ; ++k) {
+          P8_RLOAD(k);
+        }
+      }
+      float bias16[2][8];
+      {
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bias16[hb][q] = 0.f;
+          if (g.flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + T.n0 + hb * 128 + wc * 32 + fqe * 8, bias16[hb]);
+        }
+      }
 #pragma unroll
       for (int hb = 0; hb < 2; ++hb) {
         const int cl = hb * 128 + wc * 32 + fqe * 8;          // column inside the tile
-        if (need_r) {
-#pragma unroll
-          for (int i = 0; i < RQ; ++i) rq[i].load(Rt + (unsigned)(P8_DROW(i) * (int)g.ldr + cl));
-        }
         __builtin_amdgcn_sched_barrier(0);
-        float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (g.flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + T.n0 + cl, bias8);
+        float bias8[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bias8[q] = bias16[hb][q];
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(bias8[i]));     // consumed here (see the staged form below)
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -420,8 +455,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           }
           if (need_r) {
             float h[8];
-            rq[i % RQ].unpack(h);
-            if (i + RQ < 4 + IH) rq[i % RQ].load(Rt + (unsigned)(P8_DROW(i + RQ) * (int)g.ldr + cl));   // RQ blocks ahead
+            const int k = hb * NB + i;
+            asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rq[k % RQ]) : "n"(P8_RN(k)) : "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              h[2 * q] = __uint_as_float(rq[k % RQ][q] << 16);
+              h[2 * q + 1] = __uint_as_float(rq[k % RQ][q] & 0xffff0000u);
+            }
+            if (k + RQ < NT) P8_RLOAD(k + RQ);              // RQ row blocks ahead
             if (g.flags & F_RES) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] += h[q];
@@ -456,6 +497,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
         }
       }
 #undef P8_DROW
+#undef P8_ROFF
+#undef P8_RLOAD
+#undef P8_RN
     } else {
     const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
     const int er = le >> 3, ec = (le & 7) * 8;           // read-out: 8 rows x 8 lanes, 8 columns (16 B of bf16) per lane
@@ -559,7 +603,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     }
 #undef P8_RLOAD
     }
-    if (dynamic && tid == 0) *slot = id_base + 8u * fetched + xcd;     // read by every wave at the next tile's tail, many barriers later
+    if (dynamic && tid == 0) {
+      asm volatile("s_waitcnt vmcnt(8)" : "+v"(fetched) :: "memory");   // (>= 12 stores were issued after the claim)
+      *slot = id_base + 8u * fetched + xcd;                              // read by every wave at the next tile's tail, many barriers later
+    }
     T = Tn;
   }
   if (dynamic && tid == 0) {

@@ -107,3 +107,41 @@ def test_oracle_guard_catches_split_strings(tmp_path):
     assert len(_oracle_uses(str(p))) == 2
     p.write_text('import numpy as np\nx = "the oracle says"\n')
     assert not _oracle_uses(str(p))
+
+
+def test_p8_tile_claim_register_is_untouched_until_its_wait(tmp_path):
+    """The persistent 8-phase NT GEMM claims the tile after the next one with a raw-asm returning atomic at the top of the epilogue;
+    the result lands in a VGPR asynchronously and is retired by a hand-counted `s_waitcnt vmcnt(8)` in front of the slot
+    publication at the end of the epilogue.  hipcc does not know the register is in flight: if it splits that value's live range,
+    a v_mov reads the register BEFORE the atomic has returned and moves the stale copy back afterwards -- tile ids repeat and the
+    launch never ends (seen once, with the claim still issued two K-tiles before the seam, when the 256-row tile's epilogue grew by
+    eight live registers).  So the ISA of every variant is checked: the first instruction that names the claim's destination
+    register after the atomic must come after that counted wait."""
+    import shutil
+    import subprocess
+    import pytest
+    from animal2vec_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    checked = 0
+    src = "a2v_gemm_p8.hip"
+    out = tmp_path / (src + ".s")
+    cmd = [hipcc, *B.FLAGS, *B.FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = out.read_text()
+    for m in re.finditer(r"^(_Z\d+gemm_nt_bf16_p8_kernel\w*):", s, re.M):
+        body = s[m.end():s.index("s_endpgm", m.end())]
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        mfma = [i for i, l in enumerate(lines) if l.startswith("v_mfma")]
+        for n, t in enumerate(lines):
+            mm = re.match(r"global_atomic_add (v\d+), v\d+, v\d+, s\[\d+:\d+\] sc0$", t)
+            if not mm or not mfma or n < mfma[0]:
+                continue                                   # (the claims in front of the tile loop are waited for at once)
+            reg = mm.group(1)
+            first_use = next(i for i, l in enumerate(lines) if i > n and re.search(r"\b" + reg + r"\b", l))
+            waits = [i for i in range(n + 1, first_use) if lines[i] == "s_waitcnt vmcnt(8)"]
+            assert waits, (m.group(1), reg, n, first_use, lines[first_use])
+            checked += 1
+    assert checked == 6          # three tile heights x two epilogue forms
