@@ -604,7 +604,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #undef P8_RLOAD
     }
     if (dynamic && tid == 0) {
-      asm volatile("s_waitcnt vmcnt(8)" : "+v"(fetched) :: "memory");   // (>= 12 stores were issued after the claim)
+      // (the direct-store epilogue issued 2 (4 + IH) stores after the claim, the staged one 16: all but the oldest two may stay
+      //  in flight -- waiting for more of them is waiting for store acknowledgements on wave 0, and so on every barrier after it)
+      constexpr int CLAIM_N = DS ? 2 * (4 + IH) - 2 : 8;
+      asm volatile("s_waitcnt vmcnt(%1)" : "+v"(fetched) : "n"(CLAIM_N) : "memory");
       *slot = id_base + 8u * fetched + xcd;                              // read by every wave at the next tile's tail, many barriers later
     }
     T = Tn;
