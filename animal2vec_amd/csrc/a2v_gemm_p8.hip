@@ -379,6 +379,14 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     const bf16* const R = (const bf16*)g.R;
     const bool need_r = (g.flags & (F_RES | F_GELU_BWD)) != 0;
     if constexpr (DS) {
+      // The two wave groups share ONE workgroup barrier and run one barrier apart.  Without a barrier inside the epilogue, the
+      // group that gets here first stops arriving at barriers, so the other group's last barrier waits for this group's WHOLE
+      // epilogue, and then this group's first barrier of the next tile waits for the other's: the two epilogues ran one after
+      // the other (s_memtime stamps: 2 x 3.1 us on a 27 us K = 1024 tile).  One extra barrier per tile -- taken BEFORE the
+      // epilogue by the leading group (wr = 0) and AFTER it by the trailing one -- pairs the leader's with the trailer's last
+      // K-loop barrier and the trailer's with the leader's first barrier of the next tile: both epilogues run at the same time,
+      // two latency-bound waves per SIMD.  (Every wave executes exactly one of the two: the counts stay equal.)
+      if (!(stagger & 1) || wr == 0) __builtin_amdgcn_s_barrier();
       // lane (fq, fr) holds, for row block i and column half hb: row i*16 + fr, columns hb*128 + wc*32 + 8 fq + [0, 8).
       // Addresses: a uniform 64-bit tile base (SGPRs) + a 32-bit per-lane element offset inside the tile's rows.
       const int fre = le & 15, fqe = le >> 4;
@@ -500,6 +508,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #undef P8_ROFF
 #undef P8_RLOAD
 #undef P8_RN
+      if ((stagger & 1) && wr == 1) __builtin_amdgcn_s_barrier();     // the trailing group's half of the epilogue barrier (see above)
     } else {
     const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
     const int er = le >> 3, ec = (le & 7) * 8;           // read-out: 8 rows x 8 lanes, 8 columns (16 B of bf16) per lane
