@@ -48,6 +48,7 @@ struct AttnArgs {
   float scale;
   Drop drop;                      // attention dropout on the softmax probabilities (modules.py:405)
   int xcd_order;                  // 1: 1-D launch, query blocks of one (n, h) share an XCD (attn_fwd_bf16_kernel)
+  const float* qk_bound;          // (N, H) upper bound of |q_i . k_j| * scale per (n, h), or nullptr: ALiBi band limit (below)
 };
 
 #define FP32_PITCH(HD) ((HD) + 4)
@@ -287,8 +288,9 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
     const int hl = (k / nqb) * 8 + xcd;
     if (hl >= a.N * H) return;
     q0 = (k % nqb) * (64 * QB);
-    h = hl % H;
     n = hl / H;
+    h = (hl % H + n) % H;        // rotate the heads over the XCDs from clip to clip: with the ALiBi band limit a head's work goes
+                                 // with its slope, and a fixed head -> XCD map left the XCDs of the steep heads idle early
   } else {
     q0 = blockIdx.x * (64 * QB); h = blockIdx.y; n = blockIdx.z;
   }
@@ -331,6 +333,26 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
   const bool sorted = a.pos == nullptr;
   const int kd0 = sorted ? min(q0 / 64, ntile) : 0;             // tiles [kd0, kd1) overlap the query rows
   const int kd1 = sorted ? min(q0 / 64 + QB, ntile) : ntile;
+  // ---- ALiBi band limit (positions = arange, a.qk_bound given).  With B >= |q_i . k_j| scale for every pair of this (n, h) and
+  // c = slope_h max(alibi_scale_h, 0), a key j at distance |i - j| > d scores s_ij <= B - c d while the row's own diagonal key
+  // scores s_ii >= -B: its softmax weight is below exp(2B - c d) of the row sum.  Beyond d_cut = (2B + 32) / c that is e^-32 per key,
+  // 3e-11 of the row sum over 2000 keys -- three orders below one fp32 ulp of the sums the reference forms -- so key tiles wholly beyond
+  // d_cut of every query row of this workgroup are not visited.  B comes from the row norms (attn_qk_bound_kernel), so the limit
+  // is a bound, not a heuristic: it follows the learned alibi_scale and the data (c -> 0 or large B: every tile is visited).
+  int kt_lo = 0, kt_end = ntile;
+  if (sorted && a.qk_bound) {
+    const float c_nat = a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f);
+    if (c_nat > 0.f) {
+      const float dcut = (2.f * a.qk_bound[(long long)n * H + h] + 32.f) / c_nat;
+      if (dcut < 1.0e6f) {
+        const int dc = (int)dcut + 1;
+        kt_lo = max(0, (q0 - dc) / 64);
+        kt_end = min(ntile, (q0 + 64 * QB - 1 + dc) / 64 + 1);
+        kt_lo = min(kt_lo, kd0);                                // (the tiles that overlap the query rows are always visited)
+        kt_end = max(kt_end, kd1);
+      }
+    }
+  }
   const float qref = (float)q0;
   float pmul = 1.f, padd = 0.f;                                 // uniform: sPos = pmul * pos + padd for the tile being fetched
   auto pos_form = [&](int kt_) {
@@ -387,8 +409,8 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
       sPos[buf_][tid] = fmaf(a.pos ? (float)praw : (float)kv, pmul, padd);                        \
     }                                                                                             \
   }
-  AF_LOAD(0);
-  AF_STORE(0);
+  AF_LOAD(kt_lo);
+  AF_STORE(kt_lo);
   __syncthreads();
 
   // row sums of P on the matrix cores (MSUM kernels): a ones fragment as the A operand of two more MFMAs per query
@@ -409,7 +431,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
     constexpr bool TAIL = decltype(tail_tag)::value;
     const int buf = kt & 1;
     const int kv0 = kt * 64;
-    const bool more = kt + 1 < ntile;
+    const bool more = kt + 1 < kt_end;
     if (more) AF_LOAD(kt + 1);
     const char* const bK = sK[buf];
     const char* const bV = sV[buf];
@@ -540,7 +562,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
   typedef std::integral_constant<int, 0> PhAbs;
   typedef std::integral_constant<int, 1> PhKey;
   {
-    int kt = 0;
+    int kt = kt_lo;
     for (; kt < kd0; ++kt) key_tile(kt, PhKey{}, std::false_type{});            // before the query rows: always whole tiles
     if (kd0 > 0) {                                                               // units t' -> t
 #pragma unroll
@@ -548,11 +570,11 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
     }
     for (; kt < min(kd1, nfull); ++kt) key_tile(kt, PhAbs{}, std::false_type{});
     if (kt < kd1) { key_tile(kt, PhAbs{}, std::true_type{}); ++kt; }
-    if (kt < ntile) {                                                            // units t -> t''
+    if (kt < kt_end) {                                                           // units t -> t''
 #pragma unroll
       for (int b = 0; b < QB; ++b) m_run[b] += c_rel * (pos_q[b] - qref);
-      for (; kt < nfull; ++kt) key_tile(kt, PhKey{}, std::false_type{});
-      if (kt < ntile) key_tile(kt, PhKey{}, std::true_type{});
+      for (; kt < min(nfull, kt_end); ++kt) key_tile(kt, PhKey{}, std::false_type{});
+      if (kt < kt_end) key_tile(kt, PhKey{}, std::true_type{});               // (kt == nfull < ntile: the ragged last tile)
 #pragma unroll
       for (int b = 0; b < QB; ++b) m_run[b] -= c_rel * (pos_q[b] - qref);        // back to true units for the LSE
     }
@@ -767,6 +789,41 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
 int g_a2v_attn_msum = 0;     // a2v_debug_set(18, v): forward-only long-sequence calls sum P on the matrix cores (bf16 P; -4 % time, off: fp32 sums as the reference)
 int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
+// Upper bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i| * max_j |k_j| * scale (Cauchy-Schwarz), + 1 %.
+// One workgroup per (n, h); 8 lanes share a row (16 B each).  Reads q and k once: 65 MB at 32 x 2000 x 16 heads, ~20 us.
+#define A2V_QKB_MAX 65536
+__device__ float g_qk_bound_all[A2V_MAX_STREAMS][A2V_QKB_MAX];
+template <int HD>
+__global__ __launch_bounds__(256) void attn_qk_bound_kernel(const bf16* __restrict__ qkv, float* __restrict__ bound, int S, int H, float scale) {
+  static_assert(HD == 64, "8 lanes x 8 elements per row");
+  __shared__ float red[2][4];
+  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+  const long long rowstride = 3LL * H * HD;
+  const bf16* base = qkv + (long long)n * S * rowstride + (long long)h * HD + (tid & 7) * 8;
+  float mq = 0.f, mk = 0.f;
+  for (int r = tid >> 3; r < S; r += 32) {
+    const bf16x8 qv = *(const bf16x8*)(base + (long long)r * rowstride);
+    const bf16x8 kv = *(const bf16x8*)(base + (long long)r * rowstride + (long long)H * HD);
+    float sq = 0.f, sk = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float a_ = (float)qv[i], b_ = (float)kv[i]; sq += a_ * a_; sk += b_ * b_; }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { sq += __shfl_xor(sq, o, 64); sk += __shfl_xor(sk, o, 64); }
+    mq = fmaxf(mq, sq);
+    mk = fmaxf(mk, sk);
+  }
+  mq = wave_max(mq);
+  mk = wave_max(mk);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = mq; red[1][tid >> 6] = mk; }
+  __syncthreads();
+  if (tid == 0) {
+    const float q2 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    const float k2 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    bound[(long long)n * H + h] = sqrtf(q2 * k2) * scale * 1.01f;
+  }
+}
+int g_a2v_attn_band = 1;     // a2v_debug_set(19, v): ALiBi band limit of the long-sequence forward (positions = arange) on / off
+
 template <int HD, bool DROP>
 static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
@@ -779,6 +836,17 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   }
   if (a.S >= 512) {   // long sequences (the teacher's 2000 frames): 128 query rows per workgroup
     const long long nqb = (a.S + 127) / 128, heads8 = ((long long)a.N * a.H + 7) / 8 * 8;
+    a.qk_bound = nullptr;
+    if constexpr (HD == 64) {
+      const int ws = (g_a2v_attn_band && !a.pos && (long long)a.N * a.H <= A2V_QKB_MAX) ? a2v_stream_slot(st) : -1;
+      if (ws >= 0) {
+        static float* bp0 = nullptr;                 // (device address of the scratch: looked up once per process)
+        if (!bp0) (void)hipGetSymbolAddress((void**)&bp0, HIP_SYMBOL(g_qk_bound_all));
+        float* const bp = bp0 + (long long)ws * A2V_QKB_MAX;
+        hipLaunchKernelGGL((attn_qk_bound_kernel<64>), dim3(a.H, a.N), dim3(256), 0, st, (const bf16*)a.qkv, bp, a.S, a.H, a.scale);
+        a.qk_bound = bp;
+      }
+    }
     const bool xo = g_a2v_attn_xcd && heads8 * nqb < (1ll << 31);
     a.xcd_order = xo ? 1 : 0;
     const dim3 grid = xo ? dim3((unsigned)(heads8 * nqb)) : dim3((a.S + 127) / 128, a.H, a.N);
@@ -1187,7 +1255,7 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
                                  const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
                                  unsigned drop_seed, hipStream_t stream) {
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
-  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0};
+  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr};
   if (dtype == A2V_BF16) {
     const bool dr = a.drop.thresh != 0;
     if (HD == 64 && dr) attn_fwd_bf16_launch<64, true>(a, stream);

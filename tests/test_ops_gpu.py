@@ -479,6 +479,26 @@ def test_attention_teacher_arange_long(ops, dtype, S):
     assert rel_err(out2.float(), attn_ref(qkv, pos, slopes, sc2, H)) < tol(dtype, 2)
 
 
+@pytest.mark.parametrize("S", [700, 2000])
+def test_attention_alibi_band_limit_changes_nothing(ops, S):
+    """positions = arange, S >= 512: key tiles beyond d_cut = (2B + 32) / (slope * alibi_scale) of every query row of a workgroup are
+    skipped (B = bound of |q.k| scale from the row norms, attn_qk_bound_kernel).  The skipped softmax weights are below e^-32 of
+    the row sum, so the output and the lse must agree with the all-tiles run to fp32 round-off -- whatever the slopes (steep:
+    most tiles skipped; flat / zero scale: none)."""
+    N, H, hd = 2, 4, 64
+    qkv = dev(rnd(N, S, 3 * H * hd, dtype=torch.bfloat16, seed=11) * 1.5, torch.bfloat16)
+    slopes = torch.tensor(O.alibi_slopes(H)).cuda()
+    for sc in ([1.0, 1.0, 1.0, 1.0], [40.0, 3.0, 0.0, -1.0], [0.02, 0.2, 8.0, 1.0]):
+        scd = torch.tensor(sc).cuda()
+        ops.debug_set(19, 1)
+        o1, l1 = ops.attention_fwd(qkv, None, slopes, scd, H, need_lse=True)
+        ops.debug_set(19, 0)
+        o0, l0 = ops.attention_fwd(qkv, None, slopes, scd, H, need_lse=True)
+        ops.debug_set(19, 1)
+        assert torch.equal(o1, o0), sc                      # bf16 outputs: bit-identical
+        assert (l1 - l0).abs().max() < 1e-5, sc
+
+
 # ------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C_,act,affine", [(64, 0, True), (512, 1, True), (1024, 0, True), (768, 1, False), (32, 1, True)])
