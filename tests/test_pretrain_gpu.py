@@ -703,9 +703,11 @@ def test_long_sequence_pretrain_vs_oracle(dtype, tol_y, tol_g, L, T_want):
                   decoder_out=rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]))
     # d alibi_scale = -sum_ij dS_ij |i - j| is a pure cancellation: the rows of dS sum to zero only as far as
     # delta_i = rowsum(dO * O) matches sum_j P_ij dP_ij of the recomputed P, and O is stored in bf16 -- the 2^-9 mismatch is
-    # multiplied by the mean attended distance, which grows with the sequence (measured 3.4e-2 at T = 5513, 1.6e-1 at
-    # T = 11025; every other gradient stays below 3.5e-2, profiles/r02_parity_report.jsonl)
-    named = {"modality_encoders.AUDIO.alibi_scale": 8e-2 if T < 8000 else 2.5e-1} if dtype == torch.bfloat16 else {}
+    # multiplied by the mean attended distance, which grows with the sequence (measured 3.4e-2 at T = 5513; at T = 11025 between
+    # 1.6e-1 and 2.8e-1 over builds that differ only in last-bit rounding of the forward -- fp32 vs bf16 softmax sums, the order in
+    # which the teacher visits key tiles --: an ill-conditioned sum of 16 numbers, which the fp32 mode reproduces to 1e-3; every
+    # other gradient stays below 3.5e-2, profiles/r02_parity_report.jsonl)
+    named = {"modality_encoders.AUDIO.alibi_scale": 8e-2 if T < 8000 else 3.5e-1} if dtype == torch.bfloat16 else {}
     bad = [(e, k) for e, k in errs if e >= named.get(k, tol_g)]
     assert not bad, bad[:8]
 
