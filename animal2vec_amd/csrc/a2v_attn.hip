@@ -48,10 +48,11 @@ struct AttnArgs {
   float scale;
   Drop drop;                      // attention dropout on the softmax probabilities (modules.py:405)
   int xcd_order;                  // 1: 1-D launch, query blocks of one (n, h) share an XCD (attn_fwd_bf16_kernel)
-  const float* qk_bound;          // (N, H) upper bound of |q_i . k_j| * scale per (n, h), or nullptr: ALiBi band limit (below)
+  const float* qk_bound;          // (SPLIT, N, H, 2): max |q_i|^2 and max |k_j|^2 per (n, h) and row range, or nullptr: ALiBi band limit
 };
 
 #define FP32_PITCH(HD) ((HD) + 4)
+#define A2V_QKB_SPLIT 16           // row ranges of attn_qk_bound_kernel (ALiBi band limit of the long-sequence forward)
 
 // =============================================================================================
 //                                            forward
@@ -343,7 +344,15 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
   if (sorted && a.qk_bound) {
     const float c_nat = a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f);
     if (c_nat > 0.f) {
-      const float dcut = (2.f * a.qk_bound[(long long)n * H + h] + 32.f) / c_nat;
+      float q2 = 0.f, k2 = 0.f;
+#pragma unroll
+      for (int z = 0; z < A2V_QKB_SPLIT; ++z) {
+        const float* const bz = a.qk_bound + (((long long)z * a.N + n) * H + h) * 2;
+        q2 = fmaxf(q2, bz[0]);
+        k2 = fmaxf(k2, bz[1]);
+      }
+      const float bnd = sqrtf(q2 * k2) * a.scale * 1.01f;       // Cauchy-Schwarz, + 1 %
+      const float dcut = (2.f * bnd + 32.f) / c_nat;
       if (dcut < 1.0e6f) {
         const int dc = (int)dcut + 1;
         kt_lo = max(0, (q0 - dc) / 64);
@@ -789,37 +798,49 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
 int g_a2v_attn_msum = 0;     // a2v_debug_set(18, v): forward-only long-sequence calls sum P on the matrix cores (bf16 P; -4 % time, off: fp32 sums as the reference)
 int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
-// Upper bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i| * max_j |k_j| * scale (Cauchy-Schwarz), + 1 %.
-// One workgroup per (n, h); 8 lanes share a row (16 B each).  Reads q and k once: 65 MB at 32 x 2000 x 16 heads, ~20 us.
+// Ingredients of the bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i|^2 and max_j |k_j|^2 (Cauchy-Schwarz in
+// the attention kernel).  8 lanes share a row (16 B each); reads q and k once: 65 MB at 32 x 2000 x 16 heads.
 #define A2V_QKB_MAX 65536
 __device__ float g_qk_bound_all[A2V_MAX_STREAMS][A2V_QKB_MAX];
 template <int HD>
-__global__ __launch_bounds__(256) void attn_qk_bound_kernel(const bf16* __restrict__ qkv, float* __restrict__ bound, int S, int H, float scale) {
-  static_assert(HD == 64, "8 lanes x 8 elements per row");
-  __shared__ float red[2][4];
-  const int h = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void attn_qk_bound_kernel(const bf16* __restrict__ qkv, float* __restrict__ bound, int S, int H) {
+  static_assert(HD == 64, "8 lanes x 8 elements per head row");
+  // One workgroup = one clip (blockIdx.y) x one of A2V_QKB_SPLIT row ranges (blockIdx.x); a thread owns one 16-B chunk of the
+  // [q | k] part of a row -- 2 x H x 8 chunks, read as one contiguous 4-KB piece per row at H = 16 (per-head workgroups read
+  // 128-B pieces at a 6-KB stride: 1.3 TB/s) -- and keeps the running maximum of its head's |q|^2 or |k|^2 over the rows.
+  const int n = blockIdx.y, tid = threadIdx.x;
+  const int nch = 16 * H;                                  // chunks of q and of k per row: 8 H each
+  const int rows_z = (S + A2V_QKB_SPLIT - 1) / A2V_QKB_SPLIT;
+  const int rbeg = blockIdx.x * rows_z, rend = min(S, rbeg + rows_z);
   const long long rowstride = 3LL * H * HD;
-  const bf16* base = qkv + (long long)n * S * rowstride + (long long)h * HD + (tid & 7) * 8;
-  float mq = 0.f, mk = 0.f;
-  for (int r = tid >> 3; r < S; r += 32) {
-    const bf16x8 qv = *(const bf16x8*)(base + (long long)r * rowstride);
-    const bf16x8 kv = *(const bf16x8*)(base + (long long)r * rowstride + (long long)H * HD);
-    float sq = 0.f, sk = 0.f;
+  for (int c = tid; c < nch; c += 256) {
+    const bf16* base = qkv + (long long)n * S * rowstride + c * 8;      // q chunks 0 .. 8H-1, k chunks 8H .. 16H-1: contiguous
+    float mx = 0.f;
+    for (int r0 = rbeg; r0 < rend; r0 += 8) {              // eight rows' loads in flight (rows past the range repeat its last row)
+      bf16x8 v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { const float a_ = (float)qv[i], b_ = (float)kv[i]; sq += a_ * a_; sk += b_ * b_; }
+      for (int u = 0; u < 8; ++u) v[u] = *(const bf16x8*)(base + (long long)min(r0 + u, rend - 1) * rowstride);
 #pragma unroll
-    for (int o = 1; o < 8; o <<= 1) { sq += __shfl_xor(sq, o, 64); sk += __shfl_xor(sk, o, 64); }
-    mq = fmaxf(mq, sq);
-    mk = fmaxf(mk, sk);
-  }
-  mq = wave_max(mq);
-  mk = wave_max(mk);
-  if ((tid & 63) == 0) { red[0][tid >> 6] = mq; red[1][tid >> 6] = mk; }
-  __syncthreads();
-  if (tid == 0) {
-    const float q2 = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    const float k2 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-    bound[(long long)n * H + h] = sqrtf(q2 * k2) * scale * 1.01f;
+      for (int u = 0; u < 8; ++u) {
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float a_ = (float)v[u][i]; sq += a_ * a_; }
+        // sum over the 8 lanes of the head row on the VALU (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror)
+#define QKB_DPP_ADD(ctrl) sq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), ctrl, 0xF, 0xF, true))
+        QKB_DPP_ADD(0xB1);
+        QKB_DPP_ADD(0x4E);
+        QKB_DPP_ADD(0x141);
+#undef QKB_DPP_ADD
+        mx = fmaxf(mx, sq);
+      }
+    }
+    if ((c & 7) == 0 && rbeg < rend) {
+      const int h = (c >> 3) % H, which = (c >> 3) / H;    // 0: q, 1: k
+      bound[(((long long)blockIdx.x * gridDim.y + n) * H + h) * 2 + which] = mx;
+    } else if ((c & 7) == 0) {
+      const int h = (c >> 3) % H, which = (c >> 3) / H;
+      bound[(((long long)blockIdx.x * gridDim.y + n) * H + h) * 2 + which] = 0.f;
+    }
   }
 }
 int g_a2v_attn_band = 1;     // a2v_debug_set(19, v): ALiBi band limit of the long-sequence forward (positions = arange) on / off
@@ -838,12 +859,12 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
     const long long nqb = (a.S + 127) / 128, heads8 = ((long long)a.N * a.H + 7) / 8 * 8;
     a.qk_bound = nullptr;
     if constexpr (HD == 64) {
-      const int ws = (g_a2v_attn_band && !a.pos && (long long)a.N * a.H <= A2V_QKB_MAX) ? a2v_stream_slot(st) : -1;
+      const int ws = (g_a2v_attn_band && !a.pos && (long long)a.N * a.H * 2 * A2V_QKB_SPLIT <= A2V_QKB_MAX) ? a2v_stream_slot(st) : -1;
       if (ws >= 0) {
         static float* bp0 = nullptr;                 // (device address of the scratch: looked up once per process)
         if (!bp0) (void)hipGetSymbolAddress((void**)&bp0, HIP_SYMBOL(g_qk_bound_all));
         float* const bp = bp0 + (long long)ws * A2V_QKB_MAX;
-        hipLaunchKernelGGL((attn_qk_bound_kernel<64>), dim3(a.H, a.N), dim3(256), 0, st, (const bf16*)a.qkv, bp, a.S, a.H, a.scale);
+        hipLaunchKernelGGL((attn_qk_bound_kernel<64>), dim3(A2V_QKB_SPLIT, a.N), dim3(256), 0, st, (const bf16*)a.qkv, bp, a.S, a.H);
         a.qk_bound = bp;
       }
     }
