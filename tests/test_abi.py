@@ -144,4 +144,15 @@ def test_p8_tile_claim_register_is_untouched_until_its_wait(tmp_path):
             waits = [i for i in range(n + 1, first_use) if re.fullmatch(r"s_waitcnt vmcnt\((8|10|12|14)\)", lines[i])]
             assert waits, (m.group(1), reg, n, first_use, lines[first_use])
             checked += 1
+        # The K loop keeps three half-tiles of LDS-DMA in flight behind hand-counted waits: a compiler-placed s_waitcnt vmcnt(0)
+        # or a spill reload (a scratch load, which draws one) between the tile's first and last MFMA drains that pipeline at
+        # every tile -- the cost of several of the regressions fixed in round 2 (conditional loads, spilled lane constants).
+        drains = [(i, lines[i]) for i in range(mfma[0], mfma[-1])
+                  if lines[i].startswith("s_waitcnt vmcnt(0)") or lines[i].startswith("scratch_")]
+        assert not drains, (m.group(1), drains[:4])
+        # the direct-store epilogue waits for its loads with counted waits only: vmcnt(0) stays at its top (bias) and at the
+        # kernel's end -- a handful, not one per row block
+        if "ELb1E" in m.group(1):
+            tail0 = [i for i in range(mfma[-1], len(lines)) if lines[i].startswith("s_waitcnt vmcnt(0)")]
+            assert len(tail0) <= 5, (m.group(1), len(tail0))
     assert checked == 6          # three tile heights x two epilogue forms
