@@ -668,7 +668,10 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     if (g_a2v_p8_ih && ih != g_a2v_p8_ih) continue;
     const int bm = 128 + 32 * ih;
     const long long nt = (long long)cdiv(g.M, bm) * (g.N / 256);
-    const long long cost = (long long)cdiv(nt, cus) * bm;
+    // what one CU executes = rounds x the time of one tile; a shorter tile is NOT proportionally cheaper (same LDS traffic for B,
+    // same barriers, same seam: measured 0.97 of a 256-row tile for 224 rows at K = 1024 -- 53760 x 4096 x 1024 is 14 rounds of
+    // 256 rows in 396 us against 15 rounds of 224 in 412)
+    const long long cost = (long long)cdiv(nt, cus) * (ih == 4 ? 256 : (ih == 3 ? 248 : 240));
     if (best < 0 || cost < best) { best = cost; best_ih = ih; }
   }
   const int bm = 128 + 32 * best_ih;
