@@ -190,6 +190,13 @@ __device__ __forceinline__ float gelu_grad_t(float x) {
   gelu_half<FAST>(x, q, e);
   return fmaf(x * 0.39894228040143268f, e, 0.5f + copysignf(q, x));
 }
+// gelu(x) and gelu'(x) from ONE evaluation of the shared parts (forward epilogues that keep the derivative for the backward)
+__device__ __forceinline__ float gelu_with_grad(float x, float& grad) {
+  float q, e;
+  gelu_half<false>(x, q, e);
+  grad = fmaf(x * 0.39894228040143268f, e, 0.5f + copysignf(q, x));
+  return fmaf(fabsf(x), q, 0.5f * x);
+}
 __device__ __forceinline__ float gelu_f(float x) { return gelu_t<false>(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<false>(x); }
 

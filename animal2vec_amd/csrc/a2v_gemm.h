@@ -35,7 +35,9 @@ struct GemmArgs {
   Drop drop;                     // F_DROPOUT: applied to (acc + bias [gelu]) before the residual add
 };
 
-enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64 };
+enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64, F_DACT = 128 };
+// F_DACT (with F_GELU | F_STORE_PRE): C2 receives gelu'(acc + bias) instead of the pre-activation -- both come out of one
+// evaluation of the erf parts -- and (with F_GELU_BWD) R is that derivative: the backward epilogue multiplies, no transcendental.
 
 struct WgradArgs {
   ConvA a;                       // implicit A (M x K per group)
@@ -103,10 +105,17 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, i
     f32x4 v = *(const f32x4*)(stage + r * 68 + cq);
     if (m < (m_limit < 0 ? g.M : m_limit) && ncol_ok) {
       v += bias4;
-      if (g.flags & F_STORE_PRE) Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, v);
-      if (g.flags & F_GELU) {
+      if ((g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
+        f32x4 gr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
+        for (int i = 0; i < 4; ++i) { float d_; v[i] = gelu_with_grad(v[i], d_); gr[i] = d_; }
+        Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, gr);
+      } else {
+        if (g.flags & F_STORE_PRE) Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, v);
+        if (g.flags & F_GELU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = gelu_f(v[i]);
+        }
       }
       if (g.flags & F_DROPOUT) {
 #pragma unroll
@@ -116,7 +125,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, i
       if (g.flags & F_GELU_BWD) {
         f32x4 h = Vec4<T>::load(R + (long long)m * g.ldr + ccol);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] *= gelu_grad_f(h[i]);
+        for (int i = 0; i < 4; ++i) v[i] *= (g.flags & F_DACT) ? h[i] : gelu_grad_f(h[i]);
       }
       Vec4<T>::store(C + (long long)m * g.ldc + ccol, v);
       if (g.flags & F_COLSUM) {

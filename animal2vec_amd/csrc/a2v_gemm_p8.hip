@@ -393,7 +393,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
       bf16* const Ct = C + tile_off;
       bf16* const C2t = C2 + tile_off;
-      const bf16* const Rt = R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0);
+      // (made uniform explicitly: the raw-asm loads below take it as an SGPR pair, and hipcc does not always prove that itself)
+      const unsigned long long rt_ = (unsigned long long)(R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0));
+      const bf16* const Rt = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rt_ >> 32)) << 32) |
+                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rt_));
       const int rskip = T.m0 - T.mc;                        // the shifted last m-tile: rows below m0 belong to its neighbour
       const int rlo = wr * 64 + fre, rhi = 128 + wr * IH * 16 + fre;
       // Residual / pre-activation rows are fetched RQ row blocks ahead of their use, across both column halves (2 NB row blocks
@@ -452,10 +455,19 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           const unsigned eo = (unsigned)(row * (int)g.ldc + cl);
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += bias8[q];
-          if (g.flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
-          if (g.flags & F_GELU) {
+          // (not at the 256-row tile: its register allocation has no room for this branch -- 8 spills, reloaded inside the tile
+          //  seam; the launcher gives the flavour 224- or 192-row tiles)
+          if (IH < 4 && (g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
+            bf16x8 gr;                               // gelu and gelu' from one evaluation; the derivative is what is kept
+#pragma unroll                                       // (packed pair by pair: eight more live floats spill at the 256-row tile)
+            for (int q = 0; q < 8; ++q) { float d_; v[q] = gelu_with_grad(v[q], d_); gr[q] = (bf16)d_; }
+            *(bf16x8*)(C2t + eo) = gr;
+          } else {
+            if (g.flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
+            if (g.flags & F_GELU) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
+              for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
+            }
           }
           if (g.flags & F_DROPOUT) {
             const unsigned long long e0 = (unsigned long long)(T.mc + row) * g.ldc + (unsigned long long)((long long)grp * g.c_goff + T.n0 + cl);
@@ -477,7 +489,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
             }
             if (g.flags & F_GELU_BWD) {
 #pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] *= gelu_grad_f(h[q]);
+              for (int q = 0; q < 8; ++q) v[q] *= (g.flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
             }
           }
           Vec8<bf16>::store(Ct + eo, v);
@@ -558,10 +570,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
         if (m < g.M) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] += bias8[i];
-          if (g.flags & F_STORE_PRE) Vec8<bf16>::store(C2 + (long long)m * g.ldc + ccol, v);
-          if (g.flags & F_GELU) {
+          if ((g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
+            float gr[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+            for (int i = 0; i < 8; ++i) v[i] = gelu_with_grad(v[i], gr[i]);
+            Vec8<bf16>::store(C2 + (long long)m * g.ldc + ccol, gr);
+          } else {
+            if (g.flags & F_STORE_PRE) Vec8<bf16>::store(C2 + (long long)m * g.ldc + ccol, v);
+            if (g.flags & F_GELU) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i]);
+            }
           }
           if (g.flags & F_DROPOUT) {
 #pragma unroll
@@ -576,7 +595,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
             }
             if (g.flags & F_GELU_BWD) {
 #pragma unroll
-              for (int i = 0; i < 8; ++i) v[i] *= gelu_grad_f(h[i]);
+              for (int i = 0; i < 8; ++i) v[i] *= (g.flags & F_DACT) ? h[i] : gelu_grad_f(h[i]);
             }
           }
           Vec8<bf16>::store(C + (long long)m * g.ldc + ccol, v);
@@ -664,8 +683,9 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   // tile height: rounds x rows per round is what one CU executes; ties go to the taller tile
   int best_ih = 4;
   long long best = -1;
-  for (int ih = 4; ih >= 2; --ih) {
-    if (g_a2v_p8_ih && ih != g_a2v_p8_ih) continue;
+  const bool dact_store = (g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE);
+  for (int ih = (dact_store && direct) ? 3 : 4; ih >= 2; --ih) {
+    if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && g_a2v_p8_ih == 4)) continue;
     const int bm = 128 + 32 * ih;
     const long long nt = (long long)cdiv(g.M, bm) * (g.N / 256);
     // what one CU executes = rounds x the time of one tile; a shorter tile is NOT proportionally cheaper (same LDS traffic for B,

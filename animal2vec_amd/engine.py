@@ -24,6 +24,8 @@ from . import ops
 from .config import Data2VecMultiConfig
 from .params import P, Packs, ParamStore
 
+_DACT = os.environ.get("A2V_NO_DACT") is None      # (A/B switch for the gelu'-in-the-forward-epilogue flavour)
+
 
 class Engine:
     def __init__(self, cfg: Data2VecMultiConfig, store: ParamStore, dtype=torch.bfloat16):
@@ -183,8 +185,9 @@ class Engine:
                                        save_stats=save is not None)
         hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
         hpre = torch.empty(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
+        # (dact: what is kept for the backward is gelu'(fc1 out), formed with gelu in one evaluation -- not the pre-activation)
         gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre,
-                          drop=d_act1)
+                          drop=d_act1, dact=_DACT)
         t = None
         s2 = None
         if want_t or d_act2 is not None:
@@ -231,7 +234,7 @@ class Engine:
             ds2d = ops.mean_layers([ds2d, dt2], scale=1.0)
             ops.colsum(dt2, g[prefix + "mlp.fc2.bias"])          # dxsum above only saw the LN2 path
         dh = ops.linear(ds2d, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"],
-                        drop=d_act1)
+                        drop=d_act1, dact=_DACT)
         ops.linear_wgrad_pair(sv["g"], ds2d, g[prefix + "mlp.fc2.weight"], sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
         dx1 = ops.linear(dh, sp.wt[prefix + "mlp.fc1.weight"], res=ds2)
         ds1, ds1d = ops.layernorm_bwd(dx1, sv["s1"], p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], *sv["st1"],

@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, check
+from ._lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, check
 
 
 def _L():
@@ -53,7 +53,7 @@ def _drop(drop):
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride,
               a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
-              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None):
+              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False):
     """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add.
     rowidx (int32, M entries): GEMM row m reads the im2col row of flat index rowidx[m]; out stays compact."""
     flags = 0
@@ -67,6 +67,8 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
         flags |= EPI_GELU_BWD
     if pre_out is not None:
         flags |= EPI_STORE_PRE
+    if dact:
+        flags |= EPI_DACT
     if colsum is not None:
         flags |= EPI_COLSUM
     if drop is not None and drop[0] > 0:
@@ -81,7 +83,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
     return out
 
 
-def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None, drop=None):
+def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None, drop=None, dact=False):
     """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w/out/res row-major 2-D (leading dims from strides)."""
     M, K = x.shape
     N = w.shape[0]
@@ -91,7 +93,7 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
     r = gelu_bwd_aux if gelu_bwd_aux is not None else res
     return conv_gemm(x, w, out, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
                      ldb=w.stride(0), ldc=out.stride(0), bias=bias, res=r, ldr=r.stride(0) if r is not None else 0,
-                     gelu=gelu, gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum, drop=drop)
+                     gelu=gelu, gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum, drop=drop, dact=dact)
 
 
 def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=None, rowmask=None, bdiv=1,

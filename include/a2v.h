@@ -43,6 +43,10 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 #define A2V_EPI_STORE_PRE 16 /* also store the pre-activation (acc + bias) to C2 */
 #define A2V_EPI_COLSUM 32   /* atomically add column sums of the output to colsum (bias gradient) */
 #define A2V_EPI_DROPOUT 64  /* counter-based dropout(drop_p, drop_seed) of (acc+bias[gelu]) before the residual */
+#define A2V_EPI_DACT 128    /* modifier.  With GELU | STORE_PRE: C2 receives gelu'(acc + bias) instead of the pre-activation (one
+                             * evaluation of the erf parts gives both); with GELU_BWD: R holds that derivative and is multiplied in
+                             * as it is.  The Mlp's fc1 forward / fc2 input gradient pair (timm Mlp, modules.py:328-337) uses it:
+                             * the backward epilogue then has no transcendental. */
 
 /* ---------------------------------------------------------------- implicit-GEMM (MFMA) family
  * C[m][g*c_goff + n] = epi( sum_kk A_g[m][kk] * Bw[g][n][kk] ),  kk = tap*Cg + ci,

@@ -420,6 +420,31 @@ def test_wgrad_large_m(ops, dtype):
     assert rel_err(gw, dy.t() @ x) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(13440, 1024, 512), (1100, 512, 256), (300, 128, 96)])
+def test_linear_dact_pair(ops, dtype, M, N, K):
+    """A2V_EPI_DACT: the forward keeps gelu'(x W^T + b) instead of the pre-activation (one evaluation gives gelu and gelu'), the
+    backward epilogue multiplies by it -- the Mlp's fc1 / fc2-input-gradient pair of the engine.  Every GEMM kernel that serves
+    these shapes (persistent 8-phase, 128 x 128 LDS-DMA, fp32) must implement both sides."""
+    x, w, b = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2) * K ** -0.5, rnd(N, dtype=torch.float32, seed=3)
+    dy = rnd(M, N, dtype=dtype, seed=4)
+    pre = x.float() @ w.float().t() + b
+    xd, wd, bd = dev(x, dtype), dev(w, dtype), b.cuda()
+    keep = torch.empty(M, N, dtype=dtype, device="cuda")
+    out = ops.linear(xd, wd, bd, gelu=True, pre_out=keep, dact=True)
+    assert rel_err(out.float(), F.gelu(pre)) < tol(dtype)
+    pre_g = pre.clone().requires_grad_(True)
+    F.gelu(pre_g).sum().backward()
+    assert rel_err(keep.float(), pre_g.grad) < tol(dtype)
+    # backward side: dy W2-like product times the kept derivative (here: an identity-free check with a second weight)
+    w2 = rnd(N, N, dtype=dtype, seed=5) * N ** -0.5
+    cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+    dh = ops.linear(dev(dy, dtype), dev(w2, dtype), None, gelu_bwd_aux=keep, colsum=cs, dact=True)
+    ref = (dy.float() @ w2.float().t()) * keep.float().cpu()
+    assert rel_err(dh.float(), ref) < tol(dtype)
+    assert rel_err(cs, dh.float().sum(0)) < 5e-3
+
+
 # ------------------------------------------------------------------------------------------ attention
 def attn_ref(qkv, pos, slopes, scale_h, H):
     N, S, W = qkv.shape
