@@ -43,6 +43,7 @@ SIGNATURES = {
     "a2v_scatter_tokens": [_i, _p, _p, _p, _i, _i, _i, _i, _p],
     "a2v_clone_reduce": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p],
     "a2v_decoder_input": [_i, _p, _p, _p, _p, _i, _i, _i, _i, _f, _u, _p],
+    "a2v_decoder_input_rng": [_i, _p, _p, _p, _i, _i, _i, _i, _f, _u, _f, _u, _p],
     "a2v_d2v_loss": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _p],
     "a2v_ema_update": [_p, _p, _ll, _f, _p],
     "a2v_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _f, _i, _f, _p, _p, _p, _p],

@@ -85,10 +85,14 @@ __global__ __launch_bounds__(256) void clone_reduce_kernel(const T* __restrict__
 }
 
 // decoder input (base.py:162-192): out[n,t,:] = r<K ? x[n,r,:] : noise[n,r-K,:], r = restore[n,t]
+// noise == NULL: the masked positions draw N(0, noise_std) on the spot (Box-Muller, both outputs, on two counter hashes of
+// (seed, output element pair) -- the same generator as mask_frames below; the distribution of the reference's normal_(),
+// not torch's Philox stream) instead of reading a materialised (N, Tn-K, D) fp32 tensor.
 template <typename T>
 __global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict__ x, const float* __restrict__ noise,
                                                             const int* __restrict__ restore, T* __restrict__ out, int N,
-                                                            int K, int D, int Tn, Drop drop) {
+                                                            int K, int D, int Tn, Drop drop, float noise_std,
+                                                            unsigned noise_seed) {
   const int vecs = D / 8;
   const long long total = (long long)N * Tn * vecs;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -102,8 +106,19 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict_
       if (drop.thresh) {           // decoder input_dropout on the encoder tokens (base.py:163-165)
         drop_apply_n<8>(drop, ((unsigned long long)n * K + r) * D + v * 8, o);
       }
-    } else
+    } else if (noise) {
       Vec8<float>::load(noise + ((long long)n * (Tn - K) + (r - K)) * D + v * 8, o);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned long long e = (unsigned long long)i * 4 + j;
+        const float u1 = ((float)drop_hash(noise_seed, 2 * e) + 1.f) * 2.3283064365386963e-10f;
+        const float u2 = (float)drop_hash(noise_seed, 2 * e + 1) * 2.3283064365386963e-10f;
+        const float rad = noise_std * sqrtf(-2.f * __logf(u1));
+        o[2 * j] = rad * __cosf(6.283185307179586f * u2);
+        o[2 * j + 1] = rad * __sinf(6.283185307179586f * u2);
+      }
+    }
     Vec8<T>::store(out + nt * D + v * 8, o);
   }
 }
@@ -112,82 +127,110 @@ __global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict_
 // data2vec2.py:850-864,904-909,1005-1021 + compute_var statistics (:1095-1110) in one pass.
 //   masked rows:  l = (x - y[n/cb])^2 * scale ; dx = 2*(x-y)*scale*gscale ; kept rows: dx = 0
 // stats (double): [0..D) sum x, [D..2D) sum x^2, [2D..3D) sum y, [3D..4D) sum y^2, [4D] loss sum,
-// [4D+1] masked-row count.  One wave per row; lane-owned columns accumulate over a row block.
-template <typename T>
-__global__ __launch_bounds__(256) void d2v_loss_kernel(const T* __restrict__ x, const float* __restrict__ y,
-                                                       const unsigned char* __restrict__ mask, T* __restrict__ dx,
-                                                       float* __restrict__ loss_rows, double* __restrict__ stats, int N,
-                                                       int Tn, int D, int cb, float scale, float gscale,
-                                                       int rows_per_wave) {
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const long long row0 = ((long long)blockIdx.x * 4 + wid) * rows_per_wave;
-  const long long rows = (long long)N * Tn;
+// [4D+1] masked-row count.
+// One wave per (clip, frame): the target row is read once and stays in registers for the cb clones of the clip, whose rows
+// are fetched four at a time before any of them is used (a row-after-row loop with the mask test in front of each load was
+// latency-bound at 0.1 of the HBM rate).  Lane-owned columns accumulate over the wave's frames; the D2V_WAVES waves of a
+// workgroup combine in a fixed order through LDS, then one double atomic per column and statistic.
+#define D2V_WAVES 8
+template <typename T, bool ROWS>
+__global__ __launch_bounds__(64 * D2V_WAVES, 4) void d2v_loss_kernel(const T* __restrict__ x, const float* __restrict__ y,
+                                                                     const unsigned char* __restrict__ mask, T* __restrict__ dx,
+                                                                     float* __restrict__ loss_rows, double* __restrict__ stats,
+                                                                     int N, int Tn, int D, int cb, float scale, float gscale) {
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: row addresses stay in SGPRs)
+  const int groups = (N + cb - 1) / cb;
+  const long long pairs = (long long)groups * Tn;
+  const long long nw = (long long)gridDim.x * D2V_WAVES;
   const int nch = (D + 511) / 512;
+  const float g2 = 2.f * scale * gscale;
   float ls_tot = 0.f, cnt_tot = 0.f;
+  __shared__ float red[4][8][64];
   for (int c = 0; c < nch; ++c) {
-    const int col = (c * 64 + lane) * 8;
+    const int col_ = (c * 64 + lane) * 8;
+    const bool colok = col_ < D;
+    const int col = colok ? col_ : D - 8;      // lanes past the last column read a valid one and contribute / store nothing
     float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sxx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float sy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, syy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ls = 0.f, cnt = 0.f;
-    for (int rr = 0; rr < rows_per_wave; ++rr) {
-      const long long row = row0 + rr;
-      if (row >= rows || col >= D) break;
-      float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (mask[row]) {
-        const int n = (int)(row / Tn);
-        const int t = (int)(row - (long long)n * Tn);
-        float xv[8], yv[8];
-        Vec8<T>::load(x + row * D + col, xv);
-        Vec8<float>::load(y + ((long long)(n / cb) * Tn + t) * D + col, yv);
-        float l8[8];
+    for (long long p = (long long)blockIdx.x * D2V_WAVES + wid; p < pairs; p += nw) {
+      const int gi = (int)(p / Tn);
+      const int t = (int)(p - (long long)gi * Tn);
+      float yv[8];
+      Vec8<float>::load(y + ((long long)gi * Tn + t) * D + col, yv);
+      const int n0 = gi * cb;
+      const int ncl = min(cb, N - n0);                         // clones of this clip that exist (>= 1)
+      const long long stride = (long long)Tn * D;              // one clone to the next, same frame
+      for (int c0 = 0; c0 < ncl; c0 += 4) {
+        const long long base = ((long long)(n0 + c0) * Tn + t) * D + col;
+        const int nv = min(4, ncl - c0);
+        bool m[4];
+        float xv[4][8];
+        // (branch-free on the mask: the four mask bytes and the four rows are in flight together; a kept row goes through
+        //  the same arithmetic with its values selected to zero)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = mask[(long long)(n0 + c0 + min(u, nv - 1)) * Tn + t] != 0 && u < nv;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Vec8<T>::load(x + base + min(u, nv - 1) * stride, xv[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float o[8], l8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xm = m[u] ? xv[u][j] : 0.f, ym = m[u] ? yv[j] : 0.f;
+            const float d = xm - ym;
+            l8[j] = d * d * scale;
+            o[j] = d * g2;
+            sx[j] += xm; sxx[j] += xm * xm;
+            sy[j] += ym; syy[j] += ym * ym;
+          }
+          ls += ((l8[0] + l8[1]) + (l8[2] + l8[3])) + ((l8[4] + l8[5]) + (l8[6] + l8[7]));   // (a tree: one chain through all
+          if (c == 0 && lane == 0 && m[u]) cnt += 1.f;                                      //  32 values kept them all live)
+          // (pins the order: without it the compiler interleaves the four rows' updates of the 32 column sums and keeps all
+          //  64 selected values live -- 166 registers instead of 102)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(sx[j]), "+v"(sxx[j]), "+v"(sy[j]), "+v"(syy[j]));
+          if (u < nv && colok) {
+            if (ROWS) Vec8<float>::store(loss_rows + base + u * stride, l8);
+            if (dx) Vec8<T>::store(dx + base + u * stride, o);
+          }
+        }
+      }
+    }
+    for (int wv = 0; wv < D2V_WAVES; ++wv) {
+      __syncthreads();
+      if (wid == wv && colok) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float d = xv[j] - yv[j];
-          l8[j] = d * d * scale;
-          ls += l8[j];
-          o[j] = 2.f * d * scale * gscale;
-          sx[j] += xv[j]; sxx[j] += xv[j] * xv[j];
-          sy[j] += yv[j]; syy[j] += yv[j] * yv[j];
+          if (wv == 0) {
+            red[0][j][lane] = sx[j]; red[1][j][lane] = sxx[j]; red[2][j][lane] = sy[j]; red[3][j][lane] = syy[j];
+          } else {
+            red[0][j][lane] += sx[j]; red[1][j][lane] += sxx[j]; red[2][j][lane] += sy[j]; red[3][j][lane] += syy[j];
+          }
         }
-        if (loss_rows) Vec8<float>::store(loss_rows + row * D + col, l8);
-        if (c == 0 && lane == 0) cnt += 1.f;
-      } else if (loss_rows) {
-        Vec8<float>::store(loss_rows + row * D + col, o);
-      }
-      if (dx) Vec8<T>::store(dx + row * D + col, o);
-    }
-    // the 4 waves of the workgroup combine through LDS, then one double atomic per column and statistic
-    __shared__ float red[4][4][512];
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      red[wid][0][lane * 8 + j] = sx[j];
-      red[wid][1][lane * 8 + j] = sxx[j];
-      red[wid][2][lane * 8 + j] = sy[j];
-      red[wid][3][lane * 8 + j] = syy[j];
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < 4 * 512; e += 256) {
-      const int which = e >> 9, cc = e & 511;
-      const int gc = c * 512 + cc;
-      if (gc < D) {
-        const float v = red[0][which][cc] + red[1][which][cc] + red[2][which][cc] + red[3][which][cc];
-        atomicAdd(stats + which * D + gc, (double)v);
       }
     }
-    ls_tot += ls;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * 512; e += 64 * D2V_WAVES) {
+      const int which = e >> 9, j = (e >> 6) & 7, ln = e & 63;
+      const int gc = c * 512 + ln * 8 + j;
+      if (gc < D) atomicAdd(stats + which * D + gc, (double)red[which][j][ln]);
+    }
+    ls_tot += colok ? ls : 0.f;
     cnt_tot += cnt;
   }
   // loss and count: ONE double atomic per workgroup each (same-address atomics are serialised by the L2 at tens of
-  // nanoseconds apiece: one per wave and column chunk was a 4096-long chain on a single address)
-  __shared__ float red2[2][4];
+  // nanoseconds apiece)
+  __shared__ float red2[2][D2V_WAVES];
   ls_tot = wave_sum(ls_tot);
   cnt_tot = wave_sum(cnt_tot);
   if (lane == 0) { red2[0][wid] = ls_tot; red2[1][wid] = cnt_tot; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(stats + 4 * D, (double)red2[0][0] + (double)red2[0][1] + (double)red2[0][2] + (double)red2[0][3]);
-    const float cn = red2[1][0] + red2[1][1] + red2[1][2] + red2[1][3];
+    double l = 0.0;
+    float cn = 0.f;
+    for (int w = 0; w < D2V_WAVES; ++w) { l += (double)red2[0][w]; cn += red2[1][w]; }
+    atomicAdd(stats + 4 * D, l);
     if (cn != 0.f) atomicAdd(stats + 4 * D + 1, (double)cn);
   }
 }
@@ -581,29 +624,43 @@ extern "C" int a2v_clone_reduce(int dtype, const void* dxm, const void* dtok, co
   return A2V_OK;
 }
 
-extern "C" int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K,
-                                 int D, int Tn, float drop_p, unsigned drop_seed, hipStream_t st) {
-  if (N <= 0 || K <= 0 || K > Tn || D % 8 || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
+static int decoder_input_launch(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K,
+                                int D, int Tn, float drop_p, unsigned drop_seed, float noise_std, unsigned noise_seed,
+                                hipStream_t st) {
   const Drop drop = make_drop(drop_p, drop_seed);
   const int g = grid_for((long long)N * Tn * (D / 8));
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(decoder_input_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, noise, restore, (bf16*)out, N, K, D, Tn, drop),
-             hipLaunchKernelGGL(decoder_input_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, noise, restore, (float*)out, N, K, D, Tn, drop));
+             hipLaunchKernelGGL(decoder_input_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, noise, restore, (bf16*)out, N, K, D, Tn, drop, noise_std, noise_seed),
+             hipLaunchKernelGGL(decoder_input_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, noise, restore, (float*)out, N, K, D, Tn, drop, noise_std, noise_seed));
   A2V_CHECK_LAUNCH();
   return A2V_OK;
+}
+
+extern "C" int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K,
+                                 int D, int Tn, float drop_p, unsigned drop_seed, hipStream_t st) {
+  if (N <= 0 || K <= 0 || K > Tn || D % 8 || drop_p < 0.f || drop_p >= 1.f || !x || !restore || !out || (!noise && K < Tn))
+    return A2V_ERR_ARG;
+  return decoder_input_launch(dtype, x, noise, restore, out, N, K, D, Tn, drop_p, drop_seed, 0.f, 0u, st);
+}
+
+extern "C" int a2v_decoder_input_rng(int dtype, const void* x, const int* restore, void* out, int N, int K, int D, int Tn,
+                                     float noise_std, unsigned noise_seed, float drop_p, unsigned drop_seed, hipStream_t st) {
+  if (N <= 0 || K <= 0 || K > Tn || D % 8 || drop_p < 0.f || drop_p >= 1.f || !x || !restore || !out || !(noise_std >= 0.f))
+    return A2V_ERR_ARG;
+  return decoder_input_launch(dtype, x, nullptr, restore, out, N, K, D, Tn, drop_p, drop_seed, noise_std, noise_seed, st);
 }
 
 extern "C" int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsigned char* mask, void* dx, float* loss_rows,
                             double* stats, int N, int Tn, int D, int cb, float scale, float gscale, hipStream_t st) {
   if (N <= 0 || Tn <= 0 || D % 8 || cb <= 0 || !stats) return A2V_ERR_ARG;
-  const long long rows = (long long)N * Tn;
-  // ~512 workgroups (2 waves per SIMD) stream the rows; statistics leave each workgroup as one double atomic per column
-  int rpw = (int)((rows + 2047) / 2048);
-  if (rpw < 8) rpw = 8;
-  const int g = (int)((rows + 4LL * rpw - 1) / (4LL * rpw));
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(d2v_loss_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, y, mask, (bf16*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw),
-             hipLaunchKernelGGL(d2v_loss_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, y, mask, (float*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale, rpw));
+  // one (clip, frame) pair per wave and round; 2 workgroups of 8 waves per CU (103 registers)
+  const long long pairs = (long long)((N + cb - 1) / cb) * Tn;
+  long long gl = (pairs + D2V_WAVES - 1) / D2V_WAVES;
+  const int g = (int)(gl < 1 ? 1 : gl > 512 ? 512 : gl);
+#define D2V_LAUNCH(T_, R_) hipLaunchKernelGGL((d2v_loss_kernel<T_, R_>), dim3(g), dim3(64 * D2V_WAVES), 0, st, (const T_*)x, y, mask, (T_*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale)
+  if (loss_rows) { DISPATCH_T(dtype, D2V_LAUNCH(bf16, true), D2V_LAUNCH(float, true)); }
+  else { DISPATCH_T(dtype, D2V_LAUNCH(bf16, false), D2V_LAUNCH(float, false)); }
+#undef D2V_LAUNCH
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }

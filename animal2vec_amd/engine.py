@@ -561,7 +561,7 @@ class Engine:
     def forward(self, source, mask_u8, ids_keep, ids_restore, noise, *, save=True, keep_debug=False, dropout_seed=None):
         """Forward of one micro-batch (teacher targets + student + decoder + loss).  source (B,L) fp32;
         mask_u8 (B*cb,T) 1=masked; ids_keep (B*cb,K) int32 (ascending kept frames); ids_restore (B*cb,T)
-        int32; noise (B*cb,T-K,D) fp32 (row j <-> j-th masked frame).  Adds loss/variance sums to
+        int32; noise (B*cb,T-K,D) fp32 (row j <-> j-th masked frame) or a (std, seed) pair (drawn in-kernel).  Adds loss/variance sums to
         self.stats; with save=True keeps what backward() needs.  dropout_seed (int) switches the student's
         train-mode dropouts on (prenet 0.1, attention 0.1, proj 0.1, post-mlp 0.1, decoder input 0.1: yaml:139-147,
         data2vec2.py:74-77); the teacher always runs in eval mode (data2vec2.py:779-780)."""

@@ -359,9 +359,15 @@ def clone_reduce(dxm, dtok, restore, cb):
 
 
 def decoder_input(x, noise, restore, drop=None):
+    """noise: (N, T-K, D) fp32 rows, or a (std, seed) pair -- then the masked positions draw N(0, std) inside the kernel."""
     N, K, D = x.shape
     T = restore.shape[1]
     out = torch.empty(N, T, D, dtype=x.dtype, device=x.device)
+    if isinstance(noise, tuple):
+        rc = _L().a2v_decoder_input_rng(dt(x), ptr(x), ptr(restore), ptr(out), N, K, D, T, float(noise[0]),
+                                        int(noise[1]) & 0xFFFFFFFF, *(_drop(drop)), stream())
+        check(rc, "a2v_decoder_input_rng")
+        return out
     rc = _L().a2v_decoder_input(dt(x), ptr(x), ptr(noise), ptr(restore), ptr(out), N, K, D, T, *(_drop(drop)), stream())
     check(rc, "a2v_decoder_input")
     return out

@@ -11,6 +11,8 @@ import math
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -65,6 +67,7 @@ class PretrainTrainer:
         # uninterrupted one would have (the default CUDA generator is shared with everything else in the process)
         self._noise_gen = torch.Generator(device=self.store.device)
         self._noise_gen.manual_seed(seed * 7919 + 31 + self.rank)
+        self._noise_seed0 = (seed * 7919 + 31) & 0x7FFFFFFF
         self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
         self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device
@@ -98,7 +101,7 @@ class PretrainTrainer:
     # ------------------------------------------------------------------ one optimizer step
     def train_step(self, micro_batches: Sequence[dict]) -> None:
         """micro_batches: dicts with source (B,L) fp32, mask_u8, ids_keep, ids_restore, and either
-        `noise` (N,T-K,D) fp32 or None (then N(0, mask_noise_std) is drawn on device)."""
+        `noise` (N,T-K,D) fp32 or None (then N(0, mask_noise_std) is drawn on device, inside the decoder-input kernel)."""
         st, eng, o = self.store, self.engine, self.optim
         st.grad.zero_()
         eng.stats.zero_()
@@ -106,11 +109,9 @@ class PretrainTrainer:
         for j, mb in enumerate(micro_batches):
             self.sync.arm(j == nmb - 1)
             noise = mb.get("noise")
-            if noise is None:
-                N, K = mb["ids_keep"].shape
-                T = mb["ids_restore"].shape[1]
-                noise = torch.empty(N, T - K, self.cfg.embed_dim, dtype=torch.float32, device=st.device).normal_(
-                    0, self.cfg.audio.mask_noise_std, generator=self._noise_gen)
+            if noise is None:                 # drawn inside the decoder-input kernel: (std, seed), seed from the step counters
+                noise = (self.cfg.audio.mask_noise_std,
+                         (self._noise_seed0 + (self.num_updates * 131 + j) * 8191 + self.rank) & 0x7FFFFFFF)
             dseed = ((self.num_updates * 131 + j) * 257 + self.rank + 1) if self.dropout else None
             src = mb["source"]
             if self.mixup is not None:        # BC-learning mixup, train only (data2vec2.py:536-598)

@@ -179,6 +179,11 @@ int a2v_clone_reduce(int dtype, const void* dxm, const void* dtok, const int* re
 /* decoder_input (base.py:162-192): out[n,t] = restore<K ? x[n,restore] : noise[n,restore-K] */
 int a2v_decoder_input(int dtype, const void* x, const float* noise, const int* restore, void* out, int N, int K, int D,
                       int T, float drop_p, unsigned drop_seed, a2v_stream_t stream);
+/* the same with the noise rows drawn inside the kernel: N(0, noise_std) per masked (n, t, channel), a counter hash of
+ * (noise_seed, output element) -- the distribution base.py:172-176 draws with normal_(), not torch's Philox stream --
+ * so that no (N, T-K, D) fp32 tensor is written and read back. */
+int a2v_decoder_input_rng(int dtype, const void* x, const int* restore, void* out, int N, int K, int D, int T,
+                          float noise_std, unsigned noise_seed, float drop_p, unsigned drop_seed, a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- loss (data2vec2.py:850-864,904-909,
  * 1005-1021) + compute_var sums (:1095-1110).  stats: double[4*D+2] accumulated (zero first):

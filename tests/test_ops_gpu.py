@@ -691,6 +691,70 @@ def test_d2v_loss(ops, dtype):
         assert abs(float(v) - float(O.compute_var(ref))) < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 70, 768, 9), (2, 12, 33, 1024, 4), (1, 1, 17, 8, 3), (2, 4, 20, 520, 20)])
+def test_d2v_loss_clone_groups(ops, shape):
+    """clone counts that are not multiples of the kernel's group of four, channel counts that leave lanes of the last
+    512-column chunk idle, a single clone, nothing masked (K == T): same sums as the row-by-row definition"""
+    B, cb, T, D, K = shape
+    N = B * cb
+    mask = O.seeded_mask(N, T, K, 11)
+    x = rnd(N, T, D, dtype=torch.bfloat16, seed=1)
+    y = rnd(B, T, D, dtype=torch.float32, seed=2)
+    mb = mask.bool()
+    xs, ys = x.float()[mb], y.repeat_interleave(cb, 0)[mb]
+    stats = torch.zeros(4 * D + 2, dtype=torch.float64, device="cuda")
+    rows = torch.full((N, T, D), 7.0, dtype=torch.float32, device="cuda")
+    dx = ops.d2v_loss(dev(x, torch.bfloat16), y.cuda(), mask.cuda(), cb, stats=stats, loss_rows=rows)
+    st = stats.cpu()
+    scale = D ** -0.5
+    ref_rows = torch.zeros(N, T, D)
+    ref_rows[mb] = (xs - ys) ** 2 * scale
+    ref_dx = torch.zeros(N, T, D)
+    ref_dx[mb] = 2 * (xs - ys) * scale
+    assert int(st[4 * D + 1]) == int(mask.sum())
+    assert torch.allclose(rows.cpu(), ref_rows, rtol=1e-5, atol=1e-7)
+    assert rel_err(dx.float(), ref_dx) < tol(torch.bfloat16) or float(ref_dx.abs().max()) == 0.0
+    if int(mask.sum()):
+        assert abs(float(st[4 * D]) - float(ref_rows.double().sum())) / float(ref_rows.double().sum()) < 1e-5
+        for off, ref in ((0, xs), (D, xs ** 2), (2 * D, ys), (3 * D, ys ** 2)):
+            assert torch.allclose(st[off:off + D].float(), ref.double().sum(0).float(), rtol=1e-4, atol=1e-4)
+    else:
+        assert float(st.abs().max()) == 0.0
+    # the same call without the unreduced rows (the other instantiation) gives the same gradient and sums
+    stats2 = torch.zeros_like(stats)
+    dx2 = ops.d2v_loss(dev(x, torch.bfloat16), y.cuda(), mask.cuda(), cb, stats=stats2)
+    assert torch.equal(dx2, dx)
+    assert torch.allclose(stats2, stats, rtol=1e-6, atol=1e-6)       # (fp32 partial sums: the two instantiations contract differently)
+
+
+def test_decoder_input_drawn_noise(ops):
+    """a2v_decoder_input_rng: kept frames are the encoder's tokens, masked frames N(0, std) drawn in the kernel
+    (base.py:172-176): moments of the draw, repeatable per seed, different between seeds"""
+    N, T, K, D = 6, 500, 40, 256
+    mask = O.seeded_mask(N, T, K, 3)
+    ids_keep, ids_restore = O.make_maskinfo(mask)
+    tok = rnd(N, K, D, dtype=torch.bfloat16, seed=3)
+    r = ids_restore.int().cuda()
+    out = ops.decoder_input(dev(tok, torch.bfloat16), (0.01, 1234), r)
+    ref = O.decoder_input(tok.float(), ids_restore, torch.zeros(N, T - K, D))
+    mb = mask.bool()
+    assert torch.equal(out.float().cpu()[~mb], ref[~mb])
+    z = out.float().cpu()[mb] / 0.01
+    n = z.numel()
+    assert abs(float(z.mean())) < 5 / n ** 0.5
+    assert abs(float(z.std()) - 1.0) < 0.01
+    assert abs(float((z ** 4).mean()) - 3.0) < 0.1                   # kurtosis of a normal
+    assert abs(float((z[:, 0::2] * z[:, 1::2]).mean())) < 5 / (n / 2) ** 0.5      # the two Box-Muller outputs of a pair
+    assert abs(float((z[:-1] * z[1:]).mean())) < 5 / n ** 0.5                     # neighbouring frames
+    again = ops.decoder_input(dev(tok, torch.bfloat16), (0.01, 1234), r)
+    assert torch.equal(again, out)
+    other = ops.decoder_input(dev(tok, torch.bfloat16), (0.01, 1235), r)
+    assert not torch.equal(other, out)
+    fp = ops.decoder_input(dev(tok.float(), torch.float32), (0.5, 1234), r)
+    assert abs(float(fp.cpu()[mb].std()) - 0.5) < 0.005
+    assert float(fp.cpu()[mb].abs().max()) < 0.5 * 7
+
+
 def test_ema_adam_cast(ops):
     n = 100003
     g = torch.Generator().manual_seed(0)
