@@ -84,42 +84,64 @@ __global__ __launch_bounds__(256) void clone_reduce_kernel(const T* __restrict__
   }
 }
 
+// Two N(0, std) values per 32-bit word (Box-Muller, both outputs).  The radius takes the hashed word, the angle one more
+// multiply-xorshift round of it (a mixing bijection of that word: as good as a second hash for two coordinates that enter
+// through log and sin/cos, at a third of its cost -- this generator is VALU-bound on its quarter-rate integer multiplies).
+// v_log / v_sqrt / v_sin / v_cos directly: log2 of (0, 1], the angle in revolutions.
+__device__ __forceinline__ void normal_pair(unsigned h1, float std, float& z0, float& z1) {
+  unsigned h2 = (h1 ^ 0x68E31DA4u) * 0x2C1B3C6Du;
+  h2 ^= h2 >> 15;
+  const float u1 = ((float)h1 + 1.f) * 2.3283064365386963e-10f;            // (0, 1]
+  const float u2 = (float)(h2 >> 8) * 5.9604644775390625e-08f;               // [0, 1) in 2^-24 steps
+  const float rad = std * __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+  z0 = rad * __builtin_amdgcn_cosf(u2);
+  z1 = rad * __builtin_amdgcn_sinf(u2);
+}
+
 // decoder input (base.py:162-192): out[n,t,:] = r<K ? x[n,r,:] : noise[n,r-K,:], r = restore[n,t]
-// noise == NULL: the masked positions draw N(0, noise_std) on the spot (Box-Muller, both outputs, on two counter hashes of
-// (seed, output element pair) -- the same generator as mask_frames below; the distribution of the reference's normal_(),
-// not torch's Philox stream) instead of reading a materialised (N, Tn-K, D) fp32 tensor.
+// noise == NULL: the masked positions draw N(0, noise_std) on the spot -- normal_pair on the 2-D counter hash (a2v_common.h:
+// row term of (seed, output row) + pair-of-columns term); the distribution of the reference's normal_(), not torch's Philox
+// stream -- instead of reading a materialised (N, Tn-K, D) fp32 tensor.
+// One output row per wave and round (the row's source and the division by Tn are wave-uniform; the element-per-thread form
+// spent more on two 64-bit divisions per 16 bytes than on the copy).
 template <typename T>
 __global__ __launch_bounds__(256) void decoder_input_kernel(const T* __restrict__ x, const float* __restrict__ noise,
                                                             const int* __restrict__ restore, T* __restrict__ out, int N,
                                                             int K, int D, int Tn, Drop drop, float noise_std,
                                                             unsigned noise_seed) {
   const int vecs = D / 8;
-  const long long total = (long long)N * Tn * vecs;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % vecs);
-    const long long nt = i / vecs;
-    const int n = (int)(nt / Tn);
+  const int lane = threadIdx.x & 63;
+  const int rows = N * Tn;
+  const int nw = gridDim.x * 4;
+  for (int nt = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); nt < rows; nt += nw) {
+    const int n = nt / Tn;
     const int r = restore[nt];
-    float o[8];
+    T* const orow = out + (long long)nt * D;
     if (r < K) {
-      Vec8<T>::load(x + ((long long)n * K + r) * D + v * 8, o);
-      if (drop.thresh) {           // decoder input_dropout on the encoder tokens (base.py:163-165)
-        drop_apply_n<8>(drop, ((unsigned long long)n * K + r) * D + v * 8, o);
+      const long long src = ((long long)n * K + r) * D;
+      for (int v = lane; v < vecs; v += 64) {
+        float o[8];
+        Vec8<T>::load(x + src + v * 8, o);
+        if (drop.thresh) drop_apply_n<8>(drop, (unsigned long long)src + v * 8, o);      // decoder input_dropout (base.py:163-165)
+        Vec8<T>::store(orow + v * 8, o);
       }
     } else if (noise) {
-      Vec8<float>::load(noise + ((long long)n * (Tn - K) + (r - K)) * D + v * 8, o);
+      const float* const nrow = noise + ((long long)n * (Tn - K) + (r - K)) * D;
+      for (int v = lane; v < vecs; v += 64) {
+        float o[8];
+        Vec8<float>::load(nrow + v * 8, o);
+        Vec8<T>::store(orow + v * 8, o);
+      }
     } else {
+      const unsigned rt = drop_row_term(noise_seed, (unsigned)nt);
+      for (int v = lane; v < vecs; v += 64) {
+        float o[8];
+        const unsigned c0 = (unsigned)v * 4u * 0x85EBCA6Bu;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const unsigned long long e = (unsigned long long)i * 4 + j;
-        const float u1 = ((float)drop_hash(noise_seed, 2 * e) + 1.f) * 2.3283064365386963e-10f;
-        const float u2 = (float)drop_hash(noise_seed, 2 * e + 1) * 2.3283064365386963e-10f;
-        const float rad = noise_std * sqrtf(-2.f * __logf(u1));
-        o[2 * j] = rad * __cosf(6.283185307179586f * u2);
-        o[2 * j + 1] = rad * __sinf(6.283185307179586f * u2);
+        for (int j = 0; j < 4; ++j) normal_pair(drop_finalize(rt + c0 + (unsigned)j * 0x85EBCA6Bu), noise_std, o[2 * j], o[2 * j + 1]);
+        Vec8<T>::store(orow + v * 8, o);
       }
     }
-    Vec8<T>::store(out + nt * D + v * 8, o);
   }
 }
 
@@ -141,19 +163,27 @@ __global__ __launch_bounds__(64 * D2V_WAVES, 4) void d2v_loss_kernel(const T* __
   const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (uniform: row addresses stay in SGPRs)
   const int groups = (N + cb - 1) / cb;
   const long long pairs = (long long)groups * Tn;
-  const long long nw = (long long)gridDim.x * D2V_WAVES;
   const int nch = (D + 511) / 512;
+  // The 512-column chunks of a row go to neighbouring waves of the workgroup when their number divides the wave count (1, 2,
+  // 4 chunks), so that whole rows stream at any time; one chunk after the other (every wave on the same one) read 1 KB out
+  // of every 2 KB and reached half the rate.
+  const bool par = nch <= 4 && D2V_WAVES % nch == 0;
+  const int wpc = par ? D2V_WAVES / nch : D2V_WAVES;         // waves per chunk = (clip, frame) pairs per workgroup and round
+  const int slot = par ? wid / nch : wid;
+  const long long nw = (long long)gridDim.x * wpc;
   const float g2 = 2.f * scale * gscale;
   float ls_tot = 0.f, cnt_tot = 0.f;
-  __shared__ float red[4][8][64];
-  for (int c = 0; c < nch; ++c) {
+  __shared__ float red[4][4][8][64];
+  for (int cc = 0; cc < (par ? 1 : nch); ++cc) {
+    const int c = par ? wid % nch : cc;
+    const int rc = par ? c : 0;
     const int col_ = (c * 64 + lane) * 8;
     const bool colok = col_ < D;
     const int col = colok ? col_ : D - 8;      // lanes past the last column read a valid one and contribute / store nothing
     float sx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, sxx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float sy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, syy[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ls = 0.f, cnt = 0.f;
-    for (long long p = (long long)blockIdx.x * D2V_WAVES + wid; p < pairs; p += nw) {
+    for (long long p = (long long)blockIdx.x * wpc + slot; p < pairs; p += nw) {
       const int gi = (int)(p / Tn);
       const int t = (int)(p - (long long)gi * Tn);
       float yv[8];
@@ -200,21 +230,22 @@ __global__ __launch_bounds__(64 * D2V_WAVES, 4) void d2v_loss_kernel(const T* __
     for (int wv = 0; wv < D2V_WAVES; ++wv) {
       __syncthreads();
       if (wid == wv && colok) {
+        const bool first = par ? wv < nch : wv == 0;         // the first wave of each chunk writes, the others add, in order
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (wv == 0) {
-            red[0][j][lane] = sx[j]; red[1][j][lane] = sxx[j]; red[2][j][lane] = sy[j]; red[3][j][lane] = syy[j];
+          if (first) {
+            red[rc][0][j][lane] = sx[j]; red[rc][1][j][lane] = sxx[j]; red[rc][2][j][lane] = sy[j]; red[rc][3][j][lane] = syy[j];
           } else {
-            red[0][j][lane] += sx[j]; red[1][j][lane] += sxx[j]; red[2][j][lane] += sy[j]; red[3][j][lane] += syy[j];
+            red[rc][0][j][lane] += sx[j]; red[rc][1][j][lane] += sxx[j]; red[rc][2][j][lane] += sy[j]; red[rc][3][j][lane] += syy[j];
           }
         }
       }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < 4 * 512; e += 64 * D2V_WAVES) {
-      const int which = e >> 9, j = (e >> 6) & 7, ln = e & 63;
-      const int gc = c * 512 + ln * 8 + j;
-      if (gc < D) atomicAdd(stats + which * D + gc, (double)red[which][j][ln]);
+    for (int e = threadIdx.x; e < (par ? nch : 1) * 2048; e += 64 * D2V_WAVES) {
+      const int ch = e >> 11, which = (e >> 9) & 3, j = (e >> 6) & 7, ln = e & 63;
+      const int gc = (par ? ch : cc) * 512 + ln * 8 + j;
+      if (gc < D) atomicAdd(stats + which * D + gc, (double)red[ch][which][j][ln]);
     }
     ls_tot += colok ? ls : 0.f;
     cnt_tot += cnt;
@@ -541,28 +572,38 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(float* __restrict__ p
 
 // col2im for the strided dense convs' input gradient:
 //   dX[b,u,ci] = sum_{t,j : t*s - p + j = u} dA[(b,t)][j*C + ci]
+// One input frame (b, u) per group of C/8 lanes (16 bytes of channels each; a whole wave at C = 512, four frames per wave
+// at C = 128): which taps reach the frame (j = j0, j0 + s, ... with t = t0, t0 - 1, ...) is three 32-bit divisions per
+// frame, two taps in flight.  (The element-per-thread form spent two 64-bit and 2k 32-bit divisions per 16 bytes.)
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* __restrict__ dA, T* __restrict__ dX, int B, int T_in,
                                                      int T_out, int C, int k, int s, int p, long long lda,
                                                      long long ldo) {
   const int vecs = C / 8;
-  const long long total = (long long)B * T_in * vecs;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(i % vecs);
-    const long long bu = i / vecs;
-    const int b = (int)(bu / T_in), u = (int)(bu - (long long)b * T_in);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; j < k; ++j) {
-      const int num = u + p - j;
-      if (num < 0 || num % s) continue;
-      const int t = num / s;
-      if (t >= T_out) continue;
-      float x[8];
-      Vec8<T>::load(dA + ((long long)b * T_out + t) * lda + (long long)j * C + v * 8, x);
+  const int lanes = vecs >= 64 ? 64 : (vecs > 32 ? 64 : vecs > 16 ? 32 : vecs > 8 ? 16 : 8);   // lanes per frame
+  const int fpw = 64 / lanes;                                                                    // frames per wave
+  const int lane = threadIdx.x & 63;
+  const int sub = lane / lanes, l0 = lane - sub * lanes;
+  const int rows = B * T_in;
+  const int nw = gridDim.x * 4 * fpw;
+  for (int bu = (blockIdx.x * 4 + (threadIdx.x >> 6)) * fpw + sub; bu < rows; bu += nw) {
+    const int b = bu / T_in, u = bu - b * T_in;
+    const int j0 = (u + p) % s, t0 = (u + p - j0) / s;        // u + p >= 0
+    const T* const arow = dA + (long long)b * T_out * lda;
+    for (int v = l0; v < vecs; v += lanes) {
+      float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      for (int j = j0, t = t0; j < k && t >= 0; j += 2 * s, t -= 2) {
+        const bool ok0 = t < T_out, ok1 = j + s < k && t - 1 >= 0 && t - 1 < T_out;
+        const int ta = ok0 ? t : 0, tb = ok1 ? t - 1 : 0;
+        const int ja = ok0 ? j : 0, jb = ok1 ? j + s : 0;
+        float x0[8], x1[8];
+        Vec8<T>::load(arow + (long long)ta * lda + (long long)ja * C + v * 8, x0);
+        Vec8<T>::load(arow + (long long)tb * lda + (long long)jb * C + v * 8, x1);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc[q] += x[q];
+        for (int q = 0; q < 8; ++q) acc[q] += (ok0 ? x0[q] : 0.f) + (ok1 ? x1[q] : 0.f);
+      }
+      Vec8<T>::store(dX + (long long)bu * ldo + v * 8, acc);
     }
-    Vec8<T>::store(dX + bu * ldo + v * 8, acc);
   }
 }
 
@@ -628,7 +669,8 @@ static int decoder_input_launch(int dtype, const void* x, const float* noise, co
                                 int D, int Tn, float drop_p, unsigned drop_seed, float noise_std, unsigned noise_seed,
                                 hipStream_t st) {
   const Drop drop = make_drop(drop_p, drop_seed);
-  const int g = grid_for((long long)N * Tn * (D / 8));
+  if ((long long)N * Tn > 0x7FFFFFFFLL) return A2V_ERR_ARG;
+  const int g = grid_for((long long)N * Tn * 64);                 // one wave per output row
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(decoder_input_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)x, noise, restore, (bf16*)out, N, K, D, Tn, drop, noise_std, noise_seed),
              hipLaunchKernelGGL(decoder_input_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)x, noise, restore, (float*)out, N, K, D, Tn, drop, noise_std, noise_seed));
@@ -655,7 +697,9 @@ extern "C" int a2v_d2v_loss(int dtype, const void* x, const float* y, const unsi
   if (N <= 0 || Tn <= 0 || D % 8 || cb <= 0 || !stats) return A2V_ERR_ARG;
   // one (clip, frame) pair per wave and round; 2 workgroups of 8 waves per CU (103 registers)
   const long long pairs = (long long)((N + cb - 1) / cb) * Tn;
-  long long gl = (pairs + D2V_WAVES - 1) / D2V_WAVES;
+  const int nch = (D + 511) / 512;
+  const int wpc = (nch <= 4 && D2V_WAVES % nch == 0) ? D2V_WAVES / nch : D2V_WAVES;
+  long long gl = (pairs + wpc - 1) / wpc;
   const int g = (int)(gl < 1 ? 1 : gl > 512 ? 512 : gl);
 #define D2V_LAUNCH(T_, R_) hipLaunchKernelGGL((d2v_loss_kernel<T_, R_>), dim3(g), dim3(64 * D2V_WAVES), 0, st, (const T_*)x, y, mask, (T_*)dx, loss_rows, stats, N, Tn, D, cb, scale, gscale)
   if (loss_rows) { DISPATCH_T(dtype, D2V_LAUNCH(bf16, true), D2V_LAUNCH(float, true)); }
@@ -777,8 +821,11 @@ extern "C" int a2v_unpack_wgrad(float* packed, float* gw, int GN, int Cg, int k,
 
 extern "C" int a2v_col2im(int dtype, const void* dA, void* dX, int B, int T_in, int T_out, int C, int k, int s, int p,
                           long long lda, long long ldo, hipStream_t st) {
-  if (B <= 0 || C % 8 || lda % 8 || ldo % 8 || ldo < C || s <= 0) return A2V_ERR_ARG;
-  const int g = grid_for((long long)B * T_in * (C / 8));
+  if (B <= 0 || C % 8 || lda % 8 || ldo % 8 || ldo < C || s <= 0 || p < 0 || T_in <= 0 || T_out <= 0 ||
+      (long long)B * T_in > 0x7FFFFFFFLL)
+    return A2V_ERR_ARG;
+  const int lanes_ = C / 8 > 32 ? 64 : C / 8 > 16 ? 32 : C / 8 > 8 ? 16 : 8;
+  const int g = grid_for((long long)B * T_in * lanes_);        // C/8 lanes (rounded up to a power of two) per input frame
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(col2im_kernel<bf16>, dim3(g), dim3(256), 0, st, (const bf16*)dA, (bf16*)dX, B, T_in, T_out, C, k, s, p, lda, ldo),
              hipLaunchKernelGGL(col2im_kernel<float>, dim3(g), dim3(256), 0, st, (const float*)dA, (float*)dX, B, T_in, T_out, C, k, s, p, lda, ldo));

@@ -691,7 +691,8 @@ def test_d2v_loss(ops, dtype):
         assert abs(float(v) - float(O.compute_var(ref))) < 1e-5
 
 
-@pytest.mark.parametrize("shape", [(3, 5, 70, 768, 9), (2, 12, 33, 1024, 4), (1, 1, 17, 8, 3), (2, 4, 20, 520, 20)])
+@pytest.mark.parametrize("shape", [(3, 5, 70, 768, 9), (2, 12, 33, 1024, 4), (1, 1, 17, 8, 3), (2, 4, 20, 520, 20), (2, 3, 19, 1536, 5),
+                                   (1, 6, 21, 2048, 2), (1, 2, 9, 4096, 3)])
 def test_d2v_loss_clone_groups(ops, shape):
     """clone counts that are not multiples of the kernel's group of four, channel counts that leave lanes of the last
     512-column chunk idle, a single clone, nothing masked (K == T): same sums as the row-by-row definition"""

@@ -12,8 +12,14 @@ from tools.gemm_bench import timeit  # noqa: E402
 
 
 def main():
+    for B in (8, 32):
+        one(B)
+
+
+def one(B):
     dev, dt = "cuda", torch.bfloat16
-    B, cb, T, K, D = 8, 12, 2000, 140, 1024
+    cb, T, K, D = 12, 2000, 140, 1024
+    print(f"--- {B} clips x {cb} clones")
     N = B * cb
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn(N, T, D, device=dev, generator=g).to(dt)
@@ -33,6 +39,27 @@ def main():
     print(f"decoder_input rng   {1e3 * ms:9.1f} us  {N * T * D * 2 / ms / 1e6:8.1f} GB/s")
     ms = timeit(lambda: torch.empty(N, T - K, D, device=dev).normal_(0, 0.01), 10, inner=4)
     print(f"torch normal_       {1e3 * ms:9.1f} us")
+    z = torch.empty_like(x)
+    ms = timeit(lambda: z.copy_(x), 10, inner=4)
+    print(f"copy (N,T,D) bf16   {1e3 * ms:9.1f} us  {2 * N * T * D * 2 / ms / 1e6:8.1f} GB/s")
+    ms = timeit(lambda: z.zero_(), 10, inner=4)
+    print(f"fill (N,T,D) bf16   {1e3 * ms:9.1f} us  {N * T * D * 2 / ms / 1e6:8.1f} GB/s")
+    del z
+    del x, noise
+    # instance-normed target average over the top 16 layers
+    L = 16
+    layers = [torch.randn(B, T, D, device=dev, generator=g).to(dt) for _ in range(L)]
+    ms = timeit(lambda: ops.instnorm_targets(layers, 1e-5), 10, inner=2)
+    print(f"instnorm targets    {1e3 * ms:9.1f} us  {(2 * L * B * T * D * 2 + B * T * D * 4) / ms / 1e6:8.1f} GB/s (two passes)")
+    del layers
+    # col2im of the strided feature convs: (C, k, s, T_in) at 80000 samples
+    for C_, k_, s_, T_in in ((512, 3, 2, 16000), (512, 3, 2, 8000), (512, 3, 2, 4000), (128, 10, 5, 80000)):
+        p_ = k_ // 2
+        T_out = (T_in + 2 * p_ - k_) // s_ + 1
+        dA = torch.randn(B * T_out, k_ * C_, device=dev, generator=g).to(dt)
+        ms = timeit(lambda: ops.col2im(dA, B=B, T_in=T_in, T_out=T_out, C_=C_, k=k_, s=s_, p=p_), 10, inner=2)
+        print(f"col2im C={C_} k={k_} s={s_} T={T_in:6d} {1e3 * ms:9.1f} us  {(dA.numel() * 2 + B * T_in * C_ * 2) / ms / 1e6:8.1f} GB/s")
+        del dA
     out = ops.decoder_input(xk, (0.01, 5), restore).float()
     nz = out[mask.bool()]
     print("noise mean %.3e std %.5f (want 0.01) kurt %.3f" % (nz.mean().item(), nz.std().item(), ((nz / nz.std()) ** 4).mean().item()))
