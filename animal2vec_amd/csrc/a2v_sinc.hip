@@ -279,9 +279,25 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
   const int fr = lane & 15, g = lane >> 4;
   const int half = k / 2;
 
-  for (int i = tid; i < SINC_CP * SINC_MAXK; i += 256) {
-    const int c = i >> 6, j = i & 63;
-    sF[c * SINC_FP + j] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
+  // bf16 mode: the conv recompute runs on the bf16 matrix cores in split precision exactly as the forward does (x = xh + xl,
+  // w = wh + wl, three products per tile: 3 x 16 cycles instead of 8 x 32 of the exact fp32 MFMA, same sums as the forward's);
+  // the folded filter rows sit in LDS already split, [c][32 taps] bf16 each.
+  constexpr bool SPLIT = std::is_same<T, bf16>::value;
+  bf16* const sFh = (bf16*)sF;
+  bf16* const sFl = sFh + SINC_CP * 32;
+  if constexpr (SPLIT) {
+    for (int i = tid; i < SINC_CP * 32; i += 256) {
+      const int c = i >> 5, j = i & 31;
+      const float w = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+      const bf16 h = (bf16)w;
+      sFh[i] = h;
+      sFl[i] = (bf16)(w - (float)h);
+    }
+  } else {
+    for (int i = tid; i < SINC_CP * SINC_MAXK; i += 256) {
+      const int c = i >> 6, j = i & 63;
+      sF[c * SINC_FP + j] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
+    }
   }
   // per-lane channel parameters: channels c = fr + 16 jc
   float pw[8], pb_[8], pa[8], pbs[8];
@@ -363,16 +379,38 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
     f32x4 acc[8];
 #pragma unroll
     for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-    for (int ks = 0; ks < 8; ++ks) {
-      const int j = ks * 4 + g, jm = k - 1 - j;
-      const float xl = sXc[wid * 16 + fr + (j <= half ? j : half)];
-      const float xr = sXc[wid * 16 + fr + (jm >= 0 ? jm : 0)];
-      const float xa = j < half ? xl + xr : (j == half ? xl : 0.f);
+    if constexpr (SPLIT) {
+      bf16x8 xh, xl;                                   // A[row = t = fr][k = 8g + e]: folded taps, split
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int j = 8 * g + e, jm = k - 1 - j;
+        const float a_ = sXc[wid * 16 + fr + (j <= half ? j : half)];
+        const float b_ = sXc[wid * 16 + fr + (jm >= 0 ? jm : 0)];
+        const float xf = j < half ? a_ + b_ : (j == half ? a_ : 0.f);
+        const bf16 h = (bf16)xf;
+        xh[e] = h;
+        xl[e] = (bf16)(xf - (float)h);
+      }
 #pragma unroll
       for (int jc = 0; jc < 8; ++jc) {
-        const float wb = sF[(16 * jc + fr) * SINC_FP + j];                 // (columns j > half are multiplied by xa = 0)
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[jc], 0, 0, 0);
+        const bf16x8 wh = *(const bf16x8*)(sFh + (16 * jc + fr) * 32 + 8 * g);
+        const bf16x8 wl = *(const bf16x8*)(sFl + (16 * jc + fr) * 32 + 8 * g);
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, acc[jc], 0, 0, 0);
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, acc[jc], 0, 0, 0);
+        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, acc[jc], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int ks = 0; ks < 8; ++ks) {
+        const int j = ks * 4 + g, jm = k - 1 - j;
+        const float xl = sXc[wid * 16 + fr + (j <= half ? j : half)];
+        const float xr = sXc[wid * 16 + fr + (jm >= 0 ? jm : 0)];
+        const float xa = j < half ? xl + xr : (j == half ? xl : 0.f);
+#pragma unroll
+        for (int jc = 0; jc < 8; ++jc) {
+          const float wb = sF[(16 * jc + fr) * SINC_FP + j];                 // (columns j > half are multiplied by xa = 0)
+          acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[jc], 0, 0, 0);
+        }
       }
     }
     // back-prop through PSwish and LN.  values indexed [jc][r]: t = 16wid+4g+r, c = fr+16jc

@@ -60,6 +60,22 @@ def one(B):
         ms = timeit(lambda: ops.col2im(dA, B=B, T_in=T_in, T_out=T_out, C_=C_, k=k_, s=s_, p=p_), 10, inner=2)
         print(f"col2im C={C_} k={k_} s={s_} T={T_in:6d} {1e3 * ms:9.1f} us  {(dA.numel() * 2 + B * T_in * C_ * 2) / ms / 1e6:8.1f} GB/s")
         del dA
+    # SincConv front end: 127 filters x 63 taps on 10 s @ 8 kHz
+    C_, k_, Ls = 127, 63, 80000
+    xs = torch.randn(B, Ls, device=dev, generator=g)
+    filt = torch.randn(128, k_, device=dev, generator=g) * 0.1
+    filt = (filt + filt.flip(1)) * 0.5                       # band-pass rows are symmetric
+    filt[C_:] = 0
+    lw, lb = torch.ones(128, device=dev), torch.zeros(128, device=dev)
+    pa, pb = torch.ones(128, device=dev), torch.ones(128, device=dev)
+    ms = timeit(lambda: ops.sinc_fused_fwd(xs, filt, lw, lb, pa, pb, C_=C_, k=k_, dtype=dt), 10, inner=2)
+    print(f"sinc_fused_fwd      {1e3 * ms:9.1f} us  {B * Ls * 128 * 2 / ms / 1e6:8.1f} GB/s")
+    ys, mean, rstd = ops.sinc_fused_fwd(xs, filt, lw, lb, pa, pb, C_=C_, k=k_, dtype=dt)
+    dys = torch.randn(B, Ls, 128, device=dev, generator=g).to(dt)
+    dfilt, dpar = torch.zeros(128, k_, device=dev), torch.zeros(4, 128, device=dev)
+    ms = timeit(lambda: ops.sinc_fused_bwd(xs, filt, lw, lb, pa, pb, dys, mean, rstd, dfilt, dpar, C_=C_, k=k_), 10, inner=2)
+    print(f"sinc_fused_bwd      {1e3 * ms:9.1f} us  {B * Ls * 128 * 2 / ms / 1e6:8.1f} GB/s")
+    del ys, dys
     out = ops.decoder_input(xk, (0.01, 5), restore).float()
     nz = out[mask.bool()]
     print("noise mean %.3e std %.5f (want 0.01) kurt %.3f" % (nz.mean().item(), nz.std().item(), ((nz / nz.std()) ** 4).mean().item()))
