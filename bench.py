@@ -402,7 +402,10 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.micro_batch <= 0:
         per_rank = max(1, args.global_batch // world)
-        args.micro_batch = next(m for m in (32, 16, 8, 4, 2, 1) if per_rank % m == 0)
+        # the largest micro-batch that divides the rank's share: 64 clips of 10 s @ 8 kHz fit one GPU with room to spare (fewer,
+        # longer launches: +2 % over two micro-batches of 32); longer clips keep to 8
+        cap = 64 if args.samples <= 80000 else 8
+        args.micro_batch = next(m for m in (64, 32, 16, 8, 4, 2, 1) if m <= cap and per_rank % m == 0)
     if args.dry:
         return dry_run(args, world, rank)
     assert args.backend == "nccl", "the GPU path runs over RCCL; gloo is for --dry"
@@ -458,8 +461,7 @@ def main():
         try:
             tr.engine.stats.zero_()
             tr.engine.forward_backward(mbs[0]["source"], mbs[0]["mask_u8"], mbs[0]["ids_keep"], mbs[0]["ids_restore"],
-                                       torch.zeros(args.micro_batch * cfg.clone_batch, cfg.frame_counts(L)[-1] - K,
-                                                   cfg.embed_dim, device=dev))
+                                       (cfg.audio.mask_noise_std, 4321))
             s = rec.summary()
             hbm = rec.hbm_summary()
             if args.gemm_table:

@@ -15,10 +15,10 @@ run() {   # name, then rocprofv3 options
 }
 BARGS="--steps 2 --warmup 1" run stats --kernel-trace --stats
 f=$(find /tmp/cp_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_kernel_stats.csv
-BARGS="--steps 1 --warmup 0 --global-batch 32" run fetch --kernel-trace --pmc FETCH_SIZE
+BARGS="--steps 1 --warmup 0 --global-batch 64" run fetch --kernel-trace --pmc FETCH_SIZE
 f=$(find /tmp/cp_fetch -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_fetch.csv
-BARGS="--steps 1 --warmup 0 --global-batch 32" run write --kernel-trace --pmc WRITE_SIZE
+BARGS="--steps 1 --warmup 0 --global-batch 64" run write --kernel-trace --pmc WRITE_SIZE
 f=$(find /tmp/cp_write -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_write.csv
-BARGS="--steps 1 --warmup 0 --global-batch 32" run mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+BARGS="--steps 1 --warmup 0 --global-batch 64" run mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 f=$(find /tmp/cp_mfma -name "*counter_collection.csv" | head -1); [ -n "$f" ] && cp "$f" $out/${tag}_mfma.csv
 ls -la $out/${tag}_* 2>/dev/null
