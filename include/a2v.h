@@ -283,6 +283,7 @@ int a2v_add_drop(int dtype, const void* a, const void* b, const void* c, void* o
 int a2v_mask_frames(int dtype, const void* x, const unsigned char* mask_t, const unsigned char* mask_c, void* out,
                     int B, int T, int D, float noise_std, unsigned seed, int mode, a2v_stream_t stream);
 
+/* 7: + a2v_decoder_input_rng, + A2V_EPI_DACT (additive over 6: every v6 call keeps its meaning) */
 int a2v_abi_version(void);
 
 #ifdef __cplusplus
