@@ -92,7 +92,9 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 // the two column blocks j = 0, 1 of a wave give each lane 8 consecutive columns = one 16-B bf16 store; the four lanes
 // with the same MFMA column cover 64 contiguous bytes of an output row.  Replaces 128 ds_write_b32 + 32 ds_read_b128 +
 // 16 wave barriers per wave and tile (LDS-store bound: 4 KiB per wave and pass at 64 B/clk/CU).
-template <int IH, bool DS>
+// FX = 1: the flavour is fixed at compile time to BIAS | GELU | STORE_PRE | DACT (fc1 forward of a training step) -- the 256-row
+// tile has no registers to spare for that branch next to the residual / dropout / column-sum paths of the generic epilogue.
+template <int IH, bool DS, int FX = 0>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot, int cs_part) {
   unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
   float* const g_p8_cs_part = g_p8_cs_part_all[ctr_slot];
@@ -377,7 +379,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     bf16* const C = (bf16*)g.C;
     bf16* const C2 = (bf16*)g.C2;
     const bf16* const R = (const bf16*)g.R;
-    const bool need_r = (g.flags & (F_RES | F_GELU_BWD)) != 0;
+    const int flags = FX == 1 ? (F_BIAS | F_GELU | F_STORE_PRE | F_DACT) : g.flags;
+    const bool need_r = (flags & (F_RES | F_GELU_BWD)) != 0;
     if constexpr (DS) {
       // The two wave groups share ONE workgroup barrier and run one barrier apart.  Without a barrier inside the epilogue, the
       // group that gets here first stops arriving at barriers, so the other group's last barrier waits for this group's WHOLE
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
         for (int hb = 0; hb < 2; ++hb) {
 #pragma unroll
           for (int q = 0; q < 8; ++q) bias16[hb][q] = 0.f;
-          if (g.flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + T.n0 + hb * 128 + wc * 32 + fqe * 8, bias16[hb]);
+          if (flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + T.n0 + hb * 128 + wc * 32 + fqe * 8, bias16[hb]);
         }
       }
 #pragma unroll
@@ -457,19 +460,26 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           for (int q = 0; q < 8; ++q) v[q] += bias8[q];
           // (not at the 256-row tile: its register allocation has no room for this branch -- 8 spills, reloaded inside the tile
           //  seam; the launcher gives the flavour 224- or 192-row tiles)
-          if (IH < 4 && (g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
-            bf16x8 gr;                               // gelu and gelu' from one evaluation; the derivative is what is kept
-#pragma unroll                                       // (packed pair by pair: eight more live floats spill at the 256-row tile)
-            for (int q = 0; q < 8; ++q) { float d_; v[q] = gelu_with_grad(v[q], d_); gr[q] = (bf16)d_; }
-            *(bf16x8*)(C2t + eo) = gr;
+          if ((IH < 4 || FX == 1) && (flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
+            p8_u32x4 gr;                             // gelu and gelu' from one evaluation; the derivative is what is kept,
+#pragma unroll                                       // packed pair by pair, the order pinned (interleaved, the eight
+            for (int q = 0; q < 4; ++q) {            // evaluations' temporaries spill at the 256-row tile)
+              float d0, d1;
+              v[2 * q] = gelu_with_grad(v[2 * q], d0);
+              v[2 * q + 1] = gelu_with_grad(v[2 * q + 1], d1);
+              const bf16 b0 = (bf16)d0, b1 = (bf16)d1;
+              gr[q] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+              asm volatile("" : "+v"(v[2 * q]), "+v"(v[2 * q + 1]), "+v"(gr[q]));
+            }
+            *(p8_u32x4*)(C2t + eo) = gr;
           } else {
-            if (g.flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
-            if (g.flags & F_GELU) {
+            if (flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
+            if (flags & F_GELU) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
             }
           }
-          if (g.flags & F_DROPOUT) {
+          if (flags & F_DROPOUT) {
             const unsigned long long e0 = (unsigned long long)(T.mc + row) * g.ldc + (unsigned long long)((long long)grp * g.c_goff + T.n0 + cl);
             drop_apply_n<8>(g.drop, e0, v);
           }
@@ -483,24 +493,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               h[2 * q + 1] = __uint_as_float(rq[k % RQ][q] & 0xffff0000u);
             }
             if (k + RQ < NT) P8_RLOAD(k + RQ);              // RQ row blocks ahead
-            if (g.flags & F_RES) {
+            if (flags & F_RES) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] += h[q];
             }
-            if (g.flags & F_GELU_BWD) {
+            if (flags & F_GELU_BWD) {
 #pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] *= (g.flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
+              for (int q = 0; q < 8; ++q) v[q] *= (flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
             }
           }
           Vec8<bf16>::store(Ct + eo, v);
-          if (g.flags & F_COLSUM) {
+          if (flags & F_COLSUM) {
             const float own = row >= rskip ? 1.f : 0.f;        // rows of the shifted tile's neighbour are summed there
 #pragma unroll
             for (int q = 0; q < 8; ++q) cs[q] = fmaf(own, Cvt<bf16>::to(Cvt<bf16>::from(v[q])), cs[q]);
           }
           __builtin_amdgcn_sched_barrier(0);       // one row block at a time: interleaved, the blocks' temporaries spill
         }
-        if (g.flags & F_COLSUM) {                // rows live in fr (the 16 lanes of a DPP row) and in i (in-lane)
+        if (flags & F_COLSUM) {                // rows live in fr (the 16 lanes of a DPP row) and in i (in-lane)
 #pragma unroll
           for (int q = 0; q < 8; ++q) cs[q] = row16_sum(cs[q]);
           if (fre == 0) {
@@ -678,14 +688,16 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
 #define P8_ATTR(IH_, DS_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<IH_, DS_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     P8_ATTR(4, true) P8_ATTR(3, true) P8_ATTR(2, true) P8_ATTR(4, false) P8_ATTR(3, false) P8_ATTR(2, false)
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
 #undef P8_ATTR
   }
   // tile height: rounds x rows per round is what one CU executes; ties go to the taller tile
   int best_ih = 4;
   long long best = -1;
   const bool dact_store = (g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE);
-  for (int ih = (dact_store && direct) ? 3 : 4; ih >= 2; --ih) {
-    if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && g_a2v_p8_ih == 4)) continue;
+  const bool fx1 = direct && g.flags == (F_BIAS | F_GELU | F_STORE_PRE | F_DACT);      // has its own 256-row instantiation
+  for (int ih = (dact_store && direct && !fx1) ? 3 : 4; ih >= 2; --ih) {
+    if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && !fx1 && g_a2v_p8_ih == 4)) continue;
     const int bm = 128 + 32 * ih;
     const long long nt = (long long)cdiv(g.M, bm) * (g.N / 256);
     // what one CU executes = rounds x the time of one tile; a shorter tile is NOT proportionally cheaper (same LDS traffic for B,
@@ -707,7 +719,8 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX) ? 1 : 0;
 #define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
   if (direct) {
-    if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);
+    if (best_ih == 4 && fx1) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<4, true, 1>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part);
+    else if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);
   } else {
     if (best_ih == 4) P8_GO(4, false); else if (best_ih == 3) P8_GO(3, false); else P8_GO(2, false);
   }

@@ -85,6 +85,8 @@ def main():
             extra["colsum"] = torch.zeros(N, device=dev)
         if kw.get("drop"):
             extra["drop"] = (0.1, 123)
+        if kw.get("dact"):
+            extra["dact"] = True
         out = torch.empty(M, N, device=dev, dtype=dt)
         ms = timeit(lambda: ops.linear(x, w, bias if not kw.get("gelu_bwd") else None, out=out, **extra), a.reps)
         rows.append((name, M, N, K, 1, ms, 2.0 * M * N * K / ms / 1e9))
@@ -135,6 +137,7 @@ def main():
     lin("fc1 bias", 13440, 4096, 1024)
     lin("fc1 bias+gelu", 13440, 4096, 1024, gelu=True)
     lin("fc1 bias+gelu+pre", 13440, 4096, 1024, gelu=True, pre=True)
+    lin("fc1 bias+gelu+dact", 13440, 4096, 1024, gelu=True, pre=True, dact=True)
     lin("fc2dgrad gelu_bwd+colsum", 13440, 4096, 1024, gelu_bwd=True, colsum=True)
     lin("fc2dgrad gelu_bwd only", 13440, 4096, 1024, gelu_bwd=True)
     lin("fc2 bias+res", 13440, 1024, 4096, res=True)
