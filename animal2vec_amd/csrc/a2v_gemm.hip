@@ -613,6 +613,7 @@ extern "C" int a2v_stream_release(hipStream_t stream) {
 // debugging / A-B benchmarking knob: key 0 = bf16 NT kernel variant (0 register-staged, 1 LDS-DMA)
 extern int g_a2v_gemm_variant;
 extern int g_a2v_p8_ih;
+extern int g_a2v_p8_fx;
 extern int g_a2v_p8_stagger;
 extern int g_a2v_p8_dynamic;
 extern int g_a2v_attn_long;
@@ -633,6 +634,7 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 8) { g_a2v_attn_long = value; return A2V_OK; }        // long-sequence attention backward: two-pass kernel on / off
   if (key == 7) { g_a2v_p8_dynamic = value; return A2V_OK; }  // persistent kernels: dynamic tile hand-out on / off
   if (key == 6) { g_a2v_p8_stagger = value; return A2V_OK; }  // 8-phase kernels: stagger the two wave groups on / off
+  if (key == 20) { g_a2v_p8_fx = value; return A2V_OK; }    // 0: no fixed-flavour p8 epilogues
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off

@@ -92,8 +92,16 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 // the two column blocks j = 0, 1 of a wave give each lane 8 consecutive columns = one 16-B bf16 store; the four lanes
 // with the same MFMA column cover 64 contiguous bytes of an output row.  Replaces 128 ds_write_b32 + 32 ds_read_b128 +
 // 16 wave barriers per wave and tile (LDS-store bound: 4 KiB per wave and pass at 64 B/clk/CU).
-// FX = 1: the flavour is fixed at compile time to BIAS | GELU | STORE_PRE | DACT (fc1 forward of a training step) -- the 256-row
-// tile has no registers to spare for that branch next to the residual / dropout / column-sum paths of the generic epilogue.
+// FX > 0: the epilogue flags are fixed at compile time to the value FX (the launcher instantiates the 256-row tile for the five
+// flavours a training step launches most: P8_FX_* below).  The generic epilogue allocates registers for the union of every
+// path -- 16 bias values, the residual queue, dropout state, column sums, GELU temporaries -- which at 256 rows leaves room for
+// only two residual row blocks in flight and none for the gelu + gelu' store; a fixed flavour keeps four in flight (-2.5 % per
+// launch on the K = 1024 shapes).
+#define P8_FX_FC1 (F_BIAS | F_GELU | F_STORE_PRE | F_DACT)      /* fc1 forward of a training step */
+#define P8_FX_FC2D (F_GELU_BWD | F_DACT | F_COLSUM)             /* fc2 input gradient */
+#define P8_FX_BR (F_BIAS | F_RES)                               /* proj / fc2, eval (teacher) */
+#define P8_FX_BRD (F_BIAS | F_RES | F_DROPOUT)                  /* proj / fc2, train */
+#define P8_FX_R (F_RES)                                         /* fc1 / qkv input gradients joined with a second gradient */
 template <int IH, bool DS, int FX = 0>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot, int cs_part) {
   unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
@@ -379,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     bf16* const C = (bf16*)g.C;
     bf16* const C2 = (bf16*)g.C2;
     const bf16* const R = (const bf16*)g.R;
-    const int flags = FX == 1 ? (F_BIAS | F_GELU | F_STORE_PRE | F_DACT) : g.flags;
+    const int flags = FX > 0 ? FX : g.flags;
     const bool need_r = (flags & (F_RES | F_GELU_BWD)) != 0;
     if constexpr (DS) {
       // The two wave groups share ONE workgroup barrier and run one barrier apart.  Without a barrier inside the epilogue, the
@@ -413,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // Both halves' bias vectors are read before the first store for the same reason.  Stores are unconditional: the rows a
       // shifted last m-tile shares with its neighbour are computed from the same operands in the same order, so both write the
       // same bits (the launcher refuses C overlapping R).
-      constexpr int RQ = IH == 4 ? 2 : 4;    // residual row blocks in flight (4 VGPRs each; the 256-row tile has fewer to spare)
+      constexpr int RQ = (IH == 4 && FX == 0) ? 2 : 4;    // residual row blocks in flight (4 VGPRs each; the generic 256-row tile has fewer to spare)
       constexpr int NB = 4 + IH, NT = 2 * NB;
       typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
       p8_u32x4 rq[RQ];                       // (a native vector: asm operands cannot be members of the HIP uint4 struct)
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           for (int q = 0; q < 8; ++q) v[q] += bias8[q];
           // (not at the 256-row tile: its register allocation has no room for this branch -- 8 spills, reloaded inside the tile
           //  seam; the launcher gives the flavour 224- or 192-row tiles)
-          if ((IH < 4 || FX == 1) && (flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
+          if ((IH < 4 || FX > 0) && (flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
             p8_u32x4 gr;                             // gelu and gelu' from one evaluation; the derivative is what is kept,
 #pragma unroll                                       // packed pair by pair, the order pinned (interleaved, the eight
             for (int q = 0; q < 4; ++q) {            // evaluations' temporaries spill at the 256-row tile)
@@ -663,6 +671,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 int g_a2v_p8_dynamic = 2;   // a2v_debug_set(7, v): dynamic tile hand-out in the persistent NT kernel (2: first tile too)
 int g_a2v_p8_stagger = 2;   // a2v_debug_set(6, v): wave groups half a phase apart (NT and TN 8-phase kernels): 0 off, 1 only K >= 2048 (NT), 2 always
 int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swapped MFMA operands, permuted B rows) on / off
+int g_a2v_p8_fx = 1;      // a2v_debug_set(20, v): 0 = every flavour takes the generic epilogue (A/B)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
@@ -688,14 +697,20 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
 #define P8_ATTR(IH_, DS_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<IH_, DS_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     P8_ATTR(4, true) P8_ATTR(3, true) P8_ATTR(2, true) P8_ATTR(4, false) P8_ATTR(3, false) P8_ATTR(2, false)
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+#define P8_ATTRF(F_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R)
+#undef P8_ATTRF
 #undef P8_ATTR
   }
   // tile height: rounds x rows per round is what one CU executes; ties go to the taller tile
   int best_ih = 4;
   long long best = -1;
   const bool dact_store = (g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE);
-  const bool fx1 = direct && g.flags == (F_BIAS | F_GELU | F_STORE_PRE | F_DACT);      // has its own 256-row instantiation
+  int fx = 0;                                // a fixed-flavour instantiation of the 256-row tile exists for these flag sets
+  if (direct && g_a2v_p8_fx)
+    for (int f : {(int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R})
+      if (g.flags == f) fx = f;
+  const bool fx1 = fx == P8_FX_FC1;
   for (int ih = (dact_store && direct && !fx1) ? 3 : 4; ih >= 2; --ih) {
     if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && !fx1 && g_a2v_p8_ih == 4)) continue;
     const int bm = 128 + 32 * ih;
@@ -719,7 +734,13 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX) ? 1 : 0;
 #define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
   if (direct) {
-    if (best_ih == 4 && fx1) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<4, true, 1>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part);
+#define P8_GOF(F_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<4, true, F_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
+    if (best_ih == 4 && fx == P8_FX_FC1) P8_GOF(P8_FX_FC1);
+    else if (best_ih == 4 && fx == P8_FX_FC2D) P8_GOF(P8_FX_FC2D);
+    else if (best_ih == 4 && fx == P8_FX_BR) P8_GOF(P8_FX_BR);
+    else if (best_ih == 4 && fx == P8_FX_BRD) P8_GOF(P8_FX_BRD);
+    else if (best_ih == 4 && fx == P8_FX_R) P8_GOF(P8_FX_R);
+#undef P8_GOF
     else if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);
   } else {
     if (best_ih == 4) P8_GO(4, false); else if (best_ih == 3) P8_GO(3, false); else P8_GO(2, false);

@@ -140,6 +140,7 @@ def main():
     lin("fc1 bias+gelu+dact", 13440, 4096, 1024, gelu=True, pre=True, dact=True)
     lin("fc2dgrad gelu_bwd+colsum", 13440, 4096, 1024, gelu_bwd=True, colsum=True)
     lin("fc2dgrad gelu_bwd only", 13440, 4096, 1024, gelu_bwd=True)
+    lin("fc2dgrad dact+colsum", 13440, 4096, 1024, gelu_bwd=True, colsum=True, dact=True)
     lin("fc2 bias+res", 13440, 1024, 4096, res=True)
     lin("fc2 bias+res+drop", 13440, 1024, 4096, res=True, drop=True)
     lin("proj bias+res+drop", 13440, 1024, 1024, res=True, drop=True)
