@@ -92,7 +92,7 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 // the two column blocks j = 0, 1 of a wave give each lane 8 consecutive columns = one 16-B bf16 store; the four lanes
 // with the same MFMA column cover 64 contiguous bytes of an output row.  Replaces 128 ds_write_b32 + 32 ds_read_b128 +
 // 16 wave barriers per wave and tile (LDS-store bound: 4 KiB per wave and pass at 64 B/clk/CU).
-// FX > 0: the epilogue flags are fixed at compile time to the value FX (the launcher instantiates the 256-row tile for the five
+// FX > 0: the epilogue flags are fixed at compile time to the value FX (the launcher instantiates the 256-row tile for the eight
 // flavours a training step launches most: P8_FX_* below).  The generic epilogue allocates registers for the union of every
 // path -- 16 bias values, the residual queue, dropout state, column sums, GELU temporaries -- which at 256 rows leaves room for
 // only two residual row blocks in flight and none for the gelu + gelu' store; a fixed flavour keeps four in flight (-2.5 % per
@@ -102,6 +102,9 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 #define P8_FX_BR (F_BIAS | F_RES)                               /* proj / fc2, eval (teacher) */
 #define P8_FX_BRD (F_BIAS | F_RES | F_DROPOUT)                  /* proj / fc2, train */
 #define P8_FX_R (F_RES)                                         /* fc1 / qkv input gradients joined with a second gradient */
+#define P8_FX_B (F_BIAS)                                        /* qkv, the teacher's upper fc2 */
+#define P8_FX_BG (F_BIAS | F_GELU)                              /* fc1, eval (teacher) */
+#define P8_FX_PLAIN 256                                         /* no flag at all (proj input gradient); bit 8 marks "fixed" */
 template <int IH, bool DS, int FX = 0>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot, int cs_part) {
   unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     bf16* const C = (bf16*)g.C;
     bf16* const C2 = (bf16*)g.C2;
     const bf16* const R = (const bf16*)g.R;
-    const int flags = FX > 0 ? FX : g.flags;
+    const int flags = FX > 0 ? (FX & 0xFF) : g.flags;
     const bool need_r = (flags & (F_RES | F_GELU_BWD)) != 0;
     if constexpr (DS) {
       // The two wave groups share ONE workgroup barrier and run one barrier apart.  Without a barrier inside the epilogue, the
@@ -698,7 +701,7 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
 #define P8_ATTR(IH_, DS_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<IH_, DS_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     P8_ATTR(4, true) P8_ATTR(3, true) P8_ATTR(2, true) P8_ATTR(4, false) P8_ATTR(3, false) P8_ATTR(2, false)
 #define P8_ATTRF(F_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-    P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R)
+    P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R) P8_ATTRF(P8_FX_B) P8_ATTRF(P8_FX_BG) P8_ATTRF(P8_FX_PLAIN)
 #undef P8_ATTRF
 #undef P8_ATTR
   }
@@ -707,9 +710,12 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   long long best = -1;
   const bool dact_store = (g.flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE);
   int fx = 0;                                // a fixed-flavour instantiation of the 256-row tile exists for these flag sets
+  // (DACT only qualifies a pre-activation store or a GELU backward: alone it changes nothing)
+  const int eff = (g.flags & (F_STORE_PRE | F_GELU_BWD)) ? g.flags : (g.flags & ~F_DACT);
   if (direct && g_a2v_p8_fx)
-    for (int f : {(int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R})
-      if (g.flags == f) fx = f;
+    for (int f : {(int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R, (int)P8_FX_B, (int)P8_FX_BG})
+      if (eff == f) fx = f;
+  if (direct && g_a2v_p8_fx && eff == 0) fx = P8_FX_PLAIN;
   const bool fx1 = fx == P8_FX_FC1;
   for (int ih = (dact_store && direct && !fx1) ? 3 : 4; ih >= 2; --ih) {
     if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && !fx1 && g_a2v_p8_ih == 4)) continue;
@@ -740,6 +746,9 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     else if (best_ih == 4 && fx == P8_FX_BR) P8_GOF(P8_FX_BR);
     else if (best_ih == 4 && fx == P8_FX_BRD) P8_GOF(P8_FX_BRD);
     else if (best_ih == 4 && fx == P8_FX_R) P8_GOF(P8_FX_R);
+    else if (best_ih == 4 && fx == P8_FX_B) P8_GOF(P8_FX_B);
+    else if (best_ih == 4 && fx == P8_FX_BG) P8_GOF(P8_FX_BG);
+    else if (best_ih == 4 && fx == P8_FX_PLAIN) P8_GOF(P8_FX_PLAIN);
 #undef P8_GOF
     else if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);
   } else {

@@ -75,7 +75,12 @@ class GemmRecorder:
             r = rec._cg(x, w, out, **kw)
             e1.record()
             G = kw.get("G", 1)
-            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * G, e0, e1, (kw["M"], kw["N"], kw["K"], G)))
+            epi = "+".join(n for n, on in (("bias", kw.get("bias") is not None), ("gelu", kw.get("gelu")),
+                                           ("res", kw.get("res") is not None and not kw.get("gelu_bwd")),
+                                           ("gelu_bwd", kw.get("gelu_bwd")), ("pre", kw.get("pre_out") is not None),
+                                           ("dact", kw.get("dact")), ("colsum", kw.get("colsum") is not None),
+                                           ("drop", kw.get("drop") is not None and kw["drop"][0] > 0)) if on) or "plain"
+            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * G, e0, e1, (kw["M"], kw["N"], kw["K"], G, epi)))
             # algorithmic bytes: every operand element once (the im2col view re-uses each input element `taps` times)
             rec.bytes["nt"] = rec.bytes.get("nt", 0.0) + x.element_size() * G * (
                 kw["M"] * kw["K"] / kw.get("taps", 1) + kw["N"] * kw["K"] + kw["M"] * kw["N"])
@@ -87,7 +92,7 @@ class GemmRecorder:
             r = rec._wg(x, dy, gw, **kw)
             e1.record()
             rec.recs.append(("tn", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1,
-                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1))))
+                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1), "wgrad")))
             return r
 
         ops.conv_gemm, ops.conv_wgrad = cg, wg
@@ -137,7 +142,7 @@ class GemmRecorder:
             a = agg.setdefault((k,) + shape, [0, 0.0, 0.0])
             a[0] += 1; a[1] += f; a[2] += e0.elapsed_time(e1)
         rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
-        return [dict(kind=k[0], M=k[1], N=k[2], K=k[3], G=k[4], launches=v[0], ms=round(v[2], 3),
+        return [dict(kind=k[0], M=k[1], N=k[2], K=k[3], G=k[4], epilogue=k[5], launches=v[0], ms=round(v[2], 3),
                      tflops=round(v[1] / v[2] / 1e9, 1)) for k, v in rows]
 
     def summary(self):
