@@ -92,7 +92,7 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 // the two column blocks j = 0, 1 of a wave give each lane 8 consecutive columns = one 16-B bf16 store; the four lanes
 // with the same MFMA column cover 64 contiguous bytes of an output row.  Replaces 128 ds_write_b32 + 32 ds_read_b128 +
 // 16 wave barriers per wave and tile (LDS-store bound: 4 KiB per wave and pass at 64 B/clk/CU).
-// FX > 0: the epilogue flags are fixed at compile time to the value FX (the launcher instantiates the 256-row tile for the eight
+// FX > 0: the epilogue flags are fixed at compile time to the value FX (the launcher instantiates the 256- and 224-row tiles for the eight
 // flavours a training step launches most: P8_FX_* below).  The generic epilogue allocates registers for the union of every
 // path -- 16 bias values, the residual queue, dropout state, column sums, GELU temporaries -- which at 256 rows leaves room for
 // only two residual row blocks in flight and none for the gelu + gelu' store; a fixed flavour keeps four in flight (-2.5 % per
@@ -700,7 +700,8 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
 #define P8_ATTR(IH_, DS_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<IH_, DS_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     P8_ATTR(4, true) P8_ATTR(3, true) P8_ATTR(2, true) P8_ATTR(4, false) P8_ATTR(3, false) P8_ATTR(2, false)
-#define P8_ATTRF(F_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+#define P8_ATTRF(F_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
+  (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<3, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R) P8_ATTRF(P8_FX_B) P8_ATTRF(P8_FX_BG) P8_ATTRF(P8_FX_PLAIN)
 #undef P8_ATTRF
 #undef P8_ATTR
@@ -740,15 +741,21 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX) ? 1 : 0;
 #define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
   if (direct) {
-#define P8_GOF(F_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<4, true, F_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
-    if (best_ih == 4 && fx == P8_FX_FC1) P8_GOF(P8_FX_FC1);
-    else if (best_ih == 4 && fx == P8_FX_FC2D) P8_GOF(P8_FX_FC2D);
-    else if (best_ih == 4 && fx == P8_FX_BR) P8_GOF(P8_FX_BR);
-    else if (best_ih == 4 && fx == P8_FX_BRD) P8_GOF(P8_FX_BRD);
-    else if (best_ih == 4 && fx == P8_FX_R) P8_GOF(P8_FX_R);
-    else if (best_ih == 4 && fx == P8_FX_B) P8_GOF(P8_FX_B);
-    else if (best_ih == 4 && fx == P8_FX_BG) P8_GOF(P8_FX_BG);
-    else if (best_ih == 4 && fx == P8_FX_PLAIN) P8_GOF(P8_FX_PLAIN);
+#define P8_GOF(F_)                                                                                                        \
+  {                                                                                                                       \
+    if (best_ih == 4)                                                                                                     \
+      hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<4, true, F_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part); \
+    else                                                                                                                  \
+      hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<3, true, F_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part); \
+  }
+    if (best_ih >= 3 && fx == P8_FX_FC1) P8_GOF(P8_FX_FC1)
+    else if (best_ih >= 3 && fx == P8_FX_FC2D) P8_GOF(P8_FX_FC2D)
+    else if (best_ih >= 3 && fx == P8_FX_BR) P8_GOF(P8_FX_BR)
+    else if (best_ih >= 3 && fx == P8_FX_BRD) P8_GOF(P8_FX_BRD)
+    else if (best_ih >= 3 && fx == P8_FX_R) P8_GOF(P8_FX_R)
+    else if (best_ih >= 3 && fx == P8_FX_B) P8_GOF(P8_FX_B)
+    else if (best_ih >= 3 && fx == P8_FX_BG) P8_GOF(P8_FX_BG)
+    else if (best_ih >= 3 && fx == P8_FX_PLAIN) P8_GOF(P8_FX_PLAIN)
 #undef P8_GOF
     else if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);
   } else {

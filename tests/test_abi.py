@@ -155,4 +155,4 @@ def test_p8_tile_claim_register_is_untouched_until_its_wait(tmp_path):
         if "ELb1E" in m.group(1):
             tail0 = [i for i in range(mfma[-1], len(lines)) if lines[i].startswith("s_waitcnt vmcnt(0)")]
             assert len(tail0) <= 5, (m.group(1), len(tail0))
-    assert checked == 14         # three tile heights x two epilogue forms + the eight fixed-flavour 256-row instantiations
+    assert checked == 22         # three tile heights x two epilogue forms + eight fixed flavours x two tile heights
