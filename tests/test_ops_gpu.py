@@ -122,6 +122,16 @@ def test_linear_p8_kernel(ops, M, N, K, ih, direct):
         out["gbwd"] = ops.linear(xd, wd, None, gelu_bwd_aux=rd, colsum=cs)
         out["cs"] = cs
         out["drop"] = ops.linear(xd, wd, bd, res=rd, drop=(0.25, 99))
+        # the remaining flag sets that have fixed-flavour instantiations of the 256- / 224-row tiles
+        out["none"] = ops.linear(xd, wd, None)
+        out["res_nobias"] = ops.linear(xd, wd, None, res=rd)
+        out["gelu_only"] = ops.linear(xd, wd, bd, gelu=True)
+        keep = torch.empty(M, N, dtype=dtype, device="cuda")
+        out["gelu_dact"] = ops.linear(xd, wd, bd, gelu=True, pre_out=keep, dact=True)
+        out["dact"] = keep
+        cs2 = torch.zeros(N, dtype=torch.float32, device="cuda")
+        out["gbwd_dact"] = ops.linear(xd, wd, None, gelu_bwd_aux=rd, colsum=cs2, dact=True)
+        out["cs2"] = cs2
         return out
 
     _lib.load().a2v_debug_set(5, ih)          # tile height 192 / 224 / 256 rows, 0 = the launcher's choice
@@ -133,7 +143,7 @@ def test_linear_p8_kernel(ops, M, N, K, ih, direct):
         _lib.load().a2v_debug_set(5, 0)
         _lib.load().a2v_debug_set(10, 1)
     for k in new:
-        assert torch.equal(new[k], again[k]) or (k == "cs" and rel_err(new[k], again[k]) < 1e-5), k
+        assert torch.equal(new[k], again[k]) or (k in ("cs", "cs2") and rel_err(new[k], again[k]) < 1e-5), k
     _lib.load().a2v_debug_set(1, 0)
     try:
         old = run_all()
@@ -143,6 +153,15 @@ def test_linear_p8_kernel(ops, M, N, K, ih, direct):
     assert rel_err(new["pre"].float(), pre) < tol(dtype)
     assert rel_err(new["gelu"].float(), F.gelu(pre)) < tol(dtype)
     assert rel_err(new["res"].float(), pre + r) < tol(dtype)
+    assert rel_err(new["none"].float(), pre - b) < tol(dtype)
+    assert rel_err(new["res_nobias"].float(), pre - b + r) < tol(dtype)
+    assert rel_err(new["gelu_only"].float(), F.gelu(pre)) < tol(dtype)
+    assert torch.equal(new["gelu_dact"], new["gelu_only"])                 # one evaluation or two: the same gelu
+    pg = pre.clone().requires_grad_(True)
+    F.gelu(pg).sum().backward()
+    assert rel_err(new["dact"].float(), pg.grad) < tol(dtype)
+    assert rel_err(new["gbwd_dact"].float(), (pre - b) * r.float()) < tol(dtype)
+    assert rel_err(new["cs2"], new["gbwd_dact"].float().sum(0)) < 5e-3
     for k in new:          # same arithmetic order per output element (K accumulated in one chain): bit-identical
         assert torch.equal(new[k], old[k]) or rel_err(new[k].float(), old[k].float()) < 1e-5, k
 
