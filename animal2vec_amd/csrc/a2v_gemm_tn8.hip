@@ -56,14 +56,15 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
 
   // LDS position chunk c (16 B) of row r holds source chunk (((c >> 1) ^ f(r)) << 1) | (c & 1); this thread stages
   // rows mrow0 / mrow1 of every K-tile
-  const int c16 = lane & 15;
-  const int mrow0 = wid * 4 + (lane >> 4), mrow1 = mrow0 + 32;
-  unsigned sc0, sc1;
-  {
-    const int f0 = (mrow0 & 3) | (((mrow0 >> 3) & 1) << 2), f1 = (mrow1 & 3) | (((mrow1 >> 3) & 1) << 2);
-    sc0 = (unsigned)(((((c16 >> 1) ^ f0) << 1) | (c16 & 1)) * 16);
-    sc1 = (unsigned)(((((c16 >> 1) ^ f1) << 1) | (c16 & 1)) * 16);
-  }
+  // (a macro, evaluated from a laundered copy of `lane` at the top of every work unit: as loop invariants these four values
+  //  were live across the K loop, spilled at 256 registers, and their scratch reloads at each unit's start drew three
+  //  s_waitcnt vmcnt(0) -- a full drain of the previous unit's 128 atomics per wave while the next unit's K-tiles were already staged)
+#define T8_LANE_CONSTS(l_)                                                                                        \
+  const int c16 = (l_) & 15;                                                                                      \
+  const int mrow0 = wid * 4 + ((l_) >> 4), mrow1 = mrow0 + 32;                                                    \
+  const int f0_ = (mrow0 & 3) | (((mrow0 >> 3) & 1) << 2), f1_ = (mrow1 & 3) | (((mrow1 >> 3) & 1) << 2);        \
+  const unsigned sc0 = (unsigned)(((((c16 >> 1) ^ f0_) << 1) | (c16 & 1)) * 16);                                  \
+  const unsigned sc1 = (unsigned)(((((c16 >> 1) ^ f1_) << 1) | (c16 & 1)) * 16);
   auto make_unit = [&](int seq) {
     T8Unit u;
     const int id = xcd_remap(seq < units ? seq : units - 1, units);
@@ -166,6 +167,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
 
   int seq = blockIdx.x;
   T8Unit U = make_unit(seq);
+  {
+  T8_LANE_CONSTS(lane)
   T8_STAGE(pb, ldp2, U, 0, 0, T8_PLO)
   T8_STAGE(qb, ldq2, U, 0, 0, T8_QLO)
   T8_STAGE(qb, ldq2, U, 0, 1, T8_QHI)
@@ -173,11 +176,15 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
   T8_STAGE(pb, ldp2, U, 1, 0, T8_BUF + T8_PLO)
   T8_STAGE(qb, ldq2, U, 1, 0, T8_BUF + T8_QLO)
   T8_STAGE(qb, ldq2, U, 1, 1, T8_BUF + T8_QHI)
+  }
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (stagger && wr == 1) __builtin_amdgcn_s_barrier();         // wave groups half a phase apart (see a2v_gemm_p8.hip)
 
   for (; seq < units; seq += gridDim.x) {
+    int ls;                                          // the lane id from the hardware, not from a register kept across the K loop
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ls));
+    T8_LANE_CONSTS(ls)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -196,8 +203,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
     T8_KTILE(T8_BUF, 0, Un, kn0, Un, kn1)
 
     // ---- epilogue: fp32 atomics; D rows n = 4 fq + r, columns kk = fr
-    int le = lane;
-    asm volatile("" : "+v"(le));                     // keeps the lane-derived addresses out of the K loop's live set
+    int le;                                          // (again from the hardware: lane-derived addresses stay out of the K loop's live set)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
     const int fre = le & 15, fqe = le >> 4;
     float* const wt = U.wb + (long long)(wr * 64 + fqe * 4) * U.ldw + wc * 32 + fre;
 #pragma unroll
