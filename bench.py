@@ -371,6 +371,14 @@ def dry_run(args, world, rank):
     return 0
 
 
+def default_micro_batch(global_batch, world, samples):
+    """The largest micro-batch that divides the rank's share of the global batch: 64 clips of 10 s @ 8 kHz fit one GPU with
+    room to spare (fewer, longer launches: +2 % over two micro-batches of 32); longer clips keep to 8."""
+    per_rank = max(1, global_batch // world)
+    cap = 64 if samples <= 80000 else 8
+    return next(m for m in (64, 32, 16, 8, 4, 2, 1) if m <= cap and per_rank % m == 0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -406,11 +414,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     if args.micro_batch <= 0:
-        per_rank = max(1, args.global_batch // world)
-        # the largest micro-batch that divides the rank's share: 64 clips of 10 s @ 8 kHz fit one GPU with room to spare (fewer,
-        # longer launches: +2 % over two micro-batches of 32); longer clips keep to 8
-        cap = 64 if args.samples <= 80000 else 8
-        args.micro_batch = next(m for m in (64, 32, 16, 8, 4, 2, 1) if m <= cap and per_rank % m == 0)
+        args.micro_batch = default_micro_batch(args.global_batch, world, args.samples)
     if args.dry:
         return dry_run(args, world, rank)
     assert args.backend == "nccl", "the GPU path runs over RCCL; gloo is for --dry"

@@ -97,3 +97,14 @@ def test_cpu_baseline_median_and_best_leg(monkeypatch):
     assert c["cores"] == 16 and c["host_cores"] == 64 and c["kind"] == "port"
     assert abs(c["value"] - 10.0 / 9.0) < 1e-3                      # median of (10, 8, 9) s for a 10 s clip
     assert [l["threads"] for l in c["legs"]] == [16, 64] and c["legs"][1]["audio_s_per_s"] is None
+
+
+def test_default_micro_batch_per_world_size():
+    """one micro-batch per rank for the driver's 1 / 2 / 4 / 8-GPU runs of the 64-clip batch; long clips keep to 8"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert [b.default_micro_batch(64, w, 80000) for w in (1, 2, 4, 8)] == [64, 32, 16, 8]
+    assert b.default_micro_batch(64, 1, 441000) == 8 and b.default_micro_batch(4, 1, 441000) == 4
+    assert b.default_micro_batch(48, 1, 80000) == 16 and b.default_micro_batch(7, 2, 80000) == 1
