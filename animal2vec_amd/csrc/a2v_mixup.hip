@@ -2,7 +2,7 @@
 //   gain_db[b,f] = 10 log10 max( sum_k |rfft(hann * frame_f)|^2[k] * A_weight[k], 1e-8 )
 //   p = 1 / (1 + 10^((G1-G2)/20) * (1-r)/r),  G = max_f gain_db ;  out = (p s1 + (1-p) s2) / sqrt(p^2+(1-p)^2)
 // One workgroup per (clip, frame): the windowed frame and a cos/sin twiddle table live in LDS, thread k owns
-// frequency bin k (direct DFT, n_fft <= 1024) -- 0.5 GMAC per 8 clips, far below every roofline.
+// frequency bin k (direct DFT, twiddles by a rotation recurrence re-seeded from the table every 16 taps).
 #include "a2v_common.h"
 
 __global__ __launch_bounds__(256) void mixup_gain_kernel(const float* __restrict__ x, const float* __restrict__ window,
@@ -24,14 +24,24 @@ __global__ __launch_bounds__(256) void mixup_gain_kernel(const float* __restrict
   __syncthreads();
   const int nbins = n_fft / 2 + 1;
   float part = 0.f;
+  // The twiddle of tap n + 1 is the twiddle of tap n turned by the bin's own angle: one table read per 16 taps (re-seeding keeps
+  // the recurrence's drift at ~1e-6) instead of two gathered LDS reads per tap -- the table lookups, not the FMAs, bounded this
+  // kernel (three LDS reads per two FMAs); fr[n] is a broadcast read.
   for (int k = threadIdx.x; k < nbins; k += blockDim.x) {
     float re = 0.f, im = 0.f;
-    int j = 0;
-    for (int n = 0; n < n_fft; ++n) {
-      re = fmaf(fr[n], tc[j], re);
-      im = fmaf(fr[n], ts[j], im);
-      j += k;
-      if (j >= n_fft) j -= n_fft;
+    const float cd = tc[k], sd = ts[k];                   // k < n_fft / 2 + 1 <= n_fft
+    for (int n0 = 0; n0 < n_fft; n0 += 16) {
+      const int j = (int)(((long long)k * n0) % n_fft);
+      float c = tc[j], sn = ts[j];
+      const int n1 = min(n0 + 16, n_fft);
+      for (int n = n0; n < n1; ++n) {
+        const float x = fr[n];
+        re = fmaf(x, c, re);
+        im = fmaf(x, sn, im);
+        const float c2 = fmaf(c, cd, -sn * sd);
+        sn = fmaf(sn, cd, c * sd);
+        c = c2;
+      }
     }
     part += (re * re + im * im) * aweight[k];
   }

@@ -76,6 +76,9 @@ def one(B):
     ms = timeit(lambda: ops.sinc_fused_bwd(xs, filt, lw, lb, pa, pb, dys, mean, rstd, dfilt, dpar, C_=C_, k=k_), 10, inner=2)
     print(f"sinc_fused_bwd      {1e3 * ms:9.1f} us  {B * Ls * 128 * 2 / ms / 1e6:8.1f} GB/s")
     del ys, dys
+    mx = ops.Mixup(8000, 0.05, dev)
+    ms = timeit(lambda: mx.gain_db(xs), 10, inner=2)
+    print(f"mixup gain_db       {1e3 * ms:9.1f} us")
     out = ops.decoder_input(xk, (0.01, 5), restore).float()
     nz = out[mask.bool()]
     print("noise mean %.3e std %.5f (want 0.01) kurt %.3f" % (nz.mean().item(), nz.std().item(), ((nz / nz.std()) ** 4).mean().item()))
