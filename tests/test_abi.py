@@ -156,3 +156,33 @@ def test_p8_tile_claim_register_is_untouched_until_its_wait(tmp_path):
             tail0 = [i for i in range(mfma[-1], len(lines)) if lines[i].startswith("s_waitcnt vmcnt(0)")]
             assert len(tail0) <= 5, (m.group(1), len(tail0))
     assert checked == 22         # three tile heights x two epilogue forms + eight fixed flavours x two tile heights
+    # the fixed-flavour instantiations exist because the generic 256-row epilogue has no registers to spare: none of them may spill
+    for m in re.finditer(r"\.amdhsa_kernel (_Z\d+gemm_nt_bf16_p8_kernelILi[34]ELb1ELi([1-9]\d*)E\w*)(.*?)\.end_amdhsa_kernel", s, re.S):
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", m.group(3)).group(1))
+        assert scratch == 0, (m.group(1), scratch)
+
+
+def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):
+    """256 x 256 TN weight-gradient kernel: at the register limit (256) the lane constants of the staging addresses used to be
+    spilled and reloaded at the start of every work unit behind `s_waitcnt vmcnt(0)` -- a drain of the previous unit's 128
+    atomics per wave.  They come from the hardware lane id now: no scratch, and the only vmcnt(0) is the one before the kernel ends."""
+    import shutil
+    import subprocess
+    import pytest
+    from animal2vec_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = "a2v_gemm_tn8.hip"
+    out = tmp_path / (src + ".s")
+    cmd = [hipcc, *B.FLAGS, *B.FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = out.read_text()
+    m = re.search(r"^(_Z\d+gemm_tn_bf16_p8_kernel\w*):", s, re.M)
+    assert m
+    body = s[m.end():s.index("s_endpgm", m.end())]
+    lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+    assert not [l for l in lines if l.startswith("scratch_")]
+    drains = [i for i, l in enumerate(lines) if l.startswith("s_waitcnt vmcnt(0)")]
+    assert len(drains) == 1 and drains[0] >= len(lines) - 3, drains
