@@ -2,6 +2,8 @@
 import os
 import re
 
+import pytest
+
 from conftest import ROOT
 
 
@@ -186,3 +188,40 @@ def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):
     assert not [l for l in lines if l.startswith("scratch_")]
     drains = [i for i, l in enumerate(lines) if l.startswith("s_waitcnt vmcnt(0)")]
     assert len(drains) == 1 and drains[0] >= len(lines) - 3, drains
+
+
+HOT_KERNELS = {
+    "a2v_attn.hip": [r"attn_fwd_bf16_kernelILi64ELb0ELi2ELb0E", r"attn_fwd_seq48_kernel", r"attn_bwd_seq48_kernel"],
+    "a2v_conv_slab.hip": [r"conv_nt_slab2_kernel"],
+    "a2v_wgrad_slab.hip": [r"conv_wgrad_slab_kernel"],
+    "a2v_conv_dec.hip": [r"conv_dec_kernel"],
+    "a2v_norm.hip": [r"layernorm_fwd_kernelIDF16bLi2E", r"layernorm_bwd_kernelIDF16bLi2ELi8ELi[01]ELi0E",
+                     r"layernorm_bwd_kernelIDF16bLi2ELi8ELi0ELi2E", r"instnorm_"],
+    "a2v_elem.hip": [r"d2v_loss_kernel", r"decoder_input_kernel", r"col2im_kernel", r"adam_kernel", r"ema_kernel"],
+}
+
+
+@pytest.mark.parametrize("src", sorted(HOT_KERNELS))
+def test_hot_kernels_do_not_spill(src, tmp_path):
+    """The kernels that make up the pretraining step's device time are written against fixed register budgets (launch bounds,
+    accumulators in registers); a spill in one of them is a silent slowdown -- scratch traffic, and a `s_waitcnt vmcnt(0)` in front
+    of every reload that drains whatever prefetch is in flight.  Compiled with the library's own flags, each must use no scratch."""
+    import shutil
+    import subprocess
+    from animal2vec_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    out = tmp_path / (src + ".s")
+    cmd = [hipcc, *B.FLAGS, *B.FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = out.read_text()
+    seen = 0
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", s, re.S):
+        if not any(re.search(pat, m.group(1)) for pat in HOT_KERNELS[src]):
+            continue
+        seen += 1
+        scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", m.group(2)).group(1))
+        assert scratch == 0, (m.group(1), scratch)
+    assert seen >= len(HOT_KERNELS[src])
