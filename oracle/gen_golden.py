@@ -536,9 +536,6 @@ def main():
         save("tiny_finetune_train.npz", fttx)
 
 
-if __name__ == "__main__":
-    main()
-
 
 def init_fixture(refnn):
     """G18 (rows a1 / a21): initial parameter statistics of the LIVE reference model (mid dims: real 127 x 63 sinc + 512-wide
@@ -575,3 +572,7 @@ def finetune_recipes_fixture():
         out[f"finetune_mixup_{n}"] = {k: y[k] for k in ("task", "dataset", "criterion", "optimization", "optimizer", "lr_scheduler", "model")}
     with open(os.path.join(GOLD, "finetune_recipes.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
