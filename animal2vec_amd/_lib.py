@@ -64,6 +64,8 @@ SIGNATURES = {
     "a2v_pack_weight_batch": [_i, _p, _i, _p],
     "a2v_focal_loss": [_i, _p, _p, _p, _p, _ll, _i, _i, _f, _f, _f, _p],
     "a2v_mean_layers": [_i, _p, _i, _p, _ll, _f, _p],
+    "a2v_span_mask": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _f, C.c_ulonglong, _p],
+    "a2v_maskinfo": [_p, _p, _p, _p, _i, _i, _i, _p],
     "a2v_abi_version": [],
 }
 

@@ -14,7 +14,7 @@ import torch.nn as tnn
 from . import ops
 from .config import Data2VecMultiConfig
 from .engine import Engine
-from .masking import compute_mask_indices, make_maskinfo
+from .masking import DeviceMaskSampler, compute_mask_indices, make_maskinfo, mask_seed
 from .params import P, ParamStore
 from .registry import register_model
 from .trainer import get_annealed_rate
@@ -82,6 +82,8 @@ class Data2VecMultiModel(tnn.Module):
         self.num_updates = 0
         self.ema_decay = cfg.ema_decay
         self._rng = np.random.default_rng(cfg.seed)
+        self._mask_sampler, self._mask_draws = None, 0           # device span masks (masking.DeviceMaskSampler), made on first use
+        self._rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         self._packs_version = None
 
     # ------------------------------------------------------------------ construction / io
@@ -152,11 +154,17 @@ class Data2VecMultiModel(tnn.Module):
         self.num_updates = num_updates
 
     # ------------------------------------------------------------------ forward
-    def _make_mask(self, B: int, T: int, device):
+    def _sample_maskinfo(self, B: int, T: int):
+        """compute_mask + make_maskinfo of the reference's forward (base.py:401-455) on the device (a2v_span_mask)."""
         a = self.cfg.audio
-        m = compute_mask_indices((B * self.cfg.clone_batch, T), a.mask_prob, a.mask_length, self._rng,
-                                 min_masks=1, require_same_masks=True, mask_dropout=a.mask_dropout)
-        return torch.from_numpy(m).to(device)
+        if self._mask_sampler is None:
+            self._mask_sampler = DeviceMaskSampler(self.store.device, mask_prob=a.mask_prob, mask_length=a.mask_length,
+                                                   mask_dropout=a.mask_dropout)
+        if getattr(self, "_mask_release_pending", False):        # the previous forward's backward has been enqueued by now
+            self._mask_sampler.end_step()
+            self._mask_release_pending = False
+        self._mask_draws += 1
+        return self._mask_sampler.take(B * self.cfg.clone_batch, T, mask_seed(self.cfg.seed, self._mask_draws, 0, self._rank))
 
     def forward(self, source, target=None, id=None, mode=None, padding_mask=None, mask=True, features_only=False,
                 force_remove_masked=False, remove_extra_tokens=True, precomputed_mask=None, reduce=True, noise=None,
@@ -177,8 +185,10 @@ class Data2VecMultiModel(tnn.Module):
             return self._features_only(source, mask, precomputed_mask)
         B, L = source.shape
         T = cfg.frame_counts(L)[-1]
-        m = precomputed_mask if precomputed_mask is not None else self._make_mask(B, T, source.device)
-        mask_u8, keep, restore = make_maskinfo(m.to(source.device))
+        if precomputed_mask is not None:
+            mask_u8, keep, restore = make_maskinfo(precomputed_mask.to(source.device))
+        else:
+            mask_u8, keep, restore = self._sample_maskinfo(B, T)
         N, K = keep.shape
         need_grad = torch.is_grad_enabled() and self.training
         eng.stats.zero_()
@@ -188,6 +198,10 @@ class Data2VecMultiModel(tnn.Module):
         dseed = (self.cfg.seed * 7919 + self._fwd_count) if (self.training and self.dropout) else None
         dbg = eng.forward(source, mask_u8, keep, restore, noise, save=need_grad, keep_debug=unreduced_loss,
                           dropout_seed=dseed)
+        if precomputed_mask is None and not need_grad:           # (with a backward pending the masks stay in use: the
+            self._mask_sampler.end_step()                        #  slot is given back by the next forward)
+        elif precomputed_mask is None:
+            self._mask_release_pending = True
         D = cfg.embed_dim
         st = eng.stats
         loss_sum = st[4 * D].to(torch.float32).reshape(1)

@@ -329,6 +329,34 @@ def sinc_fused_bwd(x, filt, ln_w, ln_b, ps_a, ps_b, dy, mean, rstd, dfilt, dpar,
 # ----------------------------------------------------------------------------------------------
 #                                         tokens / loss / optimizer
 # ----------------------------------------------------------------------------------------------
+def span_mask(N, T, *, mask_prob, mask_length, seed, min_masks=1, mask_dropout=0.0, device="cuda", bufs=None):
+    """Device span-mask sampler + maskinfo (include/a2v.h: a2v_span_mask; reference base.py:401-455).  Returns
+    (mask_u8 (N,T), ids_keep_flat (N*T int32 -- view the first N*K as (N,K) once K is known), ids_restore (N,T) int32,
+    k_dev (1,) int32).  Asynchronous on the current stream; K = k_dev[0] is data dependent.  bufs: the same tuple (plus
+    the counts scratch) from an earlier call, to be overwritten."""
+    if bufs is None:
+        dev = torch.device(device)
+        bufs = (torch.empty(N, T, dtype=torch.uint8, device=dev), torch.empty(N * T, dtype=torch.int32, device=dev),
+                torch.empty(N, T, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
+                torch.empty(N, dtype=torch.int32, device=dev))
+    mask, keep, restore, kdev, counts = bufs
+    rc = _L().a2v_span_mask(ptr(mask), ptr(counts), ptr(keep), ptr(restore), ptr(kdev), N, T, float(mask_prob), int(mask_length),
+                            int(min_masks), float(mask_dropout), int(seed) & 0xFFFFFFFFFFFFFFFF, stream())
+    check(rc, "a2v_span_mask")
+    return bufs
+
+
+def maskinfo(mask_u8, K, rows_bad=None):
+    """make_maskinfo (base.py:427-455) of a given (N,T) uint8 mask with K kept frames per row -> ids_keep (N,K) ascending,
+    ids_restore (N,T), both int32."""
+    N, T = mask_u8.shape
+    keep = torch.empty(N, K, dtype=torch.int32, device=mask_u8.device)
+    restore = torch.empty(N, T, dtype=torch.int32, device=mask_u8.device)
+    rc = _L().a2v_maskinfo(ptr(mask_u8), ptr(keep), ptr(restore), ptr(rows_bad), N, T, int(K), stream())
+    check(rc, "a2v_maskinfo")
+    return keep, restore
+
+
 def gather_tokens(a, ids, *, cb=1, b=None, drop=None):
     """out[n,k,:] = a[n//cb, ids[n,k], :] (+ b[n, ids[n,k], :]);  a (Ba,Ta,D), ids (N,K) int32"""
     N, K = ids.shape

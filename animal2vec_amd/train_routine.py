@@ -14,7 +14,6 @@ import torch.distributed as dist
 import yaml
 
 from .config import D2vAudioConfig, D2vDecoderConfig, Data2VecMultiConfig
-from .masking import compute_mask_indices, make_maskinfo
 from .trainer import OptimConfig, PretrainTrainer
 
 
@@ -128,16 +127,14 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
         tr.engine.refresh_student_packs()
         tr.engine.refresh_teacher_packs()
         tr.num_updates = int(state.get("optimizer_history", [{}])[-1].get("num_updates", 0))
-    rng = __import__("numpy").random.default_rng(cfg.seed + rank)
     u0 = 0
     if restore_file:
         los = state.get("last_optimizer_state")
         if isinstance(los, dict) and "adam_m" in los:
-            tr.load_optimizer_state(los)                                     # exact resume: moments, counters, mixup / noise RNG
-            ex = los.get("extra") or {}
-            if "mask_rng" in ex:                                             # ... the span-mask stream and the loop position
-                rng.bit_generator.state = ex["mask_rng"]
-            u0 = int(ex.get("update_cursor", 0))
+            # exact resume: moments and counters.  Every random draw of a step (span masks, mixup, mask-token noise, dropout)
+            # is a function of (seed, num_updates, micro-batch, rank) -- no RNG state travels, each rank re-derives its own
+            tr.load_optimizer_state(los)
+            u0 = int((los.get("extra") or {}).get("update_cursor", 0))
     real = None
     for u in range(u0, u0 + updates):
         mbs = []
@@ -155,10 +152,7 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
                 g = torch.Generator().manual_seed(1000 * u + 10 * j + rank)
                 src = torch.nn.functional.layer_norm(torch.randn(clips_per_micro_batch, clip_samples, generator=g),
                                                      (clip_samples,)).cuda()
-            T = cfg.frame_counts(src.shape[1])[-1]
-            m = compute_mask_indices((src.shape[0] * cfg.clone_batch, T), cfg.audio.mask_prob, cfg.audio.mask_length, rng)
-            mu, keep, restore = make_maskinfo(torch.from_numpy(m).cuda())
-            mbs.append(dict(source=src, mask_u8=mu, ids_keep=keep, ids_restore=restore, noise=None))
+            mbs.append(dict(source=src, noise=None))        # span masks: sampled by the step itself, on the device (masking.py)
         if not mbs:
             continue
         t0 = time.perf_counter()
@@ -170,8 +164,7 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
         from . import checkpoint as ck
         # (synthetic batches are a function of the update index; a manifest epoch restarts at its first batch on resume)
         ck.save_checkpoint(save_path, tr.store, cfg={"model": {"_name": "data2vec_multi"}}, num_updates=tr.num_updates,
-                           optimizer_state=tr.optimizer_state(extra={"mask_rng": rng.bit_generator.state,
-                                                                     "update_cursor": u0 + updates}))
+                           optimizer_state=tr.optimizer_state(extra={"update_cursor": u0 + updates}))
     return tr
 
 

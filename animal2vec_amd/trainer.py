@@ -20,6 +20,7 @@ from . import ops
 from .config import Data2VecMultiConfig
 from .ddp import GradSync, grad_scale_factor, make_buckets
 from .engine import Engine
+from .masking import DeviceMaskSampler, mask_seed
 from .params import P, ParamStore, bucket_starts
 
 
@@ -57,17 +58,19 @@ class PretrainTrainer:
         self.dropout = dropout
         self.mixup = ops.Mixup(cfg.audio.sample_rate, cfg.mixing_window_length, self.store.device) \
             if (cfg.source_mixup >= 0 and cfg.mixup_prob > 0 and mixup) else None
-        self._np_rng = __import__("numpy").random.default_rng(seed + 17)
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
-        # device-side permutations: a pageable host->device copy per micro-batch would make the host wait for the
-        # stream to drain (ROCm stages such copies synchronously) and leave the GPU idle while it catches up again
+        self.seed = int(seed)
+        # Every random draw of a step -- span masks, mixup strength / permutation / per-clip bernoulli, mask-token noise,
+        # dropout -- is a pure function of (seed, num_updates, micro-batch index, rank): nothing to checkpoint, and a
+        # resumed run draws on every rank what the uninterrupted one would have.  The device generator is re-seeded per
+        # micro-batch (a host-side counter write; the permutation itself is drawn on the device: a pageable
+        # host->device copy per micro-batch would make the host wait for the stream to drain).
         self._perm_gen = torch.Generator(device=self.store.device)
-        self._perm_gen.manual_seed(seed * 7919 + 17 + self.rank)
-        # mask-token noise (base.py:172-176) from a trainer-owned generator, so that a resumed run draws what the
-        # uninterrupted one would have (the default CUDA generator is shared with everything else in the process)
-        self._noise_gen = torch.Generator(device=self.store.device)
-        self._noise_gen.manual_seed(seed * 7919 + 31 + self.rank)
-        self._noise_seed0 = (seed * 7919 + 31) & 0x7FFFFFFF
+        a = cfg.audio
+        self.mask_sampler = None
+        if self.store.device.type == "cuda":
+            self.mask_sampler = DeviceMaskSampler(self.store.device, mask_prob=a.mask_prob, mask_length=a.mask_length,
+                                                  mask_dropout=a.mask_dropout)
         self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
         self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device
@@ -100,28 +103,37 @@ class PretrainTrainer:
 
     # ------------------------------------------------------------------ one optimizer step
     def train_step(self, micro_batches: Sequence[dict]) -> None:
-        """micro_batches: dicts with source (B,L) fp32, mask_u8, ids_keep, ids_restore, and either
-        `noise` (N,T-K,D) fp32 or None (then N(0, mask_noise_std) is drawn on device, inside the decoder-input kernel)."""
+        """micro_batches: dicts with source (B,L) fp32 and, optionally, mask_u8 / ids_keep / ids_restore (a caller-supplied
+        `precomputed_mask`; absent: the step samples its span masks itself, on the device, as the reference's forward does
+        on the host -- base.py:401-455) and `noise` (N,T-K,D) fp32 (absent / None: N(0, mask_noise_std) is drawn on the
+        device, inside the decoder-input kernel)."""
         st, eng, o = self.store, self.engine, self.optim
         st.grad.zero_()
         eng.stats.zero_()
         nmb = len(micro_batches)
+        masks = self._step_masks(micro_batches)
         for j, mb in enumerate(micro_batches):
             self.sync.arm(j == nmb - 1)
             noise = mb.get("noise")
             if noise is None:                 # drawn inside the decoder-input kernel: (std, seed), seed from the step counters
                 noise = (self.cfg.audio.mask_noise_std,
-                         (self._noise_seed0 + (self.num_updates * 131 + j) * 8191 + self.rank) & 0x7FFFFFFF)
+                         ((self.seed * 7919 + 31) + (self.num_updates * 131 + j) * 8191 + self.rank) & 0x7FFFFFFF)
             dseed = ((self.num_updates * 131 + j) * 257 + self.rank + 1) if self.dropout else None
             src = mb["source"]
             if self.mixup is not None:        # BC-learning mixup, train only (data2vec2.py:536-598)
-                r = float(self._np_rng.uniform(max(1e-6, self.cfg.source_mixup), 1.0))
+                cs = mask_seed(self.seed + 17, self.num_updates, j, self.rank)
+                r = max(1e-6, self.cfg.source_mixup)
+                r = r + (1.0 - r) * ((cs >> 11) / float(1 << 53))               # U[source_mixup, 1), one per micro-batch
+                self._perm_gen.manual_seed(cs & 0x7FFFFFFFFFFFFFFF)
                 perm = torch.rand(src.shape[0], device=src.device, generator=self._perm_gen).argsort().to(torch.int32)
                 mm = None
                 if self.cfg.mixup_prob < 1:            # bernoulli(mixup_prob) per clip (data2vec2.py:540-545)
                     mm = (torch.rand(src.shape[0], device=src.device, generator=self._perm_gen) < self.cfg.mixup_prob).to(torch.uint8)
                 src = self.mixup(src, perm, r, mm)
-            eng.forward_backward(src, mb["mask_u8"], mb["ids_keep"], mb["ids_restore"], noise, dropout_seed=dseed)
+            mk = masks[j] if masks[j] is not None else (mb["mask_u8"], mb["ids_keep"], mb["ids_restore"])
+            eng.forward_backward(src, mk[0], mk[1], mk[2], noise, dropout_seed=dseed)
+        if self.mask_sampler is not None:
+            self.mask_sampler.end_step()
         self.sync.arm(False)
         D = self.cfg.embed_dim
         self.sync.finish(eng.stats)            # wait buckets; loss / count / variance sums in one packed call
@@ -153,18 +165,36 @@ class PretrainTrainer:
                 eng.refresh_teacher_packs()
         self.last = dict(stats=eng.stats, gnorm=gnorm)
 
+    def _step_masks(self, micro_batches):
+        """(mask_u8, ids_keep, ids_restore) per micro-batch that brings no mask of its own: taken from the device sampler
+        (requested during the previous step -- same shapes assumed, else drawn now), and the next step's requested."""
+        need = [j for j, mb in enumerate(micro_batches) if mb.get("mask_u8") is None]
+        out = [None] * len(micro_batches)
+        if not need:
+            return out
+        if self.mask_sampler is None:
+            raise RuntimeError("micro-batches without masks need the device sampler (a GPU): there is no host path")
+        cb = self.cfg.clone_batch
+        shapes = {}
+        for j in need:
+            B, L = micro_batches[j]["source"].shape
+            shapes[j] = (B * cb, self.cfg.frame_counts(L)[-1])
+            out[j] = self.mask_sampler.take(*shapes[j], mask_seed(self.seed, self.num_updates, j, self.rank))
+        for j in need:
+            self.mask_sampler.request(*shapes[j], mask_seed(self.seed, self.num_updates + 1, j, self.rank))
+        return out
+
     # ------------------------------------------------------------------ exact resume
     def optimizer_state(self, extra: Optional[dict] = None) -> dict:
-        """What fairseq keeps under "last_optimizer_state" (Adam moments, step count) plus this trainer's own counters and
-        every random stream a step draws from (mixup strength / permutation, mask-token noise); `extra` carries what the
-        caller owns (mask RNG state, data cursor: train_routine.py).  Layout note: this is NOT fairseq's
+        """What fairseq keeps under "last_optimizer_state" (Adam moments, step count) plus this trainer's own counters.  No
+        random stream is part of it: masks, mixup draws, mask-token noise and dropout are functions of (seed, num_updates,
+        micro-batch, rank).  `extra` carries what the caller owns (data cursor: train_routine.py).  Layout note: this is NOT fairseq's
         {"state": {param id: {exp_avg, exp_avg_sq, step}}, "param_groups"} dict -- the moments are the two flat fp32
         buffers in the flat parameter order -- so the reference can load the MODEL from these files but must start its
         optimizer afresh (`--reset-optimizer`)."""
         st = self.store
         out = {"adam_m": st.adam_m.detach().cpu(), "adam_v": st.adam_v.detach().cpu(), "num_updates": self.num_updates,
-               "ema_decay": self.ema_decay, "perm_rng": self._perm_gen.get_state().cpu(),
-               "noise_rng": self._noise_gen.get_state().cpu(), "np_rng": self._np_rng.bit_generator.state}
+               "ema_decay": self.ema_decay, "seed": self.seed}
         if extra:
             out["extra"] = dict(extra)
         return out
@@ -175,12 +205,7 @@ class PretrainTrainer:
         st.adam_v.copy_(state["adam_v"].to(st.device))
         self.num_updates = int(state["num_updates"])
         self.ema_decay = float(state.get("ema_decay", self.ema_decay))
-        if "perm_rng" in state:
-            self._perm_gen.set_state(state["perm_rng"].cpu())
-        if "noise_rng" in state:
-            self._noise_gen.set_state(state["noise_rng"].cpu())
-        if "np_rng" in state:
-            self._np_rng.bit_generator.state = state["np_rng"]
+        self.seed = int(state.get("seed", self.seed))        # the draws are functions of (seed, counters): the seed travels
 
     # ------------------------------------------------------------------ logging-side scalars (sync)
     def metrics(self) -> Dict[str, float]:

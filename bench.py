@@ -9,7 +9,10 @@ One "step" = one optimizer step on a FIXED global batch (strong scaling): micro-
 the hand-written HIP path, bucketed RCCL gradient all-reduce overlapped with backward, clip + Adam, EMA
 teacher update, operand re-pack.  Rank 0 prints ONE JSON line (contract in the task brief) carrying the
 roofline of the dominant kernel and the CPU baseline (the oracle timed on this box's host cores).
-Synthetic data: randn waveforms, per-clip normalised; seeded masks keeping K of T frames.
+Synthetic data: randn waveforms, per-clip normalised.  Span masks are sampled INSIDE the timed step, every
+step afresh, by the device sampler (a2v_span_mask; the reference samples them on the host in every forward,
+base.py:401-413); K = the kept frames per row is whatever the draw gives (T - the batch's smallest masked count).
+`--masks precomputed` is the A/B form with seeded keep-masks of `--keep` frames made once outside the loop.
 """
 import argparse
 import json
@@ -202,11 +205,13 @@ def pmc_mfma(kernel_substr):
     return round(acc / n, 4) if n else None
 
 
-def make_microbatch(cfg, B, L, K, seed, device):
+def make_microbatch(cfg, B, L, K, seed, device, masks="sampled"):
     from animal2vec_amd.masking import make_maskinfo, seeded_keep_mask
     g = torch.Generator().manual_seed(seed)
     src = torch.randn(B, L, generator=g)
     src = torch.nn.functional.layer_norm(src, (L,)).to(device)
+    if masks == "sampled":
+        return dict(source=src, noise=None)          # the step draws its own span masks (trainer._step_masks)
     T = cfg.frame_counts(L)[-1]
     mask = seeded_keep_mask(B * cfg.clone_batch, T, K, seed + 1, device=device)
     m, keep, restore = make_maskinfo(mask)
@@ -386,12 +391,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="large", choices=["large", "base", "large44k"],
                     help="large44k: BASELINE config 5 (296x149 front end @ 44.1 kHz; use --samples 220500 --keep 386)")
-    ap.add_argument("--global-batch", type=int, default=64, help="clips per optimizer step over all GPUs")
+    ap.add_argument("--global-batch", type=int, default=128,
+                    help="clips per optimizer step over all GPUs (fixed as N grows: strong scaling).  128 = the reference recipe's "
+                         "update (4 GPUs x 408 000 samples ~ 5 clips x update_freq 5 ~ 102 clips of 10 s, a2v_large_pretrain_best.yaml:"
+                         "34-36,45-47,62) rounded up to a power of two so that 1/2/4/8 ranks divide it")
     ap.add_argument("--micro-batch", type=int, default=0,
-                    help="clips per fwd/bwd launch sequence per GPU; 0 = min(32, clips per rank): 32 clips amortise the "
-                         "per-launch costs (1227 vs 1149 audio-s/s at 8, no further gain at 64) and stay under 110 GB of activations")
+                    help="clips per fwd/bwd launch sequence per GPU; 0 = the largest of 64/32/16/... that divides the rank's share "
+                         "(default_micro_batch: 64 clips of 10 s @ 8 kHz fit one GPU; longer clips keep to 8)")
     ap.add_argument("--samples", type=int, default=80000)
-    ap.add_argument("--keep", type=int, default=140)
+    ap.add_argument("--keep", type=int, default=140, help="kept frames per row of the seeded masks (--masks precomputed only)")
+    ap.add_argument("--masks", default="sampled", choices=["sampled", "precomputed"],
+                    help="sampled: span masks drawn on the device inside every timed step (default); precomputed: seeded "
+                         "keep-masks made once outside the timed loop (A/B)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--no-roofline", action="store_true")
@@ -440,7 +451,7 @@ def main():
     n_mb = args.global_batch // (world * args.micro_batch)
     tr = PretrainTrainer(cfg, dtype=dtype, device=dev, seed=0)
     L, K = args.samples, args.keep
-    mbs = [make_microbatch(cfg, args.micro_batch, L, K, 1234 + 1000 * rank + 10 * j, dev) for j in range(n_mb)]
+    mbs = [make_microbatch(cfg, args.micro_batch, L, K, 1234 + 1000 * rank + 10 * j, dev, masks=args.masks) for j in range(n_mb)]
 
     def sync():
         torch.cuda.synchronize()
@@ -451,11 +462,18 @@ def main():
     for _ in range(args.warmup):
         tr.train_step(mbs)
     sync()
+    smp = tr.mask_sampler
+    k0 = (smp.k_sum, smp.k_count)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.train_step(mbs)
     sync()
     dt = time.perf_counter() - t0
+    if args.masks == "sampled":           # mean kept frames per row over the timed steps (host ints: read back by the sampler)
+        k_mean = (smp.k_sum - k0[0]) / max(1, smp.k_count - k0[1])
+        K = int(round(k_mean))
+    else:
+        k_mean = float(K)
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -469,8 +487,13 @@ def main():
         side, tr.engine.tstream = tr.engine.tstream, None     # per-kernel timing: one stream, nothing overlapping the timed launches
         try:
             tr.engine.stats.zero_()
-            tr.engine.forward_backward(mbs[0]["source"], mbs[0]["mask_u8"], mbs[0]["ids_keep"], mbs[0]["ids_restore"],
-                                       (cfg.audio.mask_noise_std, 4321))
+            if args.masks == "sampled":
+                from animal2vec_amd.masking import mask_seed
+                mk = smp.take(args.micro_batch * cfg.clone_batch, cfg.frame_counts(L)[-1], mask_seed(0, 10 ** 6, 0, rank))
+            else:
+                mk = (mbs[0]["mask_u8"], mbs[0]["ids_keep"], mbs[0]["ids_restore"])
+            tr.engine.forward_backward(mbs[0]["source"], mk[0], mk[1], mk[2], (cfg.audio.mask_noise_std, 4321))
+            smp.end_step()
             s = rec.summary()
             hbm = rec.hbm_summary()
             if args.gemm_table:
@@ -504,7 +527,7 @@ def main():
     if rank == 0:
         audio_s = args.global_batch * L / cfg.audio.sample_rate
         value = audio_s * args.steps / dt
-        gf_fwd, gf_fb = gflop_per_clip(cfg, L, K)
+        gf_fwd, gf_fb = gflop_per_clip(cfg, L, k_mean)      # the student's share follows the kept frames actually drawn
         line = {
             "metric": {"large": "audio-seconds/s pretrain (10s@8kHz, large model)",
                        "base": "audio-seconds/s pretrain (10s@8kHz, base* model)",
@@ -514,11 +537,17 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"animal2vec-{args.model} pretrain step (student fwd+bwd, EMA-teacher targets, grad "
                                    f"all-reduce, clip+Adam, EMA) on {L}-sample clips @ {cfg.audio.sample_rate} Hz, "
-                                   f"{K}/{cfg.frame_counts(L)[-1]} frames kept, clone_batch {cfg.clone_batch}",
+                                   f"{k_mean:.1f}/{cfg.frame_counts(L)[-1]} frames kept, clone_batch {cfg.clone_batch}",
                        "global_batch": args.global_batch, "micro_batch": args.micro_batch, "micro_batches_per_rank": n_mb,
                        "parallelism": f"dp{world}", "dropout": "on (p=0.1, 5 sites)", "mixup": "on (BC, A-weighted gain)",
-                       "masks": "seeded keep-masks / gather ids precomputed once per micro-batch OUTSIDE the timed loop (SURVEY 8d); "
-                                "the reference samples them on the host every step (base.py:401-413)",
+                       "masks": ("span masks (mask_prob %g, length %d) + gather ids sampled on the device INSIDE every timed step, fresh per "
+                                 "step and micro-batch (a2v_span_mask on a side stream, one step ahead; K read back through pinned "
+                                 "memory); the reference samples them on the host in every forward (base.py:401-413)"
+                                 % (cfg.audio.mask_prob, cfg.audio.mask_length)) if args.masks == "sampled" else
+                                "seeded keep-masks / gather ids precomputed once per micro-batch OUTSIDE the timed loop (A/B form)",
+                       "kept_frames_mean": round(k_mean, 2),
+                       "global_batch_note": "strong scaling at a fixed global batch; 128 clips ~ the reference recipe's update "
+                                            "(4 GPUs x 5 clips x update_freq 5 ~ 102 clips, a2v_large_pretrain_best.yaml:34-36,45-47,62)",
                        "observed_world_size": dist.get_world_size() if use_dist else 1},
             "model_tflops_per_s": round(gf_fb * args.global_batch * args.steps / dt / 1e3, 2),
             "mfu_vs_bf16_dense_peak": round(gf_fb * args.global_batch * args.steps / dt / 1e3 / (PEAK_BF16_TFLOPS * world), 4),

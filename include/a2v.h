@@ -284,7 +284,28 @@ int a2v_add_drop(int dtype, const void* a, const void* b, const void* c, void* o
 int a2v_mask_frames(int dtype, const void* x, const unsigned char* mask_t, const unsigned char* mask_c, void* out,
                     int B, int T, int D, float noise_std, unsigned seed, int mode, a2v_stream_t stream);
 
-/* 7: + a2v_decoder_input_rng, + A2V_EPI_DACT (additive over 6: every v6 call keeps its meaning) */
+/* ---------------------------------------------------------------- span masks on the device
+ * Replaces, per forward, fairseq `compute_mask_indices` as ModalitySpecificEncoder.compute_mask calls it
+ * (nn/modalities/base.py:401-413: host numpy loop over the B*clone_batch rows + torch.from_numpy(mask).to(device)) and
+ * make_maskinfo's two argsorts (base.py:427-455).  Per row max(min_masks, int(mask_prob*T/mask_length + U)) span starts
+ * without replacement from [0, T - mask_length), spans of mask_length frames merged; every row cut down, by a uniform draw
+ * from its masked frames, to the smallest masked count of the batch (require_same_masks=True, the reference's only
+ * setting), then rint(count * mask_dropout) more frames released.  The draw is a pure function of (seed, row, frame)
+ * (counter hash; fairseq's numpy stream is third party and not reproducible: SURVEY 8c).
+ *   mask (N,T) u8 out, 1 = masked;  counts: N ints of caller-owned scratch;  ids_keep: room for N*T ints, written as
+ *   (N,K) kept frames ascending;  ids_restore (N,T): rank among the kept frames, or K + rank among the masked ones
+ *   (= argsort(argsort(mask)) with ties in frame order);  keep_out: ONE int on the device that receives K = T - masked
+ *   count (data dependent: read it back before shaping ids_keep).  2 <= T <= 16384. */
+int a2v_span_mask(unsigned char* mask, int* counts, int* ids_keep, int* ids_restore, int* keep_out, int N, int T,
+                  float mask_prob, int mask_length, int min_masks, float mask_dropout, unsigned long long seed,
+                  a2v_stream_t stream);
+/* make_maskinfo alone (base.py:427-455) for a caller-supplied mask (`precomputed_mask`) with K kept frames in every row
+ * (the reference assumes equal counts, base.py:437): ids_keep (N,K), ids_restore (N,T) as above.  rows_bad (one int the
+ * caller zeroed, may be NULL) counts the rows whose kept count is not K; such rows are left unwritten. */
+int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
+                 a2v_stream_t stream);
+
+/* 8: + a2v_span_mask, a2v_maskinfo (additive over 7, which added a2v_decoder_input_rng and A2V_EPI_DACT over 6) */
 int a2v_abi_version(void);
 
 #ifdef __cplusplus

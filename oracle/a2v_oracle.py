@@ -214,6 +214,58 @@ def seeded_mask(n_rows: int, T: int, keep: int, seed: int) -> torch.Tensor:
     return mask
 
 
+def _mix32(u):
+    u = u.astype(np.uint32)
+    u ^= u >> np.uint32(16); u *= np.uint32(0x7FEB352D); u ^= u >> np.uint32(15); u *= np.uint32(0x846CA68B); u ^= u >> np.uint32(16)
+    return u
+
+
+def _mask_hash(seed: int, purpose: int, row: int, i):
+    """the counter stream of animal2vec_amd/csrc/a2v_mask.hip::mask_hash (uint32 arithmetic)"""
+    lo, hi = np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        a = _mix32(np.asarray([np.uint32(row) * np.uint32(0x9E3779B1) + lo + np.uint32(purpose) * np.uint32(0x85EBCA6B)], dtype=np.uint32))[0]
+        return _mix32((a ^ hi) + np.asarray(i, dtype=np.uint32) * np.uint32(0xC2B2AE35) + np.uint32(0x27D4EB2F))
+
+
+def span_mask(n_rows: int, T: int, mask_prob: float, mask_length: int, seed: int, min_masks: int = 1,
+              mask_dropout: float = 0.0) -> np.ndarray:
+    """Span masks with the DISTRIBUTION of fairseq@920a548 ``compute_mask_indices`` as ModalitySpecificEncoder.compute_mask
+    calls it (nn/modalities/base.py:401-413: static span length, no_overlap False, min_masks 1, require_same_masks True,
+    mask_dropout; the same law as animal2vec_amd.masking.compute_mask_indices) drawn from the counter-based stream of the
+    device sampler (a2v_span_mask), restated here draw for draw: 'n of M without replacement' = the n smallest of the unique
+    keys (hash32 << 14 | frame).  fairseq's own numpy stream is third party and unpinned; this function pins
+    the kernel, the statistical tests pin the law.  Returns (n_rows, T) bool, equal count per row."""
+    frames = np.arange(T, dtype=np.uint64)
+    masks, counts = [], []
+    for r in range(n_rows):
+        u = float(int(_mask_hash(seed, 1, r, [0])[0]) >> 8) / 16777216.0
+        num = max(min_masks, int(float(mask_prob) * T / float(mask_length) + u))
+        min_len = mask_length
+        if T - min_len <= num:
+            min_len = T - num - 1
+        M = max(1, min(T, T - min_len))
+        num = min(num, M)
+        key = (_mask_hash(seed, 2, r, np.arange(M)).astype(np.uint64) << np.uint64(14)) | frames[:M]
+        starts = np.argsort(key)[:num]
+        m = np.zeros(T, dtype=bool)
+        for off in range(mask_length):
+            idx = starts + off
+            m[idx[idx < T]] = True
+        masks.append(m)
+        counts.append(int(m.sum()))
+    mn = min(counts)
+    n_final = mn - int(np.rint(mn * float(mask_dropout)))
+    for r, m in enumerate(masks):
+        if n_final < counts[r]:
+            idx = np.nonzero(m)[0]
+            key = (_mask_hash(seed, 3, r, idx).astype(np.uint64) << np.uint64(14)) | idx.astype(np.uint64)
+            keep_masked = idx[np.argsort(key)[:n_final]]
+            m[:] = False
+            m[keep_masked] = True
+    return np.stack(masks)
+
+
 # ------------------------------------------------------------------------------ pos-conv (a9)
 def pos_conv(p, prefix, x, cfg: OracleConfig):
     """relative_positional_encoder (nn/modalities/audio.py:90-113): (N,T,D)->(N,T,D)."""

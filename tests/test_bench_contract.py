@@ -54,7 +54,7 @@ def test_bench_spawns_its_own_ranks_gloo_dry():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["observed_world_size"] == 2 and j["dry"] is True and j["grad_sum_ok"] is True
-    assert j["steps"] == 3 and j["warmup"] == 1 and j["config"]["micro_batch"] == 32 and j["config"]["micro_batches_per_rank"] == 1
+    assert j["steps"] == 3 and j["warmup"] == 1 and j["config"]["micro_batch"] == 64 and j["config"]["micro_batches_per_rank"] == 1 and j["config"]["global_batch"] == 128
     for k in ("metric", "value", "unit", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
         assert k in j, k
 

@@ -428,3 +428,28 @@ def test_init_laws_match_the_reference_model(tmp_path):
         left = ((torch.sin(high * s2.sinc_n) - torch.sin(low * s2.sinc_n)) / (s2.sinc_n / 2)) * s2.sinc_window
         filt = torch.cat([left, 2 * bandw.view(-1, 1), left.flip(1)], dim=1) / (2 * bandw[:, None])
         assert rel_err(filt, sx[f"init.{spec}.filters"].view(c, k)) < 1e-5, spec
+
+
+def test_oracle_span_mask_follows_the_law_of_compute_mask_indices():
+    """oracle/a2v_oracle.py::span_mask restates the DEVICE sampler's counter stream (the GPU tests hold the kernel to it bit
+    for bit); here its law is compared with the numpy statement of fairseq's compute_mask_indices: equal counts per row,
+    per-frame masking frequency, kept count."""
+    import a2v_oracle as O
+    N, T, prob, length = 1024, 200, 0.65, 5
+    dm = O.span_mask(N, T, prob, length, seed=11)
+    hm = compute_mask_indices((N, T), prob, length, np.random.default_rng(5))
+    assert len(set(dm.sum(1).tolist())) == 1 and len(set(hm.sum(1).tolist())) == 1
+    fd, fh = dm.mean(0), hm.mean(0)
+    sigma = (np.maximum(fh * (1 - fh), 0.02) * 2 / N) ** 0.5
+    assert np.all(np.abs(fd - fh) < 5 * sigma)
+    assert abs(int(dm[0].sum()) - int(hm[0].sum())) <= 4
+    big = O.span_mask(96, 2000, 1.5, 2, seed=3)                     # the large recipe: ~93 % masked, K in SURVEY 8c's band
+    assert 125 <= 2000 - int(big[0].sum()) <= 156
+    assert np.array_equal(big, O.span_mask(96, 2000, 1.5, 2, seed=3))
+
+
+def test_mask_seed_is_a_distinct_function_of_every_counter():
+    from animal2vec_amd.masking import mask_seed
+    seen = {mask_seed(s, u, j, r) for s in (0, 1) for u in range(50) for j in range(8) for r in range(8)}
+    assert len(seen) == 2 * 50 * 8 * 8
+    assert all(0 <= v < 2 ** 64 for v in seen)
