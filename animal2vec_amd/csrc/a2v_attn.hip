@@ -49,6 +49,8 @@ struct AttnArgs {
   Drop drop;                      // attention dropout on the softmax probabilities (modules.py:405)
   int xcd_order;                  // 1: 1-D launch, query blocks of one (n, h) share an XCD (attn_fwd_bf16_kernel)
   const float* qk_bound;          // (SPLIT, N, H, 2): max |q_i|^2 and max |k_j|^2 per (n, h) and row range, or nullptr: ALiBi band limit
+  float* mdist;                   // (N,H,S) or nullptr: c_i = sum_j P_ij |pos_i - pos_j|, the row's mean attended distance (dropout-free P);
+                                  // the backward centres |pos_i - pos_j| on it when it forms d alibi_scale (see AttnBwdArgs::mdist)
 };
 
 #define FP32_PITCH(HD) ((HD) + 4)
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
   f32x4 o[ND];
 #pragma unroll
   for (int i = 0; i < ND; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY, l_run = 0.f, a_run = 0.f;
 
   const int ntile = (S + 63) / 64;
   for (int kt = 0; kt < ntile; ++kt) {
@@ -168,13 +170,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
     const float m_new = fmaxf(m_run, mx);
     const float alpha = __expf(m_run - m_new);
     m_run = m_new;
-    float ps = 0.f;
+    float ps = 0.f, pa = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float p = __expf(s[j][r] - m_new);
         ps += p;                                  // the normaliser is dropout-free
+        pa = fmaf(p, fabsf(pos_q - sPos[16 * j + 4 * g + r]), pa);
         if (a.drop.thresh) {
           const unsigned rt = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc));
           p = drop_keep2(a.drop, rt, (unsigned)(kv0 + 16 * j + 4 * g + r)) ? p * a.drop.scale : 0.f;
@@ -182,6 +185,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         s[j][r] = p;
       }
     l_run = l_run * alpha + ps;
+    a_run = a_run * alpha + pa;
 #pragma unroll
     for (int i = 0; i < ND; ++i) o[i] *= alpha;
 
@@ -227,6 +231,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
       Vec4<T>::store(orow + 16 * i + 4 * g, v);
     }
     if (g == 0 && a.lse) a.lse[((long long)n * H + h) * S + q] = m_run + __logf(l_tot);
+  }
+  if (a.mdist) {
+    float a_tot = a_run;
+    a_tot += __shfl_xor(a_tot, 16, 64);
+    a_tot += __shfl_xor(a_tot, 32, 64);
+    if (q < S && g == 0) a.mdist[((long long)n * H + h) * S + q] = a_tot * inv;
   }
 }
 

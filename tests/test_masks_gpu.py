@@ -91,19 +91,40 @@ def test_distribution_matches_the_host_statement_of_the_law(ops):
     sigma = (np.maximum(fh * (1 - fh), 0.02) * 2 / N) ** 0.5
     assert np.all(np.abs(fd - fh) < 5 * sigma), float(np.max(np.abs(fd - fh) / sigma))
     assert abs(K - (T - int(host[0].sum()))) <= 4                # batch minimum of ~2048 rows: a narrow extreme-value law
-    # span structure: masked runs are unions of length-5 spans -> no masked run shorter than 5 except at the cut-down rows' edges
-    # (equalisation removes single frames), so compare run-length histograms instead of asserting a minimum
-    def runs(m):
-        m = np.asarray(m, dtype=np.int8)
-        d = np.diff(np.concatenate([np.zeros((m.shape[0], 1), np.int8), m, np.zeros((m.shape[0], 1), np.int8)], 1), axis=1)
-        lens = []
-        for r in range(m.shape[0]):
-            s, e = np.nonzero(d[r] == 1)[0], np.nonzero(d[r] == -1)[0]
-            lens.append(e - s)
-        return np.concatenate(lens)
-    rd, rh = runs(dev_mask.numpy()), runs(host)
-    assert abs(rd.mean() - rh.mean()) < 0.05 * rh.mean()
-    assert abs(len(rd) - len(rh)) < 0.03 * len(rh)
+    # run structure after the cut-down: every frame of K the batch minimum moves (an extreme value of 2048 rows) is one more
+    # random hole per row, i.e. ~4 % more runs -- compared loosely here, exactly (before the cut-down) in the next test
+    rd, rh = _runs(dev_mask.numpy()), _runs(host)
+    assert abs(rd.mean() - rh.mean()) < 0.12 * rh.mean()
+    assert abs(len(rd) - len(rh)) < 0.10 * len(rh)
+
+
+def _runs(m):
+    m = np.asarray(m, dtype=np.int8)
+    d = np.diff(np.concatenate([np.zeros((m.shape[0], 1), np.int8), m, np.zeros((m.shape[0], 1), np.int8)], 1), axis=1)
+    lens = []
+    for r in range(m.shape[0]):
+        s, e = np.nonzero(d[r] == 1)[0], np.nonzero(d[r] == -1)[0]
+        lens.append(e - s)
+    return np.concatenate(lens)
+
+
+def test_spans_before_the_cut_down(ops):
+    """One row = nothing to equalise: the mask is a union of `num` spans of mask_length frames, so every masked run is at least
+    mask_length long, no start lies beyond T - mask_length, and the masked count is at most num * mask_length."""
+    T, prob, length = 300, 0.5, 6
+    starts_seen = np.zeros(T, dtype=np.int64)
+    for s in range(120):
+        m = _sample(ops, 1, T, mask_prob=prob, mask_length=length, seed=1000 + s)[0].numpy()
+        r = _runs(m)
+        assert r.min() >= length, r
+        assert int(m.sum()) <= 25 * length
+        d = np.diff(np.concatenate([[0], m[0].astype(np.int8)]))
+        starts_seen[np.nonzero(d == 1)[0]] += 1
+    assert starts_seen[T - length + 1:].sum() == 0
+    # run starts spread over the whole admissible range (uniform starts): both halves are hit about equally
+    h = (T - length) // 2
+    a, b = starts_seen[:h].sum(), starts_seen[h:T - length + 1].sum()
+    assert abs(a - b) < 5 * (a + b) ** 0.5, (a, b)
 
 
 def test_large_recipe_shape_properties(ops):
