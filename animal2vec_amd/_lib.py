@@ -27,8 +27,8 @@ SIGNATURES = {
     "a2v_conv_wgrad_rows": [_p, _i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                             _i, _p],
     "a2v_linear_wgrad_pair": [_i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p],
-    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
-    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
     "a2v_attention_bwd_fused_bias": [_i, _i, _i],
     "a2v_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _f, _i, _f, _u, _p],
     "a2v_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _f, _u, _i, _p, _p],

@@ -271,8 +271,9 @@ __device__ __forceinline__ float rows_max(float v) {
 
 // QB = 16-row query blocks per wave (workgroup = 64*QB query rows): with QB = 2 every K / V fragment read from
 // LDS feeds two MFMAs -- the QB = 1 kernel was LDS-bandwidth bound (16 KB of fragment reads per 16 MFMAs).
-template <int HD, bool DROP, int QB, bool MSUM = false>
-__global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16_kernel(AttnArgs a) {
+// MD: also form c_i = sum_j P_ij |pos_i - pos_j| (AttnArgs::mdist) -- calls that keep the LSE for a backward.
+template <int HD, bool DROP, int QB, bool MSUM = false, bool MD = false>
+__global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_fwd_bf16_kernel(AttnArgs a) {
   typedef bf16 T;
   // MSUM (experiment, a2v_debug_set(18, 1), forward-only calls): row sums of P by a ones-MFMA over the bf16 P, -4 % time.
   // Default: fp32 sums of the fp32 P on the VALU, as the reference's softmax -- normalised by the bf16 sums, d alibi_scale (a sum
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
   const float thr_acc = 4.f / scale2;
 
   int q[QB], qc[QB];
-  float pos_q[QB], m_run[QB], l_run[QB];
+  float pos_q[QB], m_run[QB], l_run[QB], a_run[QB];
   bf16x8 qf[QB][HD / 32];
   f32x4 o[QB][ND];
 #pragma unroll
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
     pos_q[b] = a.pos ? (float)a.pos[(long long)n * S + qc[b]] : (float)qc[b];
     m_run[b] = -INFINITY;
     l_run[b] = 0.f;
+    a_run[b] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < HD / 32; ++ks) qf[b][ks] = *(const bf16x8*)(qkv + (long long)qc[b] * rowstride + ks * 32 + g * 8);
 #pragma unroll
@@ -523,6 +525,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
         const float alpha = __builtin_amdgcn_exp2f((m_run[b] - m_new) * scale2);
         m_run[b] = m_new;
         if constexpr (VSUM) l_run[b] *= alpha; else lacc[b] *= alpha;
+        if constexpr (MD) a_run[b] *= alpha;
 #pragma unroll
         for (int i = 0; i < ND; ++i) o[b][i] *= alpha;
       }
@@ -530,9 +533,20 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
 #pragma unroll
     for (int b = 0; b < QB; ++b) {
       const float nm = -m_run[b] * scale2;
-      float ps = 0.f;
+      float ps = 0.f, pa = 0.f;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        // key positions of this lane's four scores: sPos holds raw positions in the |.| tiles, the per-key BIAS in the
+        // others (positions = arange there: the key's position is its index)
+        f32x4 kp = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (MD) {
+          if constexpr (PH == 1) {
+            const float k0 = (float)(kv0 + 16 * j + 4 * g);
+            kp = (f32x4){k0, k0 + 1.f, k0 + 2.f, k0 + 3.f};
+          } else {
+            kp = *(const f32x4*)(&sPos[buf][16 * j + 4 * g]);
+          }
+        }
         unsigned hp[2] = {0u, 0u};
         if (DROP) {                                 // keys kv0 + 16 j + 4 g + {0,1} and + {2,3}: one hash per pair
           const unsigned rt = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc[b]));
@@ -543,6 +557,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
         for (int r = 0; r < 4; ++r) {
           float p = __builtin_amdgcn_exp2f(fmaf(s[b][j][r], scale2, nm));
           if (VSUM) ps += p;                        // the normaliser is dropout-free
+          if constexpr (MD) pa = __builtin_fmaf(__builtin_fabsf(pos_q[b] - kp[r]), p, pa);
           if (DROP) {
             const unsigned h16 = (r & 1) ? (hp[r >> 1] >> 16) : (hp[r >> 1] & 0xFFFFu);
             p = h16 >= (a.drop.thresh >> 16) ? p * a.drop.scale : 0.f;
@@ -551,6 +566,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
         }
       }
       if (VSUM) l_run[b] += ps;
+      if constexpr (MD) a_run[b] += pa;
     }
 
     // ---- O^T += V^T P^T
@@ -622,6 +638,12 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP) ? 3 : 1) void attn_fwd_bf16
       if (g == 0 && a.lse)
         a.lse[((long long)n * H + h) * S + q[b]] = (m_run[b] * scale2 + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
     }
+    if constexpr (MD) {
+      float a_tot = a_run[b];
+      a_tot += __shfl_xor(a_tot, 16, 64);
+      a_tot += __shfl_xor(a_tot, 32, 64);
+      if (q[b] < S && g == 0) a.mdist[((long long)n * H + h) * S + q[b]] = a_tot * inv;
+    }
   }
 }
 
@@ -641,7 +663,7 @@ __device__ __forceinline__ float rows_sum(float v) {    // sum over the lanes l,
   return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
-template <bool DROP>
+template <bool DROP, bool MD = false>
 __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
   typedef bf16 T;
   constexpr int HD = 64, ND = 4, QB = 3, NKG = 9;
@@ -726,7 +748,7 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
     }
   }
   // ---- softmax over the whole row, dropout, P -> bf16 in place
-  float m_row[QB], l_row[QB];
+  float m_row[QB], l_row[QB], a_row[QB];
 #pragma unroll
   for (int b = 0; b < QB; ++b) {
     float mx = max3f(s[b][0][0], s[b][0][1], s[b][0][2]);
@@ -740,7 +762,7 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
     m_row[b] = mx;
     const float nm = -mx * scale2;
     const unsigned rt = DROP ? drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc[b])) : 0u;
-    float ps = 0.f;
+    float ps = 0.f, pa = 0.f;
 #pragma unroll
     for (int j = 0; j < NKG; ++j) {
       unsigned hp[2] = {0u, 0u};
@@ -748,10 +770,13 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
         hp[0] = drop_hash_pair(rt, (unsigned)(16 * j + 4 * g));
         hp[1] = drop_hash_pair(rt, (unsigned)(16 * j + 4 * g + 2));
       }
+      f32x4 kp = {0.f, 0.f, 0.f, 0.f};
+      if constexpr (MD) kp = *(const f32x4*)(sPos + 16 * j + 4 * g);      // (rows past S: p = 0)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[b][j][r], scale2, nm));
         ps += p;                                    // the normaliser is dropout-free
+        if constexpr (MD) pa = __builtin_fmaf(__builtin_fabsf(pos_q[b] - kp[r]), p, pa);
         if (DROP) {
           const unsigned h16 = (r & 1) ? (hp[r >> 1] >> 16) : (hp[r >> 1] & 0xFFFFu);
           p = h16 >= (a.drop.thresh >> 16) ? p * a.drop.scale : 0.f;
@@ -760,6 +785,7 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
       }
     }
     l_row[b] = rows_sum(ps);
+    a_row[b] = MD ? rows_sum(pa) : 0.f;
   }
   // ---- O^T = V^T P^T over 32-key chunks (the tenth key group is the zero rows 144..159 against p = 0)
   f32x4 o[QB][ND];
@@ -801,6 +827,7 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
       }
       if (g == 0 && a.lse)
         a.lse[((long long)n * H + h) * S + q[b]] = (m_row[b] * scale2 + __builtin_amdgcn_logf(l_row[b])) * 0.6931471805599453f;
+      if (MD && g == 0) a.mdist[((long long)n * H + h) * S + q[b]] = a_row[b] * inv;
     }
   }
 }
@@ -861,7 +888,8 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   a.xcd_order = 0;
   if constexpr (HD == 64) {
     if (a.S <= 144 && g_a2v_attn_fwd48) {
-      hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP>), dim3(1, a.H, a.N), dim3(192), AF48_LDS, st, a);
+      if (a.mdist) hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP, true>), dim3(1, a.H, a.N), dim3(192), AF48_LDS, st, a);
+      else hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP, false>), dim3(1, a.H, a.N), dim3(192), AF48_LDS, st, a);
       return;
     }
   }
@@ -881,8 +909,11 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
     const bool xo = g_a2v_attn_xcd && heads8 * nqb < (1ll << 31);
     a.xcd_order = xo ? 1 : 0;
     const dim3 grid = xo ? dim3((unsigned)(heads8 * nqb)) : dim3((a.S + 127) / 128, a.H, a.N);
-    if (!DROP && !a.lse && g_a2v_attn_msum) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, !DROP>), grid, dim3(256), 0, st, a);
+    if (a.mdist) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, false, true>), grid, dim3(256), 0, st, a);
+    else if (!DROP && !a.lse && g_a2v_attn_msum) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, !DROP>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, false>), grid, dim3(256), 0, st, a);
+  } else if (a.mdist) {
+    hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 1, false, true>), dim3((a.S + 63) / 64, a.H, a.N), dim3(256), 0, st, a);
   } else {
     hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 1>), dim3((a.S + 63) / 64, a.H, a.N), dim3(256), 0, st, a);
   }
@@ -958,6 +989,13 @@ struct AttnBwdArgs {
   Drop drop;
   int dal_part;             // s + 1: per-workgroup partial sums of d alibi_scale go to the stream's scratch set s (folded by dalibi_fold_kernel); 0: atomics
   float* bias_sum;          // (3, H, HD) fp32 or NULL: column sums of dqkv (the qkv Linear's bias gradient), whole-sequence kernel only
+  // (N,H,S) or NULL: c_i = sum_j P_ij |pos_i - pos_j| from the forward.  d alibi_scale_h = -slope_h sum_ij dS_ij |pos_i - pos_j|, and
+  // sum_j dS_ij = 0 exactly, so any per-row constant may be subtracted from the distance.  What is computed is dS_ij = P_ij (dP_ij -
+  // delta_i) with delta_i = dO_i . O_i from the ROUNDED forward output: it misses sum_j P_ij dP_ij by some e_i (bf16: 2^-9 relative),
+  // which puts -e_i P_ij into every dS_ij and -e_i c_i into the row's distance sum -- e_i times the mean attended distance, a
+  // systematic term as large as the (heavily cancelling) true sum at long sequences.  With the distance centred on c_i that term
+  // is -e_i sum_j P_ij (|.| - c_i) = 0: the gradient is as accurate as the dS values themselves.
+  const float* mdist;
 };
 
 // NT = 0: one workgroup per 64-key block, dQ summed across key blocks with fp32 atomics into dq32 (any S).
@@ -979,7 +1017,8 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
   float* const sLse = (float*)(sDS + DS_BYTES);
   float* const sDelta = sLse + 64;
   float* const sPosQ = sDelta + 64;
-  char* const sQt = (char*)(sPosQ + 64);                   // bf16 only: tr image of Q
+  float* const sMd = sPosQ + 64;
+  char* const sQt = (char*)(sMd + 64);                     // bf16 only: tr image of Q
   char* const sDOt = sQt + TILE_BYTES;                     // bf16 only: tr image of dO
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -1089,6 +1128,7 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
       sLse[tid] = ok ? a.lse[si] : INFINITY;     // exp(x - inf) = 0 -> padded query rows contribute nothing
       sDelta[tid] = ok ? a.delta[si] : 0.f;
       sPosQ[tid] = ok ? (a.pos ? (float)a.pos[(long long)n * S + qq] : (float)qq) : 0.f;
+      sMd[tid] = (ok && a.mdist) ? a.mdist[si] : 0.f;
     }
     __syncthreads();
 
@@ -1130,7 +1170,7 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
         const float dsv = pv * (dpe - sDelta[ql]);
         p[i][r] = pdrop;
         ds[i][r] = dsv;
-        dal -= dsv * dist;
+        dal -= dsv * (dist - sMd[ql]);
       }
     }
     // ---- dS -> LDS (for dQ), as [q][kv]
@@ -1282,11 +1322,11 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   return A2V_OK;
 }
 
-extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const int* pos, const float* slopes,
-                                 const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
-                                 unsigned drop_seed, hipStream_t stream) {
+extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, const int* pos,
+                                 const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
+                                 float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
-  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr};
+  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr, mdist};
   if (dtype == A2V_BF16) {
     const bool dr = a.drop.thresh != 0;
     if (HD == 64 && dr) attn_fwd_bf16_launch<64, true>(a, stream);
@@ -1316,7 +1356,7 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
 __device__ __forceinline__ int dual_off(int r, int chunk) { return r * 128 + ((chunk ^ (r & 7)) << 4); }   // [rows][64] bf16
 
 #define ABS_ROWS 192
-#define ABS_LDS (2 * ABS_ROWS * 128 + 64 * 128 + 2 * 64 * 128 + 3 * ABS_ROWS * 4 + 3 * 64 * 4)
+#define ABS_LDS (2 * ABS_ROWS * 128 + 64 * 128 + 2 * 64 * 128 + 4 * ABS_ROWS * 4 + 3 * 64 * 4)
 
 template <bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, const bf16* __restrict__ o_fwd) {
@@ -1329,7 +1369,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
   float* const sLse = (float*)(sDS + 2 * 64 * 128);
   float* const sDelta = sLse + ABS_ROWS;
   float* const sPosQ = sDelta + ABS_ROWS;
-  float* const sBias = sPosQ + ABS_ROWS;                   // [3][64]: column sums of this (n, h)'s dQ / dK / dV (bias gradient)
+  float* const sMd = sPosQ + ABS_ROWS;
+  float* const sBias = sMd + ABS_ROWS;                     // [3][64]: column sums of this (n, h)'s dQ / dK / dV (bias gradient)
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -1384,10 +1425,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
     const bool rok = tid < S;                       // thread tid < ABS_ROWS owns query row tid for delta / lse / pos
 #pragma unroll
     for (int u = 0; u < 8; ++u) oz[u] = rok ? *(const uint4*)(Of + (long long)tid * orow + u * 8) : make_uint4(0u, 0u, 0u, 0u);
-    float lse_r = INFINITY, pos_r = 0.f;            // exp(x - inf) = 0: padded queries vanish
+    float lse_r = INFINITY, pos_r = 0.f, md_r = 0.f; // exp(x - inf) = 0: padded queries vanish
     if (rok) {
       lse_r = a.lse[((long long)n * H + h) * S + tid];
       pos_r = a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid;
+      if (a.mdist) md_r = a.mdist[((long long)n * H + h) * S + tid];
     }
     ABS_FETCH_KB(0)
 #pragma unroll
@@ -1409,6 +1451,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
       sDelta[tid] = dl;
       sLse[tid] = lse_r;
       sPosQ[tid] = pos_r;
+      sMd[tid] = md_r;
     }
   }
 
@@ -1479,7 +1522,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
           const float dsv = pv * (dpe - sDelta[ql]);
           p[i][r] = pdrop;
           ds[i][r] = dsv;
-          dal -= dsv * dist;
+          dal -= dsv * (dist - sMd[ql]);
         }
       }
       // ---- dS -> LDS (for dQ), as [q][kv]
@@ -1619,7 +1662,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
 // zero-initialised destinations, no guards: rows past S re-read row S-1 and are masked by kv_ok / zero dS columns).
 #define AB48_QROWS 160            // Q / dO images: 144 rows + one zero 16-row group (the odd ninth sub-block's partner)
 #define AB48_ROWS 144
-#define AB48_LDS (2 * AB48_QROWS * 128 + 64 * 128 + AB48_ROWS * 128 + 4 * AB48_ROWS * 4 + 3 * 64 * 4)
+#define AB48_LDS (2 * AB48_QROWS * 128 + 64 * 128 + AB48_ROWS * 128 + 5 * AB48_ROWS * 4 + 3 * 64 * 4)
 
 template <bool DROP>
 __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, const bf16* __restrict__ o_fwd) {
@@ -1633,7 +1676,8 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
   float* const sDelta = sLse + AB48_ROWS;
   float* const sPosQ = sDelta + AB48_ROWS;
   unsigned* const sRowT = (unsigned*)(sPosQ + AB48_ROWS);  // dropout row terms
-  float* const sBias = (float*)(sRowT + AB48_ROWS);        // [3][64]
+  float* const sMd = (float*)(sRowT + AB48_ROWS);          // mean attended distance of the row (AttnBwdArgs::mdist)
+  float* const sBias = sMd + AB48_ROWS;                    // [3][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -1686,10 +1730,11 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     const bool rok = tid < S;                       // thread tid < 144 owns query row tid for delta / lse / pos / row term
 #pragma unroll
     for (int u = 0; u < 8; ++u) oz[u] = rok ? *(const uint4*)(Of + (long long)tid * orow + u * 8) : make_uint4(0u, 0u, 0u, 0u);
-    float lse_r = INFINITY, pos_r = 0.f;            // exp2(x - inf) = 0: padded queries vanish
+    float lse_r = INFINITY, pos_r = 0.f, md_r = 0.f; // exp2(x - inf) = 0: padded queries vanish
     if (rok) {
       lse_r = a.lse[((long long)n * H + h) * S + tid] * LOG2E;
       pos_r = a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid;
+      if (a.mdist) md_r = a.mdist[((long long)n * H + h) * S + tid];
     }
     AB48_FETCH(0)
     if (a.bias_sum) sBias[tid] = 0.f;               // 192 threads = 3 x 64 sums
@@ -1717,6 +1762,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
       sDelta[tid] = dl;
       sLse[tid] = lse_r;
       sPosQ[tid] = pos_r;
+      sMd[tid] = md_r;
       sRowT[tid] = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + min(tid, S - 1)));
     }
   }
@@ -1770,6 +1816,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
       const f32x4 lse4 = *(const f32x4*)(sLse + rb + 4 * g);
       const f32x4 del4 = *(const f32x4*)(sDelta + rb + 4 * g);
       const f32x4 pq4 = *(const f32x4*)(sPosQ + rb + 4 * g);
+      const f32x4 md4 = *(const f32x4*)(sMd + rb + 4 * g);
       const uint4 rt4 = *(const uint4*)(sRowT + rb + 4 * g);
       const unsigned rts[4] = {rt4.x, rt4.y, rt4.z, rt4.w};
 #pragma unroll
@@ -1782,7 +1829,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
         const float dsv = pv * __builtin_fmaf(pacc[r], mlt, -del4[r]);
         p_o[r] = pv * mlt;
         ds_o[r] = dsv;
-        dal = __builtin_fmaf(-dsv, dist, dal);
+        dal = __builtin_fmaf(-dsv, dist - md4[r], dal);
         // dS -> LDS as [q][kv] (for dQ): row rb + 4g + r, column 16 wid + fr (per-lane offsets formed once, ds_off[])
         *(bf16*)(sDS + rb * 128 + ds_off[r]) = (bf16)dsv;
       }
@@ -1913,13 +1960,13 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
 // (7 matmuls instead of 5) -- cheaper than 2 GB of fp32 atomics per layer at S = 2000.
 //   MODE 0: S[q][kv] = X1(Q) . own1(K), dP = X2(dO) . own2(V); dV^T += tr(X2) . P, dK^T += tr(X1) . dS
 //   MODE 1: S^T[kv][q] = X1(K) . own1(Q), dP^T = X2(V) . own2(dO); dQ^T += tr(X1) . dS^T
-#define ABL_LDS (2 * 16384 + 2 * 3 * 64 * 4)
+#define ABL_LDS (2 * 16384 + 2 * 4 * 64 * 4)
 
 template <int MODE, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
   constexpr int HD = 64, ND = 4;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* const sRowBase = (float*)(smem + 2 * 16384);     // [buf][neg | delta | pos][64] of the streamed rows
+  float* const sRowBase = (float*)(smem + 2 * 16384);     // [buf][neg | delta | pos | mean distance][64] of the streamed rows
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int fr = lane & 15, g = lane >> 4;
@@ -1980,7 +2027,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
 
   const int ntile = (S + 63) / 64;
   uint4 r1[2], r2[2];
-  float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f;
+  float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f, rs3 = 0.f;
 
 #define ABL_FETCH(t_)                                                                               \
   {                                                                                                 \
@@ -2002,6 +2049,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
       if (MODE == 0) {                                                                              \
         rs0 = ok ? -a.lse[nh * S + rc] : -INFINITY;                                                 \
         rs1 = a.delta[nh * S + rc];                                                                 \
+        rs3 = a.mdist ? a.mdist[nh * S + rc] : 0.f;                                                 \
       } else {                                                                                      \
         rs0 = ok ? 0.f : -INFINITY;                                                                 \
         rs1 = 0.f;                                                                                  \
@@ -2017,8 +2065,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
       *(uint4*)(b1 + 8192 + dual_off(r, ch)) = r2[u];                                               \
     }                                                                                               \
     if (tid < 64) {                                                                                 \
-      float* const sr = sRowBase + (buf_) * 192;                                                    \
-      sr[tid] = rs0; sr[64 + tid] = rs1; sr[128 + tid] = rs2;                                       \
+      float* const sr = sRowBase + (buf_) * 256;                                                    \
+      sr[tid] = rs0; sr[64 + tid] = rs1; sr[128 + tid] = rs2; sr[192 + tid] = rs3;                  \
     }                                                                                               \
   }
 
@@ -2033,9 +2081,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
     if (t + 1 < ntile) ABL_FETCH(t + 1)
     const char* const X1 = smem + cur * 16384;
     const char* const X2 = X1 + 8192;
-    const float* const sNeg = sRowBase + cur * 192;
+    const float* const sNeg = sRowBase + cur * 256;
     const float* const sDel = sNeg + 64;
     const float* const sPos = sNeg + 128;
+    const float* const sMdr = sNeg + 192;
 
     // two halves of the streamed tile (32 rows each), rolled: scores + softmax gradient of the half, then its
     // gradient products -- only one half's P / dS fragments are live, and the rolled loop keeps the scheduler from
@@ -2053,13 +2102,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
           a1[ks] = *(const bf16x8*)(X1 + dual_off(rb + fr, ks * 4 + g));
           a2[ks] = *(const bf16x8*)(X2 + dual_off(rb + fr, ks * 4 + g));
         }
-        float rneg[4], rdel[4], rpos[4];
+        float rneg[4], rdel[4], rpos[4], rmd[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int rl = rb + 4 * g + r;
           rneg[r] = sNeg[rl];
           rdel[r] = MODE == 0 ? sDel[rl] : 0.f;
           rpos[r] = sPos[rl];
+          rmd[r] = MODE == 0 ? sMdr[rl] : 0.f;
         }
         // dropout hash terms of the streamed rows (rows past S never matter: their P is 0)
         unsigned rterm[4] = {0u, 0u, 0u, 0u}, hp[2][2] = {{0u, 0u}, {0u, 0u}};
@@ -2102,7 +2152,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
             const float dsv = pv * (dpe - rdel[r] - cdel[og]);
             pcur[r] = pdrop;
             dcur[r] = dsv;
-            if (MODE == 0) dal -= dsv * dist;
+            if (MODE == 0) dal -= dsv * (dist - rmd[r]);
           }
           if (ih) {
             bf16x8 pf, df;
@@ -2190,7 +2240,7 @@ static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delt
   if (!seq64)
     hipLaunchKernelGGL((attn_delta_kernel<T, HD>), dim3(g), dim3(256), 0, st, (const T*)out, (const T*)a.d_out, delta, a.N, a.S, a.H);
   constexpr int TILE = BF ? 64 * HD * 2 : 64 * FP32_PITCH(HD) * 4;
-  constexpr int LDS = (BF ? 5 : 3) * TILE + (BF ? 64 * 64 * 2 : 64 * 68 * 4) + 3 * 64 * 4;
+  constexpr int LDS = (BF ? 5 : 3) * TILE + (BF ? 64 * 64 * 2 : 64 * 68 * 4) + 4 * 64 * 4;
   if constexpr (BF && HD == 64) {
     if ((a.S > ABS_ROWS && g_a2v_attn_long) || g_a2v_attn_long == 2) {       // long sequences: dK/dV pass + dQ pass, no atomics (2: every S, experiments)
       const bool dr = a.drop.thresh != 0;
@@ -2266,14 +2316,14 @@ extern "C" int a2v_attention_bwd_fused_bias(int dtype, int S, int HD) {
 }
 
 extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse,
-                                 float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos,
+                                 const float* mdist, float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos,
                                  const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
                                  float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (qkv_bias_grad && !a2v_attention_bwd_fused_bias(dtype, S, HD)) return A2V_ERR_ARG;
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || drop_p < 0.f || drop_p >= 1.f)
     return A2V_ERR_ARG;
   AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale,
-                make_drop(drop_p, drop_seed), 0, qkv_bias_grad};
+                make_drop(drop_p, drop_seed), 0, qkv_bias_grad, mdist};
   if (dtype == A2V_BF16) {
     if (HD == 64) return attn_bwd_launch<bf16, 64>(a, out, delta, stream);
     if (HD == 32) return attn_bwd_launch<bf16, 32>(a, out, delta, stream);

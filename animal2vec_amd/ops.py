@@ -167,13 +167,14 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
 #                                         attention
 # ----------------------------------------------------------------------------------------------
 def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None):
-    """qkv (N,S,3*H*HD) -> out (N,S,H*HD), lse (N,H,S)"""
+    """qkv (N,S,3*H*HD) -> out (N,S,H*HD), lse (2,N,H,S): [0] the log-sum-exp, [1] the mean attended distance
+    sum_j P_ij |pos_i - pos_j| of every row (what attention_bwd centres the ALiBi distance on; include/a2v.h)"""
     N, S, W = qkv.shape
     HD = W // (3 * H)
     out = torch.empty(N, S, H * HD, dtype=qkv.dtype, device=qkv.device)
-    lse = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
-    rc = _L().a2v_attention_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
-                                HD, HD ** -0.5, *(_drop(drop)), stream())
+    lse = torch.empty(2, N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
+    rc = _L().a2v_attention_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(lse[1]) if need_lse else None, ptr(pos), ptr(slopes),
+                                ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_fwd")
     return out, lse
 
@@ -189,7 +190,8 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, dro
     fused = bias_grad is not None and bool(_L().a2v_attention_bwd_fused_bias(dt(qkv), S, HD))
     dq32 = None if direct else torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
     delta = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
-    rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(delta), ptr(dqkv), ptr(dq32),
+    md = lse[1] if lse.dim() == 4 else None           # (a bare (N,H,S) lse: the uncentred arithmetic)
+    rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(md), ptr(delta), ptr(dqkv), ptr(dq32),
                                 ptr(dalibi), ptr(bias_grad) if fused else None, ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
                                 HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_bwd")

@@ -96,7 +96,11 @@ int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long lda, const
  * (= arange); slopes (H) fp32; alibi_scale (H) fp32 (clamped at 0 inside).
  * Replaces AltAttention.forward's q@k^T + alibi + softmax + @v (modules.py:391-407) together with
  * get_alibi_bias / masked_alibi (base.py:292-314,553-698): no (N,H,S,S) tensor is ever built. */
-int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const int* pos, const float* slopes,
+/* mdist (N,H,S) fp32 or NULL (ABI 8): c_i = sum_j P_ij |pos_i - pos_j|, the mean attended distance of row i.  Calls that keep
+ * lse for a2v_attention_bwd pass it too: the backward centres the distance on it when it forms d alibi_scale, which makes
+ * that gradient insensitive to the rounding of the saved output (sum_j dS_ij = 0 holds only up to dO.(O_rounded - O); see
+ * AttnBwdArgs::mdist in csrc/a2v_attn.hip).  NULL in both calls is the uncentred ABI-7 arithmetic. */
+int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, const int* pos, const float* slopes,
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
                       unsigned drop_seed, a2v_stream_t stream);
 /* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dalibi (H) fp32 accumulates d loss / d alibi_scale.
@@ -105,8 +109,8 @@ int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, const i
  * the kernel owns a whole (n,h) sequence and writes dQ into the q slot of dqkv itself (dq32 may be NULL);
  * otherwise dq32 (N,S,H,HD) fp32 must be zero on entry, receives dQ through atomics, and the caller casts it
  * into dqkv (a2v_cast2d). */
-int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse, float* delta,
-                      void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos, const float* slopes,
+int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse, const float* mdist,
+                      float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos, const float* slopes,
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p, unsigned drop_seed,
                       a2v_stream_t stream);
 /* qkv_bias_grad (3*H*HD fp32, accumulated) or NULL: the column sums of dqkv -- the qkv Linear's bias gradient -- formed
@@ -305,7 +309,8 @@ int a2v_span_mask(unsigned char* mask, int* counts, int* ids_keep, int* ids_rest
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 8: + a2v_span_mask, a2v_maskinfo (additive over 7, which added a2v_decoder_input_rng and A2V_EPI_DACT over 6) */
+/* 8: + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
+ * arithmetic).  7 added a2v_decoder_input_rng and A2V_EPI_DACT over 6. */
 int a2v_abi_version(void);
 
 #ifdef __cplusplus

@@ -497,6 +497,45 @@ def test_attention_fwd_bwd(ops, dtype, hd, S):
     assert rel_err(dal, sc.grad) < max(t, 2e-4)
 
 
+@pytest.mark.parametrize("S,kind", [(140, "kept"), (180, "kept"), (386, "kept"), (772, "kept"), (2000, "arange")])
+def test_alibi_scale_gradient_is_well_conditioned_in_bf16(ops, S, kind):
+    """d alibi_scale_h = -slope_h sum_ij dS_ij |p_i - p_j| cancels heavily, and dS_ij = P_ij (dP_ij - delta_i) with delta_i formed
+    from the bf16-ROUNDED forward output leaves a residue e_i = sum_j dS_ij != 0 in every row, which the uncentred sum multiplies
+    by the row's mean attended distance (8e-2 at 8 kHz, 2.4e-1 at T = 11 025).  The kernels centre the
+    distance on c_i = sum_j P_ij |p_i - p_j| (a2v.h: mdist), which removes that term exactly.  Checked on every bf16 backward kernel
+    (S <= 144 three-wave, <= 192 resident, two-pass long with kept positions, two-pass long with arange) against an fp64 autograd
+    reference on the bf16-rounded inputs, with a dO that correlates with O (what makes delta large): the centred gradient is held
+    to 2e-2; the uncentred one (mdist = NULL, the ABI-7 arithmetic) is shown to be several times worse on the long sequences."""
+    N, H, hd = 2, 4, 64
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    qkv = (rnd(N, S, 3 * H * hd, dtype=dtype, seed=11) * 1.5).double().requires_grad_(True)
+    if kind == "kept":
+        T = 2000 if S <= 200 else 11025
+        pos = torch.stack([torch.randperm(T, generator=g)[:S].sort()[0] for _ in range(N)]).int()
+    else:
+        pos = torch.arange(S).repeat(N, 1).int()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = (torch.rand(H, generator=g) * 0.2 + 0.05).double().requires_grad_(True)     # gentle slopes: long attended distances
+    ref = attn_ref(qkv, pos, slopes.double(), sc, H)
+    do = (ref.detach().float() * 0.7 + rnd(N, S, H * hd, dtype=dtype, seed=13) * 0.3).to(dtype).double()
+    ref.backward(do)
+    qd = dev(qkv.detach().float(), dtype)
+    pd = None if kind == "arange" else pos.cuda()
+    scd = sc.detach().float().cuda()
+    out, lse = ops.attention_fwd(qd, pd, slopes.cuda(), scd, H)
+    dal = torch.zeros(H, dtype=torch.float32, device="cuda")
+    dqkv = ops.attention_bwd(qd, out, dev(do.float(), dtype), lse, pd, slopes.cuda(), scd, H, dal)
+    assert rel_err(dqkv.float(), qkv.grad) < 3e-2
+    e_c = rel_err(dal, sc.grad)
+    dal0 = torch.zeros(H, dtype=torch.float32, device="cuda")
+    ops.attention_bwd(qd, out, dev(do.float(), dtype), lse[0].contiguous(), pd, slopes.cuda(), scd, H, dal0)     # bare lse: uncentred
+    e_u = rel_err(dal0, sc.grad)
+    assert e_c < 2e-2, (e_c, e_u)
+    if S >= 386:
+        assert e_u > 2.5 * e_c, (e_c, e_u)
+
+
 @pytest.mark.parametrize("S", [700, 64, 130, 257, 1000, 2000])
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_attention_teacher_arange_long(ops, dtype, S):
@@ -515,8 +554,13 @@ def test_attention_teacher_arange_long(ops, dtype, S):
     assert rel_err(out.float(), ref) < tol(dtype, 2)
     q, k, _ = qkv.float().view(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
     bias = O.alibi_bias_from_positions(pos.long(), H, sc.view(1, 1, H, 1, 1))
-    lse_ref = torch.logsumexp((q * hd ** -0.5) @ k.transpose(-2, -1) + bias, dim=-1)
-    assert (lse.cpu() - lse_ref.view_as(lse.cpu())).abs().max() < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+    sc_ = (q * hd ** -0.5) @ k.transpose(-2, -1) + bias
+    lse_ref = torch.logsumexp(sc_, dim=-1)
+    assert lse.shape == (2, N, H, S)                     # [0] log-sum-exp, [1] mean attended distance (a2v.h: mdist)
+    assert (lse[0].cpu() - lse_ref.view_as(lse[0].cpu())).abs().max() < (2e-2 if dtype == torch.bfloat16 else 1e-4)
+    dist = (pos[0].float().view(S, 1) - pos[0].float().view(1, S)).abs()
+    md_ref = (sc_.softmax(-1) * dist).sum(-1)
+    assert rel_err(lse[1], md_ref.view_as(lse[1].cpu())) < (2e-2 if dtype == torch.bfloat16 else 1e-4)
     # steep bias x long distances (a learned scale of 40-80: the per-key terms reach 1e4 accumulator units far from the diagonal)
     sc2 = sc.abs() * 64
     out2, _ = ops.attention_fwd(dev(qkv, dtype), None, slopes.cuda(), sc2.cuda(), H, need_lse=False)
