@@ -899,7 +899,7 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
     if constexpr (HD == 64) {
       const int ws = (g_a2v_attn_band && !a.pos && (long long)a.N * a.H * 2 * A2V_QKB_SPLIT <= A2V_QKB_MAX) ? a2v_stream_slot(st) : -1;
       if (ws >= 0) {
-        static float* bp0 = nullptr;                 // (device address of the scratch: looked up once per process)
+        static float* bp0_dev[A2V_MAX_DEVICES]; float*& bp0 = bp0_dev[a2v_device()];   // (device address of the scratch: looked up once per device)
         if (!bp0) (void)hipGetSymbolAddress((void**)&bp0, HIP_SYMBOL(g_qk_bound_all));
         float* const bp = bp0 + (long long)ws * A2V_QKB_MAX;
         hipLaunchKernelGGL((attn_qk_bound_kernel<64>), dim3(A2V_QKB_SPLIT, a.N), dim3(256), 0, st, (const bf16*)a.qkv, bp, a.S, a.H);

@@ -286,6 +286,15 @@ __device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, in
   tm = first + (rem - tn * rows);
 }
 
+// Host-side caches of per-DEVICE facts (symbol addresses, function attributes, CU counts) are arrays indexed by the current
+// device: one process may drive several GPUs (tests on cuda:1, one-process multi-GPU hosts).
+#define A2V_MAX_DEVICES 16
+static inline int a2v_device() {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  return (d < 0 || d >= A2V_MAX_DEVICES) ? 0 : d;
+}
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Library-owned device scratch (tile counters of the persistent GEMM, column-sum partial rows, d alibi_scale partial

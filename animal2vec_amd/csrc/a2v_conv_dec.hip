@@ -209,7 +209,7 @@ template <int CI, int CO, int GPW>
 static void conv_dec_go(const GemmArgs& g, hipStream_t stream) {
   using GM = CdGeom<CI, CO, GPW>;
   const ConvA& a = g.a;
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_dec_kernel<CI, CO, GPW>, hipFuncAttributeMaxDynamicSharedMemorySize, GM::LDS);
     attr = true;

@@ -258,7 +258,7 @@ bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
   if (a.Cg != 64 || a.stride != 1 || a.T_in != a.T_out || a.taps < 2 || a.taps > 24 || g.N > 64 || g.N % 4 ||
       a.Cv % 8 || g.K != a.taps * 64 || g.M % a.T_out != 0 || a.pad >= a.taps || a.T_out < 256)
     return false;
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_nt_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
     (void)hipFuncSetAttribute((const void*)conv_nt_slab2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CS2_LDS);

@@ -469,7 +469,7 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     return A2V_OK;
   }
   if (dtype == A2V_BF16) {
-    static bool attr = false;
+    static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
       (void)hipFuncSetAttribute((const void*)gemm_nt_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
@@ -477,7 +477,7 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     }
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(NT_THREADS), NT_LDS_BYTES, stream, g);
   } else {
-    static bool attr = false;
+    static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
     if (!attr) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
       attr = true;

@@ -339,7 +339,7 @@ template <int BM, int BN, bool CONV>
 static void launch_nt_glds(const GemmArgs& g, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int LDS = 2 * STAGE > NT_LDS_BYTES ? 2 * STAGE : NT_LDS_BYTES;
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_glds_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
@@ -352,7 +352,7 @@ template <int BM, int BN, bool CONV>
 static void launch_nt(const GemmArgs& g, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int LDS = 2 * STAGE > NT_LDS_BYTES ? 2 * STAGE : NT_LDS_BYTES;
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_fast_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g, int
 template <int TNN, int TNK>
 static void launch_tn(const WgradArgs& g, int splits, hipStream_t stream) {
   constexpr int LDS = 2 * (64 * TNN * 2 + 64 * TNK * 2);
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_fast_kernel<TNN, TNK>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;

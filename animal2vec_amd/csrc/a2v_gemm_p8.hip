@@ -691,7 +691,7 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   const long long a_span = ((long long)((g.M - 1) / a.T_out / a.bdiv) * a.bstride + (long long)a.T_out * a.pitch + g.K) * 2;
   const long long b_span = ((long long)g.N * g.ldb + g.K) * 2;
   if (a_span >= (1LL << 32) || b_span >= (1LL << 32)) return false;
-  static int cus = 0;
+  static int cus_dev[A2V_MAX_DEVICES]; int& cus = cus_dev[a2v_device()];     // (per device)
   if (!cus) {
     hipDeviceProp_t p;
     int dev = 0;

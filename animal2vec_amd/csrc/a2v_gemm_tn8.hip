@@ -249,7 +249,7 @@ bool a2v_launch_tn_bf16_p8_pair(const WgradArgs* ga, const WgradArgs* gb, hipStr
   args.nprob = gb ? 2 : 1;
   args.M = ga->M;
   const int tiles = args.pr[0].tiles + (gb ? args.pr[1].tiles : 0);
-  static int cus = 0;
+  static int cus_dev[A2V_MAX_DEVICES]; int& cus = cus_dev[a2v_device()];     // (per device)
   if (!cus) {
     hipDeviceProp_t p;
     int dev = 0;

@@ -186,7 +186,7 @@ extern "C" int a2v_span_mask(unsigned char* mask, int* counts, int* ids_keep, in
   const double spans_f = (double)mask_prob * (double)T / (double)mask_length;      // + U, truncated, in the kernel
   const size_t lds = (size_t)T * 5;
   const unsigned lo = (unsigned)seed, hi = (unsigned)(seed >> 32);
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {      // T > 13107 needs more than the default 64 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void*)span_mask_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MASK_MAX_T * 5);
     (void)hipFuncSetAttribute((const void*)span_mask_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MASK_MAX_T * 5);

@@ -126,7 +126,7 @@ __device__ float g_spread_ws[A2V_MAX_STREAMS][SPREAD * 3 * SPREAD_C];
 static float* spread_ws(hipStream_t st) {
   const int slot = a2v_stream_slot(st);
   if (slot < 0) return nullptr;                 // no set left for this stream: direct atomics
-  static float* base = nullptr;                 // address of the device symbol: looked up once
+  static float* base_dev[A2V_MAX_DEVICES]; float*& base = base_dev[a2v_device()];   // address of the device symbol: looked up once per device
   if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_spread_ws)) != hipSuccess) return nullptr;
   return base + (size_t)slot * SPREAD * 3 * SPREAD_C;
 }

@@ -48,6 +48,19 @@ class Engine:
         self.dpar = torch.zeros(4, self.sinc_cp, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ helpers
+    def close(self):
+        """Gives the side stream's scratch set back to the library (a2v_stream_release; at most 4 streams hold one)."""
+        ts, self.tstream = self.tstream, None
+        if ts is not None:
+            try:
+                from . import _lib
+                _lib.load().a2v_stream_release(ts.cuda_stream)
+            except Exception:
+                pass
+
+    def __del__(self):
+        self.close()
+
     def refresh_student_packs(self):
         self.sp.refresh()
 

@@ -103,6 +103,10 @@ class FinetuneConfig:
     layerdrop: float = 0.1                 # -> layerdrop and prenet_layerdrop
     freeze_finetune_updates: int = 10000
     layer_decay: float = 1.0               # wav2vec2.py:214-236
+    # weight_decay_scale 0 (biases, 1-D, alibi, p-swish) and the layer_decay lr scales are both `optim_overrides`
+    # (data2vec2.py:318-320, wav2vec2.py:230-236), which only fairseq's `composite` optimizer reads.  The shipped finetune
+    # recipes train with plain `adam` (finetune_mixup_100.yaml: optimizer._name adam), which ignores BOTH: False = that.
+    optim_overrides: bool = False
     target_mixup: bool = True
     source_mixup: float = 0.5
     mixup_prob: float = 1.0                # < 1: bernoulli per clip (wav2vec2.py:366-373)
@@ -326,8 +330,10 @@ class FinetuneTrainer:
             enc_step = self.num_updates - f.freeze_finetune_updates
             ops.adam_step(st.flat[self.lo:self.hi], st.grad[self.lo:self.hi], st.adam_m[self.lo:self.hi],
                           st.adam_v[self.lo:self.hi], lr=lr, beta1=b1, beta2=b2, eps=f.adam_eps, weight_decay=f.weight_decay,
-                          step=max(1, enc_step), decay_mask=None,     # plain fairseq `adam`: optim_overrides are ignored,
-                          grad_scale_dev=scale, lr_scale=self.lr_scale)   # weight_decay applies to every parameter
+                          step=max(1, enc_step),
+                          # plain fairseq `adam` ignores optim_overrides: weight decay on every parameter, no layer_decay scales
+                          decay_mask=st.decay_mask[self.lo // ALIGN:self.hi // ALIGN] if f.optim_overrides else None,
+                          grad_scale_dev=scale, lr_scale=self.lr_scale if f.optim_overrides else None)
             eng.refresh_student_packs()
         for prm, gr, m, v in ((head.w, gw, self.head_m[0], self.head_v[0]), (head.b, gb, self.head_m[1], self.head_v[1])):
             ops.adam_step(prm.view(-1), gr.contiguous().view(-1), m.view(-1), v.view(-1), lr=lr, beta1=b1, beta2=b2,

@@ -285,6 +285,12 @@ class Data2VecMultiModel(tnn.Module):
                 aug.update(drop_seed=(cfg.seed * 7919 + self._fwd_count) & 0x7FFFFFFF, p_drop=cfg.encoder_dropout,
                            p_proj=cfg.encoder_dropout, p_mlp=cfg.post_mlp_drop, p_pre=a.prenet_dropout,
                            p_att=cfg.attention_dropout, p_in=cfg.dropout_input, p_act=0.0, p_final=0.0)
+        if self.training and torch.is_grad_enabled() and not getattr(self, "_warned_features_only", False):
+            import warnings
+            self._warned_features_only = True
+            warnings.warn("Data2VecMultiModel.forward(features_only=True) returns features WITHOUT an autograd graph: a wrapper "
+                          "that trains through this call (the reference's finetune model does, wav2vec2.py:433-445) would update "
+                          "only its own head.  The native finetune path is nn.Wav2VecCcasFinetune / Engine.finetune_forward_backward.")
         with torch.no_grad():
             x, ts, _ = eng.encode_features(source, save=False, aug=aug or None)
         return {"x": x, "linear_eval_projection": None, "padding_mask": None, "layer_results": [t for _, t in ts],

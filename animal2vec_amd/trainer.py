@@ -209,7 +209,10 @@ class PretrainTrainer:
 
     # ------------------------------------------------------------------ logging-side scalars (sync)
     def metrics(self) -> Dict[str, float]:
-        """loss / sample_size, pred_var, target_var (data2vec2.py:956-970,1095-1110) -- host sync."""
+        """loss / sample_size, pred_var, target_var (data2vec2.py:956-970,1095-1110) -- host sync.  Also where the
+        representation-collapse guard of the reference's forward runs (data2vec2.py:972-988: abort when target_var / pred_var
+        fall under their minima after 5000 updates): the step itself never synchronises, so a loop that wants the guard must
+        call metrics() (animal2vec_audio_main does, every update); a loop that never does -- bench.py -- runs without it."""
         D = self.cfg.embed_dim
         s = self.last["stats"].cpu()
         n = float(s[4 * D + 1])

@@ -53,7 +53,7 @@ def run_finetune(mbs_of_step):
     g = torch.Generator().manual_seed(9)
     fmbs = [dict(source=mb["source"], target=(torch.rand(2, T, 5, generator=g) < 0.2).float().cuda()) for mb in mbs]
     f = FinetuneConfig(n_labels=5, apply_mask=False, layerdrop=0.0, dropout=0.0, activation_dropout=0.0, attention_dropout=0.0,
-                       source_mixup=-1.0, freeze_finetune_updates=1, layer_decay=0.75, warmup_updates=1, lr=1e-3, min_lr=1e-4,
+                       source_mixup=-1.0, freeze_finetune_updates=1, layer_decay=0.75, optim_overrides=True, warmup_updates=1, lr=1e-3, min_lr=1e-4,
                        max_update=10, clip_norm=1.0)
     tr = FinetuneTrainer(cfg, f, dtype=torch.float32, seed=3)
     for _ in range(3):                      # one classifier-only update, then two with the encoder

@@ -278,6 +278,8 @@ def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     assert abs(float(eng.stats[4 * D]) - ls) / ls < (2e-3 if bf else tol_y)
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
     named = {"modality_encoders.AUDIO.alibi_scale": 8e-2} if bf else {}
+    parity_report("large_full_size", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
+                  alibi=[e for e, k in errs if k.endswith("alibi_scale")][0])
     bad = [(e, k) for e, k in errs if e >= named.get(k, tol_g)]
     assert not bad, bad[:8]
     # the update direction as a whole (all 315.8 M gradient entries as one vector)
@@ -519,7 +521,7 @@ def test_finetune_trainer_freeze_and_layer_decay(tiny_golden):
     cfg = tiny_config()
     store = ParamStore(cfg)
     store.load_state_dict(p, ema)
-    f = FinetuneConfig(n_labels=12, freeze_finetune_updates=1, layer_decay=0.5, warmup_updates=1, lr=1e-3, min_lr=1e-4,
+    f = FinetuneConfig(n_labels=12, freeze_finetune_updates=1, layer_decay=0.5, optim_overrides=True, warmup_updates=1, lr=1e-3, min_lr=1e-4,
                        max_update=10, mask_length=2, mask_channel_length=4)
     tr = FinetuneTrainer(cfg, f, store=store, dtype=torch.float32, seed=3)
     mbs = [dict(source=ft["source"].cuda(), target=ft["target"].cuda()) for _ in range(2)]
@@ -855,7 +857,7 @@ def _base_star_setup(seed=0):
 def test_base_star_pretrain_vs_oracle(dtype, tol_y, tol_g):
     """BASELINE config 2's model (base*: D 768, 12 heads, 4 + 12 blocks, decoder 4 x 384, clone_batch 8) on one 10 s clip
     @ 8 kHz with 140 of 2000 frames kept: targets, decoder output, loss and every gradient against the oracle on this
-    box's CPU.  bf16 gradient bound: profiles/r02_bf16_parity.json (per-tensor table of the same comparison)."""
+    box's CPU.  bf16 gradient bound: profiles/r02_bf16_parity_base.json (per-tensor table of the same comparison)."""
     from animal2vec_amd.config import base_star_config
     torch.set_num_threads(min(16, torch.get_num_threads()))
     ocfg, p, ema, g = _base_star_setup()
