@@ -173,4 +173,6 @@ bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream);
 bool a2v_launch_conv_dec48(const GemmArgs& g, hipStream_t stream);     // a2v_conv_dec.hip: decoder grouped conv (48 channels per group, HBM-bound)
 bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream);      // a2v_conv_slab.hip: grouped-conv forward / input grads    // a2v_wgrad_slab.hip: grouped-conv weight grads     // a2v_gemm_p8.hip: 256x256 8-phase kernel
 bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream);
+bool a2v_launch_conv_strided_nt(const GemmArgs& g, hipStream_t stream);   // a2v_conv_strided.hip: dense strided convs on the 8-phase GEMMs
+bool a2v_launch_conv_strided_tn(const WgradArgs& g, hipStream_t stream);
 int a2v_tn_bf16_tiles(int N, int K);

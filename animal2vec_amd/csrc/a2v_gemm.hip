@@ -460,6 +460,10 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+  if (dtype == A2V_BF16 && !rowidx && g_a2v_gemm_p8 && a2v_launch_conv_strided_nt(g, stream)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16 && !rowidx && g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
@@ -522,6 +526,10 @@ static int conv_wgrad_impl(const int* rowidx, int dtype, const void* A, long lon
   if (N % per16 || ldp % per16 || p_goff % per16 || (((uintptr_t)P) & 15)) return A2V_ERR_ARG;
   g.P = P; g.ldp = ldp; g.p_goff = p_goff; g.W = W; g.ldw = ldw; g.w_gstride = w_gstride;
   g.M = M; g.N = N; g.K = K; g.G = G;
+  if (dtype == A2V_BF16 && !rowidx && g_a2v_tn_p8 && a2v_launch_conv_strided_tn(g, stream)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16 && !rowidx && g_a2v_tn_p8 && a2v_launch_tn_bf16_p8(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
@@ -614,6 +622,7 @@ extern "C" int a2v_stream_release(hipStream_t stream) {
 extern int g_a2v_gemm_variant;
 extern int g_a2v_p8_ih;
 extern int g_a2v_p8_fx;
+extern int g_a2v_conv_strided;
 extern int g_a2v_p8_stagger;
 extern int g_a2v_p8_dynamic;
 extern int g_a2v_attn_long;
@@ -635,6 +644,7 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 7) { g_a2v_p8_dynamic = value; return A2V_OK; }  // persistent kernels: dynamic tile hand-out on / off
   if (key == 6) { g_a2v_p8_stagger = value; return A2V_OK; }  // 8-phase kernels: stagger the two wave groups on / off
   if (key == 20) { g_a2v_p8_fx = value; return A2V_OK; }    // 0: no fixed-flavour p8 epilogues
+  if (key == 21) { g_a2v_conv_strided = value; return A2V_OK; }   // dense strided convs on the 8-phase GEMMs on / off
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off

@@ -164,6 +164,24 @@ PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
 PMC_MFMA = os.path.join("profiles", "r02_mfma_util.json")
 
 
+def select_pmc_files(model):
+    """The committed rocprofv3 --pmc summaries of THIS model's workload: the newest round that has them (profiles/rNN_pmc_traffic
+    [_<model>].json / rNN_mfma_util[_<model>].json; the large model's files carry no suffix)."""
+    global PMC_TRAFFIC, PMC_MFMA
+    suf = "" if model == "large" else "_" + model
+    for kind in ("pmc_traffic", "mfma_util"):
+        best = None
+        for rnd in range(9, 0, -1):
+            rel = os.path.join("profiles", "r%02d_%s%s.json" % (rnd, kind, suf))
+            if os.path.exists(os.path.join(ROOT, rel)):
+                best = rel
+                break
+        if kind == "pmc_traffic":
+            PMC_TRAFFIC = best or os.path.join("profiles", "none")
+        else:
+            PMC_MFMA = best or os.path.join("profiles", "none")
+
+
 def _pmc_doc(rel):
     try:
         with open(os.path.join(ROOT, rel)) as f:
@@ -446,6 +464,7 @@ def main():
     from animal2vec_amd.trainer import PretrainTrainer
 
     cfg = {"large": large_config, "base": base_star_config, "large44k": large_44k_config}.get(args.model, base_star_config)()
+    select_pmc_files(args.model)
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     assert args.global_batch % (world * args.micro_batch) == 0, "global batch must split into micro-batches per rank"
     n_mb = args.global_batch // (world * args.micro_batch)

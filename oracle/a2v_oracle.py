@@ -306,6 +306,13 @@ def alibi_bias_from_positions(pos, num_heads: int, alibi_scale):
 
 
 # ------------------------------------------------------------------------------ blocks (a11-a14)
+# Test probe (not part of the restated arithmetic): a list, or None.  d loss / d alibi_scale_h = sum over layers and (n, i, j) of
+# dS_nhij * bias_nhij / scale_h is dominated by cancellation; with a list here every student attention's backward appends
+# sum_nij |dS| |bias| per head -- scale_h times the sum of the ABSOLUTE values of that gradient's terms, the natural yardstick of
+# its rounding error (tests/test_pretrain_gpu.py::alibi_term_scale).
+ALIBI_PROBE = None
+
+
 def alt_attention(p, prefix, x, bias, num_heads):
     """AltAttention.forward (nn/modalities/modules.py:368-410), eval mode."""
     B, N, C = x.shape
@@ -317,6 +324,8 @@ def alt_attention(p, prefix, x, bias, num_heads):
     attn = q @ k.transpose(-2, -1)                                                # :392
     if bias is not None:
         attn = attn.float() + bias                                                # :394-396
+        if ALIBI_PROBE is not None and attn.requires_grad:
+            attn.register_hook(lambda g_, b_=bias.detach(): ALIBI_PROBE.append((g_.detach().abs() * b_.abs()).sum(dim=(0, 2, 3))))
     attn = attn.softmax(dim=-1, dtype=torch.float32)                              # :404
     x = (attn @ v).transpose(1, 2).reshape(B, N, C)                               # :406-407
     return F.linear(x, p[prefix + "attn.proj.weight"], p[prefix + "attn.proj.bias"])

@@ -269,6 +269,52 @@ def test_conv_fwd_and_wgrad(ops, dtype, cfg):
     assert rel_err(gw_un, wr.grad) < tol(dtype, 2)
 
 
+@pytest.mark.parametrize("Cin,k,s,pl,T,B", [(128, 10, 5, 3, 8000, 3), (512, 3, 2, 1, 4000, 3), (128, 10, 5, 3, 80000, 2)])
+def test_strided_feature_convs_on_the_8phase_gemms(ops, Cin, k, s, pl, T, B):
+    """Layers 1-4 of the feature extractor (nn/utils.py:1085-1091: k 10 / s 5 / pad 3 on 128 channels, then k 3 / s 2 / pad 1 on
+    512) as flat overlapping-row GEMMs on the persistent 8-phase kernels + the edge-frame kernels (a2v_conv_strided.hip): forward
+    and weight gradient against torch's conv1d on the bf16-rounded operands, and against the implicit-im2col kernels they replace
+    (a2v_debug_set(21, 0)) -- the rows at clip boundaries, where the flat view aliases the neighbouring clip instead of zero
+    padding, are looked at separately."""
+    from animal2vec_amd import _lib
+    dtype, Cout = torch.bfloat16, 512
+    x = rnd(B, Cin, T, dtype=dtype, seed=5)
+    w = rnd(Cout, Cin, k, dtype=dtype, seed=6, scale=(Cin * k) ** -0.5)
+    T_out = (T + 2 * pl - k) // s + 1
+    assert T == T_out * s
+    ref = conv_ref(x, w, k, s, pl, 1, T_out)
+    xcl = to_cl(x, Cin, dtype)
+    wp = dev(pack_ref(w, 1, Cin), dtype)
+    dy = rnd(B, Cout, T_out, dtype=dtype, seed=8)
+    dycl = to_cl(dy, Cout, dtype)
+    wr = w.clone().requires_grad_(True)
+    conv_ref(x, wr, k, s, pl, 1, T_out).backward(dy)
+
+    def both():
+        y = ops.conv1d_cl(xcl, wp, None, k=k, stride=s, pad=pl, groups=1, T_out=T_out, n_out=Cout)
+        gw = torch.zeros(1, Cout, k * Cin, dtype=torch.float32, device="cuda")
+        ops.conv1d_cl_wgrad(xcl, dycl, gw, k=k, stride=s, pad=pl, groups=1, T_out=T_out)
+        gw_un = torch.zeros(Cout, Cin, k, dtype=torch.float32, device="cuda")
+        ops.unpack_wgrad(gw, gw_un, GN=Cout, Cg=Cin, k=k, Cgp=Cin)
+        return y.float().transpose(1, 2).cpu(), gw_un.cpu()
+
+    y1, g1 = both()
+    _lib.load().a2v_debug_set(21, 0)
+    try:
+        y0, g0 = both()
+    finally:
+        _lib.load().a2v_debug_set(21, 1)
+    for y in (y1, y0):
+        assert rel_err(y, ref) < tol(dtype)
+    edge = [0, 1, T_out - 2, T_out - 1]                 # first / last output frames of every clip
+    assert rel_err(y1[:, :, edge], ref[:, :, edge]) < tol(dtype)
+    assert rel_err(y1, y0) < 4e-3                       # both bf16 outputs of fp32 sums in different orders
+    assert rel_err(g1, wr.grad) < tol(dtype, 2) and rel_err(g0, wr.grad) < tol(dtype, 2)
+    # the taps that hang over the clip edges see the aliasing most: their weight gradient alone
+    assert rel_err(g1[:, :, :pl], wr.grad[:, :, :pl]) < tol(dtype, 2)
+    assert rel_err(g1[:, :, k - 1:], wr.grad[:, :, k - 1:]) < tol(dtype, 2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_padded_taps(ops, dtype):
     """Cg = 48 real channels per group, taps zero-padded to 64 in the packed operand (fast bf16 path)."""
