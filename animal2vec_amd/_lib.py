@@ -94,6 +94,10 @@ def load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = C.c_int
     _lib = lib
+    # A2V_DEBUG_SET="key=value,key=value": A/B switches of a2v_debug_set for whole test / bench runs (experiments only)
+    for kv in filter(None, os.environ.get("A2V_DEBUG_SET", "").split(",")):
+        k, v = kv.split("=")
+        lib.a2v_debug_set(int(k), int(v))
     return lib
 
 

@@ -12,12 +12,15 @@ from conftest import parity_report, rel_err, split_golden
 pytestmark = pytest.mark.gpu
 
 TINY_LAYERS = [(31, 15, 1), (32, 10, 5)] + [(32, 3, 2)] * 3 + [(32, 3, 1)] + [(32, 2, 1)] * 2
-# d alibi_scale in the bf16 mode at T = 11 025 (see test_long_sequence_pretrain_vs_oracle for the derivation of this bound)
-ALIBI_BF16_LONG = 3.5e-1
+# d alibi_scale, bf16 engine against the fp32 engine on the large model at T = 11 025 (no oracle run there to measure the term scale
+# from; measured 1.3e-2): the same bound as every other gradient of that comparison
+ALIBI_BF16_LONG = 6e-2
 AL_KEY = "modality_encoders.AUDIO.alibi_scale"
-# bounds of alibi_term_scale.check: error of d alibi_scale relative to the summed magnitude of its terms (set from measured
-# values, profiles/r03_parity_report.jsonl)
-ALIBI_BACK_F32, ALIBI_BACK_BF16 = 1.0, 1.0
+# bounds of alibi_term_scale.check: the error of d alibi_scale against the summed magnitude A of its terms must stay below about ONE
+# unit roundoff of the storage type (fp32: 2^-24 = 6e-8, bound 2e-7; bf16: 2^-9 = 2e-3).  Measured (profiles/r03_parity_report.jsonl):
+# fp32 1.4e-8 .. 4.9e-8, bf16 6.9e-5 .. 6.9e-4, over condition numbers A / |g| of 20 (D = 128, 8 kHz), 452 (the large model at 8 kHz),
+# 326 (base*), 99 / 673 (T = 5513 / 11 025) -- the relative errors of round 2 (5.7e-2, 2.8e-1) are exactly condition number x this.
+ALIBI_BACK_F32, ALIBI_BACK_BF16 = 2e-7, 2e-3
 
 
 def build(cfg, p, ema, dtype):
@@ -282,9 +285,10 @@ def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
       * targets (4.4e-2 measured, bound 6e-2): the teacher runs 24 post-LN blocks over all 2000 frames in bf16, the
         average of 16 layer outputs is instance-normalised over time, which divides out the signal's scale but not
         the accumulated rounding; the reference's own bf16 autocast of the same forward is at 1.17e-1;
-      * d alibi_scale (5.4e-2 measured, bound 8e-2): 16 numbers, each the sum over 24 layers x 96 sequences x 140^2
-        score gradients times |i - j| with heavy cancellation (norm 3e-3 of a 1e3-norm gradient vector); formed from
-        bf16 probabilities.  The whole gradient vector is within 7.2e-3 (autocast oracle: 8.6e-3)."""
+      * d alibi_scale: 16 numbers, each the sum over 24 layers x 96 sequences x 140^2 score gradients times |i - j| with heavy
+        cancellation (norm 3e-3 of a 1e3-norm gradient vector; condition number 452 measured through the oracle's probe): its error
+        is bounded against the magnitude of its TERMS (alibi_term_scale: below one bf16 unit roundoff of it; 5.7e-2 relative = 452 x
+        1.3e-4), not by a relative bound a cancelling sum cannot keep.  The whole gradient vector is within 7.2e-3 (autocast oracle: 8.6e-3)."""
     from animal2vec_amd.config import large_config
     torch.set_num_threads(min(16, torch.get_num_threads()))
     ocfg = O.OracleConfig(**O.LARGE)
@@ -401,8 +405,7 @@ def test_finetune_hd64_vs_oracle(dtype, tol_y, tol_g):
             bad.append((k, e))
     parity_report("finetune_hd64_vs_oracle", dtype, allerr, logits=rel_err(logits.float(), logits_o.detach()),
                   head_w=rel_err(head.grad_w, ow.grad), head_b=rel_err(head.grad_b, ob.grad))
-    # d alibi_scale: the one cancellation-dominated tensor (see test_large_full_size_vs_oracle), 3.4e-2 .. 4.8e-2 measured here
-    bad = [(k, e) for k, e in bad if not (dtype == torch.bfloat16 and k.endswith("alibi_scale") and e < 8e-2)]
+    # (d alibi_scale needs no exception any more: 4.6e-2 in round 2, 1.7e-2 with the distance centred on the row's mean -- a2v.h: mdist)
     assert not bad, bad[:8]
 
 
@@ -693,7 +696,7 @@ def test_finetune_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     errs.sort(reverse=True)
     parity_report("finetune_large_full_size", dtype, errs, logits=rel_err(logits.float(), logits_o.detach()),
                   head_w=rel_err(head.grad_w, ow.grad), head_b=rel_err(head.grad_b, ob.grad))
-    named = {"modality_encoders.AUDIO.alibi_scale": 8e-2} if dtype == torch.bfloat16 else {}      # 2.9e-2 .. 4.4e-2 measured
+    named = {}                          # (round 2 excepted d alibi_scale at 8e-2; 2.9e-2 measured now, inside the common bound)
     bad = [(e, k) for e, k in errs if e >= named.get(k, tol_g)]
     assert len(errs) > 250 and not bad, bad[:8]
 
