@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liba2v_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT = 1, 2, 4, 8, 16, 32, 64, 128
 
 _p, _i, _ll, _f, _u = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint
@@ -66,6 +66,7 @@ SIGNATURES = {
     "a2v_mean_layers": [_i, _p, _i, _p, _ll, _f, _p],
     "a2v_span_mask": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _f, C.c_ulonglong, _p],
     "a2v_maskinfo": [_p, _p, _p, _p, _i, _i, _i, _p],
+    "a2v_split_bf16": [_p, _p, _ll, _i, _ll, _i, _p],
     "a2v_abi_version": [],
 }
 

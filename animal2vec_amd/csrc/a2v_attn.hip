@@ -275,9 +275,8 @@ __device__ __forceinline__ float rows_max(float v) {
 template <int HD, bool DROP, int QB, bool MSUM = false, bool MD = false>
 __global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_fwd_bf16_kernel(AttnArgs a) {
   typedef bf16 T;
-  // MSUM (experiment, a2v_debug_set(18, 1), forward-only calls): row sums of P by a ones-MFMA over the bf16 P, -4 % time.
-  // Default: fp32 sums of the fp32 P on the VALU, as the reference's softmax -- normalised by the bf16 sums, d alibi_scale (a sum
-  // dominated by cancellation) of the 10 s / 44.1 kHz student moved from 0.16 to 0.26-0.28 relative error against the oracle.
+  // MSUM (forward-only calls without dropout: the teacher; a2v_debug_set(18, 0) switches it off): row sums of P by a ones-MFMA over
+  // the bf16 P, -4 % time.  Calls that keep the LSE for a backward use fp32 sums of the fp32 P on the VALU, as the reference's softmax.
   constexpr bool VSUM = DROP || !MSUM;
   constexpr int ND = HD / 16;
   constexpr int NCH = HD / 8;                 // 16-B chunks per row
@@ -832,7 +831,11 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
   }
 }
 
-int g_a2v_attn_msum = 0;     // a2v_debug_set(18, v): forward-only long-sequence calls sum P on the matrix cores (bf16 P; -4 % time, off: fp32 sums as the reference)
+int g_a2v_attn_msum = 1;     // a2v_debug_set(18, v): forward-only long-sequence calls (the teacher) sum P on the matrix cores (bf16 P; -4 % kernel
+                             // time; 0: fp32 sums on the VALU).  On since round 3: targets, every gradient and the backward error of d alibi_scale
+                             // are unchanged at all four full-size comparisons (profiles/r03_parity_report.jsonl, rows "msum"); what round 2
+                             // read as a loss of accuracy (d alibi_scale 0.16 -> 0.27 at T = 11 025) is that gradient's condition number (673)
+                             // times rounding noise either way
 int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 // Ingredients of the bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i|^2 and max_j |k_j|^2 (Cauchy-Schwarz in

@@ -105,8 +105,14 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 #define P8_FX_B (F_BIAS)                                        /* qkv, the teacher's upper fc2 */
 #define P8_FX_BG (F_BIAS | F_GELU)                              /* fc1, eval (teacher) */
 #define P8_FX_PLAIN 256                                         /* no flag at all (proj input gradient); bit 8 marks "fixed" */
-template <int IH, bool DS, int FX = 0>
+// O32 (dtype A2V_BF16X3 of the C ABI): bf16 operands, fp32 C / C2 / R.  The caller hands over SPLIT operand images --
+// A3 = [A_hi | A_lo | A_hi], B3 = [B_hi | B_hi | B_lo] along K (a2v_split_bf16), so that this ordinary bf16 product over 3 K
+// is A_hi B_hi + A_lo B_hi + A_hi B_lo: every product exact, fp32 accumulation, 2^-17-relative operands -- and gets fp32-grade
+// outputs at a third of the bf16 MFMA rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.  With K three times as long the
+// epilogue is a small share of a tile, so it is plain C++ here (compiler-placed waits), not the hand-counted form below.
+template <int IH, bool DS, int FX = 0, bool O32 = false>
 __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot, int cs_part) {
+  static_assert(!O32 || (DS && FX == 0), "fp32 outputs: direct-store form, generic flags");
   unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
   float* const g_p8_cs_part = g_p8_cs_part_all[ctr_slot];
   constexpr int BM = 128 + 32 * IH;
@@ -401,6 +407,81 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // K-loop barrier and the trailer's with the leader's first barrier of the next tile: both epilogues run at the same time,
       // two latency-bound waves per SIMD.  (Every wave executes exactly one of the two: the counts stay equal.)
       if (!(stagger & 1) || wr == 0) __builtin_amdgcn_s_barrier();
+      if constexpr (O32) {
+        // fp32 outputs: lane (fq, fr) holds row i*16 + fr, columns hb*128 + wc*32 + 8 fq + [0, 8) = two 16-B stores
+        const int fre = le & 15, fqe = le >> 4;
+        const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
+        float* const Ct = (float*)g.C + tile_off;
+        float* const C2t = (float*)g.C2 + tile_off;
+        const float* const Rt = (const float*)g.R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0);
+        const int rskip = T.m0 - T.mc;
+        const int rlo = wr * 64 + fre, rhi = 128 + wr * IH * 16 + fre;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+          const int cl = hb * 128 + wc * 32 + fqe * 8;
+          float bias8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (flags & F_BIAS) Vec8<float>::load(g.bias + (long long)grp * g.N + T.n0 + cl, bias8);
+          float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int i = 0; i < 4 + IH; ++i) {
+            const int row = i < 4 ? rlo + i * 16 : rhi + (i - 4) * 16;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * hb][r] + bias8[r]; v[4 + r] = acc[i][2 * hb + 1][r] + bias8[4 + r]; }
+            const long long eo = (long long)row * g.ldc + cl;
+            if ((flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
+              float gr[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = gelu_with_grad(v[q], gr[q]);
+              Vec8<float>::store(C2t + eo, gr);
+            } else {
+              if (flags & F_STORE_PRE) Vec8<float>::store(C2t + eo, v);
+              if (flags & F_GELU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
+              }
+            }
+            if (flags & F_DROPOUT) {
+              const unsigned long long e0 = (unsigned long long)(T.mc + row) * g.ldc + (unsigned long long)((long long)grp * g.c_goff + T.n0 + cl);
+              drop_apply_n<8>(g.drop, e0, v);
+            }
+            if (need_r) {
+              float h[8];
+              Vec8<float>::load(Rt + (long long)row * g.ldr + cl, h);
+              if (flags & F_RES) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] += h[q];
+              }
+              if (flags & F_GELU_BWD) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] *= (flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
+              }
+            }
+            Vec8<float>::store(Ct + eo, v);
+            if (flags & F_COLSUM) {
+              const float own = row >= rskip ? 1.f : 0.f;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) cs[q] = fmaf(own, v[q], cs[q]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (flags & F_COLSUM) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cs[q] = row16_sum(cs[q]);
+            if (fre == 0) {
+              const int ncol = T.n0 + cl;
+              if (cs_part) {
+                float* const dst = g_p8_cs_part + ((long long)(T.m0 / BM) * 2 + wr) * g.N + ncol;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) dst[q] = cs[q];
+              } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) atomicAdd(g.colsum + (long long)grp * g.N + ncol + q, cs[q]);
+              }
+            }
+          }
+        }
+      } else {
       // lane (fq, fr) holds, for row block i and column half hb: row i*16 + fr, columns hb*128 + wc*32 + 8 fq + [0, 8).
       // Addresses: a uniform 64-bit tile base (SGPRs) + a 32-bit per-lane element offset inside the tile's rows.
       const int fre = le & 15, fqe = le >> 4;
@@ -541,6 +622,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #undef P8_ROFF
 #undef P8_RLOAD
 #undef P8_RN
+      }      // !O32
       if ((stagger & 1) && wr == 1) __builtin_amdgcn_s_barrier();     // the trailing group's half of the epilogue barrier (see above)
     } else {
     const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
@@ -676,17 +758,23 @@ int g_a2v_p8_stagger = 2;   // a2v_debug_set(6, v): wave groups half a phase apa
 int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swapped MFMA operands, permuted B rows) on / off
 int g_a2v_p8_fx = 1;      // a2v_debug_set(20, v): 0 = every flavour takes the generic epilogue (A/B)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
-bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
+static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32);
+bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, false); }
+// bf16 (split) operands, fp32 C / C2 / R (dtype A2V_BF16X3): only the direct-store form exists
+bool a2v_launch_nt_x3_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, true); }
+static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32) {
   const ConvA& a = g.a;
   const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
                      a.Cv == a.Cg;
   if (!plain || g.K % 128 != 0 || g.K < 256 || g.N % 256 != 0 || g.M < 1024) return false;
   // the direct-store form addresses A rows as row * pitch (contiguous batch items); anything else takes the staged form
   const bool contiguous = a.bdiv == 1 && (a.T_out >= g.M || a.bstride == (long long)a.T_out * a.pitch);
-  const char *c0 = (const char*)g.C, *c1 = c0 + ((long long)(g.M - 1) * g.ldc + g.N) * 2;
-  const char *r0 = (const char*)g.R, *r1 = r0 + ((long long)(g.M - 1) * g.ldr + g.N) * 2;
+  const int osz = out32 ? 4 : 2;
+  const char *c0 = (const char*)g.C, *c1 = c0 + ((long long)(g.M - 1) * g.ldc + g.N) * osz;
+  const char *r0 = (const char*)g.R, *r1 = r0 + ((long long)(g.M - 1) * g.ldr + g.N) * osz;
   const bool c_r_overlap = g.R != nullptr && r0 < c1 && c0 < r1;
-  const bool direct = g_a2v_p8_direct && contiguous && !c_r_overlap && g.G == 1 && (long long)256 * g.ldc * 2 < (1LL << 31) && (long long)256 * g.ldr * 2 < (1LL << 31);
+  const bool direct = (g_a2v_p8_direct || out32) && contiguous && !c_r_overlap && g.G == 1 && (long long)256 * g.ldc * 2 < (1LL << 31) && (long long)256 * g.ldr * 2 < (1LL << 31);
+  if (out32 && !direct) return false;
   // 32-bit byte offsets inside one group's operands
   const long long a_span = ((long long)((g.M - 1) / a.T_out / a.bdiv) * a.bstride + (long long)a.T_out * a.pitch + g.K) * 2;
   const long long b_span = ((long long)g.N * g.ldb + g.K) * 2;
@@ -700,6 +788,9 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
     cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
 #define P8_ATTR(IH_, DS_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<IH_, DS_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     P8_ATTR(4, true) P8_ATTR(3, true) P8_ATTR(2, true) P8_ATTR(4, false) P8_ATTR(3, false) P8_ATTR(2, false)
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<3, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<2, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
 #define P8_ATTRF(F_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
   (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<3, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
     P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R) P8_ATTRF(P8_FX_B) P8_ATTRF(P8_FX_BG) P8_ATTRF(P8_FX_PLAIN)
@@ -713,12 +804,12 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   int fx = 0;                                // a fixed-flavour instantiation of the 256-row tile exists for these flag sets
   // (DACT only qualifies a pre-activation store or a GELU backward: alone it changes nothing)
   const int eff = (g.flags & (F_STORE_PRE | F_GELU_BWD)) ? g.flags : (g.flags & ~F_DACT);
-  if (direct && g_a2v_p8_fx)
+  if (direct && g_a2v_p8_fx && !out32)
     for (int f : {(int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R, (int)P8_FX_B, (int)P8_FX_BG})
       if (eff == f) fx = f;
-  if (direct && g_a2v_p8_fx && eff == 0) fx = P8_FX_PLAIN;
+  if (direct && g_a2v_p8_fx && eff == 0 && !out32) fx = P8_FX_PLAIN;
   const bool fx1 = fx == P8_FX_FC1;
-  for (int ih = (dact_store && direct && !fx1) ? 3 : 4; ih >= 2; --ih) {
+  for (int ih = (dact_store && direct && !fx1 && !out32) ? 3 : 4; ih >= 2; --ih) {
     if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && !fx1 && g_a2v_p8_ih == 4)) continue;
     const int bm = 128 + 32 * ih;
     const long long nt = (long long)cdiv(g.M, bm) * (g.N / 256);
@@ -740,7 +831,11 @@ bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) {
   if (ws < 0) return false;                  // no scratch set left for this stream: the 128 x 128 kernel needs none
   const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX) ? 1 : 0;
 #define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
-  if (direct) {
+  if (out32) {
+#define P8_GO32(IH_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, true, 0, true>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
+    if (best_ih == 4) P8_GO32(4); else if (best_ih == 3) P8_GO32(3); else P8_GO32(2);
+#undef P8_GO32
+  } else if (direct) {
 #define P8_GOF(F_)                                                                                                        \
   {                                                                                                                       \
     if (best_ih == 4)                                                                                                     \

@@ -1,0 +1,48 @@
+// Split-precision operand images for the bf16x3 parity mode (dtype A2V_BF16X3): x = hi + lo + r with hi = bf16(x),
+// lo = bf16(x - hi), |r| <= 2^-17 |x|.  A product a b over split operands, a_hi b_hi + a_lo b_hi + a_hi b_lo, is three exact
+// bf16 x bf16 products accumulated in fp32 (what v_mfma_f32_16x16x32_bf16 does) and misses a b by <= 2^-16 relative -- fp32
+// grade for a 1e-3 parity bound -- at a third of the bf16 matrix rate instead of the 1/16 of the fp32 MFMA.  The images put
+// the three products side by side along the reduction axis, so that the ordinary bf16 GEMM kernels compute them:
+//   mode 0  (M, 3K)  [hi | lo | hi]      left operand of an NT product (activations)
+//   mode 1  (M, 3K)  [hi | hi | lo]      right operand (weights)
+//   mode 2  (2M, K)  [hi ; lo] stacked   operands of the weight-gradient (TN) products, which run as three launches
+//                                        (dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) into the same fp32 accumulator
+// Replaces nothing in the reference: it is how this library reaches the north-star's 1e-3 on the bf16 matrix cores.
+#include "a2v_common.h"
+
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long long M, int K,
+                                                         long long ldx, int mode) {
+  const int kv = K / 8;
+  const long long total = M * kv;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const long long m = i / kv;
+    const int c = (int)(i - m * kv) * 8;
+    float v[8];
+    Vec8<float>::load(x + m * ldx + c, v);
+    bf16x8 h, l;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      h[q] = (bf16)v[q];
+      l[q] = (bf16)(v[q] - (float)h[q]);
+    }
+    if (mode == 2) {
+      *(bf16x8*)(out + m * K + c) = h;
+      *(bf16x8*)(out + (M + m) * K + c) = l;
+    } else {
+      bf16* const row = out + m * 3 * K + c;
+      *(bf16x8*)row = h;
+      *(bf16x8*)(row + K) = mode == 0 ? l : h;
+      *(bf16x8*)(row + 2 * K) = mode == 0 ? h : l;
+    }
+  }
+}
+
+// x (M, K) fp32 with row pitch ldx (elements) -> out bf16, layout by mode (above).  K % 8 == 0, 16-B aligned pointers.
+extern "C" int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx, int mode, hipStream_t st) {
+  if (M <= 0 || K <= 0 || K % 8 || ldx % 4 || mode < 0 || mode > 2 || (((uintptr_t)x | (uintptr_t)out) & 15)) return A2V_ERR_ARG;
+  long long blocks = (M * (K / 8) + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (bf16*)out, M, K, ldx, mode);
+  A2V_CHECK_LAUNCH();
+  return A2V_OK;
+}

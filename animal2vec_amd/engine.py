@@ -28,10 +28,14 @@ _DACT = os.environ.get("A2V_NO_DACT") is None      # (A/B switch for the gelu'-i
 
 
 class Engine:
-    def __init__(self, cfg: Data2VecMultiConfig, store: ParamStore, dtype=torch.bfloat16):
+    def __init__(self, cfg: Data2VecMultiConfig, store: ParamStore, dtype=torch.bfloat16, x3: bool = False):
+        """dtype: the activation storage (bf16 = throughput mode, fp32 = parity mode).  x3 (with fp32): the bf16x3 parity mode --
+        every plain Linear product (forward, input gradient, weight gradient) runs as three exact bf16 products on the bf16
+        matrix cores over split operands (ops.split_bf16, include/a2v.h: A2V_BF16X3); everything else is the fp32 mode."""
         self.cfg, self.store, self.dtype = cfg, store, dtype
-        self.sp = Packs(store, dtype, teacher=False, need_grad=True)
-        self.tp = Packs(store, dtype, teacher=True, need_grad=False)
+        self.x3 = bool(x3)
+        self.sp = Packs(store, dtype, teacher=False, need_grad=True, x3=self.x3)
+        self.tp = Packs(store, dtype, teacher=True, need_grad=False, x3=self.x3)
         self.sp.refresh()
         self.tp.refresh()
         self.layers = cfg.conv_layers
@@ -382,6 +386,7 @@ class Engine:
         p = st.p
         H, D = cfg.num_heads, cfg.embed_dim
         a = cfg.audio
+        ops.X3_WGRAD = self.x3
         feats = self.frontend_fwd(source, save=save)
         B, T, _ = feats.shape
         asc = p[P + "alibi_scale"].view(-1)
@@ -441,6 +446,7 @@ class Engine:
         p, g = st.p, st.g
         H, D = cfg.num_heads, cfg.embed_dim
         a = cfg.audio
+        ops.X3_WGRAD = self.x3
         c = self.sv.pop("ft")
         B, T = c["B"], c["T"]
         asc = p[P + "alibi_scale"].view(-1)
@@ -583,6 +589,7 @@ class Engine:
         cb, H, D = cfg.clone_batch, cfg.num_heads, cfg.embed_dim
         a = cfg.audio
         dbg = {}
+        ops.X3_WGRAD = self.x3
         feats = self.frontend_fwd(source, save=save)                           # (B,T,D)
         B, T, _ = feats.shape
         N, K = ids_keep.shape
@@ -651,6 +658,7 @@ class Engine:
         p, g = st.p, st.g
         cb, H = cfg.clone_batch, cfg.num_heads
         a = cfg.audio
+        ops.X3_WGRAD = self.x3
         c = self.sv.pop("ctx")
         dx, mask_u8, ids_keep, ids_restore, T = c["dx"], c["mask_u8"], c["ids_keep"], c["ids_restore"], c["T"]
         if gscale != 1.0:

@@ -10,7 +10,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, check
+from ._lib import BF16, BF16X3, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, check
 
 
 def _L():
@@ -53,9 +53,10 @@ def _drop(drop):
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride,
               a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
-              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False):
+              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False, x3=None):
     """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add.
-    rowidx (int32, M entries): GEMM row m reads the im2col row of flat index rowidx[m]; out stays compact."""
+    rowidx (int32, M entries): GEMM row m reads the im2col row of flat index rowidx[m]; out stays compact.
+    x3=True: x and w are bf16 split images (split_bf16), out / res / pre_out fp32 (include/a2v.h: A2V_BF16X3)."""
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS
@@ -74,13 +75,49 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
     if drop is not None and drop[0] > 0:
         flags |= EPI_DROPOUT
     dp, ds = (drop if drop is not None and drop[0] > 0 else (0.0, 0))
-    args = (dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
+    dtype_code = dt(x) if x3 is None else BF16X3
+    args = (dtype_code, ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
             ptr(rowmask), bdiv, ptr(w), ldb, b_gstride, ptr(out), ldc, c_goff, ptr(pre_out),
             ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
             dp, ds & 0xFFFFFFFF, stream())
     rc = _L().a2v_conv_gemm(*args) if rowidx is None else _L().a2v_conv_gemm_rows(ptr(rowidx), *args)
     check(rc, "a2v_conv_gemm")
     return out
+
+
+# ---- bf16x3 parity mode (include/a2v.h: a2v_split_bf16, A2V_BF16X3): fp32 storage everywhere, the Linears' products as three
+# exact bf16 products on the bf16 matrix cores.  A weight takes part when its split image has been registered (params.Packs with
+# x3=True does that at every refresh); activations are split on the fly.
+_X3_IMAGES = {}          # data_ptr of an fp32 (N, K) operand -> bf16 (N, 3K) image [hi | hi | lo]
+X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
+
+
+def split_bf16(x, mode, out=None):
+    """fp32 (M, K) -> bf16 image: mode 0 (M, 3K) [hi|lo|hi], 1 (M, 3K) [hi|hi|lo], 2 (2M, K) [hi; lo]"""
+    M, K = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty((2 * M, K) if mode == 2 else (M, 3 * K), dtype=torch.bfloat16, device=x.device)
+    check(_L().a2v_split_bf16(ptr(x), ptr(out), M, K, x.stride(0), mode, stream()), "a2v_split_bf16")
+    return out
+
+
+def x3_register(w, image=None):
+    """(re)build the split image of the fp32 (N, K) operand w; called by params.Packs.refresh in the bf16x3 mode"""
+    key = w.data_ptr()
+    img = _X3_IMAGES.get(key)
+    img = split_bf16(w, 1, out=img[1] if img is not None and img[1].shape == (w.shape[0], 3 * w.shape[1]) else None)
+    _X3_IMAGES[key] = (w.shape, img)
+    return img
+
+
+def _x3_image(w, M):
+    """the registered split image of w if the product (M rows) is one the 8-phase kernel takes, else None"""
+    ent = _X3_IMAGES.get(w.data_ptr())
+    if ent is None or ent[0] != w.shape or w.dtype != torch.float32:
+        return None
+    N, K = w.shape
+    return ent[1] if (M >= 1024 and N % 256 == 0 and (3 * K) % 128 == 0 and 3 * K >= 256 and w.stride(0) == K) else None
 
 
 def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None, drop=None, dact=False):
@@ -91,6 +128,12 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
     if out is None:
         out = torch.empty(M, N, dtype=x.dtype, device=x.device)
     r = gelu_bwd_aux if gelu_bwd_aux is not None else res
+    img = _x3_image(w, M) if x.dtype == torch.float32 else None
+    if img is not None:
+        xs = split_bf16(x, 0)
+        return conv_gemm(xs, img, out, M=M, N=N, K=3 * K, T_in=M, T_out=M, Cg=3 * K, a_pitch=3 * K, a_bstride=0, ldb=3 * K,
+                         ldc=out.stride(0), bias=bias, res=r, ldr=r.stride(0) if r is not None else 0, gelu=gelu,
+                         gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum, drop=drop, dact=dact, x3=True)
     return conv_gemm(x, w, out, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
                      ldb=w.stride(0), ldc=out.stride(0), bias=bias, res=r, ldr=r.stride(0) if r is not None else 0,
                      gelu=gelu, gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum, drop=drop, dact=dact)
@@ -126,11 +169,29 @@ def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1,
     return gw
 
 
+def _x3_wgrad_ok(x, dy):
+    M, K = x.shape
+    N = dy.shape[1]
+    return (X3_WGRAD and x.dtype == torch.float32 and dy.dtype == torch.float32 and M >= 2048 and N % 256 == 0 and K % 256 == 0
+            and x.stride(1) == 1 and dy.stride(1) == 1)
+
+
+def _x3_wgrad_terms(x, dy):
+    """(dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) as bf16 (M, .) views of the stacked split images"""
+    M = x.shape[0]
+    xs, ds = split_bf16(x, 2), split_bf16(dy, 2)
+    return ((xs[:M], ds[:M]), (xs[M:], ds[:M]), (xs[:M], ds[M:]))
+
+
 def linear_wgrad(x, dy, gw):
     """gw[N,K] (fp32) += dy[M,N]^T @ x[M,K]"""
     M, K = x.shape
     N = dy.shape[1]
     assert gw.dtype == torch.float32 and gw.shape == (N, K)
+    if _x3_wgrad_ok(x, dy):
+        for xa, da in _x3_wgrad_terms(x, dy):
+            conv_wgrad(xa, da, gw, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=K, a_bstride=0, ldp=N, ldw=gw.stride(0))
+        return gw
     return conv_wgrad(x, dy, gw, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
                       ldp=dy.stride(0), ldw=gw.stride(0))
 
@@ -141,6 +202,12 @@ def linear_wgrad_pair(xa, dya, gwa, xb, dyb, gwb):
     Na, Nb, Kb = dya.shape[1], dyb.shape[1], xb.shape[1]
     assert xb.shape[0] == M and dya.shape[0] == M and dyb.shape[0] == M and xa.dtype == xb.dtype
     assert gwa.dtype == torch.float32 and gwb.dtype == torch.float32 and gwa.shape == (Na, Ka) and gwb.shape == (Nb, Kb)
+    if _x3_wgrad_ok(xa, dya) and _x3_wgrad_ok(xb, dyb):
+        for (xa_, da_), (xb_, db_) in zip(_x3_wgrad_terms(xa, dya), _x3_wgrad_terms(xb, dyb)):
+            rc = _L().a2v_linear_wgrad_pair(BF16, M, ptr(xa_), Ka, ptr(da_), Na, ptr(gwa), gwa.stride(0), Na, Ka,
+                                            ptr(xb_), Kb, ptr(db_), Nb, ptr(gwb), gwb.stride(0), Nb, Kb, stream())
+            check(rc, "a2v_linear_wgrad_pair")
+        return
     rc = _L().a2v_linear_wgrad_pair(dt(xa), M, ptr(xa), xa.stride(0), ptr(dya), dya.stride(0), ptr(gwa), gwa.stride(0), Na, Ka,
                                     ptr(xb), xb.stride(0), ptr(dyb), dyb.stride(0), ptr(gwb), gwb.stride(0), Nb, Kb, stream())
     check(rc, "a2v_linear_wgrad_pair")

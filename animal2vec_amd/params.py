@@ -274,7 +274,10 @@ class Packs:
     each optimizer step (student) / EMA step (teacher); in fp32 mode Linear forward operands alias
     the flat parameter buffer."""
 
-    def __init__(self, store: ParamStore, dtype: torch.dtype, teacher: bool, need_grad: bool):
+    def __init__(self, store: ParamStore, dtype: torch.dtype, teacher: bool, need_grad: bool, x3: bool = False):
+        # x3 (fp32 storage only): the Linear operands also get bf16 split images (ops.x3_register) -- the bf16x3 parity mode
+        assert not x3 or dtype == torch.float32
+        self.x3 = x3
         self.store, self.dtype, self.teacher, self.need_grad = store, dtype, teacher, need_grad
         self.src = store.t if teacher else store.p
         cfg = store.cfg
@@ -352,6 +355,20 @@ class Packs:
             self._desc = self._descriptors()
         if self._desc.shape[0]:
             ops.pack_weight_batch(self._desc, self.dtype)
+        if self.x3:
+            self._register_x3()
+
+    def _register_x3(self):
+        """split images [hi | hi | lo] of every operand that is the right-hand side of a plain Linear product: the Linears' forward
+        operands (the fp32 parameters themselves), their transposes for the input gradients, and the (k*C, Cout) images of the
+        strided feature convs' input gradients"""
+        for name, m in self.meta.items():
+            if m["kind"] == "linear":
+                ops.x3_register(self.w[name])
+                if self.need_grad:
+                    ops.x3_register(self.wt[name])
+            elif self.need_grad and m["G"] == 1 and m["stride"] > 1:
+                ops.x3_register(self.wt[name])
 
     @torch.no_grad()
     def refresh_one_by_one(self):
@@ -369,3 +386,5 @@ class Packs:
                         ops.pack_weight(src, self.wt[name], G=1, N=m["N"], Cg=m["Cg"], k=m["k"], Cgp=m["Cgp"], mode=2)
                     else:
                         ops.pack_weight(src, self.wt[name], G=m["G"], N=m["N"], Cg=m["Cg"], k=m["k"], Np=m["Np"], mode=1)
+        if self.x3:
+            self._register_x3()

@@ -46,11 +46,11 @@ def get_annealed_rate(start, end, curr_step, total_steps):
 
 class PretrainTrainer:
     def __init__(self, cfg: Data2VecMultiConfig, optim: Optional[OptimConfig] = None, dtype=torch.bfloat16,
-                 device="cuda", seed: int = 0, process_group=None, dropout: bool = True, mixup: bool = True):
+                 device="cuda", seed: int = 0, process_group=None, dropout: bool = True, mixup: bool = True, x3: bool = False):
         self.cfg, self.optim = cfg, optim or OptimConfig()
         self.store = ParamStore(cfg, device=device)
         self.store.init_reference(seed)
-        self.engine = Engine(cfg, self.store, dtype=dtype)
+        self.engine = Engine(cfg, self.store, dtype=dtype, x3=x3)
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.num_updates = 0

@@ -309,12 +309,14 @@ def cpu_baseline(model_name, L, K, sample_rate=8000):
 
 
 def parity_mode_leg(cfg, L, dev, args, clips=8, steps=2):
-    """The fp32 parity mode of the same optimizer step (fp32 storage, v_mfma_f32_16x16x4_f32: exact fp32 products, the mode the
-    `-m gpu` tests hold to 1e-3 against the oracle at BASELINE's full size) on a bounded sample: 1 warm-up + `steps` timed steps of
-    `clips` clips, masks sampled in the step like the headline."""
+    """The parity mode of the same optimizer step on a bounded sample (1 warm-up + `steps` timed steps of `clips` clips, masks
+    sampled in the step like the headline): fp32 storage with the Linear products as three exact bf16 products over split operands
+    on the bf16 matrix cores (bf16x3, include/a2v.h: A2V_BF16X3) -- the mode `-m gpu` holds to 1e-3 against the oracle at BASELINE's
+    full size -- and, beside it, the older all-v_mfma_f32_16x16x4_f32 form of the same mode."""
     from animal2vec_amd.trainer import PretrainTrainer
-    try:
-        tr = PretrainTrainer(cfg, dtype=torch.float32, device=dev, seed=0)
+
+    def leg(x3):
+        tr = PretrainTrainer(cfg, dtype=torch.float32, device=dev, seed=0, x3=x3)
         mbs = [make_microbatch(cfg, clips, L, 0, 4242, dev, masks="sampled")]
         tr.train_step(mbs)
         torch.cuda.synchronize()
@@ -324,12 +326,22 @@ def parity_mode_leg(cfg, L, dev, args, clips=8, steps=2):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         tr.engine.close()
-        return dict(dtype="f32 (fp32 storage, v_mfma_f32_16x16x4_f32: exact fp32 products)",
-                    value=round(clips * steps * L / cfg.audio.sample_rate / dt, 2), unit="audio-s/s",
+        del tr
+        torch.cuda.empty_cache()
+        return clips * steps * L / cfg.audio.sample_rate / dt, 1e3 * dt / steps
+
+    try:
+        v3, ms3 = leg(True)
+        v1, ms1 = leg(False)
+        return dict(dtype="bf16x3 (fp32 storage; Linear products = 3 exact v_mfma_f32_16x16x32_bf16 products over split operands, fp32 "
+                          "accumulation; convolutions / attention on v_mfma_f32_16x16x4_f32)",
+                    value=round(v3, 2), unit="audio-s/s", ms_per_step=round(ms3, 2),
                     tolerance="1e-3 relative L2 against the CPU oracle on targets, decoder output, loss and every parameter gradient "
-                              "(tests/test_pretrain_gpu.py::test_large_full_size_vs_oracle[float32]: measured 1e-5)",
+                              "(tests/test_pretrain_gpu.py::test_large_full_size_vs_oracle[bf16x3])",
+                    f32_mfma_mode=dict(value=round(v1, 2), ms_per_step=round(ms1, 2),
+                                       note="the same mode with every product on v_mfma_f32_16x16x4_f32 (round 2's parity mode)"),
                     sample=f"{steps} optimizer steps of {clips} clips after 1 warm-up, same step as the headline (sampled masks, dropout, "
-                           f"mixup, clip + Adam, EMA)", ms_per_step=round(1e3 * dt / steps, 2))
+                           f"mixup, clip + Adam, EMA)")
     except Exception as e:                                   # the leg must not lose the headline measurement
         return dict(value=None, note=f"parity leg failed: {type(e).__name__}: {e}")
 

@@ -34,6 +34,8 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 
 #define A2V_F32 0
 #define A2V_BF16 1
+#define A2V_BF16X3 2 /* a2v_conv_gemm only: A and Bw are bf16 SPLIT images (a2v_split_bf16) with K = 3 x the real reduction length,
+                      * C / C2 / R are fp32 -- the bf16x3 parity mode: fp32-grade results on the bf16 matrix cores */
 
 /* epilogue flags of a2v_conv_gemm */
 #define A2V_EPI_BIAS 1      /* + bias[g*N+n] */
@@ -254,7 +256,7 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   15 whole-sequence attention backward for S <= 144 (1: 48-row tiles on three waves; 0: 64-row tiles on four)
  *   16 attention forward for S <= 144 (1: whole-sequence kernel, three waves per (n, h); 0: the tiled kernel)
  *   17 attention forward for S >= 512: 1-D launch that keeps the query blocks of one (n, h) on one XCD (1) / 3-D grid (0)
- *   18 forward-only attention for S >= 512: row sums of P from the bf16 P on the matrix cores (1) / fp32 sums (0, default)
+ *   18 forward-only attention for S >= 512: row sums of P from the bf16 P on the matrix cores (1, default since round 3) / fp32 sums (0)
  *   19 attention forward for S >= 512 with positions = arange: skip key tiles beyond the ALiBi band limit (a bound from the row
  *      norms of q and k: weights below e^-32 of the row sum) (1, default) / visit every tile (0)
  *   20 fixed-flavour instantiations of the NT kernel's 256-row tile for the eight hottest epilogue flag sets (1, default) / the generic epilogue (0)
@@ -304,13 +306,27 @@ int a2v_mask_frames(int dtype, const void* x, const unsigned char* mask_t, const
 int a2v_span_mask(unsigned char* mask, int* counts, int* ids_keep, int* ids_restore, int* keep_out, int N, int T,
                   float mask_prob, int mask_length, int min_masks, float mask_dropout, unsigned long long seed,
                   a2v_stream_t stream);
+/* ---------------------------------------------------------------- bf16x3 parity mode (ABI 8)
+ * x = hi + lo (+ r, |r| <= 2^-17 |x|) with hi = bf16(x), lo = bf16(x - hi); a_hi b_hi + a_lo b_hi + a_hi b_lo misses a b by <= 2^-16
+ * relative and is three EXACT bf16 products accumulated in fp32 -- what v_mfma_f32_16x16x32_bf16 does.  a2v_split_bf16 writes the
+ * images that put those three products side by side along the reduction axis, so that the bf16 kernels compute them:
+ *   mode 0: (M, 3K) [hi | lo | hi]   left operand of a2v_conv_gemm(A2V_BF16X3, ...) (activations)
+ *   mode 1: (M, 3K) [hi | hi | lo]   right operand (weights: F.linear's W, or W^T for the input gradient)
+ *   mode 2: (2M, K) [hi ; lo]        operands of the weight-gradient products, run as three a2v_conv_wgrad(A2V_BF16, ...) calls
+ *                                    (dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) into the same fp32 accumulator
+ * a2v_conv_gemm(A2V_BF16X3) takes plain row-major operands the persistent 8-phase kernel accepts (taps 1, M >= 1024, N % 256 == 0,
+ * K % 128 == 0) and returns -4 (unsupported) otherwise: the caller keeps such shapes on A2V_F32.  The Linears of the step
+ * (north_star: "attention QKV / out-proj and FFN GEMMs as MFMA bf16 tiles ... outputs within 1e-3") run this way in the
+ * engine's bf16x3 mode; the reference has no counterpart (its fp32 is torch's). */
+int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx, int mode, a2v_stream_t stream);
+
 /* make_maskinfo alone (base.py:427-455) for a caller-supplied mask (`precomputed_mask`) with K kept frames in every row
  * (the reference assumes equal counts, base.py:437): ids_keep (N,K), ids_restore (N,T) as above.  rows_bad (one int the
  * caller zeroed, may be NULL) counts the rows whose kept count is not K; such rows are left unwritten. */
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 8: + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
+/* 8: + a2v_split_bf16 and dtype A2V_BF16X3 of a2v_conv_gemm; + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
  * arithmetic).  7 added a2v_decoder_input_rng and A2V_EPI_DACT over 6. */
 int a2v_abi_version(void);
 

@@ -1231,3 +1231,75 @@ def test_conv_decoder_kernel(ops, B, T, CI, CO):
     assert rel_err(dx.float(), xr.grad.transpose(1, 2) + res) < tol(dtype, 2)
     # K is accumulated as (tap, channel) here and as tap-major 64-wide steps there: same products, fp32 sums in another order
     assert rel_err(y.float(), y0.float()) < 4e-3 and rel_err(dx.float(), dx0.float()) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------ bf16x3 parity mode
+def test_split_bf16_images(ops):
+    x = torch.randn(300, 136, generator=torch.Generator().manual_seed(1)) * torch.logspace(-3, 3, 136)
+    xd = x.cuda()
+    h = x.bfloat16().float()
+    l = (x - h).bfloat16().float()
+    assert float((x - h - l).abs().max() / x.abs().max()) < 2 ** -16
+    i0, i1, i2 = ops.split_bf16(xd, 0).float().cpu(), ops.split_bf16(xd, 1).float().cpu(), ops.split_bf16(xd, 2).float().cpu()
+    assert torch.equal(i0, torch.cat([h, l, h], 1)) and torch.equal(i1, torch.cat([h, h, l], 1)) and torch.equal(i2, torch.cat([h, l], 0))
+
+
+@pytest.mark.parametrize("M,N,K", [(13440, 1024, 1024), (2100, 768, 512), (1100, 256, 128), (107520, 1024, 1024)])
+def test_linear_bf16x3_matches_fp64(ops, M, N, K):
+    """A2V_BF16X3: the Linear product as three exact bf16 products over split operands on the persistent 8-phase kernel, fp32 in /
+    out, every epilogue flavour -- against an fp64 product of the SAME fp32 operands.  Bound 3e-5 relative (2^-16 per product
+    + fp32 accumulation; the fp32 MFMA mode measures 1e-6, the bf16 mode 4e-3)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * K ** -0.5
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    xd, wd, bd, rd = x.cuda(), w.cuda(), b.cuda(), r.cuda()
+    big = M > 50000
+    ref = (xd.double() @ wd.double().t()).cpu() if big else x.double() @ w.double().t()
+    ops.x3_register(wd)
+    try:
+        y = ops.linear(xd, wd, bd)
+        assert rel_err(y, ref + b.double()) < 3e-5
+        if big:
+            return
+        y0 = ops.linear(xd[:512], wd, bd)                      # M < 1024: stays on the fp32 kernel
+        assert rel_err(y0, (ref + b.double())[:512]) < 1e-5
+        pre = torch.empty(M, N, device="cuda")
+        yg = ops.linear(xd, wd, bd, gelu=True, pre_out=pre)
+        assert rel_err(pre, ref + b.double()) < 3e-5 and rel_err(yg, F.gelu(ref + b.double())) < 3e-5
+        keep = torch.empty(M, N, device="cuda")
+        yd = ops.linear(xd, wd, bd, gelu=True, pre_out=keep, dact=True)
+        pg = (ref + b.double()).clone().requires_grad_(True)
+        F.gelu(pg).sum().backward()
+        assert rel_err(yd, F.gelu(ref + b.double())) < 3e-5 and rel_err(keep, pg.grad) < 3e-5
+        yr = ops.linear(xd, wd, bd, res=rd)
+        assert rel_err(yr, ref + b.double() + r.double()) < 3e-5
+        cs = torch.zeros(N, device="cuda")
+        yb = ops.linear(xd, wd, None, gelu_bwd_aux=keep, colsum=cs, dact=True)
+        assert rel_err(yb, ref * keep.double().cpu()) < 3e-5 and rel_err(cs, yb.double().sum(0)) < 1e-5
+        ydp = ops.linear(xd, wd, bd, res=rd, drop=(0.1, 77))
+        keepm = ops.dropout_mask(M * N, 0.1, 77).view(M, N).cpu().double()
+        assert rel_err(ydp, (ref + b.double()) * keepm / 0.9 + r.double()) < 3e-5
+    finally:
+        ops._X3_IMAGES.clear()
+
+
+def test_linear_wgrad_bf16x3_matches_fp64(ops):
+    M, N, K = 13440, 1024, 512
+    g = torch.Generator().manual_seed(4)
+    x, dy = torch.randn(M, K, generator=g).cuda(), torch.randn(M, N, generator=g).cuda()
+    ref = (dy.double().t() @ x.double()).cpu()
+    gw = torch.zeros(N, K, device="cuda")
+    ops.X3_WGRAD = True
+    try:
+        ops.linear_wgrad(x, dy, gw)
+        assert rel_err(gw, ref) < 3e-5
+        gwa, gwb = torch.zeros(N, K, device="cuda"), torch.zeros(K, N, device="cuda")
+        ops.linear_wgrad_pair(x, dy, gwa, dy, x, gwb)
+        assert rel_err(gwa, ref) < 3e-5 and rel_err(gwb, ref.t()) < 3e-5
+    finally:
+        ops.X3_WGRAD = False
+    gw32 = torch.zeros(N, K, device="cuda")
+    ops.linear_wgrad(x, dy, gw32)
+    assert rel_err(gw32, ref) < 1e-5

@@ -20,7 +20,10 @@ AL_KEY = "modality_encoders.AUDIO.alibi_scale"
 # unit roundoff of the storage type (fp32: 2^-24 = 6e-8, bound 2e-7; bf16: 2^-9 = 2e-3).  Measured (profiles/r03_parity_report.jsonl):
 # fp32 1.4e-8 .. 4.9e-8, bf16 6.9e-5 .. 6.9e-4, over condition numbers A / |g| of 20 (D = 128, 8 kHz), 452 (the large model at 8 kHz),
 # 326 (base*), 99 / 673 (T = 5513 / 11 025) -- the relative errors of round 2 (5.7e-2, 2.8e-1) are exactly condition number x this.
-ALIBI_BACK_F32, ALIBI_BACK_BF16 = 2e-7, 2e-3
+ALIBI_BACK = {torch.float32: 2e-7, torch.bfloat16: 2e-3, "bf16x3": 3e-5}     # (bf16x3: products exact to 2^-16 = 1.5e-5)
+
+
+X3 = "bf16x3"        # parity mode on the bf16 matrix cores: fp32 storage, the Linears as three exact bf16 products (Engine(x3=True))
 
 
 def build(cfg, p, ema, dtype):
@@ -28,6 +31,8 @@ def build(cfg, p, ema, dtype):
     from animal2vec_amd.engine import Engine
     store = ParamStore(cfg, device="cuda")
     store.load_state_dict(p, ema)
+    if dtype == X3:
+        return store, Engine(cfg, store, dtype=torch.float32, x3=True)
     return store, Engine(cfg, store, dtype=dtype)
 
 
@@ -91,7 +96,7 @@ def test_tiny_fp32_vs_reference_golden(tiny_golden):
     assert worst[1] < TOL, worst
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 3e-2, 5e-2), (X3, 1e-3, 1e-3)])
 def test_hd64_vs_oracle(dtype, tol_y, tol_g):
     """Real front end (127x63 sinc, 512-wide convs), head_dim 64, D=128: HIP path vs oracle on the box's CPU."""
     from animal2vec_amd.config import Data2VecMultiConfig, D2vAudioConfig, D2vDecoderConfig
@@ -138,7 +143,7 @@ def test_hd64_vs_oracle(dtype, tol_y, tol_g):
         allerr.append((e, k))
         if e > tol_g:
             bad.append((k, e))
-    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK_F32 if dtype == torch.float32 else ALIBI_BACK_BF16)
+    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK[dtype])
     parity_report("hd64_vs_oracle", dtype, allerr, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
                   decoder_out=rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]), alibi_rel=al_rel, alibi_cond=al_cond,
                   alibi_back=al_back)
@@ -274,7 +279,7 @@ def test_batched_operand_packing_matches_single_launches(tiny_golden, dtype):
             assert torch.equal(got, v), (kind, k)
 
 
-@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 4e-2)])
+@pytest.mark.parametrize("dtype,tol_y,tol_g", [(torch.float32, 1e-3, 1e-3), (torch.bfloat16, 2e-2, 4e-2), (X3, 1e-3, 1e-3)])
 def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     """BASELINE.json's configuration at full size (large model: D 1024, 16 heads, 8 + 16 blocks, decoder 4 x 768,
     clone_batch 12, one 10 s clip @ 8 kHz, 140 of 2000 frames kept): HIP path against the oracle run on this box's
@@ -316,7 +321,7 @@ def test_large_full_size_vs_oracle(dtype, tol_y, tol_g):
     ls = float(res["losses"]["AUDIO_regression"].sum())
     assert abs(float(eng.stats[4 * D]) - ls) / ls < (2e-3 if bf else tol_y)
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
-    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK_F32 if dtype == torch.float32 else ALIBI_BACK_BF16)
+    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK[dtype])
     parity_report("large_full_size", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]), alibi_rel=al_rel,
                   alibi_cond=al_cond, alibi_back=al_back)
     bad = [(e, k) for e, k in errs if e >= tol_g and k != AL_KEY]       # d alibi_scale: held by ats.check above (see alibi_term_scale)
@@ -740,7 +745,7 @@ def test_long_sequence_pretrain_vs_oracle(dtype, tol_y, tol_g, L, T_want):
     ls = float(res["losses"]["AUDIO_regression"].sum())
     assert abs(float(eng.stats[4 * cfg.embed_dim]) - ls) / ls < tol_y
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
-    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK_F32 if dtype == torch.float32 else ALIBI_BACK_BF16)
+    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK[dtype])
     parity_report(f"long_sequence_pretrain_T{T}", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
                   decoder_out=rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]), alibi_rel=al_rel, alibi_cond=al_cond,
                   alibi_back=al_back)
@@ -851,7 +856,7 @@ def test_config5_whole_10s_44k_vs_oracle(dtype, tol_y, tol_g):
     ls = float(res["losses"]["AUDIO_regression"].sum().detach())
     assert abs(float(eng.stats[4 * cfg.embed_dim]) - ls) / ls < tol_y
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
-    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK_F32 if dtype == torch.float32 else ALIBI_BACK_BF16)
+    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK[dtype])
     parity_report("config5_whole_10s_44k", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
                   local_features=rel_err(dbg["local_features"].float(), res["_dbg"]["local_features"]), alibi_rel=al_rel,
                   alibi_cond=al_cond, alibi_back=al_back)
@@ -1030,7 +1035,7 @@ def test_base_star_pretrain_vs_oracle(dtype, tol_y, tol_g):
     assert abs(float(eng.stats[4 * D]) - ls) / ls < tol_y
     assert int(eng.stats[4 * D + 1]) == int(res["sample_size"])
     errs = sorted(((rel_err(store.g[k], v.grad), k) for k, v in po.items()), reverse=True)
-    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK_F32 if dtype == torch.float32 else ALIBI_BACK_BF16)
+    al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, ALIBI_BACK[dtype])
     parity_report("base_star_pretrain", dtype, errs, targets=rel_err(dbg["targets"], res["_dbg"]["targets"]),
                   decoder_out=rel_err(dbg["decoder_out"].float(), res["_dbg"]["decoder_out"]), alibi_rel=al_rel, alibi_cond=al_cond,
                   alibi_back=al_back)

@@ -16,7 +16,7 @@ out=$root/gpurun_out
 mkdir -p $out
 export A2V_TEACHER_STREAM=0        # teacher on the main stream: kernel durations are not inflated by overlap
 extra=""
-[ "$script" = "bench.py" ] && extra="--cpu-baseline skip --no-roofline"
+[ "$script" = "bench.py" ] && extra="--cpu-baseline skip --no-roofline --parity-leg skip"
 cd /tmp && export TMPDIR=/tmp
 run() {   # pass name, then rocprofv3 options
   pn=$1; shift
