@@ -66,7 +66,7 @@ SIGNATURES = {
     "a2v_mean_layers": [_i, _p, _i, _p, _ll, _f, _p],
     "a2v_span_mask": [_p, _p, _p, _p, _p, _i, _i, _f, _i, _i, _f, C.c_ulonglong, _p],
     "a2v_maskinfo": [_p, _p, _p, _p, _i, _i, _i, _p],
-    "a2v_split_bf16": [_p, _p, _ll, _i, _ll, _i, _p],
+    "a2v_split_bf16": [_p, _p, _ll, _i, _ll, _ll, _i, _p],
     "a2v_abi_version": [],
 }
 

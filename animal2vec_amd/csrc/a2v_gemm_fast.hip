@@ -186,7 +186,9 @@ __device__ __forceinline__ void glds16(const char* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((gbl_cvoid_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
 }
 
-template <int BM, int BN, bool CONV>
+// OutT = float: bf16 (split) operands with fp32 C / C2 / R -- dtype A2V_BF16X3 for the shapes the persistent kernel does not take
+// (convolutions: implicit im2col of the split activation image, see a2v_split.hip)
+template <int BM, int BN, bool CONV, typename OutT = bf16>
 __global__ __launch_bounds__(256) void gemm_nt_bf16_glds_kernel(GemmArgs g) {
   constexpr int WN = BN / 64, WM = 4 / WN;
   static_assert(BM == 64 * WM, "wave tile is 64x64");
@@ -330,22 +332,29 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_glds_kernel(GemmArgs g) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  wave_epilogue<bf16>(g, stage, lane, m0 + wm * 64, n0 + wn * 64, grp);
+  wave_epilogue<OutT>(g, stage, lane, m0 + wm * 64, n0 + wn * 64, grp);
 }
 
 int g_a2v_gemm_variant = 1;      // 0: register-staged kernel, 1: LDS-DMA kernel (a2v_debug_set(0, v))
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, bool CONV, typename OutT = bf16>
 static void launch_nt_glds(const GemmArgs& g, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int LDS = 2 * STAGE > NT_LDS_BYTES ? 2 * STAGE : NT_LDS_BYTES;
   static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_glds_kernel<BM, BN, CONV>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_glds_kernel<BM, BN, CONV, OutT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     attr = true;
   }
   dim3 grid(cdiv(g.M, BM) * cdiv(g.N, BN), g.G, 1);
-  hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<BM, BN, CONV>), grid, dim3(256), LDS, stream, g);
+  hipLaunchKernelGGL((gemm_nt_bf16_glds_kernel<BM, BN, CONV, OutT>), grid, dim3(256), LDS, stream, g);
+}
+
+// bf16 split operands, fp32 outputs (A2V_BF16X3), any shape with 64-wide taps
+bool a2v_launch_nt_x3_fast(const GemmArgs& g, hipStream_t stream) {
+  if (g.a.Cg % 64 != 0 || g.K % 64 != 0) return false;
+  if (g.N <= 64) launch_nt_glds<256, 64, true, float>(g, stream); else launch_nt_glds<128, 128, true, float>(g, stream);
+  return true;
 }
 
 template <int BM, int BN, bool CONV>

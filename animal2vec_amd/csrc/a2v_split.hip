@@ -11,7 +11,7 @@
 #include "a2v_common.h"
 
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long long M, int K,
-                                                         long long ldx, int mode) {
+                                                         long long ldx, long long ldo, int mode) {
   const int kv = K / 8;
   const long long total = M * kv;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
@@ -26,10 +26,10 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
       l[q] = (bf16)(v[q] - (float)h[q]);
     }
     if (mode == 2) {
-      *(bf16x8*)(out + m * K + c) = h;
-      *(bf16x8*)(out + (M + m) * K + c) = l;
+      *(bf16x8*)(out + m * ldo + c) = h;
+      *(bf16x8*)(out + (M + m) * ldo + c) = l;
     } else {
-      bf16* const row = out + m * 3 * K + c;
+      bf16* const row = out + m * ldo + c;
       *(bf16x8*)row = h;
       *(bf16x8*)(row + K) = mode == 0 ? l : h;
       *(bf16x8*)(row + 2 * K) = mode == 0 ? h : l;
@@ -37,12 +37,16 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
   }
 }
 
-// x (M, K) fp32 with row pitch ldx (elements) -> out bf16, layout by mode (above).  K % 8 == 0, 16-B aligned pointers.
-extern "C" int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx, int mode, hipStream_t st) {
+// x (M, K) fp32 with row pitch ldx (elements) -> out bf16, layout by mode (above), output row pitch ldo (0: dense = 3 K, or K in
+// mode 2; a larger pitch leaves the caller's zero padding in place: packed conv weights whose taps are padded to 64 channels).
+// K % 8 == 0, 16-B aligned pointers.
+extern "C" int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx, long long ldo, int mode, hipStream_t st) {
   if (M <= 0 || K <= 0 || K % 8 || ldx % 4 || mode < 0 || mode > 2 || (((uintptr_t)x | (uintptr_t)out) & 15)) return A2V_ERR_ARG;
+  if (ldo == 0) ldo = mode == 2 ? K : 3LL * K;
+  if (ldo % 8 || ldo < (mode == 2 ? K : 3LL * K)) return A2V_ERR_ARG;
   long long blocks = (M * (K / 8) + 255) / 256;
   if (blocks > 65536) blocks = 65536;
-  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (bf16*)out, M, K, ldx, mode);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (bf16*)out, M, K, ldx, ldo, mode);
   A2V_CHECK_LAUNCH();
   return A2V_OK;
 }

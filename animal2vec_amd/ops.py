@@ -87,33 +87,59 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 
 # ---- bf16x3 parity mode (include/a2v.h: a2v_split_bf16, A2V_BF16X3): fp32 storage everywhere, the Linears' products as three
 # exact bf16 products on the bf16 matrix cores.  A weight takes part when its split image has been registered (params.Packs with
-# x3=True does that at every refresh); activations are split on the fly.
-_X3_IMAGES = {}          # data_ptr of an fp32 (N, K) operand -> bf16 (N, 3K) image [hi | hi | lo]
+# x3=True does that at every refresh); activations are split on the fly.  The image hangs on the weight TENSOR OBJECT (attribute
+# _a2v_x3), not in a table keyed by address: a freed weight's address is handed to the next allocation.
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
 
 
-def split_bf16(x, mode, out=None):
-    """fp32 (M, K) -> bf16 image: mode 0 (M, 3K) [hi|lo|hi], 1 (M, 3K) [hi|hi|lo], 2 (2M, K) [hi; lo]"""
+def split_bf16(x, mode, out=None, ldo=0):
+    """fp32 (M, K) -> bf16 image: mode 0 (M, 3K) [hi|lo|hi], 1 (M, 3K) [hi|hi|lo], 2 (2M, K) [hi; lo]; ldo: output row pitch
+    (the caller's `out`, zeroed where it wants padding)"""
     M, K = x.shape
     assert x.dtype == torch.float32 and x.stride(1) == 1
     if out is None:
         out = torch.empty((2 * M, K) if mode == 2 else (M, 3 * K), dtype=torch.bfloat16, device=x.device)
-    check(_L().a2v_split_bf16(ptr(x), ptr(out), M, K, x.stride(0), mode, stream()), "a2v_split_bf16")
+    check(_L().a2v_split_bf16(ptr(x), ptr(out), M, K, x.stride(0), ldo, mode, stream()), "a2v_split_bf16")
     return out
+
+
+def _x3_conv_image(w_packed, k, cv):
+    G, N, KK = w_packed.shape
+    Cgp = KK // k
+    if (3 * Cgp) % 64 or cv % 8 or w_packed.dtype != torch.float32:
+        return None
+    ent = getattr(w_packed, "_a2v_x3", None)
+    if ent is None or ent[0] != ("conv", tuple(w_packed.shape), k, cv):
+        return None
+    return ent[1]
+
+
+def x3_register_conv_pack(w_packed, k, cv):
+    """(re)build the conv split image; called by params.Packs.refresh in the bf16x3 mode"""
+    G, N, KK = w_packed.shape
+    Cgp = KK // k
+    if (3 * Cgp) % 64 or cv % 8:
+        return None
+    tag = ("conv", tuple(w_packed.shape), k, cv)
+    ent = getattr(w_packed, "_a2v_x3", None)
+    img = ent[1] if ent is not None and ent[0] == tag else torch.zeros(G, N, k * 3 * Cgp, dtype=torch.bfloat16, device=w_packed.device)
+    rows = w_packed.view(G * N * k, Cgp)
+    split_bf16(rows[:, :cv], 1, out=img.view(G * N * k, 3 * Cgp), ldo=3 * Cgp)
+    w_packed._a2v_x3 = (tag, img)
+    return img
 
 
 def x3_register(w, image=None):
     """(re)build the split image of the fp32 (N, K) operand w; called by params.Packs.refresh in the bf16x3 mode"""
-    key = w.data_ptr()
-    img = _X3_IMAGES.get(key)
-    img = split_bf16(w, 1, out=img[1] if img is not None and img[1].shape == (w.shape[0], 3 * w.shape[1]) else None)
-    _X3_IMAGES[key] = (w.shape, img)
+    ent = getattr(w, "_a2v_x3", None)
+    img = split_bf16(w, 1, out=ent[1] if ent is not None and ent[0] == w.shape else None)
+    w._a2v_x3 = (w.shape, img)
     return img
 
 
 def _x3_image(w, M):
     """the registered split image of w if the product (M rows) is one the 8-phase kernel takes, else None"""
-    ent = _X3_IMAGES.get(w.data_ptr())
+    ent = getattr(w, "_a2v_x3", None)
     if ent is None or ent[0] != w.shape or w.dtype != torch.float32:
         return None
     N, K = w.shape
@@ -153,6 +179,14 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
     M = B * T_out if rowidx is None else rowidx.numel()       # rowidx: only these rows (flat b*T_out + t), compact output
     if out is None:
         out = torch.empty((B, T_out, n_out) if rowidx is None else (M, n_out), dtype=x.dtype, device=x.device)
+    img = _x3_conv_image(w_packed, k, cv) if x.dtype == torch.float32 else None
+    if img is not None and x.is_contiguous() and Cp == G * cv:
+        # bf16x3: implicit im2col of the split activation image -- 3 cv channels per group [hi | lo | hi] against taps [hi | hi | lo]
+        xs = split_bf16(x.view(-1, cv), 0).view(Bsrc, T_in, G * 3 * cv)
+        return conv_gemm(xs, img, out, M=M, N=N, K=k * 3 * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride, pad=pad, taps=k,
+                         Cg=3 * Cg, Cv=3 * cv, a_pitch=G * 3 * cv, a_bstride=T_in * G * 3 * cv, a_goff=3 * cv if G > 1 else 0,
+                         rowmask=rowmask, bdiv=bdiv, ldb=img.stride(-2), b_gstride=img.stride(0) if G > 1 else 0, ldc=n_out,
+                         c_goff=N, bias=bias, res=res, ldr=n_out if res is not None else 0, colsum=colsum, rowidx=rowidx, x3=True)
     return conv_gemm(x, w_packed, out, M=M, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride,
                      pad=pad, taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=cv if G > 1 else 0,
                      rowmask=rowmask, bdiv=bdiv, ldb=w_packed.stride(-2), b_gstride=w_packed.stride(0) if G > 1 else 0,
@@ -223,6 +257,21 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
     N = gw_packed.shape[-2]
     n_out = dy.shape[-1]
     cv = Cg if cv is None else cv
+    if X3_WGRAD and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous() and Cg % 8 == 0:
+        # bf16x3: dY_hi^T X_hi + dY_hi^T X_lo + dY_lo^T X_hi through the bf16 weight-gradient kernels (fp32 accumulation)
+        R = x.shape[0] * x.shape[1]
+        xs = split_bf16(x.view(R, Cp), 2)
+        d2 = dy.reshape(-1, n_out)
+        ds = split_bf16(d2, 2)
+        Rd = d2.shape[0]
+        xh, xl = xs[:R].view(x.shape), xs[R:].view(x.shape)
+        dh, dl = ds[:Rd].view(dy.shape), ds[Rd:].view(dy.shape)
+        for xa, da in ((xh, dh), (xl, dh), (xh, dl)):
+            conv_wgrad(xa, da, gw_packed, M=B * T_out if rowidx is None else rowidx.numel(), N=N, K=k * Cg, G=G, T_in=T_in,
+                       T_out=T_out, stride=stride, pad=pad, rowidx=rowidx, taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1),
+                       a_bstride=x.stride(0), a_goff=cv if G > 1 else 0, rowmask=rowmask, bdiv=bdiv, ldp=n_out, p_goff=N,
+                       ldw=gw_packed.stride(-2), w_gstride=gw_packed.stride(0) if G > 1 else 0)
+        return gw_packed
     return conv_wgrad(x, dy, gw_packed, M=B * T_out if rowidx is None else rowidx.numel(), N=N, K=k * Cg, G=G, T_in=T_in,
                       T_out=T_out, stride=stride, pad=pad, rowidx=rowidx,
                       taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=cv if G > 1 else 0,

@@ -309,9 +309,11 @@ class Packs:
                 else:
                     G = cfg.audio.decoder.decoder_groups
                 N = Cout // G
-                # tap padding to 64 only for the grouped convs (dense feature-extractor convs are 128/512 wide)
-                Cgp = _padk(Cg, dtype) if G > 1 else _pad8(Cg)
-                Np = _padk(N, dtype) if G > 1 else N
+                # tap padding to 64 only for the grouped convs (dense feature-extractor convs are 128/512 wide); the bf16x3 mode
+                # runs the bf16 kernels over split images of these operands and takes the bf16 padding
+                pdt = torch.bfloat16 if x3 else dtype
+                Cgp = _padk(Cg, pdt) if G > 1 else _pad8(Cg)
+                Np = _padk(N, pdt) if G > 1 else N
                 li = int(name.split("conv_layers.")[1].split(".")[0]) if "local_encoder" in name else None
                 stride = cfg.conv_layers[li][2] if li is not None else 1
                 m = dict(kind="conv", G=G, N=N, Cg=Cg, Cgp=Cgp, Np=Np, k=k, stride=stride)
@@ -367,8 +369,12 @@ class Packs:
                 ops.x3_register(self.w[name])
                 if self.need_grad:
                     ops.x3_register(self.wt[name])
-            elif self.need_grad and m["G"] == 1 and m["stride"] > 1:
-                ops.x3_register(self.wt[name])
+            else:
+                ops.x3_register_conv_pack(self.w[name], m["k"], m["Cg"])
+                if self.need_grad and m["G"] == 1 and m["stride"] > 1:
+                    ops.x3_register(self.wt[name])
+                elif self.need_grad:
+                    ops.x3_register_conv_pack(self.wt[name], m["k"], m["N"])
 
     @torch.no_grad()
     def refresh_one_by_one(self):

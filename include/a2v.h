@@ -314,11 +314,13 @@ int a2v_span_mask(unsigned char* mask, int* counts, int* ids_keep, int* ids_rest
  *   mode 1: (M, 3K) [hi | hi | lo]   right operand (weights: F.linear's W, or W^T for the input gradient)
  *   mode 2: (2M, K) [hi ; lo]        operands of the weight-gradient products, run as three a2v_conv_wgrad(A2V_BF16, ...) calls
  *                                    (dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) into the same fp32 accumulator
- * a2v_conv_gemm(A2V_BF16X3) takes plain row-major operands the persistent 8-phase kernel accepts (taps 1, M >= 1024, N % 256 == 0,
- * K % 128 == 0) and returns -4 (unsupported) otherwise: the caller keeps such shapes on A2V_F32.  The Linears of the step
+ * ldx / ldo: row pitches of x and out in elements (ldo 0 = dense; a larger ldo leaves the caller's zero padding between rows).
+ * a2v_conv_gemm(A2V_BF16X3) runs plain row-major products on the persistent 8-phase kernel (taps 1, M >= 1024, N % 256 == 0,
+ * K % 128 == 0) and everything else with 64-wide taps -- the convolutions, as implicit im2col of the split activation image with
+ * 3 Cg channels per group and tap -- on the 128 x 128 LDS-DMA kernel; -4 (unsupported) otherwise: such shapes stay on A2V_F32.  The Linears of the step
  * (north_star: "attention QKV / out-proj and FFN GEMMs as MFMA bf16 tiles ... outputs within 1e-3") run this way in the
  * engine's bf16x3 mode; the reference has no counterpart (its fp32 is torch's). */
-int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx, int mode, a2v_stream_t stream);
+int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx, long long ldo, int mode, a2v_stream_t stream);
 
 /* make_maskinfo alone (base.py:427-455) for a caller-supplied mask (`precomputed_mask`) with K kept frames in every row
  * (the reference assumes equal counts, base.py:437): ids_keep (N,K), ids_restore (N,T) as above.  rows_bad (one int the

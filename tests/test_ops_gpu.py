@@ -1282,7 +1282,7 @@ def test_linear_bf16x3_matches_fp64(ops, M, N, K):
         keepm = ops.dropout_mask(M * N, 0.1, 77).view(M, N).cpu().double()
         assert rel_err(ydp, (ref + b.double()) * keepm / 0.9 + r.double()) < 3e-5
     finally:
-        ops._X3_IMAGES.clear()
+        del wd._a2v_x3
 
 
 def test_linear_wgrad_bf16x3_matches_fp64(ops):
@@ -1303,3 +1303,38 @@ def test_linear_wgrad_bf16x3_matches_fp64(ops):
     gw32 = torch.zeros(N, K, device="cuda")
     ops.linear_wgrad(x, dy, gw32)
     assert rel_err(gw32, ref) < 1e-5
+
+
+@pytest.mark.parametrize("Cin,Cout,k,s,pl,G,T,B", [(1024, 1024, 19, 1, 9, 16, 600, 2), (768, 768, 7, 1, 3, 16, 500, 2),
+                                                   (128, 512, 10, 5, 3, 1, 4000, 2), (512, 512, 3, 2, 1, 1, 2000, 2)])
+def test_conv_bf16x3_matches_fp64(ops, Cin, Cout, k, s, pl, G, T, B):
+    """The convolutions of the step (pos-conv g16 k19, decoder g16 k7 with 48-channel taps padded to 64, the strided feature convs)
+    in the bf16x3 mode: implicit im2col of the split activation image against split packed weights on the bf16 kernels with fp32
+    outputs; weight gradient as three bf16 products.  Against fp64 convolutions of the same fp32 operands: 3e-5."""
+    from animal2vec_amd.params import _padk
+    g = torch.Generator().manual_seed(5)
+    Cg = Cin // G
+    N = Cout // G
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cg, k, generator=g) * (Cg * k) ** -0.5
+    bias = torch.randn(Cout, generator=g)
+    T_out = T if s == 1 else (T + 2 * pl - k) // s + 1
+    ref = conv_ref(x.double(), w.double(), k, s, pl, G, T_out) + bias.double().view(1, -1, 1)
+    cgp = _padk(Cg, torch.bfloat16) if G > 1 else Cg
+    xcl = to_cl(x, Cin, torch.float32)
+    wp = dev(pack_ref(w, G, cgp), torch.float32)
+    assert ops.x3_register_conv_pack(wp, k, Cg) is not None
+    y = ops.conv1d_cl(xcl, wp, bias.cuda(), k=k, stride=s, pad=pl, groups=G, T_out=T_out, n_out=Cout, cv=Cg)
+    assert rel_err(y.transpose(1, 2), ref) < 3e-5
+    dy = torch.randn(B, Cout, T_out, generator=g)
+    wr = w.double().clone().requires_grad_(True)
+    conv_ref(x.double(), wr, k, s, pl, G, T_out).backward(dy.double())
+    gw = torch.zeros(G, N, k * cgp, dtype=torch.float32, device="cuda")
+    ops.X3_WGRAD = True
+    try:
+        ops.conv1d_cl_wgrad(xcl, to_cl(dy, Cout, torch.float32), gw, k=k, stride=s, pad=pl, groups=G, T_out=T_out, cv=Cg)
+    finally:
+        ops.X3_WGRAD = False
+    gw_un = torch.zeros(Cout, Cg, k, dtype=torch.float32, device="cuda")
+    ops.unpack_wgrad(gw, gw_un, GN=Cout, Cg=Cg, k=k, Cgp=cgp)
+    assert rel_err(gw_un, wr.grad) < 3e-5
