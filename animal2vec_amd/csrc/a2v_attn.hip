@@ -647,11 +647,13 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_f
 }
 
 // ---------------------------------------------------------------------------------------------
-// bf16, HD = 64, S <= 144 (the student's 140 kept frames): whole-sequence forward.  One workgroup of THREE waves per (n, h);
+// bf16, HD = 64, S <= 160 (the student's kept frames: 140 in round 2's seeded masks, 143 .. 155 as the sampler draws them at 96 ..
+// 768 rows): whole-sequence forward.  One workgroup of up to FOUR waves per (n, h) -- a wave without query rows leaves at once --;
 // K and V of all S keys are staged once (the tiled kernel above re-fetched them for each of its three 64-row query blocks
 // and padded 140 to 192 on both axes), each wave owns 48 query rows (three 16-row blocks) against every key, and the whole
 // score row is in registers: ONE pass of softmax (no running maximum, no rescale), one barrier in the kernel.
-#define AF48_ROWS 160             // K / V images: 144 rows + one zero 16-row group (the odd ninth key group's MFMA partner)
+#define AF48_ROWS 160             // K / V images: ten 16-key groups (an odd last group's MFMA partner is a zero group)
+#define AF48_MAXS 160
 #define AF48_LDS (2 * AF48_ROWS * 128 + AF48_ROWS * 4)
 __device__ __forceinline__ float rows_sum(float v) {    // sum over the lanes l, l^16, l^32, l^48 (see rows_max)
   const unsigned u = __float_as_uint(v);
@@ -663,9 +665,9 @@ __device__ __forceinline__ float rows_sum(float v) {    // sum over the lanes l,
 }
 
 template <bool DROP, bool MD = false>
-__global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
   typedef bf16 T;
-  constexpr int HD = 64, ND = 4, QB = 3, NKG = 9;
+  constexpr int HD = 64, ND = 4, QB = 3, NKG = 10;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sK = smem;                                   // [160][64] row image
   char* const sV = sK + AF48_ROWS * 128;                   // [160][64] tr image
@@ -684,11 +686,12 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
 
   // ---- every global load of the kernel first: K / V rows (zero past S), positions, this wave's Q fragments
   {
-    constexpr int NQ = (AF48_ROWS * 8 + 191) / 192;
+    constexpr int NQ = (AF48_ROWS * 8 + 191) / 192;        // (192 or 256 threads: sized for the smaller launch)
+    const int nthr = blockDim.x;
     uint4 kz[NQ], vz[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      const int c = tid + nthr * u, r = c >> 3, ch = c & 7;
       kz[u] = make_uint4(0u, 0u, 0u, 0u);
       vz[u] = kz[u];
       if (r < S) {
@@ -700,7 +703,7 @@ __global__ __launch_bounds__(192, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
     if (tid < AF48_ROWS) sPos[tid] = tid < S ? (a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid) : 0.f;
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      const int c = tid + nthr * u, r = c >> 3, ch = c & 7;
       if (c < AF48_ROWS * 8) {
         *(uint4*)(sK + rowimg_off<HD>(r, ch)) = kz[u];
         *(uint4*)(sV + trimg_off<HD>(r, ch * 8)) = vz[u];
@@ -890,9 +893,10 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = 0;
   if constexpr (HD == 64) {
-    if (a.S <= 144 && g_a2v_attn_fwd48) {
-      if (a.mdist) hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP, true>), dim3(1, a.H, a.N), dim3(192), AF48_LDS, st, a);
-      else hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP, false>), dim3(1, a.H, a.N), dim3(192), AF48_LDS, st, a);
+    if (a.S <= AF48_MAXS && g_a2v_attn_fwd48) {
+      const int nthr = a.S > 144 ? 256 : 192;             // 48 query rows per wave
+      if (a.mdist) hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP, true>), dim3(1, a.H, a.N), dim3(nthr), AF48_LDS, st, a);
+      else hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP, false>), dim3(1, a.H, a.N), dim3(nthr), AF48_LDS, st, a);
       return;
     }
   }
@@ -1663,8 +1667,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
 // log2 units, delta, position, dropout row term) are formed once into LDS and read as one 16-B vector per four rows.
 // The next key block's K / V fragments and K tile are fetched by loads NOTHING else touches until the block change (no
 // zero-initialised destinations, no guards: rows past S re-read row S-1 and are masked by kv_ok / zero dS columns).
-#define AB48_QROWS 160            // Q / dO images: 144 rows + one zero 16-row group (the odd ninth sub-block's partner)
-#define AB48_ROWS 144
+#define AB48_QROWS 160            // Q / dO images: ten 16-row groups (an odd last sub-block's partner is a zero group)
+#define AB48_ROWS 160             // S <= 160: ten query groups (wave w owns w, w + 3, w + 6, w + 9), up to four 48-key blocks
 #define AB48_LDS (2 * AB48_QROWS * 128 + 64 * 128 + AB48_ROWS * 128 + 5 * AB48_ROWS * 4 + 3 * 64 * 4)
 
 template <bool DROP>
@@ -1743,7 +1747,8 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     if (a.bias_sum) sBias[tid] = 0.f;               // 192 threads = 3 x 64 sums
     if (tid < 128) *(uint4*)(sKt + 48 * 128 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);         // key rows 48..63: zero for good
 #pragma unroll
-    for (int u = 0; u < AB48_ROWS * 8 / 192; ++u) *(uint4*)(sDS + (tid + 192 * u) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int u = 0; u < (AB48_ROWS * 8 + 191) / 192; ++u)
+      if (tid + 192 * u < AB48_ROWS * 8) *(uint4*)(sDS + (tid + 192 * u) * 16) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
       const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
@@ -1770,9 +1775,9 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     }
   }
 
-  f32x4 dq[3][ND];
+  f32x4 dq[4][ND];
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int i = 0; i < ND; ++i) dq[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dal = 0.f;
@@ -1905,7 +1910,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
       for (int i = 0; i < ND; ++i)
         kfr[i] = tr_frag(sKt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sKt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
 #pragma unroll
-      for (int t = 0; t < 3; ++t) {
+      for (int t = 0; t < 4; ++t) {
         const int qg = wid + 3 * t;
         if (qg >= nsub) continue;                  // uniform
         const int rq = 16 * qg + fr;
@@ -1920,7 +1925,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
 #undef AB48_FETCH
   // ---- dQ into the q slot of dqkv: rows q = 16 (wid + 3t) + 4g + r, col d = 16i + fr
 #pragma unroll
-  for (int t = 0; t < 3; ++t)
+  for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qr = 16 * (wid + 3 * t) + 4 * g + r;
@@ -1935,7 +1940,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     for (int i = 0; i < ND; ++i) {
       float sq = 0.f;
 #pragma unroll
-      for (int t = 0; t < 3; ++t)
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int qr = 16 * (wid + 3 * t) + 4 * g + r;

@@ -518,6 +518,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if os.environ.get("A2V_BENCH_STEP_TIMES") == "1":      # diagnosis only: wall time of every step, synchronised (not a measurement)
+        for i in range(args.warmup + args.steps + 4):
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            tr.train_step(mbs)
+            torch.cuda.synchronize()
+            print(f"[step {i}] {1e3 * (time.perf_counter() - t_):.1f} ms  K={tr.mask_sampler.last_k}  "
+                  f"reserved={torch.cuda.memory_reserved() / 2**30:.1f} GiB", file=sys.stderr, flush=True)
     for _ in range(args.warmup):
         tr.train_step(mbs)
     sync()

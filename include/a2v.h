@@ -253,8 +253,8 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   8 long-sequence attention backward (0 tiled kernel + dQ atomics, 1 two-pass, 2 two-pass for every S)
  *   10 persistent NT kernel epilogue (1 direct stores, 0 staged through LDS)     13 decoder grouped-conv kernel on / off
  *   14 grouped-conv slab kernel form (1: 384-row slabs, two workgroups per CU; 0: 1024-row slabs)
- *   15 whole-sequence attention backward for S <= 144 (1: 48-row tiles on three waves; 0: 64-row tiles on four)
- *   16 attention forward for S <= 144 (1: whole-sequence kernel, three waves per (n, h); 0: the tiled kernel)
+ *   15 whole-sequence attention backward for S <= 160 (1: 48-row tiles on three waves; 0: 64-row tiles on four)
+ *   16 attention forward for S <= 160 (1: whole-sequence kernel, 48 query rows per wave; 0: the tiled kernel)
  *   17 attention forward for S >= 512: 1-D launch that keeps the query blocks of one (n, h) on one XCD (1) / 3-D grid (0)
  *   18 forward-only attention for S >= 512: row sums of P from the bf16 P on the matrix cores (1, default since round 3) / fp32 sums (0)
  *   19 attention forward for S >= 512 with positions = arange: skip key tiles beyond the ALiBi band limit (a bound from the row

@@ -52,3 +52,13 @@ def run():
         assert abs(ls - lr) / lr < tol, (dtype, ls, lr)
         assert ge < (1e-3 if dtype == torch.float32 else 0.15), (dtype, ge)
         print(f"smoke ok [{dtype}]: loss {ls:.4f} vs oracle {lr:.4f}; grad rel err {ge:.2e}")
+    # the step's span masks come from the device sampler: bit-exact against the oracle's restatement of its stream
+    from animal2vec_amd import ops
+    mk, keep_flat, restore, kdev, _ = ops.span_mask(24, 500, mask_prob=1.5, mask_length=2, seed=9)
+    torch.cuda.synchronize()
+    ref_mask = torch.from_numpy(O.span_mask(24, 500, 1.5, 2, 9))
+    K = int(kdev)
+    ik, ir = O.make_maskinfo(ref_mask)
+    assert torch.equal(mk.cpu().bool(), ref_mask) and K == ik.shape[1]
+    assert torch.equal(keep_flat[:24 * K].view(24, K).cpu().long(), ik) and torch.equal(restore.cpu().long(), ir)
+    print(f"smoke ok [span masks]: 24 x 500 frames, K = {K}, bit-exact vs the oracle")
