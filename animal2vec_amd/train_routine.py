@@ -136,6 +136,7 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
             tr.load_optimizer_state(los)
             u0 = int((los.get("extra") or {}).get("update_cursor", 0))
     real = None
+    primed = False
     for u in range(u0, u0 + updates):
         mbs = []
         for j in range(update_freq):
@@ -152,6 +153,9 @@ def animal2vec_audio_main(cfg, optim: Optional[OptimConfig] = None, *, updates: 
                 g = torch.Generator().manual_seed(1000 * u + 10 * j + rank)
                 src = torch.nn.functional.layer_norm(torch.randn(clips_per_micro_batch, clip_samples, generator=g),
                                                      (clip_samples,)).cuda()
+            if not primed:                                  # size the allocator once per run (trainer.prime_memory)
+                tr.prime_memory(src.shape[0], src.shape[1])
+                primed = True
             mbs.append(dict(source=src, noise=None))        # span masks: sampled by the step itself, on the device (masking.py)
         if not mbs:
             continue

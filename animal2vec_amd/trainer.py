@@ -165,6 +165,28 @@ class PretrainTrainer:
                 eng.refresh_teacher_packs()
         self.last = dict(stats=eng.stats, gnorm=gnorm)
 
+    def prime_memory(self, clips: int, samples: int) -> int:
+        """The kept-frame count K of a step is drawn with its masks, and every activation of the student is K rows long per
+        sequence: steps with a K the allocator has not seen yet grow its pools (hipMalloc of tens of GiB: seconds on a fresh
+        process) and fragment them.  One forward / backward of a micro-batch of this shape at a K above what the sampler will
+        draw -- gradients and statistics discarded -- sizes the pools once; later steps find their blocks.  Returns that K."""
+        from .masking import make_maskinfo, seeded_keep_mask
+        cfg, eng = self.cfg, self.engine
+        T = cfg.frame_counts(samples)[-1]
+        N = clips * cfg.clone_batch
+        self.mask_sampler.take(N, T, mask_seed(self.seed + 1, 0, 0, self.rank))      # one draw of this shape: the level of K
+        self.mask_sampler.end_step()
+        k0 = self.mask_sampler.last_k
+        k_cap = min(T - 1, k0 + max(8, k0 // 16))
+        m, keep, restore = make_maskinfo(seeded_keep_mask(N, T, k_cap, 12345, device=self.store.device))
+        src = torch.zeros(clips, samples, dtype=torch.float32, device=self.store.device)
+        src[:, ::7] = 1.0
+        eng.stats.zero_()
+        eng.forward_backward(src, m, keep, restore, (cfg.audio.mask_noise_std, 1), dropout_seed=1 if self.dropout else None)
+        self.store.grad.zero_()
+        eng.stats.zero_()
+        return k_cap
+
     def _step_masks(self, micro_batches):
         """(mask_u8, ids_keep, ids_restore) per micro-batch that brings no mask of its own: taken from the device sampler
         (requested during the previous step -- same shapes assumed, else drawn now), and the next step's requested."""

@@ -518,6 +518,9 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # untimed, before the warm-up: size the allocator's pools at a kept-frame count above what the sampler draws (K varies from step
+    # to step; an unseen larger K costs a multi-second hipMalloc on a fresh process -- trainer.prime_memory)
+    k_primed = tr.prime_memory(args.micro_batch, L) if args.masks == "sampled" else None
     if os.environ.get("A2V_BENCH_STEP_TIMES") == "1":      # diagnosis only: wall time of every step, synchronised (not a measurement)
         for i in range(args.warmup + args.steps + 4):
             torch.cuda.synchronize()
@@ -612,7 +615,7 @@ def main():
                                  "memory); the reference samples them on the host in every forward (base.py:401-413)"
                                  % (cfg.audio.mask_prob, cfg.audio.mask_length)) if args.masks == "sampled" else
                                 "seeded keep-masks / gather ids precomputed once per micro-batch OUTSIDE the timed loop (A/B form)",
-                       "kept_frames_mean": round(k_mean, 2),
+                       "kept_frames_mean": round(k_mean, 2), "allocator_primed_at_kept_frames": k_primed,
                        "global_batch_note": "strong scaling at a fixed global batch; 128 clips ~ the reference recipe's update "
                                             "(4 GPUs x 5 clips x update_freq 5 ~ 102 clips, a2v_large_pretrain_best.yaml:34-36,45-47,62)",
                        "observed_world_size": dist.get_world_size() if use_dist else 1},
