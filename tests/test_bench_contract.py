@@ -1,4 +1,4 @@
-"""CPU: the committed default bench line (profiles/r02_bench_default.json, written by `python bench.py` on the GPU box)
+"""CPU: the committed default bench line (the newest profiles/rNN_bench_default.json, written by `python bench.py` on the GPU box)
 carries every field of the driver's contract, with consistent values; bench.py spawns its own ranks."""
 import json
 import os
@@ -6,8 +6,13 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _newest_bench_line():
+    import glob
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_bench_default.json")))[-1]
+
+
 def test_default_bench_line_contract():
-    with open(os.path.join(ROOT, "profiles", "r02_bench_default.json")) as f:
+    with open(_newest_bench_line()) as f:
         j = json.load(f)
     with open(os.path.join(ROOT, "BASELINE.json")) as f:
         base = json.load(f)
@@ -35,6 +40,11 @@ def test_default_bench_line_contract():
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and len(c["legs"]) >= 1
     assert "median" in c["sample"] and "warm-up" in c["sample"]
     assert j["value"] / c["value"] > 10          # the north-star's >= 10x the host-CPU path on one GPU
+    if "r03" <= os.path.basename(_newest_bench_line())[:3]:
+        # round 3: masks sampled inside the timed step, the 1e-3 mode's rate beside the headline
+        assert "INSIDE every timed step" in j["config"]["masks"] and 120 < j["config"]["kept_frames_mean"] < 170
+        pm = j["parity_mode"]
+        assert pm["value"] > 0 and pm["unit"] == "audio-s/s" and "1e-3" in pm["tolerance"] and pm["value"] > pm["f32_mfma_mode"]["value"]
 
 
 def _run_bench(*argv, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
