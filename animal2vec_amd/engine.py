@@ -34,6 +34,7 @@ class Engine:
         matrix cores over split operands (ops.split_bf16, include/a2v.h: A2V_BF16X3); everything else is the fp32 mode."""
         self.cfg, self.store, self.dtype = cfg, store, dtype
         self.x3 = bool(x3)
+        self.k_cap = {}          # (sequences, frames) -> kept-frame capacity of the student's allocations (ops.set_row_cap)
         self.sp = Packs(store, dtype, teacher=False, need_grad=True, x3=self.x3)
         self.tp = Packs(store, dtype, teacher=True, need_grad=False, x3=self.x3)
         self.sp.refresh()
@@ -201,7 +202,7 @@ class Engine:
         x1, m1, r1 = ops.layernorm_fwd(s1, params[prefix + "norm1.weight"], params[prefix + "norm1.bias"], eps,
                                        save_stats=save is not None)
         hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
-        hpre = torch.empty(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
+        hpre = ops._E(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
         # (dact: what is kept for the backward is gelu'(fc1 out), formed with gelu in one evaluation -- not the pre-activation)
         gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre,
                           drop=d_act1, dact=_DACT)
@@ -216,7 +217,7 @@ class Engine:
                 x2o, m2, r2 = ops.layernorm_fwd(s2, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
                                                 save_stats=save is not None)
             else:
-                s2 = torch.empty_like(t) if save is not None else None
+                s2 = ops._EL(t) if save is not None else None
                 x2o, m2, r2 = ops.layernorm_fwd(t, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
                                                 res=x1, save_stats=save is not None, sum_out=s2)
         else:
@@ -590,9 +591,11 @@ class Engine:
         a = cfg.audio
         dbg = {}
         ops.X3_WGRAD = self.x3
+        N, K = ids_keep.shape
+        # student activations at the capacity K_cap this shape was primed for (trainer.prime_memory), whatever K the masks drew
+        ops.set_row_cap(N, K, self.k_cap.get((N, mask_u8.shape[1])))
         feats = self.frontend_fwd(source, save=save)                           # (B,T,D)
         B, T, _ = feats.shape
-        N, K = ids_keep.shape
         asc = p[P + "alibi_scale"].view(-1)
         # ---- teacher targets from the student's local features (data2vec2.py:811-818): no gradient, independent of the
         # student until the loss -> on a side stream, so its kernels fill the CUs the student's kernels leave idle
@@ -647,9 +650,11 @@ class Engine:
         if keep_debug:
             dbg.update(local_features=feats, targets=y, x_pos=x_pos, decoder_in=dec_in, decoder_out=dec_out,
                        loss_rows=loss_rows)
+        if not save:
+            ops.set_row_cap(0, 0, None)
         if save:
             self.sv["ctx"] = dict(dx=dx, mask_u8=mask_u8, ids_keep=ids_keep, ids_restore=ids_restore, T=T, d_pre=d_pre,
-                                  d_dec=d_dec, rows=rows, d_in=d_in)
+                                  d_dec=d_dec, rows=rows, d_in=d_in, row_cap=(N, K, self.k_cap.get((N, T))))
         return dbg
 
     def backward(self, gscale: float = 1.0):
@@ -660,6 +665,7 @@ class Engine:
         a = cfg.audio
         ops.X3_WGRAD = self.x3
         c = self.sv.pop("ctx")
+        ops.set_row_cap(*c["row_cap"])
         dx, mask_u8, ids_keep, ids_restore, T = c["dx"], c["mask_u8"], c["ids_keep"], c["ids_restore"], c["T"]
         if gscale != 1.0:
             dx.mul_(gscale)
@@ -681,6 +687,7 @@ class Engine:
         dxk = self.posconv_bwd(dtok, mask_u8, cb, c["rows"], ids_restore, T)   # (N,K,D): pos-conv path + dtok, kept rows
         self._ready("posconv")
         dfeat = ops.clone_reduce(None, dxk, ids_restore, cb)                   # (B,T,D)
+        ops.set_row_cap(0, 0, None)
         self.frontend_bwd(dfeat)
         self.sv.clear()
 

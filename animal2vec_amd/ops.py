@@ -41,6 +41,38 @@ def per16(t: torch.Tensor) -> int:
     return 16 // t.element_size()
 
 
+# ---- allocation at capacity.  The student's activations are (sequences x kept frames K) rows long, and K is drawn with the masks:
+# with exact-size allocations every step whose K exceeds all earlier ones needs a whole new generation of blocks from the caching
+# allocator while the old, slightly smaller ones stay cached -- 169 -> 215 -> 236 GiB reserved over ten 64-clip steps (measured), each
+# growth a hipMalloc of tens of GiB inside a step.  Between set_row_cap(N, K, K_cap) and the next call, every tensor this module
+# allocates that is K-proportional by SHAPE (first dimension N*K, leading (N, K), or last dimension K) gets the storage it would need at
+# K_cap and is returned as a view of its first elements: allocation sizes no longer depend on the draw.
+_ROWCAP = None
+
+
+def set_row_cap(N, K, K_cap):
+    global _ROWCAP
+    _ROWCAP = (N * K, N, K, K_cap) if (K_cap and 0 < K <= K_cap) else None
+
+
+def _E(*shape, dtype, device):
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    rc = _ROWCAP
+    if rc is not None and shape:
+        rows, N, K, Kc = rc
+        n = 1
+        for d in shape:
+            n *= d
+        if n and n % rows == 0 and (shape[0] == rows or (len(shape) >= 2 and shape[0] == N and shape[1] == K) or shape[-1] == K):
+            return torch.empty(n // K * Kc, dtype=dtype, device=device)[:n].view(shape)
+    return torch.empty(shape, dtype=dtype, device=device)
+
+
+def _EL(x):
+    return _E(tuple(x.shape), dtype=x.dtype, device=x.device)
+
+
 def _drop(drop):
     """(p, seed) or None -> C arguments"""
     if drop is None or drop[0] <= 0:
@@ -98,7 +130,7 @@ def split_bf16(x, mode, out=None, ldo=0):
     M, K = x.shape
     assert x.dtype == torch.float32 and x.stride(1) == 1
     if out is None:
-        out = torch.empty((2 * M, K) if mode == 2 else (M, 3 * K), dtype=torch.bfloat16, device=x.device)
+        out = _E((2 * M, K) if mode == 2 else (M, 3 * K), dtype=torch.bfloat16, device=x.device)
     check(_L().a2v_split_bf16(ptr(x), ptr(out), M, K, x.stride(0), ldo, mode, stream()), "a2v_split_bf16")
     return out
 
@@ -152,7 +184,7 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
     N = w.shape[0]
     assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
     if out is None:
-        out = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        out = _E(M, N, dtype=x.dtype, device=x.device)
     r = gelu_bwd_aux if gelu_bwd_aux is not None else res
     img = _x3_image(w, M) if x.dtype == torch.float32 else None
     if img is not None:
@@ -178,7 +210,7 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
     N = n_out // G
     M = B * T_out if rowidx is None else rowidx.numel()       # rowidx: only these rows (flat b*T_out + t), compact output
     if out is None:
-        out = torch.empty((B, T_out, n_out) if rowidx is None else (M, n_out), dtype=x.dtype, device=x.device)
+        out = _E((B, T_out, n_out) if rowidx is None else (M, n_out), dtype=x.dtype, device=x.device)
     img = _x3_conv_image(w_packed, k, cv) if x.dtype == torch.float32 else None
     if img is not None and x.is_contiguous() and Cp == G * cv:
         # bf16x3: implicit im2col of the split activation image -- 3 cv channels per group [hi | lo | hi] against taps [hi | hi | lo]
@@ -287,8 +319,8 @@ def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None)
     sum_j P_ij |pos_i - pos_j| of every row (what attention_bwd centres the ALiBi distance on; include/a2v.h)"""
     N, S, W = qkv.shape
     HD = W // (3 * H)
-    out = torch.empty(N, S, H * HD, dtype=qkv.dtype, device=qkv.device)
-    lse = torch.empty(2, N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
+    out = _E(N, S, H * HD, dtype=qkv.dtype, device=qkv.device)
+    lse = _E(2, N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
     rc = _L().a2v_attention_fwd(dt(qkv), ptr(qkv), ptr(out), ptr(lse), ptr(lse[1]) if need_lse else None, ptr(pos), ptr(slopes),
                                 ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_fwd")
@@ -301,11 +333,11 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, dro
     over dqkv."""
     N, S, W = qkv.shape
     HD = W // (3 * H)
-    dqkv = torch.empty_like(qkv)
+    dqkv = _EL(qkv)
     direct = bool(_L().a2v_attention_bwd_direct_dq(dt(qkv), S, HD))
     fused = bias_grad is not None and bool(_L().a2v_attention_bwd_fused_bias(dt(qkv), S, HD))
     dq32 = None if direct else torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
-    delta = torch.empty(N, H, S, dtype=torch.float32, device=qkv.device)
+    delta = _E(N, H, S, dtype=torch.float32, device=qkv.device)
     md = lse[1] if lse.dim() == 4 else None           # (a bare (N,H,S) lse: the uncentred arithmetic)
     rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(md), ptr(delta), ptr(dqkv), ptr(dq32),
                                 ptr(dalibi), ptr(bias_grad) if fused else None, ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
@@ -325,9 +357,9 @@ def layernorm_fwd(x, gamma, beta, eps, *, res=None, act=0, save_stats=True, out=
     """x (..., C) contiguous rows.  Returns y, mean, rstd."""
     C_ = x.shape[-1]
     M = x.numel() // C_
-    y = out if out is not None else torch.empty_like(x)
-    mean = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
-    rstd = torch.empty(M, dtype=torch.float32, device=x.device) if save_stats else None
+    y = out if out is not None else _EL(x)
+    mean = _E(M, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = _E(M, dtype=torch.float32, device=x.device) if save_stats else None
     rc = _L().a2v_layernorm_fwd(dt(x), ptr(x), ptr(res), ptr(gamma), ptr(beta), ptr(y), ptr(sum_out), ptr(mean),
                                 ptr(rstd), ptr(post), M, C_, C_, C_, eps, act, *(_drop(drop)), stream())
     check(rc, "a2v_layernorm_fwd")
@@ -339,9 +371,9 @@ def layernorm_bwd(dy, x, gamma, beta, mean, rstd, *, act=0, dgamma=None, dbeta=N
     """drop_mode 1: mask incoming dy (dropout followed this LN); drop_mode 2: also return dropout(dx) (second result)."""
     C_ = x.shape[-1]
     M = x.numel() // C_
-    dx = out if out is not None else torch.empty_like(x)
+    dx = out if out is not None else _EL(x)
     mode = drop_mode if (drop is not None and drop[0] > 0) else 0
-    dx_drop = torch.empty_like(x) if mode == 2 else None
+    dx_drop = _EL(x) if mode == 2 else None
     rc = _L().a2v_layernorm_bwd(dt(x), ptr(dy), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(dx), ptr(dres),
                                 ptr(dgamma), ptr(dbeta), ptr(dxsum), M, C_, C_, C_, act, *(_drop(drop)), mode, ptr(dx_drop),
                                 stream())
@@ -357,9 +389,9 @@ def instnorm_targets(layers: Sequence[torch.Tensor], eps=1e-5):
     B, T, D = layers[0].shape
     dev = layers[0].device
     arr = (C.c_void_p * L)(*[ptr(t) for t in layers])
-    mean = torch.empty(L * B * D, dtype=torch.float32, device=dev)
-    rstd = torch.empty(L * B * D, dtype=torch.float32, device=dev)
-    y = torch.empty(B, T, D, dtype=torch.float32, device=dev)
+    mean = _E(L * B * D, dtype=torch.float32, device=dev)
+    rstd = _E(L * B * D, dtype=torch.float32, device=dev)
+    y = _E(B, T, D, dtype=torch.float32, device=dev)
     rc = _L().a2v_instnorm_targets(dt(layers[0]), arr, L, ptr(mean), ptr(rstd), ptr(y), B, T, D, eps, stream())
     check(rc, "a2v_instnorm_targets")
     return y
@@ -369,7 +401,7 @@ def mean_layers(layers: Sequence[torch.Tensor], scale=None):
     """scale * sum of same-shaped tensors (default 1/L: the mean)."""
     L = len(layers)
     arr = (C.c_void_p * L)(*[ptr(t) for t in layers])
-    out = torch.empty_like(layers[0])
+    out = _EL(layers[0])
     rc = _L().a2v_mean_layers(dt(layers[0]), arr, L, ptr(out), out.numel(), 1.0 / L if scale is None else scale, stream())
     check(rc, "a2v_mean_layers")
     return out
@@ -381,7 +413,7 @@ def focal_loss(logits2d, targets2d, loss_sum, *, alpha=0.25, gamma=2.0, gscale=1
     M, ld = logits2d.shape
     C_ = targets2d.shape[1]
     assert targets2d.dtype == torch.float32 and targets2d.shape[0] == M and loss_sum.dtype == torch.float64
-    dl = torch.empty_like(logits2d) if want_grad else None
+    dl = _EL(logits2d) if want_grad else None
     rc = _L().a2v_focal_loss(dt(logits2d), ptr(logits2d), ptr(targets2d), ptr(dl), ptr(loss_sum), M, C_, ld, alpha, gamma,
                              gscale, stream())
     check(rc, "a2v_focal_loss")
@@ -399,7 +431,7 @@ def colsum(x2d, out):
 #                                         sinc front end
 # ----------------------------------------------------------------------------------------------
 def sinc_filters_fwd(low_hz, band_hz, n_, window, *, C_, Cp, k, min_low_hz, min_band_hz, sample_rate):
-    filt = torch.empty(Cp, k, dtype=torch.float32, device=low_hz.device)
+    filt = _E(Cp, k, dtype=torch.float32, device=low_hz.device)
     rc = _L().a2v_sinc_filters_fwd(ptr(low_hz), ptr(band_hz), ptr(n_), ptr(window), ptr(filt), C_, Cp, k,
                                    float(min_low_hz), float(min_band_hz), float(sample_rate), stream())
     check(rc, "a2v_sinc_filters_fwd")
@@ -426,9 +458,9 @@ def sinc_out_channels(C_, k):
 
 def sinc_fused_fwd(x, filt, ln_w, ln_b, ps_a, ps_b, *, C_, k, dtype, eps=1e-5, save_stats=True):
     B, L = x.shape
-    y = torch.empty(B, L, sinc_out_channels(C_, k), dtype=dtype, device=x.device)
-    mean = torch.empty(B, L, dtype=torch.float32, device=x.device) if save_stats else None
-    rstd = torch.empty(B, L, dtype=torch.float32, device=x.device) if save_stats else None
+    y = _E(B, L, sinc_out_channels(C_, k), dtype=dtype, device=x.device)
+    mean = _E(B, L, dtype=torch.float32, device=x.device) if save_stats else None
+    rstd = _E(B, L, dtype=torch.float32, device=x.device) if save_stats else None
     rc = _L().a2v_sinc_fused_fwd(dt(y), ptr(x), ptr(filt), ptr(ln_w), ptr(ln_b), ptr(ps_a), ptr(ps_b), ptr(y), ptr(mean),
                                  ptr(rstd), B, L, C_, k, eps, stream())
     check(rc, "a2v_sinc_fused_fwd")
@@ -438,7 +470,7 @@ def sinc_fused_fwd(x, filt, ln_w, ln_b, ps_a, ps_b, *, C_, k, dtype, eps=1e-5, s
 def sinc_fused_bwd(x, filt, ln_w, ln_b, ps_a, ps_b, dy, mean, rstd, dfilt, dpar, *, C_, k):
     B, L = x.shape
     cp = sinc_out_channels(C_, k)
-    scratch = torch.empty(B, L, cp, dtype=torch.float32, device=x.device) if cp != 128 else None     # blocked kernels: dconv
+    scratch = _E(B, L, cp, dtype=torch.float32, device=x.device) if cp != 128 else None     # blocked kernels: dconv
     rc = _L().a2v_sinc_fused_bwd(dt(dy), ptr(x), ptr(filt), ptr(ln_w), ptr(ln_b), ptr(ps_a), ptr(ps_b), ptr(dy), ptr(mean),
                                  ptr(rstd), ptr(dfilt), ptr(dpar), ptr(scratch), B, L, C_, k, stream())
     check(rc, "a2v_sinc_fused_bwd")
@@ -454,9 +486,9 @@ def span_mask(N, T, *, mask_prob, mask_length, seed, min_masks=1, mask_dropout=0
     the counts scratch) from an earlier call, to be overwritten."""
     if bufs is None:
         dev = torch.device(device)
-        bufs = (torch.empty(N, T, dtype=torch.uint8, device=dev), torch.empty(N * T, dtype=torch.int32, device=dev),
-                torch.empty(N, T, dtype=torch.int32, device=dev), torch.empty(1, dtype=torch.int32, device=dev),
-                torch.empty(N, dtype=torch.int32, device=dev))
+        bufs = (_E(N, T, dtype=torch.uint8, device=dev), _E(N * T, dtype=torch.int32, device=dev),
+                _E(N, T, dtype=torch.int32, device=dev), _E(1, dtype=torch.int32, device=dev),
+                _E(N, dtype=torch.int32, device=dev))
     mask, keep, restore, kdev, counts = bufs
     rc = _L().a2v_span_mask(ptr(mask), ptr(counts), ptr(keep), ptr(restore), ptr(kdev), N, T, float(mask_prob), int(mask_length),
                             int(min_masks), float(mask_dropout), int(seed) & 0xFFFFFFFFFFFFFFFF, stream())
@@ -468,8 +500,8 @@ def maskinfo(mask_u8, K, rows_bad=None):
     """make_maskinfo (base.py:427-455) of a given (N,T) uint8 mask with K kept frames per row -> ids_keep (N,K) ascending,
     ids_restore (N,T), both int32."""
     N, T = mask_u8.shape
-    keep = torch.empty(N, K, dtype=torch.int32, device=mask_u8.device)
-    restore = torch.empty(N, T, dtype=torch.int32, device=mask_u8.device)
+    keep = _E(N, K, dtype=torch.int32, device=mask_u8.device)
+    restore = _E(N, T, dtype=torch.int32, device=mask_u8.device)
     rc = _L().a2v_maskinfo(ptr(mask_u8), ptr(keep), ptr(restore), ptr(rows_bad), N, T, int(K), stream())
     check(rc, "a2v_maskinfo")
     return keep, restore
@@ -479,7 +511,7 @@ def gather_tokens(a, ids, *, cb=1, b=None, drop=None):
     """out[n,k,:] = a[n//cb, ids[n,k], :] (+ b[n, ids[n,k], :]);  a (Ba,Ta,D), ids (N,K) int32"""
     N, K = ids.shape
     Ta, D = a.shape[1], a.shape[2]
-    out = torch.empty(N, K, D, dtype=a.dtype, device=a.device)
+    out = _E(N, K, D, dtype=a.dtype, device=a.device)
     rc = _L().a2v_gather_tokens(dt(a), ptr(a), ptr(b), ptr(ids), ptr(out), N, K, D, Ta, cb, *(_drop(drop)), stream())
     check(rc, "a2v_gather_tokens")
     return out
@@ -487,7 +519,7 @@ def gather_tokens(a, ids, *, cb=1, b=None, drop=None):
 
 def scatter_tokens(dtok, restore, T):
     N, K, D = dtok.shape
-    out = torch.empty(N, T, D, dtype=dtok.dtype, device=dtok.device)
+    out = _E(N, T, D, dtype=dtok.dtype, device=dtok.device)
     rc = _L().a2v_scatter_tokens(dt(dtok), ptr(dtok), ptr(restore), ptr(out), N, K, D, T, stream())
     check(rc, "a2v_scatter_tokens")
     return out
@@ -498,7 +530,7 @@ def clone_reduce(dxm, dtok, restore, cb):
     only the dtok term (it then already carries the pos-conv input gradient of the kept rows)."""
     N, K, D = dtok.shape
     T = restore.shape[1]
-    out = torch.empty(N // cb, T, D, dtype=dtok.dtype, device=dtok.device)
+    out = _E(N // cb, T, D, dtype=dtok.dtype, device=dtok.device)
     rc = _L().a2v_clone_reduce(dt(dtok), ptr(dxm), ptr(dtok), ptr(restore), ptr(out), N // cb, cb, K, D, T, stream())
     check(rc, "a2v_clone_reduce")
     return out
@@ -508,7 +540,7 @@ def decoder_input(x, noise, restore, drop=None):
     """noise: (N, T-K, D) fp32 rows, or a (std, seed) pair -- then the masked positions draw N(0, std) inside the kernel."""
     N, K, D = x.shape
     T = restore.shape[1]
-    out = torch.empty(N, T, D, dtype=x.dtype, device=x.device)
+    out = _E(N, T, D, dtype=x.dtype, device=x.device)
     if isinstance(noise, tuple):
         rc = _L().a2v_decoder_input_rng(dt(x), ptr(x), ptr(restore), ptr(out), N, K, D, T, float(noise[0]),
                                         int(noise[1]) & 0xFFFFFFFF, *(_drop(drop)), stream())
@@ -522,7 +554,7 @@ def decoder_input(x, noise, restore, drop=None):
 def d2v_loss(x, y, mask_u8, cb, *, stats, want_dx=True, gscale=1.0, loss_rows=None):
     """x (N,T,D), y (B,T,D) fp32, mask (N,T) uint8.  stats: double[4D+2] accumulated."""
     N, T, D = x.shape
-    dx = torch.empty_like(x) if want_dx else None
+    dx = _EL(x) if want_dx else None
     rc = _L().a2v_d2v_loss(dt(x), ptr(x), ptr(y), ptr(mask_u8), ptr(dx), ptr(loss_rows), ptr(stats), N, T, D, cb,
                            D ** -0.5, gscale, stream())
     check(rc, "a2v_d2v_loss")
@@ -553,7 +585,7 @@ class Mixup:
     def gain_db(self, x):
         B, L = x.shape
         nframes = (L - self.n_fft) // self.hop + 1
-        g = torch.empty(B, nframes, dtype=torch.float32, device=x.device)
+        g = _E(B, nframes, dtype=torch.float32, device=x.device)
         rc = _L().a2v_mixup_gain(ptr(x), ptr(self.window), ptr(self.aw), ptr(g), B, L, self.n_fft, self.hop, self.floor,
                                  stream())
         check(rc, "a2v_mixup_gain")
@@ -563,7 +595,7 @@ class Mixup:
         """x (B,L) fp32, perm (B) int32 device tensor, r in (0,1] -> mixed (B,L); mix_mask (B) uint8: only those clips
         are mixed (mixup_prob < 1), None = all"""
         g = self.gain_db(x)
-        out = torch.empty_like(x)
+        out = _EL(x)
         assert mix_mask is None or (mix_mask.dtype == torch.uint8 and mix_mask.numel() == x.shape[0])
         rc = _L().a2v_mixup_apply(ptr(x), ptr(perm), ptr(g), ptr(out), x.shape[0], x.shape[1], g.shape[1], float(r),
                                   ptr(mix_mask), stream())
@@ -573,7 +605,7 @@ class Mixup:
 
 def dropout_mask(n, p, seed, device="cuda"):
     """keep-mask (uint8) of linear indices [0,n) for a dropout site -- what every kernel regenerates."""
-    keep = torch.empty(n, dtype=torch.uint8, device=device)
+    keep = _E(n, dtype=torch.uint8, device=device)
     rc = _L().a2v_dropout_mask(ptr(keep), n, float(p), int(seed) & 0xFFFFFFFF, stream())
     check(rc, "a2v_dropout_mask")
     return keep
@@ -581,7 +613,7 @@ def dropout_mask(n, p, seed, device="cuda"):
 
 def dropout_mask2d(rows, cols, p, seed, device="cuda"):
     """keep-mask (rows, cols) uint8 of the attention-probability dropout site: rows = (n*H + h)*S + q, cols = key."""
-    keep = torch.empty(rows, cols, dtype=torch.uint8, device=device)
+    keep = _E(rows, cols, dtype=torch.uint8, device=device)
     rc = _L().a2v_dropout_mask2d(ptr(keep), rows, cols, float(p), int(seed) & 0xFFFFFFFF, stream())
     check(rc, "a2v_dropout_mask2d")
     return keep
@@ -629,7 +661,7 @@ def unpack_wgrad(packed, gw, *, GN, Cg, k, Cgp):
 
 def col2im(dA, *, B, T_in, T_out, C_, k, s, p, out=None):
     """out (B,T_in,>=C_) may be wider than C_ (extra channels untouched)."""
-    dX = out if out is not None else torch.empty(B, T_in, C_, dtype=dA.dtype, device=dA.device)
+    dX = out if out is not None else _E(B, T_in, C_, dtype=dA.dtype, device=dA.device)
     rc = _L().a2v_col2im(dt(dA), ptr(dA), ptr(dX), B, T_in, T_out, C_, k, s, p, dA.stride(-2), dX.stride(-2), stream())
     check(rc, "a2v_col2im")
     return dX
@@ -646,7 +678,7 @@ def cast2d(src, dst):
 def add_drop(a, b, c=None, *, drop=None, out=None):
     """out = a + dropout(b + c); a, c optional; drop = (p, seed) or None."""
     assert b.is_contiguous() and (a is None or a.is_contiguous()) and (c is None or c.is_contiguous())
-    out = torch.empty_like(b) if out is None else out
+    out = _EL(b) if out is None else out
     dp, ds = (drop if drop is not None else (0.0, 0))
     rc = _L().a2v_add_drop(dt(b), ptr(a), ptr(b), ptr(c), ptr(out), b.numel(), float(dp), int(ds) & 0xFFFFFFFF, stream())
     check(rc, "a2v_add_drop")
@@ -658,7 +690,7 @@ def mask_frames(x, mask_t=None, mask_c=None, *, noise_std=0.0, seed=0, backward=
     B, T, D = x.shape
     assert x.is_contiguous() and (mask_t is None or (mask_t.dtype == torch.uint8 and mask_t.is_contiguous()))
     assert mask_c is None or (mask_c.dtype == torch.uint8 and mask_c.is_contiguous() and mask_c.shape == (B, D))
-    out = torch.empty_like(x) if out is None else out
+    out = _EL(x) if out is None else out
     rc = _L().a2v_mask_frames(dt(x), ptr(x), ptr(mask_t), ptr(mask_c), ptr(out), B, T, D, float(noise_std),
                               int(seed) & 0xFFFFFFFF, 1 if backward else 0, stream())
     check(rc, "a2v_mask_frames")
