@@ -1671,9 +1671,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
 #define AB48_ROWS 160             // S <= 160: ten query groups (wave w owns w, w + 3, w + 6, w + 9), up to four 48-key blocks
 #define AB48_LDS (2 * AB48_QROWS * 128 + 64 * 128 + AB48_ROWS * 128 + 5 * AB48_ROWS * 4 + 3 * 64 * 4)
 
-template <bool DROP>
-__global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, const bf16* __restrict__ o_fwd) {
-  constexpr int HD = 64, ND = 4;
+// NW waves: a key block is 16 NW keys (48 or 64).  The key blocks of a sequence run one after the other, so what counts is their
+// number: S = 152 (what the sampler draws at 768 rows) is 4 blocks of 48 but 3 of 64 -- the launcher picks NW = 4 where that saves a
+// block (S <= 64, 97 .. 128, 145 .. 160) and NW = 3 otherwise.
+template <bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, const bf16* __restrict__ o_fwd) {
+  constexpr int HD = 64, ND = 4, NT = 64 * NW, KB = 16 * NW, NTQ = (AB48_ROWS / 16 + NW - 1) / NW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sQ = smem;                                   // [160][64] dual-use image
   char* const sDO = sQ + AB48_QROWS * 128;
@@ -1703,13 +1706,13 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
   const float scale2 = a.scale * LOG2E;
   const int nsub = (S + 15) >> 4;                  // 16-row query groups (<= 9)
   const int npair = (nsub + 1) >> 1;
-  const int nkb = (S + 47) / 48;
+  const int nkb = (S + KB - 1) / KB;
 
   bf16x8 kf_n[2], vf_n[2], kt_n[2];
   int praw = 0;
 #define AB48_FETCH(kb_)                                                                                         \
   {                                                                                                             \
-    const int kvc_ = min((kb_) * 48 + wid * 16 + fr, S - 1);                                                    \
+    const int kvc_ = min((kb_) * KB + wid * 16 + fr, S - 1);                                                    \
     const bf16* krow_ = qkv + (long long)kvc_ * rowstride + (long long)H * HD + g * 8;                          \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                          \
       kf_n[ks] = *(const bf16x8*)(krow_ + ks * 32);                                                             \
@@ -1717,16 +1720,16 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     }                                                                                                           \
     if (a.pos) praw = a.pos[(long long)n * S + kvc_];                                                           \
     _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
-      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;                                                      \
-      kt_n[u] = *(const bf16x8*)(qkv + (long long)min((kb_) * 48 + r, S - 1) * rowstride + (long long)H * HD + ch * 8); \
+      const int c = tid + NT * u, r = c >> 3, ch = c & 7;                                                       \
+      kt_n[u] = *(const bf16x8*)(qkv + (long long)min((kb_) * KB + r, S - 1) * rowstride + (long long)H * HD + ch * 8); \
     }                                                                                                           \
   }
   {
-    constexpr int NQ = (AB48_QROWS * 8 + 191) / 192;       // 7 chunks of Q and of dO per thread
+    constexpr int NQ = (AB48_QROWS * 8 + NT - 1) / NT;     // 7 (5) chunks of Q and of dO per thread
     uint4 qz[NQ], dz[NQ], oz[8];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      const int c = tid + NT * u, r = c >> 3, ch = c & 7;
       qz[u] = make_uint4(0u, 0u, 0u, 0u);
       dz[u] = qz[u];
       if (r < S) {
@@ -1744,14 +1747,14 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
       if (a.mdist) md_r = a.mdist[((long long)n * H + h) * S + tid];
     }
     AB48_FETCH(0)
-    if (a.bias_sum) sBias[tid] = 0.f;               // 192 threads = 3 x 64 sums
-    if (tid < 128) *(uint4*)(sKt + 48 * 128 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);         // key rows 48..63: zero for good
+    if (a.bias_sum && tid < 192) sBias[tid] = 0.f;  // 3 x 64 sums
+    if (NW == 3 && tid < 128) *(uint4*)(sKt + 48 * 128 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);         // key rows 48..63: zero for good
 #pragma unroll
-    for (int u = 0; u < (AB48_ROWS * 8 + 191) / 192; ++u)
-      if (tid + 192 * u < AB48_ROWS * 8) *(uint4*)(sDS + (tid + 192 * u) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int u = 0; u < (AB48_ROWS * 8 + NT - 1) / NT; ++u)
+      if (tid + NT * u < AB48_ROWS * 8) *(uint4*)(sDS + (tid + NT * u) * 16) = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
-      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      const int c = tid + NT * u, r = c >> 3, ch = c & 7;
       if (c < AB48_QROWS * 8) {
         *(uint4*)(sQ + dual_off(r, ch)) = qz[u];
         *(uint4*)(sDO + dual_off(r, ch)) = dz[u];
@@ -1775,9 +1778,9 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     }
   }
 
-  f32x4 dq[4][ND];
+  f32x4 dq[NTQ][ND];
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NTQ; ++t)
 #pragma unroll
     for (int i = 0; i < ND; ++i) dq[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dal = 0.f;
@@ -1790,7 +1793,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
 
 #pragma unroll 1
   for (int kb = 0; kb < nkb; ++kb) {
-    const int kv = kb * 48 + wid * 16 + fr;        // this lane's key column
+    const int kv = kb * KB + wid * 16 + fr;        // this lane's key column
     const bool kv_ok = kv < S;
     const int kvc = kv_ok ? kv : S - 1;
     const float pos_kv = a.pos ? (float)praw : (float)kvc;
@@ -1800,7 +1803,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     // (the barrier that ended the previous key block's phase B -- or the prologue's -- protects sKt and sDS)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      const int c = tid + 192 * u, r = c >> 3, ch = c & 7;
+      const int c = tid + NT * u, r = c >> 3, ch = c & 7;
       *(bf16x8*)(sKt + trimg_off<HD>(r, ch * 8)) = kt_n[u];
     }
     if (kb + 1 < nkb) AB48_FETCH(kb + 1)           // next key block's operands arrive under this block's math
@@ -1903,15 +1906,15 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     // ---------------- phase B: dQ[q rows of groups wid, wid+3, wid+6][d] += dS K : A = dS rows, B = K (k = kv, col = d)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      if (kb * 48 + 32 * ks >= S) continue;        // no keys in this half (uniform)
+      if (kb * KB + 32 * ks >= S) continue;        // no keys in this half (uniform)
       const int r_lo = 32 * ks + 8 * g + qq, r_hi = r_lo + 4;
       bf16x8 kfr[ND];
 #pragma unroll
       for (int i = 0; i < ND; ++i)
         kfr[i] = tr_frag(sKt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sKt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int qg = wid + 3 * t;
+      for (int t = 0; t < NTQ; ++t) {
+        const int qg = wid + NW * t;
         if (qg >= nsub) continue;                  // uniform
         const int rq = 16 * qg + fr;
         const int ch = ks * 4 + g;
@@ -1925,10 +1928,10 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
 #undef AB48_FETCH
   // ---- dQ into the q slot of dqkv: rows q = 16 (wid + 3t) + 4g + r, col d = 16i + fr
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < NTQ; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int qr = 16 * (wid + 3 * t) + 4 * g + r;
+      const int qr = 16 * (wid + NW * t) + 4 * g + r;
       if (qr < S) {
         bf16* dst = (bf16*)a.dqkv + ((long long)n * S + qr) * rowstride + (long long)h * HD;
 #pragma unroll
@@ -1940,10 +1943,10 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
     for (int i = 0; i < ND; ++i) {
       float sq = 0.f;
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < NTQ; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int qr = 16 * (wid + 3 * t) + 4 * g + r;
+          const int qr = 16 * (wid + NW * t) + 4 * g + r;
           sq += qr < S ? (float)(bf16)(dq[t][i][r] * a.scale) : 0.f;
         }
       sq += __shfl_xor(sq, 16, 64);
@@ -1951,7 +1954,7 @@ __global__ __launch_bounds__(192, 2) void attn_bwd_seq48_kernel(AttnBwdArgs a, c
       if (g == 0) atomicAdd(&sBias[16 * i + fr], sq);
     }
     __syncthreads();
-    atomicAdd(a.bias_sum + (long long)(tid >> 6) * H * HD + (long long)h * HD + (tid & 63), sBias[tid]);
+    if (tid < 192) atomicAdd(a.bias_sum + (long long)(tid >> 6) * H * HD + (long long)h * HD + (tid & 63), sBias[tid]);
   }
   dal = wave_sum(dal);
   dalibi_finish(dal, a.dalibi, h, a.dal_part, slope, asc);
@@ -2267,12 +2270,20 @@ static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delt
     }
     if (a.S <= AB48_ROWS && g_a2v_attn_seq48) {
       const bool dr = a.drop.thresh != 0;
-      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
-      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
+      (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
       const dim3 grid(1, a.H, a.N);
       set_part(grid);
-      if (dr) hipLaunchKernelGGL((attn_bwd_seq48_kernel<true>), grid, dim3(192), AB48_LDS, st, a, (const bf16*)out);
-      else hipLaunchKernelGGL((attn_bwd_seq48_kernel<false>), grid, dim3(192), AB48_LDS, st, a, (const bf16*)out);
+      const bool four = (a.S + 63) / 64 < (a.S + 47) / 48;            // four waves where 64-key blocks save a block
+      if (four) {
+        if (dr) hipLaunchKernelGGL((attn_bwd_seq48_kernel<true, 4>), grid, dim3(256), AB48_LDS, st, a, (const bf16*)out);
+        else hipLaunchKernelGGL((attn_bwd_seq48_kernel<false, 4>), grid, dim3(256), AB48_LDS, st, a, (const bf16*)out);
+      } else {
+        if (dr) hipLaunchKernelGGL((attn_bwd_seq48_kernel<true, 3>), grid, dim3(192), AB48_LDS, st, a, (const bf16*)out);
+        else hipLaunchKernelGGL((attn_bwd_seq48_kernel<false, 3>), grid, dim3(192), AB48_LDS, st, a, (const bf16*)out);
+      }
       fold(grid);
       A2V_CHECK_LAUNCH();
       return A2V_OK;

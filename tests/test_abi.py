@@ -192,7 +192,8 @@ def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):
 
 
 HOT_KERNELS = {
-    "a2v_attn.hip": [r"attn_fwd_bf16_kernelILi64ELb0ELi2ELb0E", r"attn_fwd_seq48_kernel", r"attn_bwd_seq48_kernel"],
+    "a2v_attn.hip": [r"attn_fwd_bf16_kernelILi64ELb0ELi2ELb[01]ELb0E", r"attn_fwd_seq48_kernel", r"attn_bwd_seq48_kernel"],
+    "a2v_mask.hip": [r"span_mask_rows_kernel", r"span_mask_finish_kernel"],
     "a2v_conv_slab.hip": [r"conv_nt_slab2_kernel"],
     "a2v_wgrad_slab.hip": [r"conv_wgrad_slab_kernel"],
     "a2v_conv_dec.hip": [r"conv_dec_kernel"],
