@@ -33,6 +33,8 @@ struct GemmArgs {
   int M, N, K, G;
   int flags;
   Drop drop;                     // F_DROPOUT: applied to (acc + bias [gelu]) before the residual add
+  long long drop_base;           // added to the dropout element index m * ldc + col: a launch on a row range of a larger output
+                                 // (the tail rows the persistent kernel hands to the 128 x 128 kernel) keeps the whole tensor's mask
 };
 
 enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64, F_DACT = 128 };
@@ -119,7 +121,7 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, i
       }
       if (g.flags & F_DROPOUT) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i, v[i]);
+        for (int i = 0; i < 4; ++i) v[i] = drop_apply(g.drop, (unsigned long long)m * g.ldc + ccol + i + (unsigned long long)g.drop_base, v[i]);
       }
       if (g.flags & F_RES) v += Vec4<T>::load(R + (long long)m * g.ldr + ccol);
       if (g.flags & F_GELU_BWD) {

@@ -449,6 +449,7 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
   g.C = C; g.ldc = ldc; g.c_goff = c_goff; g.C2 = C2; g.R = R; g.ldr = ldr;
   g.bias = bias; g.colsum = colsum; g.M = M; g.N = N; g.K = K; g.G = G; g.flags = flags;
   g.drop = make_drop((flags & F_DROPOUT) ? drop_p : 0.f, drop_seed);
+  g.drop_base = 0;
   if ((flags & F_DROPOUT) && !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
   const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
   dim3 grid(tiles, G, 1);
@@ -628,6 +629,7 @@ extern int g_a2v_gemm_variant;
 extern int g_a2v_p8_ih;
 extern int g_a2v_p8_fx;
 extern int g_a2v_conv_strided;
+extern int g_a2v_p8_tail;
 extern int g_a2v_p8_stagger;
 extern int g_a2v_p8_dynamic;
 extern int g_a2v_attn_long;
@@ -649,7 +651,8 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 7) { g_a2v_p8_dynamic = value; return A2V_OK; }  // persistent kernels: dynamic tile hand-out on / off
   if (key == 6) { g_a2v_p8_stagger = value; return A2V_OK; }  // 8-phase kernels: stagger the two wave groups on / off
   if (key == 20) { g_a2v_p8_fx = value; return A2V_OK; }    // 0: no fixed-flavour p8 epilogues
-  if (key == 21) { g_a2v_conv_strided = value; return A2V_OK; }   // dense strided convs on the 8-phase GEMMs on / off
+  if (key == 21) { g_a2v_conv_strided = value; return A2V_OK; }
+  if (key == 22) { g_a2v_p8_tail = value; return A2V_OK; }        // persistent NT kernel: nearly empty last round -> 128 x 128 kernel   // dense strided convs on the 8-phase GEMMs on / off
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off

@@ -758,11 +758,12 @@ int g_a2v_p8_stagger = 2;   // a2v_debug_set(6, v): wave groups half a phase apa
 int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swapped MFMA operands, permuted B rows) on / off
 int g_a2v_p8_fx = 1;      // a2v_debug_set(20, v): 0 = every flavour takes the generic epilogue (A/B)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
-static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32);
+int g_a2v_p8_tail = 1;    // a2v_debug_set(22, v): a nearly empty last round of tiles goes to the 128 x 128 kernel (1) / stays here (0)
+static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bool allow_tail = true);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, false); }
 // bf16 (split) operands, fp32 C / C2 / R (dtype A2V_BF16X3): only the direct-store form exists
 bool a2v_launch_nt_x3_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, true); }
-static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32) {
+static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bool allow_tail) {
   const ConvA& a = g.a;
   const bool plain = a.taps == 1 && a.pad == 0 && a.rowmask == nullptr && a.stride == 1 && a.T_in == a.T_out &&
                      a.Cv == a.Cg;
@@ -820,6 +821,34 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32) {
     if (best < 0 || cost < best) { best = cost; best_ih = ih; }
   }
   const int bm = 128 + 32 * best_ih;
+  // A last round with few tiles leaves most CUs idle for a whole tile time (M = 768 x 151 kept frames, N = 1024: 7.08 rounds of
+  // 256-row tiles -- 12 % of the launch for 1 % of the work).  The rows of that round go to the 128 x 128 LDS-DMA kernel instead: a
+  // quarter of the work per tile, spread over four times as many CUs, issued right behind this launch.
+  if (g_a2v_p8_tail && allow_tail && direct && !out32 && g.G == 1) {
+    const int tiles_n = g.N / 256;
+    const long long nt_all = (long long)cdiv(g.M, bm) * tiles_n;
+    const long long full = nt_all / cus, rem = nt_all % cus;
+    if (full >= 2 && rem > 0 && rem * 4 <= cus) {
+      const long long rows_main = (full * cus / tiles_n) * bm;
+      if (rows_main >= 1024 && rows_main < g.M && g.M - rows_main >= 64 && a.Cg % 64 == 0 && g.K % 64 == 0) {
+        GemmArgs gm = g;
+        gm.M = (int)rows_main;
+        gm.a.T_in = gm.a.T_out = gm.M;
+        GemmArgs gt = g;
+        gt.M = g.M - (int)rows_main;
+        gt.a.T_in = gt.a.T_out = gt.M;
+        gt.a.bstride = 0;
+        gt.a.ptr = (const char*)a.ptr + rows_main * a.pitch * 2;
+        gt.C = (char*)g.C + rows_main * g.ldc * 2;
+        if (g.C2) gt.C2 = (char*)g.C2 + rows_main * g.ldc * 2;
+        if (g.R) gt.R = (const char*)g.R + rows_main * g.ldr * 2;
+        gt.drop_base = g.drop_base + rows_main * g.ldc;
+        const bool ok = p8_launch_impl(gm, stream, false, false);     // (the main part is a whole number of rounds by construction)
+        if (ok && a2v_launch_nt_bf16_fast(gt, stream)) return true;
+        if (ok) return false;                            // cannot happen (eligibility checked above); never leave half a product
+      }
+    }
+  }
   const int ntiles = cdiv(g.M, bm) * (g.N / 256);
   // staggering the wave groups: one group's epilogue (conversions, GELU, stores) runs under the other group's MFMAs.  With the
   // LDS-staged epilogue of round 1 it cost a few per cent at K = 1024; with the direct-store epilogue it pays on every shape

@@ -261,6 +261,7 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *      norms of q and k: weights below e^-32 of the row sum) (1, default) / visit every tile (0)
  *   20 fixed-flavour instantiations of the NT kernel's 256-row tile for the eight hottest epilogue flag sets (1, default) / the generic epilogue (0)
  *   21 dense strided convs of the feature extractor on the 8-phase GEMMs + edge-frame kernels (1, default) / implicit-im2col 128 x 128 kernels (0)
+ *   22 persistent NT kernel: the rows of a nearly empty last round of tiles go to the 128 x 128 kernel (1, default) / stay (0)
  * No launch state goes through here (ABI 5's key 9, the tile-counter set, is gone: the stream argument selects it). */
 int a2v_debug_set(int key, int value);
 

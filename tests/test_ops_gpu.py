@@ -1338,3 +1338,42 @@ def test_conv_bf16x3_matches_fp64(ops, Cin, Cout, k, s, pl, G, T, B):
     gw_un = torch.zeros(Cout, Cg, k, dtype=torch.float32, device="cuda")
     ops.unpack_wgrad(gw, gw_un, GN=Cout, Cg=Cg, k=k, Cgp=cgp)
     assert rel_err(gw_un, wr.grad) < 3e-5
+
+
+def test_linear_tail_round_goes_to_the_small_kernel(ops):
+    """M = 768 x 151 rows, N = 1024: 7.08 rounds of 256-row tiles on 256 CUs.  The launcher gives the 1280 rows of the last,
+    nearly empty round to the 128 x 128 kernel (a2v_debug_set(22)): outputs must be what the unsplit launch writes -- bit for bit
+    on the persistent kernel's rows, to bf16 rounding on the tail rows (another summation order) -- including the dropout mask,
+    which is a function of the element's index in the WHOLE output, and the column sums."""
+    from animal2vec_amd import _lib
+    dtype = torch.bfloat16
+    M, N, K = 768 * 151, 1024, 1024
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn(M, K, generator=g) * 0.5).to(dtype).cuda()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dtype).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    r = torch.randn(M, N, generator=g).to(dtype).cuda()
+    rows_main = 7 * 256 * 256 // 4
+
+    def run():
+        y1 = ops.linear(x, w, b, res=r, drop=(0.1, 1234))
+        cs = torch.zeros(N, device="cuda")
+        y2 = ops.linear(x, w, None, gelu_bwd_aux=r, colsum=cs, dact=True)
+        return y1, y2, cs
+
+    a1, a2, acs = run()
+    _lib.load().a2v_debug_set(22, 0)
+    try:
+        b1, b2, bcs = run()
+    finally:
+        _lib.load().a2v_debug_set(22, 1)
+    assert torch.equal(a1[:rows_main], b1[:rows_main]) and torch.equal(a2[:rows_main], b2[:rows_main])
+    assert rel_err(a1[rows_main:].float(), b1[rows_main:].float()) < 4e-3
+    assert rel_err(a2[rows_main:].float(), b2[rows_main:].float()) < 4e-3
+    assert rel_err(acs, bcs) < 1e-4
+    # same dropout decisions in the tail: dropped elements carry exactly the residual
+    keep = ops.dropout_mask(M * N, 0.1, 1234).view(M, N)[rows_main:]
+    dropped = keep == 0
+    assert torch.equal(a1[rows_main:][dropped], r[rows_main:][dropped])
+    ref = (x[rows_main:].float() @ w.float().t() + b) * keep.float() / 0.9 + r[rows_main:].float()
+    assert rel_err(a1[rows_main:].float(), ref) < 1e-2
