@@ -164,7 +164,12 @@ class Data2VecMultiModel(tnn.Module):
             self._mask_sampler.end_step()
             self._mask_release_pending = False
         self._mask_draws += 1
-        return self._mask_sampler.take(B * self.cfg.clone_batch, T, mask_seed(self.cfg.seed, self._mask_draws, 0, self._rank))
+        N = B * self.cfg.clone_batch
+        out = self._mask_sampler.take(N, T, mask_seed(self.cfg.seed, self._mask_draws, 0, self._rank))
+        if (N, T) not in self.engine.k_cap:                      # allocate the student's tensors at a fixed kept-frame capacity from
+            k0 = self._mask_sampler.last_k                      # the first draw on (trainer.prime_memory explains why)
+            self.engine.k_cap[(N, T)] = min(T - 1, k0 + max(12, k0 // 8))
+        return out
 
     def forward(self, source, target=None, id=None, mode=None, padding_mask=None, mask=True, features_only=False,
                 force_remove_masked=False, remove_extra_tokens=True, precomputed_mask=None, reduce=True, noise=None,
