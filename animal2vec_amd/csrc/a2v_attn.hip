@@ -241,6 +241,170 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16x3 forward (dtype A2V_BF16X3: fp32 q / k / v / out, the parity mode on the bf16 matrix cores).  The kernel above with every
+// product split: x = hi + lo (hi = bf16(x), lo = bf16(x - hi)), S^T = K_hi Q_hi^T + K_lo Q_hi^T + K_hi Q_lo^T and
+// O^T = V_hi^T P_hi^T + V_lo^T P_hi^T + V_hi^T P_lo^T -- three exact bf16 products per tile, fp32 accumulation, 2^-16 relative --
+// 48 v_mfma_f32_16x16x32_bf16 (768 pipe cycles) per 64-key tile and wave against 128 v_mfma_f32_16x16x4_f32 (4096 cycles).
+// K / V tiles are split when they are staged (four bf16 images in LDS), Q when it is loaded, P in registers; softmax is fp32.
+__device__ __forceinline__ void split8(const float* v, bf16x8& h, bf16x8& l) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    h[i] = (bf16)v[i];
+    l[i] = (bf16)(v[i] - (float)h[i]);
+  }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnArgs a) {
+  constexpr int ND = HD / 16, NCH = HD / 8;
+  constexpr int TILE_BYTES = 64 * HD * 2;
+  __shared__ __attribute__((aligned(16))) char sKh[TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char sKl[TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char sVh[TILE_BYTES];
+  __shared__ __attribute__((aligned(16))) char sVl[TILE_BYTES];
+  __shared__ float sPos[64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int q0 = blockIdx.x * 64, h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const float* qkv = (const float*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  const float coef = -a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f);
+
+  const int q = q0 + wid * 16 + fr;
+  const int qc = q < S ? q : S - 1;
+  const float pos_q = a.pos ? (float)a.pos[(long long)n * S + qc] : (float)qc;
+  bf16x8 qh[HD / 32], ql[HD / 32];
+#pragma unroll
+  for (int ks = 0; ks < HD / 32; ++ks) {
+    float v[8];
+    Vec8<float>::load(qkv + (long long)qc * rowstride + ks * 32 + g * 8, v);
+    split8(v, qh[ks], ql[ks]);
+  }
+  f32x4 o[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) o[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f, a_run = 0.f;
+
+  const int ntile = (S + 63) / 64;
+  for (int kt = 0; kt < ntile; ++kt) {
+    const int kv0 = kt * 64;
+    __syncthreads();
+    for (int c = tid; c < 64 * NCH; c += 256) {
+      const int r = c / NCH, ch = c % NCH;
+      float kv_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vv_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (kv0 + r < S) {
+        const float* base = qkv + (long long)(kv0 + r) * rowstride + ch * 8;
+        Vec8<float>::load(base + (long long)H * HD, kv_);
+        Vec8<float>::load(base + 2LL * H * HD, vv_);
+      }
+      bf16x8 kh_, kl_, vh_, vl_;
+      split8(kv_, kh_, kl_);
+      split8(vv_, vh_, vl_);
+      *(bf16x8*)(sKh + rowimg_off<HD>(r, ch)) = kh_;
+      *(bf16x8*)(sKl + rowimg_off<HD>(r, ch)) = kl_;
+      *(bf16x8*)(sVh + trimg_off<HD>(r, ch * 8)) = vh_;
+      *(bf16x8*)(sVl + trimg_off<HD>(r, ch * 8)) = vl_;
+    }
+    if (tid < 64) {
+      const int kv = kv0 + tid;
+      sPos[tid] = kv < S ? (a.pos ? (float)a.pos[(long long)n * S + kv] : (float)kv) : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < HD / 32; ++ks) {
+        const bf16x8 kh_ = *(const bf16x8*)(sKh + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
+        const bf16x8 kl_ = *(const bf16x8*)(sKl + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], acc, 0, 0, 0);
+      }
+      s[j] = acc;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kvl = 16 * j + 4 * g + r;
+        float v = s[j][r] * a.scale + coef * fabsf(pos_q - sPos[kvl]);
+        v = (kv0 + kvl < S) ? v : -INFINITY;
+        s[j][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    m_run = m_new;
+    float ps = 0.f, pa = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float p = __expf(s[j][r] - m_new);
+        ps += p;
+        pa = fmaf(p, fabsf(pos_q - sPos[16 * j + 4 * g + r]), pa);
+        if (a.drop.thresh) {
+          const unsigned rt = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc));
+          p = drop_keep2(a.drop, rt, (unsigned)(kv0 + 16 * j + 4 * g + r)) ? p * a.drop.scale : 0.f;
+        }
+        s[j][r] = p;
+      }
+    l_run = l_run * alpha + ps;
+    a_run = a_run * alpha + pa;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) o[i] *= alpha;
+
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {
+      bf16x8 ph, pl;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p0 = s[2 * st][r], p1 = s[2 * st + 1][r];
+        ph[r] = (bf16)p0; pl[r] = (bf16)(p0 - (float)ph[r]);
+        ph[4 + r] = (bf16)p1; pl[4 + r] = (bf16)(p1 - (float)ph[4 + r]);
+      }
+      const int qq = (lane & 15) >> 2, pp = lane & 3;
+      const int r_lo = 32 * st + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const bf16x8 vh_ = tr_frag(sVh + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sVh + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+        const bf16x8 vl_ = tr_frag(sVl + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sVl + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl_, ph, o[i], 0, 0, 0);
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh_, pl, o[i], 0, 0, 0);
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh_, ph, o[i], 0, 0, 0);
+      }
+    }
+  }
+  float l_tot = l_run;
+  l_tot += __shfl_xor(l_tot, 16, 64);
+  l_tot += __shfl_xor(l_tot, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q < S) {
+    float* orow = (float*)a.out + ((long long)n * S + q) * ((long long)H * HD) + (long long)h * HD;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      f32x4 v = o[i] * inv;
+      Vec4<float>::store(orow + 16 * i + 4 * g, v);
+    }
+    if (g == 0 && a.lse) a.lse[((long long)n * H + h) * S + q] = m_run + __logf(l_tot);
+  }
+  if (a.mdist) {
+    float a_tot = a_run;
+    a_tot += __shfl_xor(a_tot, 16, 64);
+    a_tot += __shfl_xor(a_tot, 32, 64);
+    if (q < S && g == 0) a.mdist[((long long)n * H + h) * S + q] = a_tot * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bf16 forward, software pipelined: the K/V tile kt+1 is fetched into registers while tile kt (in LDS) is
 // consumed and is written into the other LDS buffer afterwards -> one barrier per tile and no exposed global
 // latency (the un-pipelined kernel above sat in s_waitcnt/s_barrier for ~50 % of its wave cycles).
@@ -1341,6 +1505,14 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
     else if (HD == 32 && dr) attn_fwd_bf16_launch<32, true>(a, stream);
     else if (HD == 32) attn_fwd_bf16_launch<32, false>(a, stream);
     else return A2V_ERR_ARG;
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
+  if (dtype == A2V_BF16X3) {          // fp32 storage, split products on the bf16 matrix cores
+    const dim3 grid((a.S + 63) / 64, a.H, a.N);
+    if (HD == 64) hipLaunchKernelGGL((attn_fwd_x3_kernel<64>), grid, dim3(256), 0, stream, a);
+    else if (HD == 32) hipLaunchKernelGGL((attn_fwd_x3_kernel<32>), grid, dim3(256), 0, stream, a);
+    else return A2V_ERR_UNSUPPORTED;
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }

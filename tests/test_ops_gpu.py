@@ -1377,3 +1377,33 @@ def test_linear_tail_round_goes_to_the_small_kernel(ops):
     assert torch.equal(a1[rows_main:][dropped], r[rows_main:][dropped])
     ref = (x[rows_main:].float() @ w.float().t() + b) * keep.float() / 0.9 + r[rows_main:].float()
     assert rel_err(a1[rows_main:].float(), ref) < 1e-2
+
+
+@pytest.mark.parametrize("S,kind", [(151, "kept"), (700, "arange"), (2000, "arange")])
+def test_attention_fwd_bf16x3_matches_fp64(ops, S, kind):
+    """A2V_BF16X3 attention forward: fp32 in / out, both products as three exact bf16 products (K, V split when staged, Q when
+    loaded, P in registers), fp32 softmax.  Output, LSE and the mean attended distance against an fp64 reference: 3e-5."""
+    N, H, hd = 2, 4, 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(N, S, 3 * H * hd, generator=g)
+    if kind == "kept":
+        pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int()
+    else:
+        pos = torch.arange(S).repeat(N, 1).int()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = torch.rand(H, generator=g) + 0.3
+    ref = attn_ref(qkv.double(), pos, slopes.double(), sc.double(), H)
+    q, k, _ = qkv.double().view(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = O.alibi_bias_from_positions(pos.long(), H, sc.view(1, 1, H, 1, 1)).double()
+    sc_ = (q * hd ** -0.5) @ k.transpose(-2, -1) + bias
+    ops.X3_WGRAD = True
+    try:
+        out, lse = ops.attention_fwd(qkv.cuda(), None if kind == "arange" else pos.cuda(), slopes.cuda(), sc.cuda(), H)
+    finally:
+        ops.X3_WGRAD = False
+    out32, lse32 = ops.attention_fwd(qkv.cuda(), None if kind == "arange" else pos.cuda(), slopes.cuda(), sc.cuda(), H)
+    assert rel_err(out, ref) < 3e-5, rel_err(out, ref)
+    assert rel_err(out32, ref) < 1e-5
+    assert float((lse[0].cpu().double() - torch.logsumexp(sc_, -1)).abs().max()) < 1e-4
+    dist = (pos.double().unsqueeze(2) - pos.double().unsqueeze(1)).abs().unsqueeze(1)
+    assert rel_err(lse[1], (sc_.softmax(-1) * dist).sum(-1)) < 1e-4
