@@ -591,6 +591,7 @@ class Engine:
         a = cfg.audio
         dbg = {}
         ops.X3_WGRAD = self.x3
+        ops.X3_BACKWARD = False
         N, K = ids_keep.shape
         # student activations at the capacity K_cap this shape was primed for (trainer.prime_memory), whatever K the masks drew
         ops.set_row_cap(N, K, self.k_cap.get((N, mask_u8.shape[1])))
@@ -664,6 +665,7 @@ class Engine:
         cb, H = cfg.clone_batch, cfg.num_heads
         a = cfg.audio
         ops.X3_WGRAD = self.x3
+        ops.X3_BACKWARD = self.x3
         c = self.sv.pop("ctx")
         ops.set_row_cap(*c["row_cap"])
         dx, mask_u8, ids_keep, ids_restore, T = c["dx"], c["mask_u8"], c["ids_keep"], c["ids_restore"], c["T"]
@@ -689,6 +691,7 @@ class Engine:
         dfeat = ops.clone_reduce(None, dxk, ids_restore, cb)                   # (B,T,D)
         ops.set_row_cap(0, 0, None)
         self.frontend_bwd(dfeat)
+        ops.X3_BACKWARD = False
         self.sv.clear()
 
     def forward_backward(self, source, mask_u8, ids_keep, ids_restore, noise, *, backward=True, gscale=1.0,

@@ -122,6 +122,19 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 # x3=True does that at every refresh); activations are split on the fly.  The image hangs on the weight TENSOR OBJECT (attribute
 # _a2v_x3), not in a table keyed by address: a freed weight's address is handed to the next allocation.
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
+X3_BACKWARD = False      # set by the engine while it runs a backward: a gradient tensor is the left operand of its input-gradient product
+                         # AND of a weight-gradient product -- its [hi | lo | hi] image is made once and kept on the tensor object
+                         # between the two calls (never in the forward: the saved activations would keep their images alive)
+
+
+def _x3_m0(t):
+    """the [hi | lo | hi] image of a (M, K) fp32 tensor; cached on the tensor object during a backward"""
+    img = getattr(t, "_a2v_x3m0", None)
+    if img is None:
+        img = split_bf16(t, 0)
+        if X3_BACKWARD:
+            t._a2v_x3m0 = img
+    return img
 
 
 def split_bf16(x, mode, out=None, ldo=0):
@@ -188,7 +201,7 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
     r = gelu_bwd_aux if gelu_bwd_aux is not None else res
     img = _x3_image(w, M) if x.dtype == torch.float32 else None
     if img is not None:
-        xs = split_bf16(x, 0)
+        xs = _x3_m0(x)
         return conv_gemm(xs, img, out, M=M, N=N, K=3 * K, T_in=M, T_out=M, Cg=3 * K, a_pitch=3 * K, a_bstride=0, ldb=3 * K,
                          ldc=out.stride(0), bias=bias, res=r, ldr=r.stride(0) if r is not None else 0, gelu=gelu,
                          gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum, drop=drop, dact=dact, x3=True)
@@ -243,10 +256,10 @@ def _x3_wgrad_ok(x, dy):
 
 
 def _x3_wgrad_terms(x, dy):
-    """(dY_hi, X_hi), (dY_hi, X_lo), (dY_lo, X_hi) as bf16 (M, .) views of the stacked split images"""
-    M = x.shape[0]
-    xs, ds = split_bf16(x, 2), split_bf16(dy, 2)
-    return ((xs[:M], ds[:M]), (xs[M:], ds[:M]), (xs[:M], ds[M:]))
+    """(X_hi, dY_hi), (X_lo, dY_hi), (X_hi, dY_lo) as bf16 column views (pitch 3 K / 3 N) of the [hi | lo | hi] images"""
+    K, N = x.shape[1], dy.shape[1]
+    xs, ds = _x3_m0(x), _x3_m0(dy)
+    return ((xs[:, :K], ds[:, :N]), (xs[:, K:2 * K], ds[:, :N]), (xs[:, :K], ds[:, N:2 * N]))
 
 
 def linear_wgrad(x, dy, gw):
@@ -256,7 +269,7 @@ def linear_wgrad(x, dy, gw):
     assert gw.dtype == torch.float32 and gw.shape == (N, K)
     if _x3_wgrad_ok(x, dy):
         for xa, da in _x3_wgrad_terms(x, dy):
-            conv_wgrad(xa, da, gw, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=K, a_bstride=0, ldp=N, ldw=gw.stride(0))
+            conv_wgrad(xa, da, gw, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=3 * K, a_bstride=0, ldp=3 * N, ldw=gw.stride(0))
         return gw
     return conv_wgrad(x, dy, gw, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
                       ldp=dy.stride(0), ldw=gw.stride(0))
@@ -270,8 +283,8 @@ def linear_wgrad_pair(xa, dya, gwa, xb, dyb, gwb):
     assert gwa.dtype == torch.float32 and gwb.dtype == torch.float32 and gwa.shape == (Na, Ka) and gwb.shape == (Nb, Kb)
     if _x3_wgrad_ok(xa, dya) and _x3_wgrad_ok(xb, dyb):
         for (xa_, da_), (xb_, db_) in zip(_x3_wgrad_terms(xa, dya), _x3_wgrad_terms(xb, dyb)):
-            rc = _L().a2v_linear_wgrad_pair(BF16, M, ptr(xa_), Ka, ptr(da_), Na, ptr(gwa), gwa.stride(0), Na, Ka,
-                                            ptr(xb_), Kb, ptr(db_), Nb, ptr(gwb), gwb.stride(0), Nb, Kb, stream())
+            rc = _L().a2v_linear_wgrad_pair(BF16, M, ptr(xa_), 3 * Ka, ptr(da_), 3 * Na, ptr(gwa), gwa.stride(0), Na, Ka,
+                                            ptr(xb_), 3 * Kb, ptr(db_), 3 * Nb, ptr(gwb), gwb.stride(0), Nb, Kb, stream())
             check(rc, "a2v_linear_wgrad_pair")
         return
     rc = _L().a2v_linear_wgrad_pair(dt(xa), M, ptr(xa), xa.stride(0), ptr(dya), dya.stride(0), ptr(gwa), gwa.stride(0), Na, Ka,

@@ -308,7 +308,7 @@ def cpu_baseline(model_name, L, K, sample_rate=8000):
                 legs=legs)
 
 
-def parity_mode_leg(cfg, L, dev, args, clips=8, steps=2):
+def parity_mode_leg(cfg, L, dev, args, clips=16, steps=2):
     """The parity mode of the same optimizer step on a bounded sample (1 warm-up + `steps` timed steps of `clips` clips, masks
     sampled in the step like the headline): fp32 storage with the Linear products as three exact bf16 products over split operands
     on the bf16 matrix cores (bf16x3, include/a2v.h: A2V_BF16X3) -- the mode `-m gpu` holds to 1e-3 against the oracle at BASELINE's
