@@ -675,8 +675,9 @@ def test_layernorm_residual_in(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_instnorm_targets(ops, dtype):
-    B, T, D, Ln = 2, 200, 64, 3
+@pytest.mark.parametrize("B,T,D,Ln", [(2, 200, 64, 3), (3, 301, 1024, 16), (2, 77, 512, 5), (1, 2000, 1024, 12)])
+def test_instnorm_targets(ops, dtype, B, T, D, Ln):
+    """make_targets: (the D % 512 == 0 shapes take the statistics-in-registers kernel, the others the frame-per-wave one)"""
     ts = [(rnd(B, T, D, dtype=dtype, seed=10 + i) * (i + 1) + i).to(dtype).float() for i in range(Ln)]
     ref = O.make_targets([t.clone() for t in ts], Ln)
     y = ops.instnorm_targets([dev(t, dtype) for t in ts])
