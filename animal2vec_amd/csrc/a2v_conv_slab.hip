@@ -21,6 +21,9 @@ typedef __attribute__((address_space(1))) const void cs_gbl_cvoid_t;
 #define CS_LDS (CS_SLAB_BYTES + 2 * CS_B_BYTES)      // 150528
 #define CS_NLD ((CS_SLAB_ROWS * 8 + 511) / 512)      // 16-B chunks per thread: 17
 
+// OutT = float: bf16 operands, fp32 C / R (one of the three bf16 products of a convolution in the bf16x3 parity mode; the second
+// and third accumulate through the residual: R = C)
+template <typename OutT = bf16>
 __global__ __launch_bounds__(512) void conv_nt_slab_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sB = smem + CS_SLAB_BYTES;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(512) void conv_nt_slab_kernel(GemmArgs g) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    wave_epilogue<bf16>(g, stage, lane, clip * T + t_base + wid * 128 + h * 64, 0, grp, 0, m_limit);
+    wave_epilogue<OutT>(g, stage, lane, clip * T + t_base + wid * 128 + h * 64, 0, grp, 0, m_limit);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -260,7 +263,8 @@ bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
     return false;
   static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
-    (void)hipFuncSetAttribute((const void*)conv_nt_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_nt_slab_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
+    (void)hipFuncSetAttribute((const void*)conv_nt_slab_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
     (void)hipFuncSetAttribute((const void*)conv_nt_slab2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, CS2_LDS);
     attr = true;
   }
@@ -272,6 +276,22 @@ bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
     return true;
   }
   dim3 grid(nclips * cdiv(a.T_out, CS_BM), g.G, 1);
-  hipLaunchKernelGGL(conv_nt_slab_kernel, grid, dim3(512), CS_LDS, stream, g);
+  hipLaunchKernelGGL(conv_nt_slab_kernel<bf16>, grid, dim3(512), CS_LDS, stream, g);
+  return true;
+}
+
+// bf16 operands, fp32 outputs (dtype A2V_BF16X3 with 64-wide taps: one bf16 product of a split convolution)
+bool a2v_launch_conv_slab_o32(const GemmArgs& g, hipStream_t stream) {
+  const ConvA& a = g.a;
+  if (a.Cg != 64 || a.stride != 1 || a.T_in != a.T_out || a.taps < 2 || a.taps > 24 || g.N > 64 || g.N % 4 ||
+      a.Cv % 8 || g.K != a.taps * 64 || g.M % a.T_out != 0 || a.pad >= a.taps || a.T_out < 256 || a.rowidx)
+    return false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)conv_nt_slab_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, CS_LDS);
+    attr = true;
+  }
+  dim3 grid((g.M / a.T_out) * cdiv(a.T_out, CS_BM), g.G, 1);
+  hipLaunchKernelGGL(conv_nt_slab_kernel<float>, grid, dim3(512), CS_LDS, stream, g);
   return true;
 }

@@ -171,6 +171,7 @@ bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream);
 bool a2v_launch_nt_x3_p8(const GemmArgs& g, hipStream_t stream);      // bf16 split operands, fp32 C / C2 / R (A2V_BF16X3)
 bool a2v_launch_nt_x3_fast(const GemmArgs& g, hipStream_t stream);    // the same for convolutions / shapes the 8-phase kernel refuses
+bool a2v_launch_conv_slab_o32(const GemmArgs& g, hipStream_t stream); // grouped convs with 64-wide taps: slab kernel, fp32 outputs
 bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream);   // a2v_gemm_tn8.hip: 256x256 weight gradients of the Linears
 bool a2v_launch_tn_bf16_p8_pair(const WgradArgs* ga, const WgradArgs* gb, hipStream_t stream);   // two of them in one launch
 bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream);

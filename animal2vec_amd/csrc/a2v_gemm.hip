@@ -454,7 +454,9 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
   const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
   dim3 grid(tiles, G, 1);
   if (dtype == A2V_BF16X3) {         // split bf16 operands, fp32 outputs: the persistent 8-phase kernel, else the 128 x 128 LDS-DMA kernel
-    if (!(!rowidx && a2v_launch_nt_x3_p8(g, stream)) && !a2v_launch_nt_x3_fast(g, stream)) return A2V_ERR_UNSUPPORTED;
+    if (!(!rowidx && a2v_launch_conv_slab_o32(g, stream)) && !(!rowidx && a2v_launch_nt_x3_p8(g, stream)) &&
+        !a2v_launch_nt_x3_fast(g, stream))
+      return A2V_ERR_UNSUPPORTED;
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }

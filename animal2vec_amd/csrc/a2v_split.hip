@@ -10,30 +10,47 @@
 // Replaces nothing in the reference: it is how this library reaches the north-star's 1e-3 on the bf16 matrix cores.
 #include "a2v_common.h"
 
+template <int U>
+__device__ __forceinline__ void split_store(bf16* __restrict__ out, long long M, int K, long long ldo, int mode, long long m, int c,
+                                            const float* v) {
+  bf16x8 h, l;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    h[q] = (bf16)v[q];
+    l[q] = (bf16)(v[q] - (float)h[q]);
+  }
+  if (mode == 2) {
+    *(bf16x8*)(out + m * ldo + c) = h;
+    *(bf16x8*)(out + (M + m) * ldo + c) = l;
+  } else {
+    bf16* const row = out + m * ldo + c;
+    *(bf16x8*)row = h;
+    *(bf16x8*)(row + K) = mode == 0 ? l : h;
+    *(bf16x8*)(row + 2 * K) = mode == 0 ? h : l;
+  }
+}
+
+// four 8-element chunks per thread and trip, all eight 16-B loads issued before the first store (one chunk per trip ran at 3.2 TB/s)
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, bf16* __restrict__ out, long long M, int K,
                                                          long long ldx, long long ldo, int mode) {
   const int kv = K / 8;
   const long long total = M * kv;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-    const long long m = i / kv;
-    const int c = (int)(i - m * kv) * 8;
-    float v[8];
-    Vec8<float>::load(x + m * ldx + c, v);
-    bf16x8 h, l;
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i0 = (long long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+    float v[4][8];
+    long long mm[4];
+    int cc[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      h[q] = (bf16)v[q];
-      l[q] = (bf16)(v[q] - (float)h[q]);
+    for (int u = 0; u < 4; ++u) {
+      const long long i = i0 + u * stride;
+      const long long ic = i < total ? i : total - 1;
+      mm[u] = ic / kv;
+      cc[u] = (int)(ic - mm[u] * kv) * 8;
+      Vec8<float>::load(x + mm[u] * ldx + cc[u], v[u]);
     }
-    if (mode == 2) {
-      *(bf16x8*)(out + m * ldo + c) = h;
-      *(bf16x8*)(out + (M + m) * ldo + c) = l;
-    } else {
-      bf16* const row = out + m * ldo + c;
-      *(bf16x8*)row = h;
-      *(bf16x8*)(row + K) = mode == 0 ? l : h;
-      *(bf16x8*)(row + 2 * K) = mode == 0 ? h : l;
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (i0 + u * stride < total) split_store<0>(out, M, K, ldo, mode, mm[u], cc[u], v[u]);
   }
 }
 
@@ -44,8 +61,9 @@ extern "C" int a2v_split_bf16(const float* x, void* out, long long M, int K, lon
   if (M <= 0 || K <= 0 || K % 8 || ldx % 4 || mode < 0 || mode > 2 || (((uintptr_t)x | (uintptr_t)out) & 15)) return A2V_ERR_ARG;
   if (ldo == 0) ldo = mode == 2 ? K : 3LL * K;
   if (ldo % 8 || ldo < (mode == 2 ? K : 3LL * K)) return A2V_ERR_ARG;
-  long long blocks = (M * (K / 8) + 255) / 256;
-  if (blocks > 65536) blocks = 65536;
+  long long blocks = (M * (K / 8) + 1023) / 1024;          // four chunks per thread
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
   hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, (bf16*)out, M, K, ldx, ldo, mode);
   A2V_CHECK_LAUNCH();
   return A2V_OK;

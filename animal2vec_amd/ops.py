@@ -171,6 +171,10 @@ def x3_register_conv_pack(w_packed, k, cv):
     rows = w_packed.view(G * N * k, Cgp)
     split_bf16(rows[:, :cv], 1, out=img.view(G * N * k, 3 * Cgp), ldo=3 * Cgp)
     w_packed._a2v_x3 = (tag, img)
+    if Cgp == 64 and N <= 64:       # the slab kernel's shapes: hi and lo packs apart, the three products as three launches
+        hl = getattr(w_packed, "_a2v_x3hl", None)
+        hl = split_bf16(w_packed.view(G * N, KK), 2, out=hl[2] if hl is not None and hl[2].shape == (2 * G * N, KK) else None)
+        w_packed._a2v_x3hl = (hl[:G * N].view(G, N, KK), hl[G * N:].view(G, N, KK), hl)
     return img
 
 
@@ -225,6 +229,20 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
     if out is None:
         out = _E((B, T_out, n_out) if rowidx is None else (M, n_out), dtype=x.dtype, device=x.device)
     img = _x3_conv_image(w_packed, k, cv) if x.dtype == torch.float32 else None
+    hl = getattr(w_packed, "_a2v_x3hl", None) if img is not None else None
+    if (hl is not None and x.is_contiguous() and stride == 1 and T_in == T_out and T_out >= 256 and rowidx is None and Cg == 64
+            and N <= 64 and N % 4 == 0 and cv % 8 == 0 and 2 <= k <= 24):
+        # bf16x3 on the slab kernel (64-wide taps): X_hi W_hi (+ bias, residual), then X_lo W_hi and X_hi W_lo accumulated through R = out
+        R_ = Bsrc * T_in
+        xs = split_bf16(x.view(R_, Cp), 2)
+        xh, xl = xs[:R_].view(x.shape), xs[R_:].view(x.shape)
+        kw = dict(M=M, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride, pad=pad, taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1),
+                  a_bstride=x.stride(0), a_goff=cv if G > 1 else 0, rowmask=rowmask, bdiv=bdiv, ldb=w_packed.stride(-2),
+                  b_gstride=w_packed.stride(0) if G > 1 else 0, ldc=n_out, c_goff=N, x3=True)
+        conv_gemm(xh, hl[0], out, bias=bias, res=res, ldr=n_out if res is not None else 0, **kw)
+        conv_gemm(xl, hl[0], out, res=out, ldr=n_out, **kw)
+        conv_gemm(xh, hl[1], out, res=out, ldr=n_out, colsum=colsum, **kw)
+        return out
     if img is not None and x.is_contiguous() and Cp == G * cv:
         # bf16x3: implicit im2col of the split activation image -- 3 cv channels per group [hi | lo | hi] against taps [hi | hi | lo]
         xs = split_bf16(x.view(-1, cv), 0).view(Bsrc, T_in, G * 3 * cv)
