@@ -261,8 +261,15 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
 // parameter gradients accumulate in registers over all tiles of the block; the dconv accumulator
 // layout is directly the A operand (k = time, order permuted) of dW = dconv^T . Xpad.
 // grads: dfilt [Cp][k] fp32 (atomic), dpar [4][128] fp32 (atomic): d ln_w, d ln_b, d ps_a, d ps_b
+// EIGHT waves: wave (wt, wc) owns time steps 16 wt + [0, 16) of the 64-step tile and channels 64 wc + [0, 64).  As four waves x 128
+// channels the kernel needed 512 registers per lane (dW 64, acc / dh / h 96, eight values of each of four parameters and four
+// parameter gradients 64, ...): one wave per SIMD, a third of its VALU instructions were v_accvgpr moves and nothing ran under the
+// exp / rcp chains, the cross-lane sums (ds_bpermute round trips) or the fp32 MFMAs -- 0.06 of its HBM roofline.  Half the channels
+// per wave fit in 256 registers, two waves share a SIMD, and the only thing the halves exchange is the LayerNorm backward's two
+// row sums (through LDS, one more barrier per tile); the 16-lane sums are DPP adds.
+#define SB_NJ 4      // 16-channel blocks per wave
 template <typename T>
-__global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ filt,
+__global__ __launch_bounds__(512) void sinc_fused_bwd_kernel(const float* __restrict__ x, const float* __restrict__ filt,
                                                              const float* __restrict__ ln_w, const float* __restrict__ ln_b,
                                                              const float* __restrict__ ps_a, const float* __restrict__ ps_b,
                                                              const T* __restrict__ dy, const float* __restrict__ mean_in,
@@ -274,8 +281,10 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
   float* sX = sF + SINC_CP * SINC_FP;               // 2 x [128]
   float* sMean = sX + 256;                          // 2 x [64]
   float* sRstd = sMean + 128;                       // 2 x [64]
-  T* sDy = (T*)(sRstd + 128);                       // 2 x [64][SINC_CP + 8]
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  float* sRed = sRstd + 128;                        // [channel half][64 t][2]: partial row sums of the LayerNorm backward
+  T* sDy = (T*)(sRed + 256);                        // 2 x [64][SINC_CP + 8]
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wid & 3, wc = wid >> 2, cb0 = 64 * wc;
   const int fr = lane & 15, g = lane >> 4;
   const int half = k / 2;
 
@@ -286,37 +295,40 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
   bf16* const sFh = (bf16*)sF;
   bf16* const sFl = sFh + SINC_CP * 32;
   if constexpr (SPLIT) {
-    for (int i = tid; i < SINC_CP * 32; i += 256) {
+    for (int i = tid; i < SINC_CP * 32; i += 512) {
       const int c = i >> 5, j = i & 31;
-      const float w = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+      const float w = (c < C && j <= half) ? filt[(long long)c * k + j] * (j == half ? 0.5f : 1.f) : 0.f;   // (centre: see xf below)
       const bf16 h = (bf16)w;
       sFh[i] = h;
       sFl[i] = (bf16)(w - (float)h);
     }
   } else {
-    for (int i = tid; i < SINC_CP * SINC_MAXK; i += 256) {
+    for (int i = tid; i < SINC_CP * SINC_MAXK; i += 512) {
       const int c = i >> 6, j = i & 63;
-      sF[c * SINC_FP + j] = (c < C && j < k) ? filt[(long long)c * k + j] : 0.f;
+      sF[c * SINC_FP + j] = (c < C && j <= half) ? filt[(long long)c * k + j] * (j == half ? 0.5f : 1.f) : 0.f;
     }
   }
-  // per-lane channel parameters: channels c = fr + 16 jc
-  float pw[8], pb_[8], pa[8], pbs[8];
+  // per-lane channel parameters: channels c = cb0 + fr + 16 jc
+  float pw[SB_NJ], pb_[SB_NJ], pa[SB_NJ], pbs[SB_NJ];
 #pragma unroll
-  for (int jc = 0; jc < 8; ++jc) {
-    const int c = fr + 16 * jc;
+  for (int jc = 0; jc < SB_NJ; ++jc) {
+    const int c = cb0 + fr + 16 * jc;
     const bool ok = c < C;
     pw[jc] = ok ? ln_w[c] : 0.f; pb_[jc] = ok ? ln_b[c] : 0.f;
     pa[jc] = ok ? ps_a[c] : 0.f; pbs[jc] = ok ? ps_b[c] : 0.f;
   }
-  float gw[8], gb[8], ga[8], gbs[8];
+  float pbl[SB_NJ];                                 // -ps_b log2(e): exp(-ps_b y) = exp2(pbl y), one multiply less per element
 #pragma unroll
-  for (int jc = 0; jc < 8; ++jc) { gw[jc] = 0.f; gb[jc] = 0.f; ga[jc] = 0.f; gbs[jc] = 0.f; }
+  for (int jc = 0; jc < SB_NJ; ++jc) pbl[jc] = -1.44269504088896f * pbs[jc];
+  float gw[SB_NJ], gb[SB_NJ], ga[SB_NJ], gbs[SB_NJ];
+#pragma unroll
+  for (int jc = 0; jc < SB_NJ; ++jc) { gw[jc] = 0.f; gb[jc] = 0.f; ga[jc] = 0.f; gbs[jc] = 0.f; }
   // symmetric band-pass rows (see the forward): taps are folded, j <-> k-1-j, so both the conv recompute and the filter
   // gradient run over half + 1 <= 32 folded taps; dfilt[c][j] (j < half) receives d/dW[c][j] + d/dW[c][k-1-j] -- the one
   // number a2v_sinc_filters_bwd reads (it sums the two mirrored entries) -- and the mirrored entries stay untouched
-  f32x4 dW[8][2];                                   // [jc][jt]: rows c = 16jc+4g+r, cols folded tap = 16jt+fr
+  f32x4 dW[SB_NJ][2];                               // [jc][jt]: rows c = cb0+16jc+4g+r, cols folded tap = 16jt+fr
 #pragma unroll
-  for (int jc = 0; jc < 8; ++jc)
+  for (int jc = 0; jc < SB_NJ; ++jc)
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt) dW[jc][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -327,28 +339,30 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
   // Staging of tile it + 1 (signal, LayerNorm statistics, the 64 x 128 dy tile) is requested before tile it is worked on
   // and written to the other LDS buffers after it: one barrier per tile, no exposed global round trip (this kernel runs one
   // workgroup per CU, so nothing else hides it).
-  constexpr int DYCH = 64 * (SINC_CP / 8) / 256;      // dy chunks (8 elements) per thread: 4
+  constexpr int DYCH = 64 * (SINC_CP / 8) / 512;      // dy chunks (8 elements) per thread: 2
   struct Stage { float xv, mv, rv; Raw8<T> dyv[DYCH]; };
-  auto stage_fetch = [&](long long tile_, Stage& st) {
-    const int b_ = (int)(tile_ / tiles_per_clip);
-    const int t0_ = (int)(tile_ - (long long)b_ * tiles_per_clip) * 64;
-    st.xv = tid < 128 ? x[(long long)b_ * L + reflect_idx(t0_ - half + tid, L)] : 0.f;
-    st.mv = 0.f; st.rv = 0.f;
-    if (tid < 64 && t0_ + tid < L) { st.mv = mean_in[(long long)b_ * L + t0_ + tid]; st.rv = rstd_in[(long long)b_ * L + t0_ + tid]; }
+  auto stage_fetch = [&](int tid, int b_, int t0_, Stage& st) {
+    // every thread loads (clamped indices; stage_store keeps what it needs): no control flow around the loads -- inside exec-masked
+    // regions the compiler closed each one with s_waitcnt vmcnt(0), a global round trip exposed in every tile.  Rows past L get the
+    // last row's statistics: their dy is zeroed below, so nothing of them reaches a sum.
+    st.xv = x[(long long)b_ * L + reflect_idx(t0_ - half + (tid & 127), L)];
+    const int ts_ = min(t0_ + (tid & 63), L - 1);
+    st.mv = mean_in[(long long)b_ * L + ts_];
+    st.rv = rstd_in[(long long)b_ * L + ts_];
 #pragma unroll
     for (int u = 0; u < DYCH; ++u) {
-      const int i = tid + 256 * u;
+      const int i = tid + 512 * u;
       const int r = i / (SINC_CP / 8), cc = (i % (SINC_CP / 8)) * 8;
       const int tt = t0_ + r < L ? t0_ + r : L - 1;                       // (rows past L are zeroed by the t0 + tl >= L test below)
       st.dyv[u].load(dy + ((long long)b_ * L + tt) * SINC_CP + cc);
     }
   };
-  auto stage_store = [&](int buf, const Stage& st) {
+  auto stage_store = [&](int tid, int buf, const Stage& st) {
     if (tid < 128) sX[buf * 128 + tid] = st.xv;
     if (tid < 64) { sMean[buf * 64 + tid] = st.mv; sRstd[buf * 64 + tid] = st.rv; }
 #pragma unroll
     for (int u = 0; u < DYCH; ++u) {
-      const int i = tid + 256 * u;
+      const int i = tid + 512 * u;
       const int r = i / (SINC_CP / 8), cc = (i % (SINC_CP / 8)) * 8;
       float v[8];
       st.dyv[u].unpack(v);
@@ -356,45 +370,58 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
     }
   };
   const long long tile_first = (long long)blockIdx.x * tiles_per_blk;
+  // (clip, first step) of the current tile, advanced by hand: the 64-bit division per tile was ~300 scalar instructions
+  int b = (int)(tile_first / tiles_per_clip);
+  int t0 = (int)(tile_first - (long long)b * tiles_per_clip) * 64;
   {
     Stage st0;
-    if (tile_first < ntiles) { stage_fetch(tile_first, st0); stage_store(0, st0); }
+    if (tile_first < ntiles) { stage_fetch(tid, b, t0, st0); stage_store(tid, 0, st0); }
   }
   __syncthreads();
-  for (int it = 0; it < tiles_per_blk; ++it) {
+  for (int it = 0; it < tiles_per_blk; ++it, t0 += 64) {
     const long long tile = tile_first + it;
     if (tile >= ntiles) break;
-    const int b = (int)(tile / tiles_per_clip);
-    const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
+    if (t0 >= tiles_per_clip * 64) { t0 = 0; ++b; }
     const int cb_ = it & 1;
     const bool more = it + 1 < tiles_per_blk && tile + 1 < ntiles;
+    // lane-derived indices are re-formed from opaque copies in every tile: hoisted out of the loop (dozens of LDS addresses and
+    // masks) they were spilled to scratch and reloaded, with a full vmcnt wait, in front of their uses
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    const int tid_o = tid;                            // (the staging addresses may stay hoisted: a dozen registers)
+    const int fr = lane_o & 15, g = lane_o >> 4;
+    // always fetched (the last tile of a block re-fetches itself and drops it): behind `if (more)` the loaded registers met the
+    // untaken path's in copies placed right after the loads -- a wait for the global round trip at the top of every tile
     Stage stn;
-    if (more) stage_fetch(tile + 1, stn);
+    {
+      const bool wrap = t0 + 64 >= tiles_per_clip * 64;
+      stage_fetch(tid_o, more ? (wrap ? b + 1 : b) : b, more ? (wrap ? 0 : t0 + 64) : t0, stn);
+    }
     const float* const sXc = sX + cb_ * 128;
     const float* const sMc = sMean + cb_ * 64;
     const float* const sRc = sRstd + cb_ * 64;
     const T* const sDc = sDy + (size_t)cb_ * 64 * (SINC_CP + 8);
 
     // conv recompute: D[row t = 4g+r][col c = fr+16jc]; A = X[t=fr][tap], B = filt[c][tap]
-    f32x4 acc[8];
+    f32x4 acc[SB_NJ];
 #pragma unroll
-    for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int jc = 0; jc < SB_NJ; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if constexpr (SPLIT) {
-      bf16x8 xh, xl;                                   // A[row = t = fr][k = 8g + e]: folded taps, split
+      // A[row = t = fr][k = 8g + e]: folded taps, split.  xf[t][j] = x[t + j] + x[t + k-1-j] for EVERY j: at the centre tap
+      // (j = half = k-1-j) that is 2 x, against a filter column stored halved (exact); columns j > half meet zero weights
+      bf16x8 xh, xl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int j = 8 * g + e, jm = k - 1 - j;
-        const float a_ = sXc[wid * 16 + fr + (j <= half ? j : half)];
-        const float b_ = sXc[wid * 16 + fr + (jm >= 0 ? jm : 0)];
-        const float xf = j < half ? a_ + b_ : (j == half ? a_ : 0.f);
+        const int j = 8 * g + e;
+        const float xf = sXc[wt * 16 + fr + j] + sXc[wt * 16 + fr + max(k - 1 - j, 0)];
         const bf16 h = (bf16)xf;
         xh[e] = h;
         xl[e] = (bf16)(xf - (float)h);
       }
 #pragma unroll
-      for (int jc = 0; jc < 8; ++jc) {
-        const bf16x8 wh = *(const bf16x8*)(sFh + (16 * jc + fr) * 32 + 8 * g);
-        const bf16x8 wl = *(const bf16x8*)(sFl + (16 * jc + fr) * 32 + 8 * g);
+      for (int jc = 0; jc < SB_NJ; ++jc) {
+        const bf16x8 wh = *(const bf16x8*)(sFh + (cb0 + 16 * jc + fr) * 32 + 8 * g);
+        const bf16x8 wl = *(const bf16x8*)(sFl + (cb0 + 16 * jc + fr) * 32 + 8 * g);
         acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, acc[jc], 0, 0, 0);
         acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, acc[jc], 0, 0, 0);
         acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, acc[jc], 0, 0, 0);
@@ -402,100 +429,112 @@ __global__ __launch_bounds__(256) void sinc_fused_bwd_kernel(const float* __rest
     } else {
 #pragma unroll 4
       for (int ks = 0; ks < 8; ++ks) {
-        const int j = ks * 4 + g, jm = k - 1 - j;
-        const float xl = sXc[wid * 16 + fr + (j <= half ? j : half)];
-        const float xr = sXc[wid * 16 + fr + (jm >= 0 ? jm : 0)];
-        const float xa = j < half ? xl + xr : (j == half ? xl : 0.f);
+        const int j = ks * 4 + g;
+        const float xa = sXc[wt * 16 + fr + j] + sXc[wt * 16 + fr + max(k - 1 - j, 0)];
 #pragma unroll
-        for (int jc = 0; jc < 8; ++jc) {
-          const float wb = sF[(16 * jc + fr) * SINC_FP + j];                 // (columns j > half are multiplied by xa = 0)
+        for (int jc = 0; jc < SB_NJ; ++jc) {
+          const float wb = sF[(cb0 + 16 * jc + fr) * SINC_FP + j];                 // (zero for j > half, halved at j = half)
           acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa, wb, acc[jc], 0, 0, 0);
         }
       }
     }
-    // back-prop through PSwish and LN.  values indexed [jc][r]: t = 16wid+4g+r, c = fr+16jc
-    f32x4 dh[8], hh[8];
+    // back-prop through PSwish and LN.  values indexed [jc][r]: t = 16wt+4g+r, c = cb0+fr+16jc
+    f32x4 dh[SB_NJ], hh[SB_NJ];
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float mr[4], rr[4];                                // this lane's four rows' statistics
 #pragma unroll
-    for (int jc = 0; jc < 8; ++jc) {
-      const bool cok = fr + 16 * jc < C;
+    for (int r = 0; r < 4; ++r) { mr[r] = sMc[wt * 16 + 4 * g + r]; rr[r] = sRc[wt * 16 + 4 * g + r]; }
+#pragma unroll
+    for (int jc = 0; jc < SB_NJ; ++jc) {
+      const bool cok = cb0 + fr + 16 * jc < C;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int tl = wid * 16 + 4 * g + r;
-        const float h = (acc[jc][r] - sMc[tl]) * sRc[tl];
+        const int tl = wt * 16 + 4 * g + r;
+        const float h = (acc[jc][r] - mr[r]) * rr[r];
         const float yl = h * pw[jc] + pb_[jc];
-        const float sg = __builtin_amdgcn_rcpf(1.f + __expf(-pbs[jc] * yl));
-        float dz = cok ? Cvt<T>::to(sDc[tl * (SINC_CP + 8) + fr + 16 * jc]) : 0.f;
-        if (t0 + tl >= L) dz = 0.f;
-        ga[jc] += dz * yl * sg;
-        gbs[jc] += dz * yl * pa[jc] * sg * (1.f - sg) * yl;
-        const float dyl = dz * pa[jc] * (sg + yl * pbs[jc] * sg * (1.f - sg));
-        gw[jc] += dyl * h;
+        const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(pbl[jc] * yl));    // sigmoid(ps_b yl)
+        const float dzv = Cvt<T>::to(sDc[tl * (SINC_CP + 8) + cb0 + fr + 16 * jc]);      // (unconditional: a select, not a branch)
+        const float dz = (cok && t0 + tl < L) ? dzv : 0.f;
+        // z = ps_a yl sg:  dz/d ps_a = yl sg,  dz/d ps_b = ps_a yl^2 sg (1 - sg),  dz/d yl = ps_a (sg + ps_b yl sg (1 - sg))
+        const float u = yl * fmaf(-sg, sg, sg);
+        const float A = dz * pa[jc];
+        ga[jc] = fmaf(dz, yl * sg, ga[jc]);
+        gbs[jc] = fmaf(A * u, yl, gbs[jc]);
+        const float dyl = A * fmaf(pbs[jc], u, sg);
+        gw[jc] = fmaf(dyl, h, gw[jc]);
         gb[jc] += dyl;
         const float d = dyl * pw[jc];
         dh[jc][r] = d;
-        hh[jc][r] = cok ? h : 0.f;
+        hh[jc][r] = h;                                  // (padded channels: d = 0 here and the result is masked below)
         s1[r] += d;
-        s2[r] += d * hh[jc][r];
+        s2[r] = fmaf(d, h, s2[r]);
       }
+      // the block's parameter-gradient sums are formed HERE (opaque uses): left to the scheduler they sink to the end of the tile
+      // and the 64 products feeding them stay live across the filter-gradient MFMAs (spilled accumulators, reloaded with vmcnt(0))
+      asm volatile("" : "+v"(ga[jc]), "+v"(gbs[jc]), "+v"(gw[jc]), "+v"(gb[jc]));
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      s1[r] = row16_sum(s1[r]);
+      s2[r] = row16_sum(s2[r]);
+      if (fr == 0) *(float2*)(sRed + (wc * 64 + wt * 16 + 4 * g + r) * 2) = make_float2(s1[r], s2[r]);
+    }
+    __syncthreads();                                  // the other channel half's sums (this tile's, written above)
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s1[r] += __shfl_xor(s1[r], o, 64); s2[r] += __shfl_xor(s2[r], o, 64); }
-      s1[r] *= invC; s2[r] *= invC;
+    for (int r = 0; r < 4; ++r) {
+      const float2 o = *(const float2*)(sRed + ((wc ^ 1) * 64 + wt * 16 + 4 * g + r) * 2);
+      s1[r] = (s1[r] + o.x) * invC;
+      s2[r] = (s2[r] + o.y) * invC;
     }
     // dconv[t][c] = rstd * (dh - mean(dh) - h * mean(dh*h)), zero for padded channel / time
 #pragma unroll
-    for (int jc = 0; jc < 8; ++jc) {
-      const bool cok = fr + 16 * jc < C;
+    for (int jc = 0; jc < SB_NJ; ++jc) {
+      const bool cok = cb0 + fr + 16 * jc < C;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int tl = wid * 16 + 4 * g + r;
-        const float v = sRc[tl] * (dh[jc][r] - s1[r] - hh[jc][r] * s2[r]);
+        const int tl = wt * 16 + 4 * g + r;
+        const float v = rr[r] * (dh[jc][r] - s1[r] - hh[jc][r] * s2[r]);
         dh[jc][r] = (cok && t0 + tl < L) ? v : 0.f;
       }
     }
-    // dW[c][tap] += sum_t dconv[t][c] * xpad[t + tap]: k-step r has k-slot g <-> t = 16wid+4g+r
+    // dW[c][tap] += sum_t dconv[t][c] * xpad[t + tap]: k-step r has k-slot g <-> t = 16wt+4g+r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int tl = wid * 16 + 4 * g + r;
+      const int tl = wt * 16 + 4 * g + r;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
-        const int j = 16 * jt + fr, jm = k - 1 - j;      // B[k=t][col = folded tap j]
-        const float xl = sXc[tl + (j <= half ? j : half)];
-        const float xr = sXc[tl + (jm >= 0 ? jm : 0)];
-        const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
+        const int j = 16 * jt + fr;                      // B[k=t][col = folded tap j]; column half sums 2 x (halved at the flush),
+        const float xb = sXc[tl + j] + sXc[tl + max(k - 1 - j, 0)];      // columns j > half are never flushed
 #pragma unroll
-        for (int jc = 0; jc < 8; ++jc)
+        for (int jc = 0; jc < SB_NJ; ++jc)
           dW[jc][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[jc][r], xb, dW[jc][jt], 0, 0, 0);
       }
     }
-    if (more) stage_store(cb_ ^ 1, stn);
+    if (more) stage_store(tid_o, cb_ ^ 1, stn);
     __syncthreads();
   }
-  // flush: filter gradient rows c = 16jc+4g+r, cols tap = 16jt+fr
+  // flush: filter gradient rows c = cb0+16jc+4g+r, cols tap = 16jt+fr
 #pragma unroll
-  for (int jc = 0; jc < 8; ++jc)
+  for (int jc = 0; jc < SB_NJ; ++jc)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int c = 16 * jc + 4 * g + r;
+      const int c = cb0 + 16 * jc + 4 * g + r;
       if (c >= C) continue;
 #pragma unroll
       for (int jt = 0; jt < 2; ++jt) {
         const int tap = 16 * jt + fr;
-        if (tap <= half) atomicAdd(dfilt + (long long)c * k + tap, dW[jc][jt][r]);
+        if (tap <= half) atomicAdd(dfilt + (long long)c * k + tap, tap == half ? 0.5f * dW[jc][jt][r] : dW[jc][jt][r]);
       }
     }
   // per-channel parameter grads: reduce over the 4 lane groups (same fr), then atomics
 #pragma unroll
-  for (int jc = 0; jc < 8; ++jc) {
+  for (int jc = 0; jc < SB_NJ; ++jc) {
     float a0 = gw[jc], a1 = gb[jc], a2 = ga[jc], a3 = gbs[jc];
     a0 += __shfl_xor(a0, 16, 64); a0 += __shfl_xor(a0, 32, 64);
     a1 += __shfl_xor(a1, 16, 64); a1 += __shfl_xor(a1, 32, 64);
     a2 += __shfl_xor(a2, 16, 64); a2 += __shfl_xor(a2, 32, 64);
     a3 += __shfl_xor(a3, 16, 64); a3 += __shfl_xor(a3, 32, 64);
-    const int c = fr + 16 * jc;
+    const int c = cb0 + fr + 16 * jc;
     if (g == 0 && c < C) {
       atomicAdd(dpar + c, a0);
       atomicAdd(dpar + SINC_CP + c, a1);
@@ -913,18 +952,19 @@ extern "C" int a2v_sinc_fused_bwd(int dtype, const float* x, const float* filt, 
     return A2V_OK;
   }
   const long long ntiles = (long long)B * ((L + 63) / 64);
-  int tpb = (int)((ntiles + 511) / 512);        // ~2 workgroups per CU: every workgroup flushes its dW / parameter sums with atomics once
+  int tpb = (int)((ntiles + 255) / 256);        // one 8-wave workgroup per CU (168 registers: a second one does not fit), one round:
+                                                // every workgroup flushes its dW / parameter sums once, 16 K atomics onto 8 K addresses
   if (tpb < 1) tpb = 1;
   const int grid = (int)((ntiles + tpb - 1) / tpb);
   const int esz = dtype == A2V_BF16 ? 2 : 4;
-  const int lds = (SINC_CP * SINC_FP + 256 + 256) * 4 + 2 * 64 * (SINC_CP + 8) * esz;
+  const int lds = (SINC_CP * SINC_FP + 256 + 256 + 256) * 4 + 2 * 64 * (SINC_CP + 8) * esz;
   if (dtype == A2V_BF16) {
     (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(sinc_fused_bwd_kernel<bf16>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
+    hipLaunchKernelGGL(sinc_fused_bwd_kernel<bf16>, dim3(grid), dim3(512), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
                        (const bf16*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpb);
   } else if (dtype == A2V_F32) {
     (void)hipFuncSetAttribute((const void*)sinc_fused_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(sinc_fused_bwd_kernel<float>, dim3(grid), dim3(256), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
+    hipLaunchKernelGGL(sinc_fused_bwd_kernel<float>, dim3(grid), dim3(512), lds, st, x, filt, ln_w, ln_b, ps_alpha, ps_beta,
                        (const float*)dy, mean, rstd, dfilt, dpar, B, L, C, k, tpb);
   } else
     return A2V_ERR_DTYPE;
