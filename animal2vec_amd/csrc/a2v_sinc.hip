@@ -116,7 +116,12 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int j = 8 * g + e;
-        const float w = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+        // (clamped loads used unconditionally: behind `c < C && j <= half` each of the 64 was its own exec region closed by
+        // s_waitcnt vmcnt(0) -- 64 global round trips in a row at the head of every workgroup, longer than its 20 tiles of work)
+        // s_waitcnt vmcnt(0) -- 64 global round trips in a row at the head of every workgroup, longer than its 20 tiles of work;
+        // and a select is sunk back into a branch: the mask is a FACTOR, which needs the loaded value whatever it is)
+        const float wv = filt[(long long)min(c, C - 1) * k + min(j, half)];
+        const float w = wv * ((c < C && j <= half) ? (j == half ? 0.5f : 1.f) : 0.f);   // (centre: see xf)
         const bf16 h = (bf16)w;
         wah[jc][e] = h;
         wal[jc][e] = (bf16)(w - (float)h);
@@ -128,7 +133,8 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int c = 16 * jc + fr, j = 4 * ks + g;
-        wa[jc][ks] = (c < C && j <= half) ? filt[(long long)c * k + j] : 0.f;
+        const float wv = filt[(long long)min(c, C - 1) * k + min(j, half)];
+        wa[jc][ks] = wv * ((c < C && j <= half) ? (j == half ? 0.5f : 1.f) : 0.f);
       }
   }
   for (int i = tid; i < SINC_CP; i += 256) {
@@ -144,36 +150,35 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
 
   // the padded signal of tile it + 1 is requested before tile it is multiplied and lands in the other half of sX after it:
   // one barrier per tile and no exposed global round trip (was: load -> barrier -> compute, twice a barrier per tile)
-  auto xsrc = [&](long long tile_) {
-    const int b_ = (int)(tile_ / tiles_per_clip);
-    const int t0_ = (int)(tile_ - (long long)b_ * tiles_per_clip) * 64;
-    return x[(long long)b_ * L + reflect_idx(t0_ - half + (tid & 127), L)];
-  };
+  auto xsrc = [&](int b_, int t0_) { return x[(long long)b_ * L + reflect_idx(t0_ - half + (tid & 127), L)]; };
   const long long tile_first = (long long)blockIdx.x * tiles_per_blk;
-  if (tile_first < ntiles && tid < 128) sX[tid] = xsrc(tile_first);
+  // (clip, first step) of the current tile, advanced by hand (a 64-bit division per tile is ~150 scalar instructions, and there were two)
+  int b = (int)(tile_first / tiles_per_clip);
+  int t0 = (int)(tile_first - (long long)b * tiles_per_clip) * 64;
+  if (tile_first < ntiles && tid < 128) sX[tid] = xsrc(b, t0);
   __syncthreads();
-  for (int it = 0; it < tiles_per_blk; ++it) {
+  for (int it = 0; it < tiles_per_blk; ++it, t0 += 64) {
     const long long tile = tile_first + it;
     if (tile >= ntiles) break;
-    const int b = (int)(tile / tiles_per_clip);
-    const int t0 = (int)(tile - (long long)b * tiles_per_clip) * 64;
+    if (t0 >= tiles_per_clip * 64) { t0 = 0; ++b; }
     const float* sXc = sX + (it & 1) * 128;
     const bool more = it + 1 < tiles_per_blk && tile + 1 < ntiles;
-    float xnext = 0.f;
-    if (more && tid < 128) xnext = xsrc(tile + 1);
+    // (every thread, every tile: no control flow around the load; the last tile re-reads itself)
+    const bool wrap = t0 + 64 >= tiles_per_clip * 64;
+    const float xnext = xsrc(more ? (wrap ? b + 1 : b) : b, more ? (wrap ? 0 : t0 + 64) : t0);
 
     f32x4 acc[8];
 #pragma unroll
     for (int jc = 0; jc < 8; ++jc) acc[jc] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int tl = wid * 16 + fr;                     // local time of this lane
     if constexpr (SPLIT) {
-      bf16x8 xh, xl;                                   // B[k = 8g + e][col = t]: folded taps, split
+      // B[k = 8g + e][col = t]: folded taps, split.  xf[t][j] = x[t + j] + x[t + k-1-j] for EVERY j: at the centre tap that is 2 x,
+      // against a filter value stored halved (exact); taps j > half meet zero weights
+      bf16x8 xh, xl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int j = 8 * g + e, jm = k - 1 - j;
-        const float a_ = sXc[tl + (j <= half ? j : half)];
-        const float b_ = sXc[tl + (jm >= 0 ? jm : 0)];
-        const float xf = j < half ? a_ + b_ : (j == half ? a_ : 0.f);
+        const int j = 8 * g + e;
+        const float xf = sXc[tl + j] + sXc[tl + max(k - 1 - j, 0)];
         const bf16 h = (bf16)xf;
         xh[e] = h;
         xl[e] = (bf16)(xf - (float)h);
@@ -187,11 +192,8 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
     } else {
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
-        const int j = ks * 4 + g;                        // folded tap: B[k = j][col = t] = x[t+j] + x[t+k-1-j] (j < half), x[t+half]
-        const int jm = k - 1 - j;
-        const float xl = sXc[tl + (j <= half ? j : half)];
-        const float xr = sXc[tl + (jm >= 0 ? jm : 0)];
-        const float xb = j < half ? xl + xr : (j == half ? xl : 0.f);
+        const int j = ks * 4 + g;                        // folded tap: B[k = j][col = t] = x[t+j] + x[t+k-1-j] (centre: 2 x, weight halved)
+        const float xb = sXc[tl + j] + sXc[tl + max(k - 1 - j, 0)];
 #pragma unroll
         for (int jc = 0; jc < 8; ++jc) acc[jc] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[jc][ks], xb, acc[jc], 0, 0, 0);
       }
@@ -297,7 +299,8 @@ __global__ __launch_bounds__(512) void sinc_fused_bwd_kernel(const float* __rest
   if constexpr (SPLIT) {
     for (int i = tid; i < SINC_CP * 32; i += 512) {
       const int c = i >> 5, j = i & 31;
-      const float w = (c < C && j <= half) ? filt[(long long)c * k + j] * (j == half ? 0.5f : 1.f) : 0.f;   // (centre: see xf below)
+      const float wv = filt[(long long)min(c, C - 1) * k + min(j, half)];
+      const float w = wv * ((c < C && j <= half) ? (j == half ? 0.5f : 1.f) : 0.f);   // (centre: see xf below; the mask is a factor)
       const bf16 h = (bf16)w;
       sFh[i] = h;
       sFl[i] = (bf16)(w - (float)h);
@@ -305,7 +308,8 @@ __global__ __launch_bounds__(512) void sinc_fused_bwd_kernel(const float* __rest
   } else {
     for (int i = tid; i < SINC_CP * SINC_MAXK; i += 512) {
       const int c = i >> 6, j = i & 63;
-      sF[c * SINC_FP + j] = (c < C && j <= half) ? filt[(long long)c * k + j] * (j == half ? 0.5f : 1.f) : 0.f;
+      const float wv = filt[(long long)min(c, C - 1) * k + min(j, half)];
+      sF[c * SINC_FP + j] = wv * ((c < C && j <= half) ? (j == half ? 0.5f : 1.f) : 0.f);
     }
   }
   // per-lane channel parameters: channels c = cb0 + fr + 16 jc
@@ -314,8 +318,11 @@ __global__ __launch_bounds__(512) void sinc_fused_bwd_kernel(const float* __rest
   for (int jc = 0; jc < SB_NJ; ++jc) {
     const int c = cb0 + fr + 16 * jc;
     const bool ok = c < C;
-    pw[jc] = ok ? ln_w[c] : 0.f; pb_[jc] = ok ? ln_b[c] : 0.f;
-    pa[jc] = ok ? ps_a[c] : 0.f; pbs[jc] = ok ? ps_b[c] : 0.f;
+    const int cc_ = min(c, C - 1);                  // (clamped, unconditional loads)
+    const float l0 = ln_w[cc_], l1 = ln_b[cc_], l2 = ps_a[cc_], l3 = ps_b[cc_];
+    const float okf = ok ? 1.f : 0.f;               // (a factor, not a select: selects are sunk back into exec regions)
+    pw[jc] = l0 * okf; pb_[jc] = l1 * okf;
+    pa[jc] = l2 * okf; pbs[jc] = l3 * okf;
   }
   float pbl[SB_NJ];                                 // -ps_b log2(e): exp(-ps_b y) = exp2(pbl y), one multiply less per element
 #pragma unroll
