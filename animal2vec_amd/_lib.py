@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liba2v_hip.so")
+# A2V_LIB_PATH: another build of the same library (tools/build_prev.sh: same-box A/B of two revisions); never a fallback
+LIB_PATH = os.environ.get("A2V_LIB_PATH") or os.path.join(_HERE, "liba2v_hip.so")
 
 F32, BF16, BF16X3 = 0, 1, 2
 EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT = 1, 2, 4, 8, 16, 32, 64, 128

@@ -48,15 +48,32 @@ __global__ __launch_bounds__(512) void conv_nt_slab_kernel(GemmArgs g) {
   {
     const bf16* xb = (const bf16*)a.ptr + (long long)(clip / a.bdiv) * a.bstride + (long long)grp * a.goff;
     const unsigned char* mk = a.rowmask ? a.rowmask + (long long)clip * a.T_in : nullptr;
+    // Every load is issued unconditionally from a clamped address and masked afterwards with an opaque AND: written as
+    // `if (in range && !mask[row]) load`, each chunk was its own exec region -- mask byte load, s_waitcnt vmcnt(0), data load --
+    // i.e. CS_NLD global round trips one after the other at the head of every workgroup of a masked layer (and a select
+    // with a load behind it is turned back into exactly that branch by the code generator).
     uint4 rg[CS_NLD];
+    unsigned keep[CS_NLD], mraw[CS_NLD];
+    const int chmax = a.Cv / 8 - 1;
+    // (no row mask: the byte is read from the activations themselves and ANDed away -- a branch around the byte load brought the wait back)
+    const unsigned char* const mkp = mk ? mk : (const unsigned char*)xb;
+    unsigned mkm = mk ? 0xFFu : 0u;
+    asm volatile("" : "+s"(mkm));
 #pragma unroll
     for (int u = 0; u < CS_NLD; ++u) {
       const int idx = tid + 512 * u;
       const int row = idx >> 3, ch = idx & 7;
       const int rs = t_base - a.pad + row;
-      rg[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (row < rows_needed && ch * 8 < a.Cv && (unsigned)rs < (unsigned)a.T_in && !(mk && mk[rs]))
-        rg[u] = *(const uint4*)(xb + (long long)rs * a.pitch + ch * 8);
+      const int rsc = min(max(rs, 0), a.T_in - 1);
+      rg[u] = *(const uint4*)(xb + (long long)rsc * a.pitch + min(ch, chmax) * 8);
+      mraw[u] = mkp[rsc];                                                        // (raw: nothing touches it before the data is due)
+      keep[u] = (row < rows_needed && ch <= chmax && rs == rsc) ? 0xFFFFFFFFu : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < CS_NLD; ++u) {
+      unsigned m = keep[u] & (0u - (unsigned)((mraw[u] & mkm) == 0u));
+      asm volatile("" : "+v"(m));
+      rg[u].x &= m; rg[u].y &= m; rg[u].z &= m; rg[u].w &= m;
     }
 #pragma unroll
     for (int u = 0; u < CS_NLD; ++u) {
@@ -159,15 +176,32 @@ __global__ __launch_bounds__(512, 2) void conv_nt_slab2_kernel(GemmArgs g) {
   {
     const bf16* xb = (const bf16*)a.ptr + (long long)(clip / a.bdiv) * a.bstride + (long long)grp * a.goff;
     const unsigned char* mk = a.rowmask ? a.rowmask + (long long)clip * a.T_in : nullptr;
+    // Every load is issued unconditionally from a clamped address and masked afterwards with an opaque AND: written as
+    // `if (in range && !mask[row]) load`, each chunk was its own exec region -- mask byte load, s_waitcnt vmcnt(0), data load --
+    // i.e. CS2_NLD global round trips one after the other at the head of every workgroup of a masked layer (and a select
+    // with a load behind it is turned back into exactly that branch by the code generator).
     uint4 rg[CS2_NLD];
+    unsigned keep[CS2_NLD], mraw[CS2_NLD];
+    const int chmax = a.Cv / 8 - 1;
+    // (no row mask: the byte is read from the activations themselves and ANDed away -- a branch around the byte load brought the wait back)
+    const unsigned char* const mkp = mk ? mk : (const unsigned char*)xb;
+    unsigned mkm = mk ? 0xFFu : 0u;
+    asm volatile("" : "+s"(mkm));
 #pragma unroll
     for (int u = 0; u < CS2_NLD; ++u) {
       const int idx = tid + 512 * u;
       const int row = idx >> 3, ch = idx & 7;
       const int rs = t_base - a.pad + row;
-      rg[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (row < rows_needed && ch * 8 < a.Cv && (unsigned)rs < (unsigned)a.T_in && !(mk && mk[rs]))
-        rg[u] = *(const uint4*)(xb + (long long)rs * a.pitch + ch * 8);
+      const int rsc = min(max(rs, 0), a.T_in - 1);
+      rg[u] = *(const uint4*)(xb + (long long)rsc * a.pitch + min(ch, chmax) * 8);
+      mraw[u] = mkp[rsc];                                                        // (raw: nothing touches it before the data is due)
+      keep[u] = (row < rows_needed && ch <= chmax && rs == rsc) ? 0xFFFFFFFFu : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < CS2_NLD; ++u) {
+      unsigned m = keep[u] & (0u - (unsigned)((mraw[u] & mkm) == 0u));
+      asm volatile("" : "+v"(m));
+      rg[u].x &= m; rg[u].y &= m; rg[u].z &= m; rg[u].w &= m;
     }
 #pragma unroll
     for (int u = 0; u < CS2_NLD; ++u) {

@@ -31,7 +31,7 @@ __device__ __forceinline__ bf16x8 ws_frag(const char* p) {      // rows r .. r+3
 #define WS_P_BYTES (64 * WS_PITCH)
 #define WS_STAGE (WS_P_BYTES + WS_SLAB_ROWS * WS_PITCH)
 
-template <int CPW>
+template <int CPW, bool MASKED>
 __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int clips_per_unit) {
   __shared__ __attribute__((aligned(16))) char smem[2 * WS_STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -52,9 +52,56 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
   const bool p_ok = sch * 8 < g.N;
   const bool x_ok = sch * 8 < a.Cv;
   const bool x2 = srow < taps - 1;                     // this thread also stages slab row 64 + srow
-  uint4 rp, rx0, rx1;
+  uint4 rp = {0u, 0u, 0u, 0u}, rx0 = rp, rx1 = rp;
+  unsigned mkm = a.rowmask ? 0xFFu : 0u;
+  asm volatile("" : "+s"(mkm));
+  unsigned m0 = 0u, m1 = 0u;                           // row-mask bytes of the two slab rows (in flight with the data)
+  bool edge = true;
+  unsigned kp, k0, k1;                                 // all-ones where the staged chunk is real data, zero where it is padding / masked
+// (unconditional loads from clamped addresses, masked afterwards with an opaque AND: as `if (in range && !mask[row]) load` each
+// of the three was its own exec region, and with a row mask -- the first pos-conv layer -- the mask byte's round trip was waited
+// for (vmcnt(0), the dY load included) before the data load was even issued: two exposed global round trips per 64-row step)
+#define WS_LOAD_M(s_)                                                                                     \
+  {                                                                                                      \
+    const int cl = c0 + (s_) / spc;                                                                      \
+    const int t0 = ((s_) - ((s_) / spc) * spc) * 64;                                                     \
+    const int tp = min(t0 + srow, T - 1);                                                                \
+    if (p_ok) rp = *(const uint4*)((const bf16*)g.P + ((long long)cl * T + tp) * g.ldp + (long long)grp * g.p_goff + sch * 8); \
+    const bf16* xb = (const bf16*)a.ptr + (long long)(cl / a.bdiv) * a.bstride + (long long)grp * a.goff + sch * 8; \
+    const unsigned char* mk = a.rowmask ? a.rowmask + (long long)cl * a.T_in : nullptr;                  \
+    const int ra = t0 - a.pad + srow, rac = min(max(ra, 0), a.T_in - 1);                                 \
+    const int rb = ra + 64, rbc = min(max(rb, 0), a.T_in - 1);                                           \
+    /* (thread-constant conditions only -- narrow groups (decoder: 24 of 64 channels) and the taps - 1 extra slab rows */ \
+    /* are not worth a load per lane -- nothing that depends on loaded data) */                          \
+    if (x_ok) rx0 = *(const uint4*)(xb + (long long)rac * a.pitch);                                      \
+    if (x2 && x_ok) rx1 = *(const uint4*)(xb + (long long)rbc * a.pitch);                                \
+    if (mk) { m0 = mk[rac]; m1 = mk[x2 ? rbc : rac]; }    /* (raw; consumed in WS_STORE, like the data) */ \
+    kp = (p_ok && t0 + srow < T) ? 0xFFFFFFFFu : 0u;                                                     \
+    k0 = (x_ok && ra == rac) ? 0xFFFFFFFFu : 0u;                                                         \
+    k1 = (x2 && x_ok && rb == rbc) ? 0xFFFFFFFFu : 0u;                                                   \
+    /* lanes that never load keep the zeros they were initialised with; the rest needs masking only where a clip edge or a */ \
+    /* row mask is in play (uniform): in the steps between, the 12 ANDs per lane are issue time a 32-MFMA step (k = 7) feels */ \
+    edge = mk != nullptr || t0 - a.pad < 0 || t0 - a.pad + 63 + taps > a.T_in || t0 + 64 > T;            \
+  }
+#define WS_STORE_M(buf_)                                                                                  \
+  {                                                                                                      \
+    char* sp_ = smem + (buf_) * WS_STAGE;                                                                \
+    if (edge) {                                                                                          \
+      k0 &= 0u - (unsigned)((m0 & mkm) == 0u); k1 &= 0u - (unsigned)((m1 & mkm) == 0u);                   \
+      asm volatile("" : "+v"(kp), "+v"(k0), "+v"(k1));                                                   \
+      rp.x &= kp; rp.y &= kp; rp.z &= kp; rp.w &= kp;                                                    \
+      rx0.x &= k0; rx0.y &= k0; rx0.z &= k0; rx0.w &= k0;                                                \
+      rx1.x &= k1; rx1.y &= k1; rx1.z &= k1; rx1.w &= k1;                                                \
+    }                                                                                                    \
+    *(uint4*)(sp_ + srow * WS_PITCH + sch * 16) = rp;                                                    \
+    *(uint4*)(sp_ + WS_P_BYTES + srow * WS_PITCH + sch * 16) = rx0;                                      \
+    if (x2) *(uint4*)(sp_ + WS_P_BYTES + (64 + srow) * WS_PITCH + sch * 16) = rx1;                       \
+  }
+
+// no row mask (every layer but the first pos-conv one): the plain form -- conditional loads, no masking arithmetic; the
+// branch-free form above costs a k = 7 step (32 MFMAs) 4-9 % (same-box A/B)
   const uint4 zero4 = {0u, 0u, 0u, 0u};
-#define WS_LOAD(s_)                                                                                      \
+#define WS_LOAD_P(s_)                                                                                      \
   {                                                                                                      \
     const int cl = c0 + (s_) / spc;                                                                      \
     const int t0 = ((s_) - ((s_) / spc) * spc) * 64;                                                     \
@@ -68,7 +115,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
     const int rb = ra + 64;                                                                              \
     if (x2 && x_ok && (unsigned)rb < (unsigned)a.T_in && !(mk && mk[rb])) rx1 = *(const uint4*)(xb + (long long)rb * a.pitch); \
   }
-#define WS_STORE(buf_)                                                                                   \
+#define WS_STORE_P(buf_)                                                                                   \
   {                                                                                                      \
     char* sp_ = smem + (buf_) * WS_STAGE;                                                                \
     *(uint4*)(sp_ + srow * WS_PITCH + sch * 16) = rp;                                                    \
@@ -82,8 +129,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
 #pragma unroll
     for (int j = 0; j < CPW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  WS_LOAD(0);
-  WS_STORE(0);
+  if constexpr (MASKED) { WS_LOAD_M(0); WS_STORE_M(0); } else { WS_LOAD_P(0); WS_STORE_P(0); }
   __syncthreads();
 
   const int gq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
@@ -91,7 +137,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
   const int ct0 = wid * CPW;
   for (int st = 0; st < nsteps; ++st) {
     const int buf = st & 1;
-    if (st + 1 < nsteps) WS_LOAD(st + 1);
+    // (unconditional, the last step re-fetches itself: with the loads and their consuming stores behind `if (st + 1 < nsteps)` the
+    // wait-count pass saw a path on which a load stays pending across the back edge and put s_waitcnt vmcnt(0) in front of the
+    // NEXT load into the same registers -- dY, slab row, second slab row fetched one round trip after the other)
+    if constexpr (MASKED) {
+      WS_LOAD_M(min(st + 1, nsteps - 1));
+      __builtin_amdgcn_sched_barrier(0);    // (the fragment reads / MFMAs below are scheduled on their own, not threaded through the address arithmetic above)
+    } else {
+      if (st + 1 < nsteps) WS_LOAD_P(st + 1);
+    }
     const char* sp_ = smem + buf * WS_STAGE + lane_base;          // this lane's (row 8 gq + q, column 4 p) of the dY tile
     const char* sx_ = sp_ + WS_P_BYTES;                           // ... and of the X slab
 #pragma unroll
@@ -109,11 +163,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
         for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
       }
     }
-    if (st + 1 < nsteps) WS_STORE(buf ^ 1);
+    if constexpr (MASKED) {
+      __builtin_amdgcn_sched_barrier(0);    // (the masking ANDs wait for the global loads: after the step's last MFMA, not among them)
+      WS_STORE_M(buf ^ 1);
+    } else {
+      if (st + 1 < nsteps) WS_STORE_P(buf ^ 1);
+    }
     __syncthreads();
   }
-#undef WS_LOAD
-#undef WS_STORE
+#undef WS_LOAD_M
+#undef WS_STORE_M
+#undef WS_LOAD_P
+#undef WS_STORE_P
 
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
@@ -142,9 +203,12 @@ bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream) {
   const int cpu = cdiv(nclips, units);
   units = cdiv(nclips, cpu);
   dim3 grid(units, g.G, 1);
-  if (a.taps * 4 <= 32)
-    hipLaunchKernelGGL((conv_wgrad_slab_kernel<4>), grid, dim3(512), 0, stream, g, cpu);
-  else
-    hipLaunchKernelGGL((conv_wgrad_slab_kernel<10>), grid, dim3(512), 0, stream, g, cpu);
+  if (a.taps * 4 <= 32) {
+    if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<4, true>), grid, dim3(512), 0, stream, g, cpu);
+    else hipLaunchKernelGGL((conv_wgrad_slab_kernel<4, false>), grid, dim3(512), 0, stream, g, cpu);
+  } else {
+    if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<10, true>), grid, dim3(512), 0, stream, g, cpu);
+    else hipLaunchKernelGGL((conv_wgrad_slab_kernel<10, false>), grid, dim3(512), 0, stream, g, cpu);
+  }
   return true;
 }
