@@ -46,7 +46,8 @@ def get_annealed_rate(start, end, curr_step, total_steps):
 
 class PretrainTrainer:
     def __init__(self, cfg: Data2VecMultiConfig, optim: Optional[OptimConfig] = None, dtype=torch.bfloat16,
-                 device="cuda", seed: int = 0, process_group=None, dropout: bool = True, mixup: bool = True, x3: bool = False):
+                 device="cuda", seed: int = 0, process_group=None, dropout: bool = True, mixup: bool = True, x3: bool = False,
+                 grad_wire=None):
         self.cfg, self.optim = cfg, optim or OptimConfig()
         self.store = ParamStore(cfg, device=device)
         self.store.init_reference(seed)
@@ -71,7 +72,7 @@ class PretrainTrainer:
         if self.store.device.type == "cuda":
             self.mask_sampler = DeviceMaskSampler(self.store.device, mask_prob=a.mask_prob, mask_length=a.mask_length,
                                                   mask_dropout=a.mask_dropout)
-        self.sync = GradSync(self.store.grad, self._make_buckets(), process_group)
+        self.sync = GradSync(self.store.grad, self._make_buckets(), process_group, wire_dtype=grad_wire)     # (ddp.GradSync: wire dtype)
         self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)

@@ -460,6 +460,9 @@ def main():
                     help="sampled: span masks drawn on the device inside every timed step (default); precomputed: seeded "
                          "keep-masks made once outside the timed loop (A/B)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--grad-wire", default="fp32", choices=["fp32", "bf16"],
+                    help="dtype of the gradient buckets on the links (ddp.GradSync): bf16 halves the all-reduce bytes, as the reference's "
+                         "fp16 recipe does, for two conversion passes over the flat gradient; fp32 (default) reduces the buffer in place")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--parity-leg", default="auto", choices=["auto", "skip"],
@@ -508,7 +511,7 @@ def main():
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     assert args.global_batch % (world * args.micro_batch) == 0, "global batch must split into micro-batches per rank"
     n_mb = args.global_batch // (world * args.micro_batch)
-    tr = PretrainTrainer(cfg, dtype=dtype, device=dev, seed=0)
+    tr = PretrainTrainer(cfg, dtype=dtype, device=dev, seed=0, grad_wire=torch.bfloat16 if args.grad_wire == "bf16" else None)
     L, K = args.samples, args.keep
     mbs = [make_microbatch(cfg, args.micro_batch, L, K, 1234 + 1000 * rank + 10 * j, dev, masks=args.masks) for j in range(n_mb)]
 
@@ -609,7 +612,8 @@ def main():
                                    f"all-reduce, clip+Adam, EMA) on {L}-sample clips @ {cfg.audio.sample_rate} Hz, "
                                    f"{k_mean:.1f}/{cfg.frame_counts(L)[-1]} frames kept, clone_batch {cfg.clone_batch}",
                        "global_batch": args.global_batch, "micro_batch": args.micro_batch, "micro_batches_per_rank": n_mb,
-                       "parallelism": f"dp{world}", "dropout": "on (p=0.1, 5 sites)", "mixup": "on (BC, A-weighted gain)",
+                       "parallelism": f"dp{world}", "grad_all_reduce": f"{args.grad_wire} buckets, overlapped with backward",
+                       "dropout": "on (p=0.1, 5 sites)", "mixup": "on (BC, A-weighted gain)",
                        "masks": ("span masks (mask_prob %g, length %d) + gather ids sampled on the device INSIDE every timed step, fresh per "
                                  "step and micro-batch (a2v_span_mask on a side stream, one step ahead; K read back through pinned "
                                  "memory); the reference samples them on the host in every forward (base.py:401-413)"

@@ -51,6 +51,18 @@ def _worker(rank, world, port, q):
             sync.arm(True)
             sync.on_ready("decoder")
             sync.on_ready("decoder")
+        # bf16 on the wire: every rank ends on the sum of the bf16-rounded gradients (two ranks: one rounding of an exact sum),
+        # whether a bucket went out during backward or in finish(); the statistics stay in their own dtype
+        grad_w = local.clone()
+        sync_w = GradSync(grad_w, buckets, wire_dtype=torch.bfloat16)
+        sync_w.arm(True)
+        for ev in list(buckets)[1:]:
+            sync_w.on_ready(ev)
+        stats_w = torch.tensor([2.0, 3.0], dtype=torch.float64)
+        sync_w.finish(stats_w)
+        want = (others[0].bfloat16() + others[1].bfloat16()).float()
+        assert torch.equal(grad_w, want)
+        assert stats_w.tolist() == [2.0 * world, 3.0 * world]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

@@ -21,10 +21,10 @@ from animal2vec_amd.config import tiny_config
 from animal2vec_amd.trainer import PretrainTrainer, OptimConfig
 from animal2vec_amd import masking
 
-def run(force):
+def run(force, wire=None):
     os.environ["A2V_DDP_FORCE"] = "1" if force else "0"
     cfg = tiny_config()
-    tr = PretrainTrainer(cfg, OptimConfig(lr=1e-3, warmup_updates=1, max_update=10), dtype=torch.float32, seed=3)
+    tr = PretrainTrainer(cfg, OptimConfig(lr=1e-3, warmup_updates=1, max_update=10), dtype=torch.float32, seed=3, grad_wire=wire)
     assert tr.sync.active == force
     L = 3200
     T = cfg.frame_counts(L)[-1]
@@ -46,12 +46,19 @@ torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 a, ta, ma = run(True)
 b, tb, mb = run(False)
+c, tc, mc = run(True, torch.bfloat16)
 dist.destroy_process_group()
 # fp32 atomics in the weight-gradient kernels make two runs differ in the last bits (~1e-7 after Adam); a bucket
 # reduced before its producer finished would move parameters by O(lr) = 1e-3
 assert float((a - b).abs().max()) < 5e-6 and float((ta - tb).abs().max()) < 5e-6, float((a - b).abs().max())
 assert abs(ma["loss"] - mb["loss"]) < 1e-5 * abs(mb["loss"])
-print("RCCL_PATH_OK", ma["loss"])
+# bf16 buckets on the wire: every gradient is rounded to bf16 (2^-9 relative) before Adam, whose normalised step moves by that
+# fraction of lr at most where the second moment is dominated by the current gradient: parameters within a few lr * 2^-8 = 4e-6
+# ... and exactly the fp32 run's where a bucket was never converted back (a missed copy leaves the gradient un-reduced: identical)
+dc = float((c - b).abs().max())
+assert 0.0 < dc < 5e-5, dc
+assert abs(mc["loss"] - mb["loss"]) < 1e-3 * abs(mb["loss"])
+print("RCCL_PATH_OK", ma["loss"], dc)
 """
 
 
