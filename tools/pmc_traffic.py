@@ -46,8 +46,8 @@ def main():
         rows[k] = dict(launches=n, read_bytes_per_launch=round(rd), write_bytes_per_launch=round(wr),
                        hbm_bytes_per_launch=round(rd + wr), avg_us_under_pmc=round(f[2] / max(1, f[1]), 2))
     tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in rows.values())
-    doc = dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over one micro-batch of 8 clips "
-                    "(bench.py --steps 1 --warmup 0 --global-batch <micro-batch>); FETCH_SIZE x2 (gfx950 correction), KiB -> bytes",
+    doc = dict(note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/collect_profiles.sh: bench.py --steps 1 "
+                    "--warmup 0 --global-batch <one micro-batch>; the headline config: 64 clips); FETCH_SIZE x2 (gfx950 correction), KiB -> bytes",
                total_hbm_bytes=tot, kernels=rows)
     with open(out, "w") as f:
         json.dump(doc, f, indent=1)
