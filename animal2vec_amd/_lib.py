@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # A2V_LIB_PATH: another build of the same library (tools/build_prev.sh: same-box A/B of two revisions); never a fallback
 LIB_PATH = os.environ.get("A2V_LIB_PATH") or os.path.join(_HERE, "liba2v_hip.so")
 
-F32, BF16, BF16X3 = 0, 1, 2
+F32, BF16, BF16X3, BF16X3S = 0, 1, 2, 3
 EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT = 1, 2, 4, 8, 16, 32, 64, 128
 
 _p, _i, _ll, _f, _u = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint

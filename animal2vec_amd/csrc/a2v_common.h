@@ -23,6 +23,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 #define A2V_F32 0
 #define A2V_BF16 1
 #define A2V_BF16X3 2        // a2v_conv_gemm only: bf16 split operand images (a2v_split_bf16), fp32 C / C2 / R
+#define A2V_BF16X3S 3       // a2v_conv_gemm only: [hi ; lo] stacked images, the three products of a 64-wide grouped conv in one pass
 #define A2V_ERR_UNSUPPORTED (-4)
 
 #define A2V_CHECK_LAUNCH()                                   \

@@ -433,7 +433,7 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
                              long long ldr, const float* bias, float* colsum, int M, int N, int K, int G, int flags,
                              float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || G <= 0) return A2V_ERR_ARG;
-  if (dtype != A2V_F32 && dtype != A2V_BF16 && dtype != A2V_BF16X3) return A2V_ERR_DTYPE;
+  if (dtype != A2V_F32 && dtype != A2V_BF16 && dtype != A2V_BF16X3 && dtype != A2V_BF16X3S) return A2V_ERR_DTYPE;
   const int esz = dtype == A2V_F32 ? 4 : 2;
   GemmArgs g;
   g.a = ConvA{A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, (Cv <= 0 || Cv > Cg) ? Cg : Cv, rowmask, bdiv < 1 ? 1 : bdiv, rowidx};
@@ -453,6 +453,14 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
   if ((flags & F_DROPOUT) && !(drop_p > 0.f && drop_p < 1.f)) return A2V_ERR_ARG;
   const int tiles = cdiv(M, NT_BM) * cdiv(N, NT_BN);
   dim3 grid(tiles, G, 1);
+  if (dtype == A2V_BF16X3S) {        // [hi ; lo] stacked operands: the three products of a 64-wide grouped conv in one pass
+    if (rowidx || M % T_out) return A2V_ERR_UNSUPPORTED;
+    const long long a_lo = (long long)cdiv(M / T_out, g.a.bdiv) * a_bstride;
+    const long long b_lo = G > 1 ? (long long)G * b_gstride : (long long)N * ldb;
+    if (!a2v_launch_conv_slab3(g, a_lo, b_lo, stream)) return A2V_ERR_UNSUPPORTED;
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16X3) {         // split bf16 operands, fp32 outputs: the persistent 8-phase kernel, else the 128 x 128 LDS-DMA kernel
     if (!(!rowidx && a2v_launch_conv_slab_o32(g, stream)) && !(!rowidx && a2v_launch_nt_x3_p8(g, stream)) &&
         !a2v_launch_nt_x3_fast(g, stream))

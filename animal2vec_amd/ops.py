@@ -5,12 +5,13 @@ fallback: without the library, or on a CPU tensor, they raise.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
 
 from . import _lib
-from ._lib import BF16, BF16X3, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, check
+from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, check
 
 
 def _L():
@@ -88,7 +89,8 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
               gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False, x3=None):
     """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add.
     rowidx (int32, M entries): GEMM row m reads the im2col row of flat index rowidx[m]; out stays compact.
-    x3=True: x and w are bf16 split images (split_bf16), out / res / pre_out fp32 (include/a2v.h: A2V_BF16X3)."""
+    x3=True: x and w are bf16 split images (split_bf16), out / res / pre_out fp32 (include/a2v.h: A2V_BF16X3);
+    x3="stacked": x and w are [hi ; lo] stacked images, the three products in one pass (A2V_BF16X3S)."""
     flags = 0
     if bias is not None:
         flags |= EPI_BIAS
@@ -107,7 +109,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
     if drop is not None and drop[0] > 0:
         flags |= EPI_DROPOUT
     dp, ds = (drop if drop is not None and drop[0] > 0 else (0.0, 0))
-    dtype_code = dt(x) if x3 is None else BF16X3
+    dtype_code = dt(x) if x3 is None else (BF16X3S if x3 == "stacked" else BF16X3)
     args = (dtype_code, ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
             ptr(rowmask), bdiv, ptr(w), ldb, b_gstride, ptr(out), ldc, c_goff, ptr(pre_out),
             ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
@@ -121,6 +123,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 # exact bf16 products on the bf16 matrix cores.  A weight takes part when its split image has been registered (params.Packs with
 # x3=True does that at every refresh); activations are split on the fly.  The image hangs on the weight TENSOR OBJECT (attribute
 # _a2v_x3), not in a table keyed by address: a freed weight's address is handed to the next allocation.
+X3_CONV_FUSED = os.environ.get("A2V_X3_CONV_FUSED", "1") != "0"     # 64 outputs per group: the three split products of a 64-wide grouped conv in one launch (A/B switch)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
 X3_BACKWARD = False      # set by the engine while it runs a backward: a gradient tensor is the left operand of its input-gradient product
                          # AND of a weight-gradient product -- its [hi | lo | hi] image is made once and kept on the tensor object
@@ -239,6 +242,10 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
         kw = dict(M=M, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride, pad=pad, taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1),
                   a_bstride=x.stride(0), a_goff=cv if G > 1 else 0, rowmask=rowmask, bdiv=bdiv, ldb=w_packed.stride(-2),
                   b_gstride=w_packed.stride(0) if G > 1 else 0, ldc=n_out, c_goff=N, x3=True)
+        if N == 64 and colsum is None and X3_CONV_FUSED:
+            # 64 outputs per group (the pos-conv): one pass over both slabs (conv_nt_slab3_kernel); xs / hl[2] ARE the stacked images
+            kw["x3"] = "stacked"
+            return conv_gemm(xs, hl[2], out, bias=bias, res=res, ldr=n_out if res is not None else 0, **kw)
         conv_gemm(xh, hl[0], out, bias=bias, res=res, ldr=n_out if res is not None else 0, **kw)
         conv_gemm(xl, hl[0], out, res=out, ldr=n_out, **kw)
         conv_gemm(xh, hl[1], out, res=out, ldr=n_out, colsum=colsum, **kw)

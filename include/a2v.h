@@ -36,6 +36,12 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 #define A2V_BF16 1
 #define A2V_BF16X3 2 /* a2v_conv_gemm only: A and Bw are bf16 SPLIT images (a2v_split_bf16) with K = 3 x the real reduction length,
                       * C / C2 / R are fp32 -- the bf16x3 parity mode: fp32-grade results on the bf16 matrix cores */
+#define A2V_BF16X3S 3 /* a2v_conv_gemm only (ABI 9): grouped stride-1 convolutions with 64-wide taps and 64 outputs per group
+                       * (taps 2..24, T_out >= 256, flags within BIAS | RES).  A and Bw are [hi ; lo] STACKED images
+                       * (a2v_split_bf16 mode 2): the lo image of A starts ceil(M / T_out / bdiv) * a_bstride elements after A,
+                       * the lo pack of Bw starts G * b_gstride (G > 1; else N * ldb) elements after Bw; Cg / K / pitches are
+                       * the bf16 convolution's.  One pass forms X_hi W_hi + X_lo W_hi + X_hi W_lo; C / R are fp32.
+                       * Anything else: A2V_ERR_UNSUPPORTED (run the three products as three A2V_BF16X3 calls with R = C). */
 
 /* epilogue flags of a2v_conv_gemm */
 #define A2V_EPI_BIAS 1      /* + bias[g*N+n] */
@@ -329,7 +335,8 @@ int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx,
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 8: + a2v_split_bf16 and dtype A2V_BF16X3 of a2v_conv_gemm; + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
+/* 9: + dtype A2V_BF16X3S of a2v_conv_gemm (nothing else changed).
+ * 8: + a2v_split_bf16 and dtype A2V_BF16X3 of a2v_conv_gemm; + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
  * arithmetic).  7 added a2v_decoder_input_rng and A2V_EPI_DACT over 6. */
 int a2v_abi_version(void);
 

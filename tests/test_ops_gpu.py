@@ -1341,6 +1341,42 @@ def test_conv_bf16x3_matches_fp64(ops, Cin, Cout, k, s, pl, G, T, B):
     assert rel_err(gw_un, wr.grad) < 3e-5
 
 
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv_bf16x3_one_pass_slab_kernel(ops, masked):
+    """A2V_BF16X3S (conv_nt_slab3_kernel): the pos-conv's three split products in one pass over stacked [hi ; lo] images -- bias,
+    fp32 residual, ragged last row block (T = 600 = 384 + 216), and the student's first layer: clones of a clip (bdiv) under a row
+    mask.  Against the fp64 convolution of the same fp32 operands (3e-5) and against the three-launch form (same products, another
+    summation order: 2e-6)."""
+    from animal2vec_amd.params import _padk
+    g = torch.Generator().manual_seed(11)
+    Cin = Cout = 1024
+    k, pl, G, T, Bsrc, cb = 19, 9, 16, 600, 2, 3 if masked else 1
+    Cg = Cin // G
+    B = Bsrc * cb
+    x = torch.randn(Bsrc, Cin, T, generator=g)
+    w = torch.randn(Cout, Cg, k, generator=g) * (Cg * k) ** -0.5
+    bias = torch.randn(Cout, generator=g)
+    res = torch.randn(B, T, Cout, generator=g)
+    mask = (torch.rand(B, T, generator=g) < 0.6) if masked else torch.zeros(B, T, dtype=torch.bool)
+    xin = x.repeat_interleave(cb, 0) * (~mask).unsqueeze(1).to(x.dtype)
+    ref = conv_ref(xin.double(), w.double(), k, 1, pl, G, T) + bias.double().view(1, -1, 1) + res.double().transpose(1, 2)
+    xcl = to_cl(x, Cin, torch.float32)
+    wp = dev(pack_ref(w, G, _padk(Cg, torch.bfloat16)), torch.float32)
+    assert ops.x3_register_conv_pack(wp, k, Cg) is not None
+    kw = dict(k=k, stride=1, pad=pl, groups=G, T_out=T, n_out=Cout, cv=Cg, res=res.cuda())
+    if masked:
+        kw.update(rowmask=mask.to(torch.uint8).cuda(), bdiv=cb, n_batch=B)
+    assert ops.X3_CONV_FUSED
+    y1 = ops.conv1d_cl(xcl, wp, bias.cuda(), **kw)
+    ops.X3_CONV_FUSED = False
+    try:
+        y3 = ops.conv1d_cl(xcl, wp, bias.cuda(), **kw)
+    finally:
+        ops.X3_CONV_FUSED = True
+    assert rel_err(y1.transpose(1, 2), ref) < 3e-5
+    assert rel_err(y1, y3) < 2e-6
+
+
 def test_linear_tail_round_goes_to_the_small_kernel(ops):
     """M = 768 x 151 rows, N = 1024: 7.08 rounds of 256-row tiles on 256 CUs.  The launcher gives the 1280 rows of the last,
     nearly empty round to the 128 x 128 kernel (a2v_debug_set(22)): outputs must be what the unsplit launch writes -- bit for bit
