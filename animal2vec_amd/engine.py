@@ -197,8 +197,8 @@ class Engine:
         d_act1, d_act2 = mk(p_act, 3), mk(p_act, 3, 0x632BE5AB)
         att, lse = ops.attention_fwd(qkv.view(N, S, 3 * D), pos, self.store.alibi_slopes, alibi_scale, H,
                                      need_lse=save is not None, drop=d_att)
-        s1 = ops.linear(att.view(N * S, D), pk.w[prefix + "attn.proj.weight"], params[prefix + "attn.proj.bias"], res=x2,
-                        drop=d_proj)
+        att2 = att.view(N * S, D)        # (the object kept for the backward: in the bf16x3 mode its split image rides on it)
+        s1 = ops.linear(att2, pk.w[prefix + "attn.proj.weight"], params[prefix + "attn.proj.bias"], res=x2, drop=d_proj)
         x1, m1, r1 = ops.layernorm_fwd(s1, params[prefix + "norm1.weight"], params[prefix + "norm1.bias"], eps,
                                        save_stats=save is not None)
         hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
@@ -225,7 +225,7 @@ class Engine:
             x2o, m2, r2 = ops.layernorm_fwd(s2, params[prefix + "norm2.weight"], params[prefix + "norm2.bias"], eps,
                                             save_stats=save is not None)
         if save is not None:
-            self.sv[save] = dict(x=x2, qkv=qkv, att=att, lse=lse, s1=s1, st1=(m1, r1), x1=x1, hpre=hpre, g=gact, s2=s2,
+            self.sv[save] = dict(x=x2, qkv=qkv, att=att, att2=att2, lse=lse, s1=s1, st1=(m1, r1), x1=x1, hpre=hpre, g=gact, s2=s2,
                                  st2=(m2, r2), N=N, S=S, drops=(d_att, d_proj, d_mlp), act=(d_act1, d_act2))
         return x2o.view(N, S, D), (t.view(N, S, D) if t is not None else None)
 
@@ -263,7 +263,7 @@ class Engine:
                                  st.alibi_slopes, alibi_scale, H, g[P + "alibi_scale"].view(-1), drop=d_att,
                                  bias_grad=g[prefix + "attn.qkv.bias"])
         dq2 = dqkv.view(N * S, 3 * D)
-        ops.linear_wgrad_pair(sv["att"].view(N * S, D), ds1d, g[prefix + "attn.proj.weight"],
+        ops.linear_wgrad_pair(sv["att2"], ds1d, g[prefix + "attn.proj.weight"],
                               sv["x"], dq2, g[prefix + "attn.qkv.weight"])
         dxin = ops.linear(dq2, sp.wt[prefix + "attn.qkv.weight"], res=ds1)
         return dxin.view(N, S, D)
@@ -618,6 +618,7 @@ class Engine:
         # kept frames as flat rows n*T + t: the last pos-conv layer is only evaluated there (compact), with the
         # gathered local features added in its LayerNorm kernel
         rows = (torch.arange(N, device=ids_keep.device, dtype=torch.int32).unsqueeze(1) * T + ids_keep).reshape(-1)
+        ops.X3_KEEP = self.x3 and save          # bf16x3: the split images of the saved activations serve the backward's weight gradients
         tok_f = ops.gather_tokens(feats, ids_keep, cb=cb)                      # (N,K,D)
         tok = self.posconv_fwd(feats, sp, p, mask_u8, cb, save=save, rows=rows, post=tok_f.view(N * K, D)).view(N, K, D)
         x_pos = tok
@@ -644,6 +645,7 @@ class Engine:
         # ---- decoder + loss
         dec_in = ops.decoder_input(x, noise, ids_restore, drop=d_dec)          # (N,T,D)
         dec_out = self.decoder_fwd(dec_in, save=save)
+        ops.X3_KEEP = False
         loss_rows = torch.empty(N, T, D, dtype=torch.float32, device=x.device) if keep_debug else None
         if join is not None:
             torch.cuda.current_stream().wait_event(join)

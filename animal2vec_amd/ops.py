@@ -125,19 +125,32 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 # _a2v_x3), not in a table keyed by address: a freed weight's address is handed to the next allocation.
 X3_CONV_FUSED = os.environ.get("A2V_X3_CONV_FUSED", "1") != "0"     # 64 outputs per group: the three split products of a 64-wide grouped conv in one launch (A/B switch)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
+X3_KEEP = False          # set by the engine during the student's saving forward: operand images stay on the activations for the backward
 X3_BACKWARD = False      # set by the engine while it runs a backward: a gradient tensor is the left operand of its input-gradient product
                          # AND of a weight-gradient product -- its [hi | lo | hi] image is made once and kept on the tensor object
                          # between the two calls (never in the forward: the saved activations would keep their images alive)
 
 
-def _x3_m0(t):
-    """the [hi | lo | hi] image of a (M, K) fp32 tensor; cached on the tensor object during a backward"""
-    img = getattr(t, "_a2v_x3m0", None)
-    if img is None:
-        img = split_bf16(t, 0)
-        if X3_BACKWARD:
-            t._a2v_x3m0 = img
+def _x3_cached(t, mode, holder=None):
+    """The split image of a 2-D fp32 tensor (mode 0: [hi | lo | hi], mode 2: [hi ; lo]), kept on a tensor OBJECT (`holder`, default
+    t itself; never in a table keyed by address: a freed tensor's address is handed to the next allocation) while the engine says a
+    second product will want it: during a backward (a gradient is the left operand of its input-gradient product and of a
+    weight-gradient product) and during the student's saving forward (the input of a Linear / conv is the operand of its
+    weight-gradient product in the backward: the engine saves the very object it passed to the forward product)."""
+    key = "_a2v_x3m0" if mode == 0 else "_a2v_x3m2"
+    h = t if holder is None else holder
+    M, K = t.shape
+    img = getattr(h, key, None)
+    if img is not None and tuple(img.shape) == ((M, 3 * K) if mode == 0 else (2 * M, K)):
+        return img
+    img = split_bf16(t, mode)
+    if X3_BACKWARD or X3_KEEP:
+        setattr(h, key, img)
     return img
+
+
+def _x3_m0(t):
+    return _x3_cached(t, 0)
 
 
 def split_bf16(x, mode, out=None, ldo=0):
@@ -237,7 +250,7 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
             and N <= 64 and N % 4 == 0 and cv % 8 == 0 and 2 <= k <= 24):
         # bf16x3 on the slab kernel (64-wide taps): X_hi W_hi (+ bias, residual), then X_lo W_hi and X_hi W_lo accumulated through R = out
         R_ = Bsrc * T_in
-        xs = split_bf16(x.view(R_, Cp), 2)
+        xs = _x3_cached(x.view(R_, Cp), 2, holder=x)
         xh, xl = xs[:R_].view(x.shape), xs[R_:].view(x.shape)
         kw = dict(M=M, N=N, K=k * Cg, G=G, T_in=T_in, T_out=T_out, stride=stride, pad=pad, taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1),
                   a_bstride=x.stride(0), a_goff=cv if G > 1 else 0, rowmask=rowmask, bdiv=bdiv, ldb=w_packed.stride(-2),
@@ -330,9 +343,9 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
     if X3_WGRAD and x.dtype == torch.float32 and dy.dtype == torch.float32 and x.is_contiguous() and dy.is_contiguous() and Cg % 8 == 0:
         # bf16x3: dY_hi^T X_hi + dY_hi^T X_lo + dY_lo^T X_hi through the bf16 weight-gradient kernels (fp32 accumulation)
         R = x.shape[0] * x.shape[1]
-        xs = split_bf16(x.view(R, Cp), 2)
+        xs = _x3_cached(x.view(R, Cp), 2, holder=x)
         d2 = dy.reshape(-1, n_out)
-        ds = split_bf16(d2, 2)
+        ds = _x3_cached(d2, 2, holder=dy)
         Rd = d2.shape[0]
         xh, xl = xs[:R].view(x.shape), xs[R:].view(x.shape)
         dh, dl = ds[:Rd].view(dy.shape), ds[Rd:].view(dy.shape)

@@ -318,6 +318,7 @@ def parity_mode_leg(cfg, L, dev, args, clips=16, steps=2):
     def leg(x3):
         tr = PretrainTrainer(cfg, dtype=torch.float32, device=dev, seed=0, x3=x3)
         mbs = [make_microbatch(cfg, clips, L, 0, 4242, dev, masks="sampled")]
+        tr.prime_memory(clips, L)                 # untimed, as the headline: pools sized above the kept-frame counts the sampler draws
         tr.train_step(mbs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

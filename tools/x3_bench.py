@@ -18,6 +18,7 @@ def main():
     x3 = "--f32" not in sys.argv
     tr = PretrainTrainer(cfg, dtype=torch.float32, device=dev, seed=0, x3=x3)
     mbs = [bench.make_microbatch(cfg, 8, 80000, 0, 4242, dev, masks="sampled")]
+    tr.prime_memory(8, 80000)
     tr.train_step(mbs)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
