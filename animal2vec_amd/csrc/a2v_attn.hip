@@ -2133,6 +2133,324 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_seq48_kernel(AttnBwdArgs 
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16x3 (dtype A2V_BF16X3), HD = 64, S <= 160: the whole-sequence backward above for fp32 q / k / v / dO / O / dqkv with every one
+// of its five products as three exact bf16 products over split operands (x = hi + lo: X_lo Y_hi + X_hi Y_lo + X_hi Y_hi, fp32
+// accumulation) -- fp32-grade gradients at a third of the bf16 matrix rate instead of the 1/16 of v_mfma_f32_16x16x4_f32, on which
+// the parity mode's student attention backward ran (6 % of its step).  Q and dO live in LDS as hi and lo dual-use images, the key
+// block's K tile and the dS rows likewise; K / V fragments, P and dS are split in registers.  Softmax, ALiBi, dropout, delta and
+// the d alibi_scale sum are the fp32 arithmetic of the kernels above (delta from the fp32 O and dO in global memory).
+#define AX3_LDS (4 * AB48_QROWS * 128 + 2 * 64 * 128 + 2 * AB48_ROWS * 128 + 5 * AB48_ROWS * 4 + 3 * 64 * 4)
+
+template <bool DROP, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_x3_kernel(AttnBwdArgs a, const float* __restrict__ o_fwd) {
+  constexpr int HD = 64, ND = 4, NT = 64 * NW, KB = 16 * NW, NTQ = (AB48_ROWS / 16 + NW - 1) / NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const sQh = smem;                                  // [160][64] dual-use images, hi / lo
+  char* const sQl = sQh + AB48_QROWS * 128;
+  char* const sDOh = sQl + AB48_QROWS * 128;
+  char* const sDOl = sDOh + AB48_QROWS * 128;
+  char* const sKth = sDOl + AB48_QROWS * 128;              // [64][64] tr images of the key block's K (rows 16 NW.. stay zero)
+  char* const sKtl = sKth + 64 * 128;
+  char* const sDSh = sKtl + 64 * 128;                      // [160 q][64 kv] row images (cols 16 NW.. stay zero)
+  char* const sDSl = sDSh + AB48_ROWS * 128;
+  float* const sLse = (float*)(sDSl + AB48_ROWS * 128);    // lse * log2(e); +inf on padded rows
+  float* const sDelta = sLse + AB48_ROWS;
+  float* const sPosQ = sDelta + AB48_ROWS;
+  unsigned* const sRowT = (unsigned*)(sPosQ + AB48_ROWS);  // dropout row terms
+  float* const sMd = (float*)(sRowT + AB48_ROWS);
+  float* const sBias = sMd + AB48_ROWS;                    // [3][64]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int fr = lane & 15, g = lane >> 4;
+  const int qq = (lane & 15) >> 2, pp = lane & 3;
+  const int h = blockIdx.y, n = blockIdx.z;
+  const int S = a.S, H = a.H;
+  const long long rowstride = 3LL * H * HD;
+  const long long orow = (long long)H * HD;
+  const float* qkv = (const float*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  const float* dO = (const float*)a.d_out + (long long)n * S * orow + (long long)h * HD;
+  const float* Of = o_fwd + (long long)n * S * orow + (long long)h * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float slope = a.slopes[h];
+  const float asc = a.alibi_scale[h];
+  const float coef2 = -slope * fmaxf(asc, 0.f) * LOG2E;
+  const float scale2 = a.scale * LOG2E;
+  const int nsub = (S + 15) >> 4;
+  const int nkb = (S + KB - 1) / KB;
+
+  float kraw[2][8], vraw[2][8], ktraw[2][8];               // the next key block's operands, fp32 as loaded
+  int praw = 0;
+#define AX3_LD8(dst_, src_) { const f32x4 a_ = *(const f32x4*)(src_), b_ = *(const f32x4*)((src_) + 4); \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { (dst_)[e_] = a_[e_]; (dst_)[4 + e_] = b_[e_]; } }
+#define AX3_FETCH(kb_)                                                                                          \
+  {                                                                                                             \
+    const int kvc_ = min((kb_) * KB + wid * 16 + fr, S - 1);                                                    \
+    const float* krow_ = qkv + (long long)kvc_ * rowstride + (long long)H * HD + g * 8;                         \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                          \
+      AX3_LD8(kraw[ks], krow_ + ks * 32)                                                                        \
+      AX3_LD8(vraw[ks], krow_ + (long long)H * HD + ks * 32)                                                    \
+    }                                                                                                           \
+    if (a.pos) praw = a.pos[(long long)n * S + kvc_];                                                           \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                             \
+      const int c = tid + NT * u, r = c >> 3, ch = c & 7;                                                       \
+      AX3_LD8(ktraw[u], qkv + (long long)min((kb_) * KB + min(r, KB - 1), S - 1) * rowstride + (long long)H * HD + ch * 8) \
+    }                                                                                                           \
+  }
+  {
+    constexpr int NQ = (AB48_QROWS * 8 + NT - 1) / NT;     // chunks (8 elements) of Q and of dO per thread
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int c = tid + NT * u, r = c >> 3, ch = c & 7;
+      if (c < AB48_QROWS * 8) {
+        float qv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dv_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (r < S) {
+          AX3_LD8(qv, qkv + (long long)r * rowstride + ch * 8)
+          AX3_LD8(dv_, dO + (long long)r * orow + ch * 8)
+        }
+        bf16x8 hh, ll;
+        split8(qv, hh, ll);
+        *(bf16x8*)(sQh + dual_off(r, ch)) = hh;
+        *(bf16x8*)(sQl + dual_off(r, ch)) = ll;
+        split8(dv_, hh, ll);
+        *(bf16x8*)(sDOh + dual_off(r, ch)) = hh;
+        *(bf16x8*)(sDOl + dual_off(r, ch)) = ll;
+      }
+    }
+    AX3_FETCH(0)
+    if (a.bias_sum && tid < 192) sBias[tid] = 0.f;
+    // key rows / dS columns beyond the block's 16 NW keys: zero for good
+    if (NW == 3 && tid < 128) {
+      *(uint4*)(sKth + 48 * 128 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+      *(uint4*)(sKtl + 48 * 128 + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+    }
+#pragma unroll
+    for (int u = 0; u < (AB48_ROWS * 8 + NT - 1) / NT; ++u)
+      if (tid + NT * u < AB48_ROWS * 8) {
+        *(uint4*)(sDSh + (tid + NT * u) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        *(uint4*)(sDSl + (tid + NT * u) * 16) = make_uint4(0u, 0u, 0u, 0u);
+      }
+    if (tid < AB48_ROWS) {                           // per-row operands; delta from the fp32 O and dO
+      const bool rok = tid < S;
+      float dl = 0.f, lse_r = INFINITY, pos_r = 0.f, md_r = 0.f;
+      if (rok) {
+#pragma unroll 4
+        for (int u = 0; u < 16; ++u) {
+          const f32x4 ov = *(const f32x4*)(Of + (long long)tid * orow + 4 * u);
+          const f32x4 dv4 = *(const f32x4*)(dO + (long long)tid * orow + 4 * u);
+          dl += ov[0] * dv4[0] + ov[1] * dv4[1] + ov[2] * dv4[2] + ov[3] * dv4[3];
+        }
+        lse_r = a.lse[((long long)n * H + h) * S + tid] * LOG2E;
+        pos_r = a.pos ? (float)a.pos[(long long)n * S + tid] : (float)tid;
+        if (a.mdist) md_r = a.mdist[((long long)n * H + h) * S + tid];
+      }
+      sDelta[tid] = dl;
+      sLse[tid] = lse_r;
+      sPosQ[tid] = pos_r;
+      sMd[tid] = md_r;
+      sRowT[tid] = drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + min(tid, S - 1)));
+    }
+  }
+
+  f32x4 dq[NTQ][ND];
+#pragma unroll
+  for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+    for (int i = 0; i < ND; ++i) dq[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dal = 0.f;
+  int ds_off[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ql = 4 * g + r, col = wid * 16 + fr;
+    ds_off[r] = ql * 128 + ((((col >> 3) ^ ((ql >> 1) & 7)) & 7) << 4) + ((col & 7) << 1);
+  }
+
+#pragma unroll 1
+  for (int kb = 0; kb < nkb; ++kb) {
+    const int kv = kb * KB + wid * 16 + fr;
+    const bool kv_ok = kv < S;
+    const int kvc = kv_ok ? kv : S - 1;
+    const float pos_kv = a.pos ? (float)praw : (float)kvc;
+    bf16x8 kfh[2], kfl[2], vfh[2], vfl[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) { split8(kraw[ks], kfh[ks], kfl[ks]); split8(vraw[ks], vfh[ks], vfl[ks]); }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int c = tid + NT * u, r = c >> 3, ch = c & 7;
+      if (r < KB) {
+        bf16x8 hh, ll;
+        split8(ktraw[u], hh, ll);
+        *(bf16x8*)(sKth + trimg_off<HD>(r, ch * 8)) = hh;
+        *(bf16x8*)(sKtl + trimg_off<HD>(r, ch * 8)) = ll;
+      }
+    }
+    if (kb + 1 < nkb) AX3_FETCH(kb + 1)
+    if (kb == 0) __syncthreads();                  // Q / dO images and the per-row operands
+
+    f32x4 dk[ND], dv[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) { dk[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; dv[i] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    auto rows16 = [&](int rb, f32x4& p_o, f32x4& ds_o) {
+      f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int o_ = dual_off(rb + fr, ks * 4 + g);
+        const bf16x8 qh_ = *(const bf16x8*)(sQh + o_), ql_ = *(const bf16x8*)(sQl + o_);
+        const bf16x8 dh_ = *(const bf16x8*)(sDOh + o_), dl_ = *(const bf16x8*)(sDOl + o_);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql_, kfh[ks], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh_, kfl[ks], sacc, 0, 0, 0);
+        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh_, kfh[ks], sacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl_, vfh[ks], pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh_, vfl[ks], pacc, 0, 0, 0);
+        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh_, vfh[ks], pacc, 0, 0, 0);
+      }
+      const f32x4 lse4 = *(const f32x4*)(sLse + rb + 4 * g);
+      const f32x4 del4 = *(const f32x4*)(sDelta + rb + 4 * g);
+      const f32x4 pq4 = *(const f32x4*)(sPosQ + rb + 4 * g);
+      const f32x4 md4 = *(const f32x4*)(sMd + rb + 4 * g);
+      const uint4 rt4 = *(const uint4*)(sRowT + rb + 4 * g);
+      const unsigned rts[4] = {rt4.x, rt4.y, rt4.z, rt4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float dist = __builtin_fabsf(pq4[r] - pos_kv);
+        const float e2 = __builtin_fmaf(sacc[r], scale2, __builtin_fmaf(dist, coef2, -lse4[r]));
+        const float pv = kv_ok ? __builtin_amdgcn_exp2f(e2) : 0.f;
+        float mlt = 1.f;
+        if (DROP) mlt = drop_keep2(a.drop, rts[r], (unsigned)kvc) ? a.drop.scale : 0.f;
+        const float dsv = pv * __builtin_fmaf(pacc[r], mlt, -del4[r]);
+        p_o[r] = pv * mlt;
+        ds_o[r] = dsv;
+        dal = __builtin_fmaf(-dsv, dist - md4[r], dal);
+        const bf16 dh1 = (bf16)dsv;
+        *(bf16*)(sDSh + rb * 128 + ds_off[r]) = dh1;
+        *(bf16*)(sDSl + rb * 128 + ds_off[r]) = (bf16)(dsv - (float)dh1);
+      }
+    };
+    auto pair_products = [&](int pr, const f32x4& p0, const f32x4& p1, const f32x4& d0, const f32x4& d1) {
+      float pv8[8], dv8[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { pv8[r] = p0[r]; pv8[4 + r] = p1[r]; dv8[r] = d0[r]; dv8[4 + r] = d1[r]; }
+      bf16x8 pfh, pfl, dfh, dfl;
+      split8(pv8, pfh, pfl);
+      split8(dv8, dfh, dfl);
+      const int r_lo = 32 * pr + 4 * g + qq, r_hi = r_lo + 16;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int chl = 2 * i + (pp >> 1), sub = (pp & 1) << 3;
+        const int o_lo = dual_off(r_lo, chl) + sub, o_hi = dual_off(r_hi, chl) + sub;
+        const bf16x8 doh = tr_frag(sDOh + o_lo, sDOh + o_hi), dol = tr_frag(sDOl + o_lo, sDOl + o_hi);
+        const bf16x8 qfh = tr_frag(sQh + o_lo, sQh + o_hi), qfl = tr_frag(sQl + o_lo, sQl + o_hi);
+        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dol, pfh, dv[i], 0, 0, 0);
+        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doh, pfl, dv[i], 0, 0, 0);
+        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doh, pfh, dv[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfl, dfh, dk[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfh, dfl, dk[i], 0, 0, 0);
+        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfh, dfh, dk[i], 0, 0, 0);
+      }
+    };
+#pragma unroll 1
+    for (int pr = 0; pr < (nsub >> 1); ++pr) {
+      f32x4 p0, p1, d0, d1;
+      rows16(32 * pr, p0, d0);
+      rows16(32 * pr + 16, p1, d1);
+      pair_products(pr, p0, p1, d0, d1);
+    }
+    if (nsub & 1) {
+      f32x4 p0, d0;
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      rows16(16 * (nsub - 1), p0, d0);
+      pair_products(nsub >> 1, p0, z, d0, z);
+    }
+    if (kv_ok) {
+      float* dkv = (float*)a.dqkv + ((long long)n * S + kv) * rowstride + (long long)h * HD;
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        *(f32x4*)(dkv + (long long)H * HD + 16 * i + 4 * g) = dk[i] * a.scale;
+        *(f32x4*)(dkv + 2LL * H * HD + 16 * i + 4 * g) = dv[i];
+      }
+    }
+    if (a.bias_sum) {
+#pragma unroll
+      for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sk = kv_ok ? dk[i][r] * a.scale : 0.f;
+          float sv_ = kv_ok ? dv[i][r] : 0.f;
+          sk = row16_sum(sk);
+          sv_ = row16_sum(sv_);
+          if (fr == 0) {
+            atomicAdd(&sBias[64 + 16 * i + 4 * g + r], sk);
+            atomicAdd(&sBias[128 + 16 * i + 4 * g + r], sv_);
+          }
+        }
+    }
+    __syncthreads();           // dS of every row and the K tile are in LDS
+
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      if (kb * KB + 32 * ks >= S) continue;
+      const int r_lo = 32 * ks + 8 * g + qq, r_hi = r_lo + 4;
+      bf16x8 kh_[ND], kl_[ND];
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int o_lo = trimg_off<HD>(r_lo, 16 * i + 4 * pp), o_hi = trimg_off<HD>(r_hi, 16 * i + 4 * pp);
+        kh_[i] = tr_frag(sKth + o_lo, sKth + o_hi);
+        kl_[i] = tr_frag(sKtl + o_lo, sKtl + o_hi);
+      }
+#pragma unroll
+      for (int t = 0; t < NTQ; ++t) {
+        const int qg = wid + NW * t;
+        if (qg >= nsub) continue;
+        const int rq = 16 * qg + fr;
+        const int ch = ks * 4 + g;
+        const int o_ = rq * 128 + (((ch ^ ((rq >> 1) & 7)) & 7) << 4);
+        const bf16x8 ah_ = *(const bf16x8*)(sDSh + o_), al_ = *(const bf16x8*)(sDSl + o_);
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+          dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_, kh_[i], dq[t][i], 0, 0, 0);
+          dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, kl_[i], dq[t][i], 0, 0, 0);
+          dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, kh_[i], dq[t][i], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();           // the next key block overwrites the K tile and dS
+  }
+#undef AX3_FETCH
+#undef AX3_LD8
+#pragma unroll
+  for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qr = 16 * (wid + NW * t) + 4 * g + r;
+      if (qr < S) {
+        float* dst = (float*)a.dqkv + ((long long)n * S + qr) * rowstride + (long long)h * HD;
+#pragma unroll
+        for (int i = 0; i < ND; ++i) dst[16 * i + fr] = dq[t][i][r] * a.scale;
+      }
+    }
+  if (a.bias_sum) {
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      float sq = 0.f;
+#pragma unroll
+      for (int t = 0; t < NTQ; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qr = 16 * (wid + NW * t) + 4 * g + r;
+          sq += qr < S ? dq[t][i][r] * a.scale : 0.f;
+        }
+      sq += __shfl_xor(sq, 16, 64);
+      sq += __shfl_xor(sq, 32, 64);
+      if (g == 0) atomicAdd(&sBias[16 * i + fr], sq);
+    }
+    __syncthreads();
+    if (tid < 192) atomicAdd(a.bias_sum + (long long)(tid >> 6) * H * HD + (long long)h * HD + (tid & 63), sBias[tid]);
+  }
+  dal = wave_sum(dal);
+  dalibi_finish(dal, a.dalibi, h, a.dal_part, slope, asc);
+}
+
+// ---------------------------------------------------------------------------------------------
 // bf16, HD = 64, long sequences (finetuning attends over all T = 2000 frames): two passes, no atomics, no fp32 dQ
 // scratch.  MODE 0 (dK, dV): a workgroup owns 128 keys (32 per wave, as B-operand fragments in registers) and
 // streams the queries; MODE 1 (dQ): it owns 128 queries and streams the keys.  The streamed side comes through LDS
@@ -2494,6 +2812,7 @@ static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delt
 // 1 when a2v_attention_bwd writes dQ directly into the q slot of dqkv for this (dtype, S) (dq32 unused, may be
 // NULL); 0 when dQ is left in dq32 (fp32, zeroed by the caller) and must be cast into dqkv afterwards.
 extern "C" int a2v_attention_bwd_direct_dq(int dtype, int S, int HD) {
+  if (dtype == A2V_BF16X3) return HD == 64 && S <= AB48_ROWS ? 1 : 0;
   if (dtype != A2V_BF16) return 0;
   if (S <= 64 * A2V_ATTN_SEQ_TILES) return 1;
   return HD == 64 && g_a2v_attn_long ? 1 : 0;
@@ -2503,6 +2822,7 @@ extern "C" int a2v_attention_bwd_direct_dq(int dtype, int S, int HD) {
 // the caller casts it into the q slot of dqkv (a2v_cast2d).
 // 1 when a2v_attention_bwd can also accumulate the column sums of dqkv (qkv_bias_grad) for this (dtype, S, HD)
 extern "C" int a2v_attention_bwd_fused_bias(int dtype, int S, int HD) {
+  if (dtype == A2V_BF16X3) return HD == 64 && S <= AB48_ROWS ? 1 : 0;
   return dtype == A2V_BF16 && HD == 64 && S <= ABS_ROWS && g_a2v_attn_long != 2 ? 1 : 0;
 }
 
@@ -2519,6 +2839,26 @@ extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, co
     if (HD == 64) return attn_bwd_launch<bf16, 64>(a, out, delta, stream);
     if (HD == 32) return attn_bwd_launch<bf16, 32>(a, out, delta, stream);
     return A2V_ERR_ARG;
+  }
+  if (dtype == A2V_BF16X3) {          // fp32 storage; S <= 160 at HD = 64: split products on the bf16 matrix cores, else the fp32 kernels
+    if (HD == 64 && S <= AB48_ROWS) {
+      const int ws = a.dalibi ? a2v_stream_slot(stream) : -1;
+      const dim3 grid(1, H, N);
+      a.dal_part = (a.dalibi && ws >= 0 && (long long)grid.y * grid.z <= A2V_DAL_PART_MAX) ? ws + 1 : 0;
+      const bool dr = a.drop.thresh != 0;
+      const bool four = (S + 63) / 64 < (S + 47) / 48;
+#define AX3_GO(D_, W_)                                                                                                       \
+  {                                                                                                                           \
+    (void)hipFuncSetAttribute((const void*)attn_bwd_x3_kernel<D_, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, AX3_LDS);   \
+    hipLaunchKernelGGL((attn_bwd_x3_kernel<D_, W_>), grid, dim3(64 * W_), AX3_LDS, stream, a, (const float*)out);            \
+  }
+      if (four) { if (dr) AX3_GO(true, 4) else AX3_GO(false, 4) } else { if (dr) AX3_GO(true, 3) else AX3_GO(false, 3) }
+#undef AX3_GO
+      if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(H), dim3(256), 0, stream, a.dalibi, (int)(grid.x * grid.z), ws);
+      A2V_CHECK_LAUNCH();
+      return A2V_OK;
+    }
+    dtype = A2V_F32;
   }
   if (dtype == A2V_F32) {
     if (HD == 64) return attn_bwd_launch<float, 64>(a, out, delta, stream);

@@ -124,6 +124,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 # x3=True does that at every refresh); activations are split on the fly.  The image hangs on the weight TENSOR OBJECT (attribute
 # _a2v_x3), not in a table keyed by address: a freed weight's address is handed to the next allocation.
 X3_CONV_FUSED = os.environ.get("A2V_X3_CONV_FUSED", "1") != "0"     # 64 outputs per group: the three split products of a 64-wide grouped conv in one launch (A/B switch)
+X3_ATTN_BWD = os.environ.get("A2V_X3_ATTN_BWD", "1") != "0"          # whole-sequence attention backward with split products (A/B switch)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
 X3_KEEP = False          # set by the engine during the student's saving forward: operand images stay on the activations for the backward
 X3_BACKWARD = False      # set by the engine while it runs a backward: a gradient tensor is the left operand of its input-gradient product
@@ -387,12 +388,14 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, dro
     N, S, W = qkv.shape
     HD = W // (3 * H)
     dqkv = _EL(qkv)
-    direct = bool(_L().a2v_attention_bwd_direct_dq(dt(qkv), S, HD))
-    fused = bias_grad is not None and bool(_L().a2v_attention_bwd_fused_bias(dt(qkv), S, HD))
+    # bf16x3 run (fp32 storage): whole sequences of up to 160 tokens at HD = 64 take the split-product backward (attn_bwd_x3_kernel)
+    code = BF16X3 if (X3_WGRAD and X3_ATTN_BWD and qkv.dtype == torch.float32 and HD == 64) else dt(qkv)
+    direct = bool(_L().a2v_attention_bwd_direct_dq(code, S, HD))
+    fused = bias_grad is not None and bool(_L().a2v_attention_bwd_fused_bias(code, S, HD))
     dq32 = None if direct else torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
     delta = _E(N, H, S, dtype=torch.float32, device=qkv.device)
     md = lse[1] if lse.dim() == 4 else None           # (a bare (N,H,S) lse: the uncentred arithmetic)
-    rc = _L().a2v_attention_bwd(dt(qkv), ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(md), ptr(delta), ptr(dqkv), ptr(dq32),
+    rc = _L().a2v_attention_bwd(code, ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(md), ptr(delta), ptr(dqkv), ptr(dq32),
                                 ptr(dalibi), ptr(bias_grad) if fused else None, ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
                                 HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_bwd")

@@ -1416,6 +1416,48 @@ def test_linear_tail_round_goes_to_the_small_kernel(ops):
     assert rel_err(a1[rows_main:].float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("S,p_", [(151, 0.1), (97, 0.0), (160, 0.1), (48, 0.0), (129, 0.1)])
+def test_attention_bwd_bf16x3_matches_fp64(ops, S, p_):
+    """The student's attention backward of the bf16x3 mode (attn_bwd_x3_kernel: whole sequence, S <= 160, HD = 64, every product as
+    three bf16 products over split operands) against fp64 autograd of the same fp32 operands: dqkv 3e-5, the bias gradient (column
+    sums, fused) 3e-5, d alibi_scale by its backward-error bound; S = 151 / 160 / 129 on four waves (64-key blocks), 97 / 48 on three;
+    sorted random positions, attention dropout; and against the fp32-MFMA kernel of the same call."""
+    N, H, hd, seed = 2, 3, 64, 31
+    g = torch.Generator().manual_seed(S)
+    qkv = torch.randn(N, S, 3 * H * hd, generator=g).requires_grad_(True)
+    pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = (torch.rand(H, generator=g) + 0.5).requires_grad_(True)
+    q, k, v = qkv.double().reshape(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = O.alibi_bias_from_positions(pos.long(), H, sc.double().view(1, 1, H, 1, 1))
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1) + bias).softmax(-1)
+    drop = None
+    if p_ > 0:
+        keep = ops.dropout_mask2d(N * H * S, S, p_, seed).view(N, H, S, S).double().cpu()
+        att = att * keep / (1 - p_)
+        drop = (p_, seed)
+    ref = (att @ v).transpose(1, 2).reshape(N, S, H * hd)
+    do = torch.randn(N, S, H * hd, generator=g)
+    ref.backward(do.double())
+    qd, dod = qkv.detach().cuda(), do.cuda()
+    args = (pos.cuda(), slopes.cuda(), sc.detach().cuda(), H)
+    ops.X3_WGRAD = True
+    try:
+        out, lse = ops.attention_fwd(qd, *args, drop=drop)
+        dal = torch.zeros(H, device="cuda")
+        bg = torch.zeros(3 * H * hd, device="cuda")
+        dqkv = ops.attention_bwd(qd, out, dod, lse, *args, dal, drop=drop, bias_grad=bg)
+    finally:
+        ops.X3_WGRAD = False
+    dal32 = torch.zeros(H, device="cuda")
+    dq32 = ops.attention_bwd(qd, out, dod, lse, *args, dal32, drop=drop)
+    assert rel_err(out, ref) < 3e-5
+    assert rel_err(dqkv, qkv.grad) < 3e-5, rel_err(dqkv, qkv.grad)
+    assert rel_err(dqkv, dq32) < 3e-5
+    assert rel_err(bg, qkv.grad.sum((0, 1))) < 3e-5
+    assert rel_err(dal, sc.grad) < 2e-3 and rel_err(dal32, sc.grad) < 2e-3, (rel_err(dal, sc.grad), rel_err(dal32, sc.grad))
+
+
 @pytest.mark.parametrize("S,kind", [(151, "kept"), (700, "arange"), (2000, "arange")])
 def test_attention_fwd_bf16x3_matches_fp64(ops, S, kind):
     """A2V_BF16X3 attention forward: fp32 in / out, both products as three exact bf16 products (K, V split when staged, Q when
