@@ -37,7 +37,9 @@ struct GemmArgs {
                                  // (the tail rows the persistent kernel hands to the 128 x 128 kernel) keeps the whole tensor's mask
 };
 
-enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64, F_DACT = 128 };
+enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64, F_DACT = 128, F_X3IMG = 256 };
+// F_X3IMG (dtype A2V_BF16X3 on the persistent kernel only): C is written as the bf16 [hi | lo | hi] split image of the result (row pitch
+// ldc >= 3 N bf16 elements) instead of fp32 -- for a result that only further products read (the Mlp's hidden activation)
 // F_DACT (with F_GELU | F_STORE_PRE): C2 receives gelu'(acc + bias) instead of the pre-activation -- both come out of one
 // evaluation of the erf parts -- and (with F_GELU_BWD) R is that derivative: the backward epilogue multiplies, no transcendental.
 

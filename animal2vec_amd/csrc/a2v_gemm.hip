@@ -461,6 +461,11 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+  if ((flags & F_X3IMG) && (dtype != A2V_BF16X3 || rowidx || !a2v_launch_nt_x3_p8(g, stream))) return A2V_ERR_UNSUPPORTED;
+  if (flags & F_X3IMG) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16X3) {         // split bf16 operands, fp32 outputs: the persistent 8-phase kernel, else the 128 x 128 LDS-DMA kernel
     if (!(!rowidx && a2v_launch_conv_slab_o32(g, stream)) && !(!rowidx && a2v_launch_nt_x3_p8(g, stream)) &&
         !a2v_launch_nt_x3_fast(g, stream))

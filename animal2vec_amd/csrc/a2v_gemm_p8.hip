@@ -412,7 +412,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
         const int fre = le & 15, fqe = le >> 4;
         const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
         float* const Ct = (float*)g.C + tile_off;
-        float* const C2t = (float*)g.C2 + tile_off;
+        // (F_X3IMG: ldc is the pitch of the bf16 image in C; the fp32 pre-activation / derivative tensor C2 is dense, pitch N)
+        const long long ldc2 = (flags & F_X3IMG) ? (long long)g.N : g.ldc;
+        float* const C2t = (float*)g.C2 + ((long long)T.mc * ldc2 + (long long)grp * g.c_goff + T.n0);
         const float* const Rt = (const float*)g.R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0);
         const int rskip = T.m0 - T.mc;
         const int rlo = wr * 64 + fre, rhi = 128 + wr * IH * 16 + fre;
@@ -433,9 +435,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               float gr[8];
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] = gelu_with_grad(v[q], gr[q]);
-              Vec8<float>::store(C2t + eo, gr);
+              Vec8<float>::store(C2t + (long long)row * ldc2 + cl, gr);
             } else {
-              if (flags & F_STORE_PRE) Vec8<float>::store(C2t + eo, v);
+              if (flags & F_STORE_PRE) Vec8<float>::store(C2t + (long long)row * ldc2 + cl, v);
               if (flags & F_GELU) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
@@ -457,7 +459,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
                 for (int q = 0; q < 8; ++q) v[q] *= (flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
               }
             }
-            Vec8<float>::store(Ct + eo, v);
+            if (flags & F_X3IMG) {         // the result leaves as its [hi | lo | hi] image (bf16, pitch ldc): nothing reads it as fp32
+              bf16* const ci = (bf16*)g.C + ((long long)(T.mc + row) * g.ldc + T.n0 + cl);
+              bf16x8 hh, ll;
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { hh[q] = (bf16)v[q]; ll[q] = (bf16)(v[q] - (float)hh[q]); }
+              *(bf16x8*)ci = hh;
+              *(bf16x8*)(ci + g.N) = ll;
+              *(bf16x8*)(ci + 2 * g.N) = hh;
+            } else {
+              Vec8<float>::store(Ct + eo, v);
+            }
             if (flags & F_COLSUM) {
               const float own = row >= rskip ? 1.f : 0.f;
 #pragma unroll
@@ -776,6 +788,7 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   const bool c_r_overlap = g.R != nullptr && r0 < c1 && c0 < r1;
   const bool direct = (g_a2v_p8_direct || out32) && contiguous && !c_r_overlap && g.G == 1 && (long long)256 * g.ldc * 2 < (1LL << 31) && (long long)256 * g.ldr * 2 < (1LL << 31);
   if (out32 && !direct) return false;
+  if ((g.flags & F_X3IMG) && (!out32 || (g.flags & (F_RES | F_GELU_BWD | F_DROPOUT)) || g.ldc < 3LL * g.N || g.ldc % 8 || g.G != 1)) return false;
   // 32-bit byte offsets inside one group's operands
   const long long a_span = ((long long)((g.M - 1) / a.T_out / a.bdiv) * a.bstride + (long long)a.T_out * a.pitch + g.K) * 2;
   const long long b_span = ((long long)g.N * g.ldb + g.K) * 2;

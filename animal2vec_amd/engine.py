@@ -204,8 +204,9 @@ class Engine:
         hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
         hpre = ops._E(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
         # (dact: what is kept for the backward is gelu'(fc1 out), formed with gelu in one evaluation -- not the pre-activation)
+        # (bf16x3: nothing but fc2's two products reads the hidden activation -- it leaves the epilogue as its split image, ops.X3Image)
         gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre,
-                          drop=d_act1, dact=_DACT)
+                          drop=d_act1, dact=_DACT, out_image=self.x3)
         t = None
         s2 = None
         if want_t or d_act2 is not None:

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, check
+from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_X3IMG, check
 
 
 def _L():
@@ -86,7 +86,7 @@ def _drop(drop):
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride,
               a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
-              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False, x3=None):
+              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False, x3=None, x3img=False):
     """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add.
     rowidx (int32, M entries): GEMM row m reads the im2col row of flat index rowidx[m]; out stays compact.
     x3=True: x and w are bf16 split images (split_bf16), out / res / pre_out fp32 (include/a2v.h: A2V_BF16X3);
@@ -108,6 +108,8 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
         flags |= EPI_COLSUM
     if drop is not None and drop[0] > 0:
         flags |= EPI_DROPOUT
+    if x3img:                          # out is the bf16 [hi | lo | hi] image of the result (pitch ldc), include/a2v.h: A2V_EPI_X3IMG
+        flags |= EPI_X3IMG
     dp, ds = (drop if drop is not None and drop[0] > 0 else (0.0, 0))
     dtype_code = dt(x) if x3 is None else (BF16X3S if x3 == "stacked" else BF16X3)
     args = (dtype_code, ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
@@ -124,6 +126,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 # x3=True does that at every refresh); activations are split on the fly.  The image hangs on the weight TENSOR OBJECT (attribute
 # _a2v_x3), not in a table keyed by address: a freed weight's address is handed to the next allocation.
 X3_CONV_FUSED = os.environ.get("A2V_X3_CONV_FUSED", "1") != "0"     # 64 outputs per group: the three split products of a 64-wide grouped conv in one launch (A/B switch)
+X3_OUT_IMAGE = os.environ.get("A2V_X3_OUT_IMAGE", "1") != "0"         # the Mlp's hidden activation leaves fc1 as its split image only (A/B switch)
 X3_ATTN_BWD = os.environ.get("A2V_X3_ATTN_BWD", "1") != "0"          # whole-sequence attention backward with split products (A/B switch)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
 X3_KEEP = False          # set by the engine during the student's saving forward: operand images stay on the activations for the backward
@@ -150,8 +153,21 @@ def _x3_cached(t, mode, holder=None):
     return img
 
 
+class X3Image:
+    """A (M, K) fp32 activation of a bf16x3 run that exists ONLY as its [hi | lo | hi] split image -- the Mlp's hidden activation,
+    which nothing but two products reads (fc2's forward, fc2's weight gradient): linear(..., out_image=True) writes the image from
+    the GEMM epilogue (A2V_EPI_X3IMG) and skips the fp32 tensor and its split pass.  Only the split-product paths accept one."""
+    dtype = torch.float32
+
+    def __init__(self, img, M, K):
+        self.img, self.shape, self.device = img, (M, K), img.device
+
+    def stride(self, i):
+        return (self.shape[1], 1)[i]
+
+
 def _x3_m0(t):
-    return _x3_cached(t, 0)
+    return t.img if isinstance(t, X3Image) else _x3_cached(t, 0)
 
 
 def split_bf16(x, mode, out=None, ldo=0):
@@ -212,15 +228,26 @@ def _x3_image(w, M):
     return ent[1] if (M >= 1024 and N % 256 == 0 and (3 * K) % 128 == 0 and 3 * K >= 256 and w.stride(0) == K) else None
 
 
-def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None, drop=None, dact=False):
-    """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w/out/res row-major 2-D (leading dims from strides)."""
+def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None, pre_out=None, colsum=None, drop=None, dact=False,
+           out_image=False):
+    """out[M,N] = epi(x[M,K] @ w[N,K]^T).  x/w/out/res row-major 2-D (leading dims from strides).
+    out_image (bf16x3 runs): where the split-product path takes this product and the result's own products will too, the result is
+    returned as an X3Image (written by the epilogue) instead of an fp32 tensor."""
     M, K = x.shape
     N = w.shape[0]
     assert w.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
-    if out is None:
-        out = _E(M, N, dtype=x.dtype, device=x.device)
     r = gelu_bwd_aux if gelu_bwd_aux is not None else res
     img = _x3_image(w, M) if x.dtype == torch.float32 else None
+    if isinstance(x, X3Image) and img is None:
+        raise RuntimeError("an image-only activation needs the split-product path (registered weight image, M >= 1024)")
+    if (out_image and img is not None and X3_WGRAD and X3_OUT_IMAGE and out is None and r is None and (drop is None or drop[0] <= 0)
+            and M >= 2048 and N % 256 == 0):
+        oimg = _E(M, 3 * N, dtype=torch.bfloat16, device=w.device)
+        conv_gemm(_x3_m0(x), img, oimg, M=M, N=N, K=3 * K, T_in=M, T_out=M, Cg=3 * K, a_pitch=3 * K, a_bstride=0, ldb=3 * K,
+                  ldc=3 * N, bias=bias, gelu=gelu, pre_out=pre_out, colsum=colsum, dact=dact, x3=True, x3img=True)
+        return X3Image(oimg, M, N)
+    if out is None:
+        out = _E(M, N, dtype=x.dtype, device=w.device)
     if img is not None:
         xs = _x3_m0(x)
         return conv_gemm(xs, img, out, M=M, N=N, K=3 * K, T_in=M, T_out=M, Cg=3 * K, a_pitch=3 * K, a_bstride=0, ldb=3 * K,
@@ -290,8 +317,11 @@ def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1,
 def _x3_wgrad_ok(x, dy):
     M, K = x.shape
     N = dy.shape[1]
-    return (X3_WGRAD and x.dtype == torch.float32 and dy.dtype == torch.float32 and M >= 2048 and N % 256 == 0 and K % 256 == 0
-            and x.stride(1) == 1 and dy.stride(1) == 1)
+    ok = (X3_WGRAD and x.dtype == torch.float32 and dy.dtype == torch.float32 and M >= 2048 and N % 256 == 0 and K % 256 == 0
+          and x.stride(1) == 1 and dy.stride(1) == 1)
+    if isinstance(x, X3Image) and not ok:
+        raise RuntimeError("an image-only activation needs the split-product weight-gradient path")
+    return ok
 
 
 def _x3_wgrad_terms(x, dy):

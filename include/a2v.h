@@ -51,6 +51,9 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 #define A2V_EPI_STORE_PRE 16 /* also store the pre-activation (acc + bias) to C2 */
 #define A2V_EPI_COLSUM 32   /* atomically add column sums of the output to colsum (bias gradient) */
 #define A2V_EPI_DROPOUT 64  /* counter-based dropout(drop_p, drop_seed) of (acc+bias[gelu]) before the residual */
+#define A2V_EPI_X3IMG 256   /* dtype A2V_BF16X3 only (ABI 9), plain row-major products the persistent kernel takes, no RES / GELU_BWD / DROPOUT:
+                             * C is written as the bf16 [hi | lo | hi] split image of the result (row pitch ldc >= 3 N bf16 elements; a
+                             * pre-activation / derivative tensor C2 stays fp32 with row pitch N) instead of fp32 -- for a result that only further A2V_BF16X3 products read; else A2V_ERR_UNSUPPORTED */
 #define A2V_EPI_DACT 128    /* modifier.  With GELU | STORE_PRE: C2 receives gelu'(acc + bias) instead of the pre-activation (one
                              * evaluation of the erf parts gives both); with GELU_BWD: R holds that derivative and is multiplied in
                              * as it is.  The Mlp's fc1 forward / fc2 input gradient pair (timm Mlp, modules.py:328-337) uses it:
@@ -335,7 +338,7 @@ int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx,
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 9: + dtype A2V_BF16X3S of a2v_conv_gemm (nothing else changed).
+/* 9: + dtype A2V_BF16X3S and epilogue flag A2V_EPI_X3IMG of a2v_conv_gemm; a2v_attention_bwd takes dtype A2V_BF16X3 (signatures unchanged).
  * 8: + a2v_split_bf16 and dtype A2V_BF16X3 of a2v_conv_gemm; + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
  * arithmetic).  7 added a2v_decoder_input_rng and A2V_EPI_DACT over 6. */
 int a2v_abi_version(void);

@@ -1286,6 +1286,42 @@ def test_linear_bf16x3_matches_fp64(ops, M, N, K):
         del wd._a2v_x3
 
 
+def test_linear_bf16x3_image_only_output(ops):
+    """A2V_EPI_X3IMG: fc1's result (bias + GELU, with the derivative store) leaves the epilogue as its [hi | lo | hi] image only
+    (ops.X3Image): the image is the split of what the fp32-output launch writes, bit for bit, the derivative store is unchanged, and
+    the two products that read it (fc2 forward, fc2 weight gradient) give what they give from the fp32 tensor."""
+    M, K, N = 4096, 256, 512
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(M, K, generator=g).cuda()
+    w1 = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+    b1 = torch.randn(N, generator=g).cuda()
+    w2 = (torch.randn(K, N, generator=g) * N ** -0.5).cuda()
+    dy = torch.randn(M, K, generator=g).cuda()
+    ops.x3_register(w1)
+    ops.x3_register(w2)
+    ops.X3_WGRAD = True
+    try:
+        pre_a, pre_b = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+        h32 = ops.linear(x, w1, b1, gelu=True, pre_out=pre_a, dact=True)
+        himg = ops.linear(x, w1, b1, gelu=True, pre_out=pre_b, dact=True, out_image=True)
+        assert isinstance(himg, ops.X3Image) and himg.shape == (M, N)
+        assert torch.equal(himg.img, ops.split_bf16(h32, 0)) and torch.equal(pre_a, pre_b)
+        y32, yimg = ops.linear(h32, w2), ops.linear(himg, w2)
+        assert torch.equal(y32, yimg)
+        ga, gb = torch.zeros(K, N, device="cuda"), torch.zeros(K, N, device="cuda")
+        ops.linear_wgrad(h32, dy, ga)
+        ops.linear_wgrad(himg, dy, gb)
+        assert rel_err(ga, gb) < 1e-6
+        del w2._a2v_x3
+        with pytest.raises(RuntimeError):
+            ops.linear(himg, w2)
+    finally:
+        ops.X3_WGRAD = False
+        for w in (w1, w2):
+            if hasattr(w, "_a2v_x3"):
+                del w._a2v_x3
+
+
 def test_linear_wgrad_bf16x3_matches_fp64(ops):
     M, N, K = 13440, 1024, 512
     g = torch.Generator().manual_seed(4)
