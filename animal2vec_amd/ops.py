@@ -403,7 +403,7 @@ def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None)
     HD = W // (3 * H)
     out = _E(N, S, H * HD, dtype=qkv.dtype, device=qkv.device)
     lse = _E(2, N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
-    # bf16x3 run (fp32 storage): the forward's two products split on the bf16 matrix cores (the backward stays on the fp32 MFMA)
+    # bf16x3 run (fp32 storage): the forward's two products split on the bf16 matrix cores (the backward: attention_bwd below)
     code = BF16X3 if (X3_WGRAD and qkv.dtype == torch.float32 and HD in (32, 64)) else dt(qkv)
     rc = _L().a2v_attention_fwd(code, ptr(qkv), ptr(out), ptr(lse), ptr(lse[1]) if need_lse else None, ptr(pos), ptr(slopes),
                                 ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)), stream())

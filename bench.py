@@ -334,8 +334,8 @@ def parity_mode_leg(cfg, L, dev, args, clips=16, steps=2):
     try:
         v3, ms3 = leg(True)
         v1, ms1 = leg(False)
-        return dict(dtype="bf16x3 (fp32 storage; every Linear, convolution and attention-forward product = 3 exact v_mfma_f32_16x16x32_bf16 "
-                          "products over split operands, fp32 accumulation; attention backward on v_mfma_f32_16x16x4_f32; fp32 LayerNorm / softmax)",
+        return dict(dtype="bf16x3 (fp32 storage; every Linear, convolution and attention product, forward and backward, = 3 exact "
+                          "v_mfma_f32_16x16x32_bf16 products over split operands, fp32 accumulation; fp32 LayerNorm / softmax / GELU)",
                     value=round(v3, 2), unit="audio-s/s", ms_per_step=round(ms3, 2),
                     tolerance="1e-3 relative L2 against the CPU oracle on targets, decoder output, loss and every parameter gradient "
                               "(tests/test_pretrain_gpu.py::test_large_full_size_vs_oracle[bf16x3])",
