@@ -593,6 +593,7 @@ class Engine:
         dbg = {}
         ops.X3_WGRAD = self.x3
         ops.X3_BACKWARD = False
+        ops.X3_KEEP = False                  # (set for the student's part below; a forward that raised must not leave it on)
         N, K = ids_keep.shape
         # student activations at the capacity K_cap this shape was primed for (trainer.prime_memory), whatever K the masks drew
         ops.set_row_cap(N, K, self.k_cap.get((N, mask_u8.shape[1])))
