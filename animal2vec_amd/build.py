@@ -14,7 +14,7 @@ SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_gemm_p8.hip", "a2v_gemm_tn8
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in arch VGPRs (no kernel here needs > 256 registers), which removes the
 # v_accvgpr_read/write copies around every VALU use of an accumulator (softmax, epilogues: 96 of 417 VALU per attention step)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form"]
-FLAGS += os.environ.get("A2V_HIPCC_FLAGS", "").split()      # experiment switches (-DP8_NT_STORE ...): same-box A/B with tools/build_prev.sh
+FLAGS += os.environ.get("A2V_HIPCC_FLAGS", "").split()      # extra -D switches of experiment builds (same-box A/B with tools/build_prev.sh)
 # a2v_attn.hip without the SLP vectoriser: paired into v_pk_fma_f32 the ALiBi term loses the |.| source modifier (one extra
 # v_and per score), and packed fp32 ops cost more issue time between MFMAs than two plain ones
 FILE_FLAGS = {"a2v_attn.hip": ["-fno-slp-vectorize"]}
