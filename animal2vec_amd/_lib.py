@@ -95,11 +95,17 @@ def load() -> C.CDLL:
             raise A2VError(f"liba2v_hip.so does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = C.c_int
-    _lib = lib
-    # A2V_DEBUG_SET="key=value,key=value": A/B switches of a2v_debug_set for whole test / bench runs (experiments only)
+    # A2V_DEBUG_SET="key=value,key=value": A/B switches of a2v_debug_set for whole test / bench runs (experiments only).
+    # Applied BEFORE the handle is cached: a malformed or unknown entry fails every load(), never half of the switches silently.
     for kv in filter(None, os.environ.get("A2V_DEBUG_SET", "").split(",")):
-        k, v = kv.split("=")
-        lib.a2v_debug_set(int(k), int(v))
+        try:
+            k, v = kv.split("=")
+            k, v = int(k), int(v)
+        except ValueError as e:
+            raise A2VError(f"A2V_DEBUG_SET: malformed entry {kv!r} (want key=value with integers)") from e
+        if lib.a2v_debug_set(k, v) != 0:
+            raise A2VError(f"A2V_DEBUG_SET: a2v_debug_set({k}, {v}) was refused (unknown key)")
+    _lib = lib
     return lib
 
 

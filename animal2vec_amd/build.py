@@ -86,5 +86,38 @@ def build_abi_client(force: bool = False, verbose: bool = True) -> str:
     return out
 
 
+def build_variant(tag: str, defines, verbose: bool = False) -> str:
+    """Experiment / diagnostic builds next to the product library (liba2v_hip_<tag>.so, own object directory): same sources with
+    extra -D switches, e.g. build_variant("stamp", ["-DP8_STAMP"]) for tools/inkernel_clock.py.  Selected at run time with
+    A2V_LIB_PATH; never loaded by default, never built by build()."""
+    obj_dir = os.path.join(CSRC, "build_" + tag)
+    os.makedirs(obj_dir, exist_ok=True)
+    lib = os.path.join(HERE, f"liba2v_hip_{tag}.so")
+    hipcc = _hipcc()
+    hdrs = [os.path.join(CSRC, "a2v_common.h"), os.path.join(CSRC, "a2v_gemm.h")]
+
+    def cc(s):
+        src, obj = os.path.join(CSRC, s), os.path.join(obj_dir, s.replace(".hip", ".o"))
+        if _stale(obj, [src, *hdrs]):
+            cmd = [hipcc, *FLAGS, *defines, *FILE_FLAGS.get(s, []), "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode:
+                raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(cc, SOURCES))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError(f"link failed:\n{r.stderr}")
+    return lib
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:          # python -m animal2vec_amd.build --variant stamp -DP8_STAMP
+        i = sys.argv.index("--variant")
+        print(build_variant(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    else:
+        print(build(force="--force" in sys.argv))

@@ -280,7 +280,23 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 // column, so the ~64 tiles resident on one XCD at a time form an 8 x 8 patch that re-uses 8 A panels and 8
 // B panels out of its 4 MiB L2 instead of streaming every B panel from the Infinity Cache (N = 4096: 4x less
 // L2-miss traffic than row-major order).
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+// mode 1 ("W-stationary", a2v_debug_set(23), tiles_n % 4 == 0): the n-tiles are cut into groups of four and the ids walk ALL
+// m-tiles of one n-group (8 m x 4 n patches, column by column inside a patch) before the next n-group starts: the 32
+// workgroups of an XCD keep reading the same four B panels (2 MiB at K = 1024) round after round while the A panels stream,
+// and the XCDs that work on different n-groups walk the same m-range at the same time (their A reads meet in the Infinity
+// Cache).  mode 0 re-streams every B panel once per 8 m-tiles.
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn, int mode = 0) {
+  if (mode == 1) {
+    const int per_ng = tiles_m * 4;
+    const int ng = id / per_ng, r = id - ng * per_ng;
+    const int mg = r >> 5, r2 = r & 31;
+    const int first = mg * 8;
+    const int rows = tiles_m - first < 8 ? tiles_m - first : 8;
+    const int c = r2 / rows;
+    tn = ng * 4 + c;
+    tm = first + (r2 - c * rows);
+    return;
+  }
   const int gsz = 8 * tiles_n;
   const int grp = id / gsz, rem = id - grp * gsz;
   const int first = grp * 8;

@@ -68,6 +68,15 @@ __global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__
 }
 
 __device__ unsigned g_p8_ctr_all[A2V_MAX_STREAMS][9];      // one counter set per stream (a2v_stream_slot)
+#ifdef P8_STAMP
+// Diagnostic build only (MI355X_MICROARCH.md, DVFS give-back item 6; tools/inkernel_clock.py): wave 0 of every workgroup stamps
+// s_memtime (shader cycles) and s_memrealtime (100 MHz) around its whole tile loop into this buffer, which nothing else reads:
+// in-kernel clock = d(memtime) / d(memrealtime) x 100 MHz.  The product library contains none of this.
+__device__ unsigned long long g_p8_stamp[256][4];
+extern "C" int a2v_diag_p8_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p8_stamp), sizeof(unsigned long long) * 256 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
 
 struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
@@ -123,6 +132,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   const int tiles_m = (g.M + BM - 1) / BM;
   const int ntiles = tiles_m * tiles_n;
   const int grp = blockIdx.y;
+  const int tmode = (stagger >> 1) & 1;          // tile order (tile_coords): 1 = W-stationary n-groups
   const ConvA& a = g.a;
   const int lr = lane >> 3;
   const char* const abase = (const char*)a.ptr + (long long)grp * a.goff * 2;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     P8Tile t;
     const int id = xcd_remap(seq < ntiles ? seq : ntiles - 1, ntiles);
     int tm, tn;
-    tile_coords(id, tiles_m, tiles_n, tm, tn);
+    tile_coords(id, tiles_m, tiles_n, tm, tn, tmode);
     t.m0 = tm * BM;
     t.n0 = tn * 256;
     t.mc = t.m0;
@@ -320,6 +330,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   // wave of a SIMD issues LDS reads / DMA while the other owns the MFMA pipe (in lock step both queue for it at once).
   if ((stagger & 1) && wr == 1) __builtin_amdgcn_s_barrier();
 
+#ifdef P8_STAMP
+  unsigned long long st_c0 = 0, st_r0 = 0;
+  if (wid == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+#endif
   int seq_next = 0;
   for (; seq < ntiles; seq = seq_next) {
     // (at the end of the list the "next tile" is this tile again: harmless re-fetches of valid data into dead
@@ -354,7 +368,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
         asm volatile("" : "+s"(tm_), "+s"(tn_));
         const int idn = xcd_remap(seq_next, tm_ * tn_);
         int tmn, tnn;
-        tile_coords(idn, tm_, tn_, tmn, tnn);
+        tile_coords(idn, tm_, tn_, tmn, tnn, tmode);
         Tn.m0 = tmn * BM;
         Tn.n0 = tnn * 256;
         Tn.mc = Tn.m0 + BM <= g.M ? Tn.m0 : g.M - BM;
@@ -522,6 +536,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
       p8_u32x4 rq[RQ];                       // (a native vector: asm operands cannot be members of the HIP uint4 struct)
 #define P8_DROW(i_) ((i_) < 4 ? rlo + (i_) * 16 : rhi + ((i_) - 4) * 16)
+#ifdef P8_STORE_SC1
+      // experiment build: write-through stores that do not stay in the XCD's L2 (MI355X_MICROARCH.md, store flavours); the data
+      // registers must survive until the store has read them (s_nop 1, cdna_hip_programming.md 5.7 item 1)
+      const unsigned long long ctb_ = (unsigned long long)Ct, c2b_ = (unsigned long long)C2t;
+      const bf16* const Ct_u = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ctb_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ctb_));
+      const bf16* const C2t_u = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c2b_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)c2b_));
+#define P8_ST16(base_, eo_, val_) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"((eo_) * 2u), "v"(val_), "s"(base_##_u) : "memory")
+#else
+#define P8_ST16(base_, eo_, val_) *(p8_u32x4*)((base_) + (eo_)) = (val_)
+#endif
       // (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, as the compiler's own loads here; s_nop: the base may have
       //  just been written by v_readfirstlane / v_readlane, and a VMEM instruction reading such an SGPR needs 5 wait states)
 #define P8_ROFF(k_) ((unsigned)(P8_DROW((k_) % NB) * (int)g.ldr + ((k_) / NB) * 128 + wc * 32 + fqe * 8) * 2u)
@@ -575,7 +599,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               gr[q] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
               asm volatile("" : "+v"(v[2 * q]), "+v"(v[2 * q + 1]), "+v"(gr[q]));
             }
-            *(p8_u32x4*)(C2t + eo) = gr;
+            P8_ST16(C2t, eo, gr);
           } else {
             if (flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
             if (flags & F_GELU) {
@@ -606,7 +630,19 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               for (int q = 0; q < 8; ++q) v[q] *= (flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
             }
           }
+#ifdef P8_STORE_SC1
+          {
+            p8_u32x4 ov;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const bf16 b0 = (bf16)v[2 * q], b1 = (bf16)v[2 * q + 1];
+              ov[q] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+            }
+            P8_ST16(Ct, eo, ov);
+          }
+#else
           Vec8<bf16>::store(Ct + eo, v);
+#endif
           if (flags & F_COLSUM) {
             const float own = row >= rskip ? 1.f : 0.f;        // rows of the shifted tile's neighbour are summed there
 #pragma unroll
@@ -631,6 +667,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
         }
       }
 #undef P8_DROW
+#undef P8_ST16
 #undef P8_ROFF
 #undef P8_RLOAD
 #undef P8_RN
@@ -755,6 +792,12 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     }
     T = Tn;
   }
+#ifdef P8_STAMP
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 256) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    g_p8_stamp[blockIdx.x][0] = st_c0; g_p8_stamp[blockIdx.x][1] = c1; g_p8_stamp[blockIdx.x][2] = st_r0; g_p8_stamp[blockIdx.x][3] = r1;
+  }
+#endif
   if (dynamic && tid == 0) {
     if (atomicAdd(&g_p8_ctr[8], 1u) == gridDim.x - 1) {
 #pragma unroll
@@ -770,6 +813,7 @@ int g_a2v_p8_stagger = 2;   // a2v_debug_set(6, v): wave groups half a phase apa
 int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swapped MFMA operands, permuted B rows) on / off
 int g_a2v_p8_fx = 1;      // a2v_debug_set(20, v): 0 = every flavour takes the generic epilogue (A/B)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
+int g_a2v_p8_tmode = 0;   // a2v_debug_set(23, v): tile order of the persistent NT kernel: 0 = 8 m-tiles x all n-tiles, 1 = W-stationary groups of four n-tiles (N >= 2048)
 int g_a2v_p8_tail = 1;    // a2v_debug_set(22, v): a nearly empty last round of tiles goes to the 128 x 128 kernel (1) / stays here (0)
 static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bool allow_tail = true);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, false); }
@@ -866,7 +910,9 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   // staggering the wave groups: one group's epilogue (conversions, GELU, stores) runs under the other group's MFMAs.  With the
   // LDS-staged epilogue of round 1 it cost a few per cent at K = 1024; with the direct-store epilogue it pays on every shape
   // (53760 x 4096 x 1024: 430 -> 395 us, 13440 x 4096 x 1024: 117 -> 104 us, K = 4096 unchanged; weight gradients 407 -> 371 us)
-  const int stagger = ((g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048)) ? 1 : 0) ;
+  const int tiles_n_ = g.N / 256;
+  const int stagger = ((g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048)) ? 1 : 0) |
+                      ((g_a2v_p8_tmode && tiles_n_ > 4 && tiles_n_ % 4 == 0) ? 2 : 0);      // bit 1: tile order
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);
   const int ws = a2v_stream_slot(stream);

@@ -32,6 +32,7 @@ class Engine:
         """dtype: the activation storage (bf16 = throughput mode, fp32 = parity mode).  x3 (with fp32): the bf16x3 parity mode --
         every plain Linear product (forward, input gradient, weight gradient) runs as three exact bf16 products on the bf16
         matrix cores over split operands (ops.split_bf16, include/a2v.h: A2V_BF16X3); everything else is the fp32 mode."""
+        self.tstream = None      # (first: __del__ -> close() must find it even when the constructor raises below)
         self.cfg, self.store, self.dtype = cfg, store, dtype
         self.x3 = bool(x3)
         self.k_cap = {}          # (sequences, frames) -> kept-frame capacity of the student's allocations (ops.set_row_cap)
@@ -55,10 +56,13 @@ class Engine:
     # ------------------------------------------------------------------ helpers
     def close(self):
         """Gives the side stream's scratch set back to the library (a2v_stream_release; at most 4 streams hold one)."""
-        ts, self.tstream = self.tstream, None
+        ts, self.tstream = getattr(self, "tstream", None), None
         if ts is not None:
             try:
                 from . import _lib
+                # the set (tile counters, column-sum partials) may still be in use by a persistent GEMM queued on that stream: a new
+                # Engine's stream could be handed the same set -- drain the stream before the set goes back to the pool
+                ts.synchronize()
                 _lib.load().a2v_stream_release(ts.cuda_stream)
             except Exception:
                 pass

@@ -81,7 +81,7 @@ import numpy as np  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 from .ddp import GradSync, make_buckets  # noqa: E402
-from .masking import compute_mask_indices  # noqa: E402
+from .masking import mask_seed  # noqa: E402
 from .params import ALIGN, P, bucket_starts  # noqa: E402
 
 
@@ -158,18 +158,24 @@ def _to_device(arr: np.ndarray, device) -> torch.Tensor:
 
 
 def make_aug(fcfg: FinetuneConfig, B: int, T: int, D: int, n_prenet: int, n_blocks: int, rng: np.random.Generator,
-             noise_std: float, device="cuda", train_dropout: bool = True) -> dict:
-    """The per-micro-batch random draws of the train form (what Engine.finetune_forward takes as `aug`)."""
+             noise_std: float, device="cuda", train_dropout: bool = True, mask_seeds=None) -> dict:
+    """The per-micro-batch random draws of the train form (what Engine.finetune_forward takes as `aug`).
+    The time masks (B, T) and channel masks (B, D) of apply_mask (reference nn/modalities/base.py:370-425, 457-485) come from the
+    DEVICE sampler (a2v_span_mask: the law of fairseq's compute_mask_indices with require_same_masks, min_masks 1 over frames / 0
+    over channels), two launches each on the current stream -- no host loop, no copy.  mask_seeds = (time, channel) 64-bit
+    seeds, a pure function of (run seed, update, micro-batch, rank) at the callers (masking.mask_seed), so a resumed run
+    repeats them; None draws them from `rng`."""
     aug: Dict[str, object] = {}
+    if mask_seeds is None:
+        mask_seeds = (int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 62)))
     if fcfg.apply_mask and fcfg.mask_prob > 0:
-        m = compute_mask_indices((B, T), fcfg.mask_prob, fcfg.mask_length, rng, min_masks=1, require_same_masks=True)
-        aug["mask_t"] = _to_device(m.astype(np.uint8), device)
+        aug["mask_t"] = ops.span_mask(B, T, mask_prob=fcfg.mask_prob, mask_length=fcfg.mask_length, seed=mask_seeds[0],
+                                      min_masks=1, device=device)[0]
         aug["noise_std"] = 0.0 if fcfg.zero_mask else noise_std
         aug["noise_seed"] = int(rng.integers(0, 2 ** 31))
     if fcfg.apply_mask and fcfg.mask_channel_prob > 0:
-        mc = compute_mask_indices((B, D), fcfg.mask_channel_prob, fcfg.mask_channel_length, rng, min_masks=0,
-                                  require_same_masks=True)
-        aug["mask_c"] = _to_device(mc.astype(np.uint8), device)
+        aug["mask_c"] = ops.span_mask(B, D, mask_prob=fcfg.mask_channel_prob, mask_length=fcfg.mask_channel_length,
+                                      seed=mask_seeds[1], min_masks=0, device=device)[0]
     aug["active"] = [bool(fcfg.layerdrop == 0 or rng.random() > fcfg.layerdrop) for _ in range(n_blocks)]
     if not any(aug["active"][n_prenet:]):          # the reference divides by zero layer results here; keep one block
         aug["active"][-1] = True
@@ -228,6 +234,7 @@ class FinetuneTrainer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.num_updates = 0
+        self.seed = int(seed)
         self.rng = np.random.default_rng(seed * 1000 + 17 + self.rank)
         self._perm_gen = torch.Generator(device=dev)            # device-side permutations: no pageable H2D copy per micro-batch
         self._perm_gen.manual_seed(seed * 7919 + 29 + self.rank)
@@ -294,7 +301,9 @@ class FinetuneTrainer:
             self.sync.arm(j == nmb - 1 and not frozen)
             src, tgt = self._mix(mb["source"], mb["target"])
             B, T = tgt.shape[0], tgt.shape[1]
-            aug = make_aug(f, B, T, self.cfg.embed_dim, a.prenet_depth, n_blocks, self.rng, a.mask_noise_std, device=st.device)
+            seeds = (mask_seed(self.seed, self.num_updates, 2 * j, self.rank), mask_seed(self.seed, self.num_updates, 2 * j + 1, self.rank))
+            aug = make_aug(f, B, T, self.cfg.embed_dim, a.prenet_depth, n_blocks, self.rng, a.mask_noise_std, device=st.device,
+                           mask_seeds=seeds)
             eng.finetune_forward_backward(src, tgt, head, aug=aug, head_only=frozen)
             ntok += B * T
         self.sync.arm(False)
@@ -416,6 +425,7 @@ class Wav2VecCcasFinetune(tnn.Module):
         """wav2vec2.py:84-87 (fairseq calls it after every optimizer step): also the moment to rebuild the operand
         images of whatever the optimizer just changed."""
         self.num_updates = num_updates
+        self._aug_draws = 0
         self.sync_head()
         self.encoder.engine.refresh_student_packs()
 
@@ -447,8 +457,12 @@ class Wav2VecCcasFinetune(tnn.Module):
                 tgt = target.to(source.device, torch.float32) if target is not None else None
                 source, target = bc_mix(self._mixup_op, f, cfg, source, tgt, self._rng, self._perm_gen)
                 T = cfg.frame_counts(source.shape[1])[-1]
+                self._aug_draws = getattr(self, "_aug_draws", 0) + 1            # micro-batches since the last set_num_updates
+                rank = dist.get_rank() if dist.is_initialized() else 0         # (resolved at the draw: the group may be set up late)
+                seeds = (mask_seed(cfg.seed, self.num_updates, 2 * self._aug_draws, rank),
+                         mask_seed(cfg.seed, self.num_updates, 2 * self._aug_draws + 1, rank))
                 aug = make_aug(f, source.shape[0], T, cfg.embed_dim, a.prenet_depth, a.prenet_depth + cfg.depth, self._rng,
-                               a.mask_noise_std, device=source.device)
+                               a.mask_noise_std, device=source.device, mask_seeds=seeds)
                 head_only = self.num_updates < f.freeze_finetune_updates
             logits = _FinetuneLogits.apply(self._anchor, self, source, aug, head_only)
         else:

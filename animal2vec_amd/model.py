@@ -14,7 +14,7 @@ import torch.nn as tnn
 from . import ops
 from .config import Data2VecMultiConfig
 from .engine import Engine
-from .masking import DeviceMaskSampler, compute_mask_indices, make_maskinfo, mask_seed
+from .masking import DeviceMaskSampler, make_maskinfo, mask_seed
 from .params import P, ParamStore
 from .registry import register_model
 from .trainer import get_annealed_rate
@@ -82,8 +82,10 @@ class Data2VecMultiModel(tnn.Module):
         self.num_updates = 0
         self.ema_decay = cfg.ema_decay
         self._rng = np.random.default_rng(cfg.seed)
-        self._mask_sampler, self._mask_draws = None, 0           # device span masks (masking.DeviceMaskSampler), made on first use
-        self._rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+        # device span masks (masking.DeviceMaskSampler), made on first use; _mask_draws counts the forwards since the last
+        # set_num_updates: a draw is a pure function of (seed, num_updates, draw, rank) -- nothing to checkpoint, a resumed run
+        # repeats what the uninterrupted one would have drawn
+        self._mask_sampler, self._mask_draws = None, 0
         self._packs_version = None
 
     # ------------------------------------------------------------------ construction / io
@@ -151,9 +153,16 @@ class Data2VecMultiModel(tnn.Module):
                 ops.ema_update(st.teacher, st.flat[st.sh_lo:st.sh_hi], self.ema_decay)
                 self.engine.refresh_teacher_packs()
             self.engine.refresh_student_packs()               # the optimizer just stepped
+        if num_updates != self.num_updates:
+            self._mask_draws = 0
         self.num_updates = num_updates
 
     # ------------------------------------------------------------------ forward
+    @staticmethod
+    def _dist_rank() -> int:
+        """resolved at every draw: torch.distributed may be initialised after the model was built"""
+        return torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+
     def _sample_maskinfo(self, B: int, T: int):
         """compute_mask + make_maskinfo of the reference's forward (base.py:401-455) on the device (a2v_span_mask)."""
         a = self.cfg.audio
@@ -165,7 +174,7 @@ class Data2VecMultiModel(tnn.Module):
             self._mask_release_pending = False
         self._mask_draws += 1
         N = B * self.cfg.clone_batch
-        out = self._mask_sampler.take(N, T, mask_seed(self.cfg.seed, self._mask_draws, 0, self._rank))
+        out = self._mask_sampler.take(N, T, mask_seed(self.cfg.seed, self.num_updates, self._mask_draws, self._dist_rank()))
         if (N, T) not in self.engine.k_cap:                      # allocate the student's tensors at a fixed kept-frame capacity from
             k0 = self._mask_sampler.last_k                      # the first draw on (trainer.prime_memory explains why)
             self.engine.k_cap[(N, T)] = min(T - 1, k0 + max(12, k0 // 8))
@@ -264,9 +273,10 @@ class Data2VecMultiModel(tnn.Module):
             if precomputed_mask is not None:
                 m = precomputed_mask.to(source.device).to(torch.uint8)
             elif a.mask_prob > 0:
-                m = torch.from_numpy(compute_mask_indices((B, T), a.mask_prob, a.mask_length, self._rng, min_masks=1,
-                                                          require_same_masks=True, mask_dropout=a.mask_dropout)
-                                     .astype(np.uint8)).to(source.device)
+                self._mask_draws += 1
+                m = ops.span_mask(B, T, mask_prob=a.mask_prob, mask_length=a.mask_length, min_masks=1, mask_dropout=a.mask_dropout,
+                                  seed=mask_seed(cfg.seed, self.num_updates, 2 * self._mask_draws, self._dist_rank()),
+                                  device=source.device)[0]
             else:
                 m = None
             if m is not None:
@@ -275,9 +285,9 @@ class Data2VecMultiModel(tnn.Module):
                 aug.update(mask_t=mu8, noise_std=0.0 if a.encoder_zero_mask else a.mask_noise_std,
                            noise_seed=int(self._rng.integers(0, 2 ** 31)))
             if a.mask_channel_prob > 0:                          # base.py:471-484
-                mc = compute_mask_indices((B, cfg.embed_dim), a.mask_channel_prob, a.mask_channel_length, self._rng,
-                                          min_masks=0, require_same_masks=True)
-                aug["mask_c"] = torch.from_numpy(mc.astype(np.uint8)).to(source.device)
+                aug["mask_c"] = ops.span_mask(B, cfg.embed_dim, mask_prob=a.mask_channel_prob, mask_length=a.mask_channel_length,
+                                              min_masks=0, device=source.device,
+                                              seed=mask_seed(cfg.seed, self.num_updates, 2 * self._mask_draws + 1, self._dist_rank()))[0]
         if self.training:
             nb = a.prenet_depth + cfg.depth
             if cfg.layerdrop > 0 or a.prenet_layerdrop > 0:      # modules.py:89-94, data2vec2.py:651-655
