@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--which", default="teacher,student")
     ap.add_argument("--student-rows", type=int, default=384, help="32 clips x 12 clones at micro-batch 32")
+    ap.add_argument("--student-s", type=int, default=140, help="kept frames per row (152: what the sampler draws at 768 rows)")
     ap.add_argument("--no-drop", action="store_true")
     ap.add_argument("--debug-set", action="append", default=[], help="key=value for a2v_debug_set (A/B experiments)")
     a = ap.parse_args()
@@ -53,7 +54,7 @@ def main():
         fl = 4.0 * S * S * hd * H * N
         out["teacher_fwd"] = dict(us=round(us, 1), tflops=round(fl / us / 1e6, 1), frac_of_2p5pf=round(fl / us / 1e6 / 2500, 4))
     if "student" in a.which:
-        N, S = a.student_rows, 140
+        N, S = a.student_rows, a.student_s
         g = torch.Generator().manual_seed(1)
         pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int().cuda()
         qkv = torch.randn(N, S, 3 * H * hd, device="cuda").bfloat16()
