@@ -69,7 +69,10 @@ SIGNATURES = {
     "a2v_maskinfo": [_p, _p, _p, _p, _i, _i, _i, _p],
     "a2v_split_bf16": [_p, _p, _ll, _i, _ll, _ll, _i, _p],
     "a2v_abi_version": [],
+    "a2v_query_workspace": [],
+    "a2v_bind_workspace": [_p, _p, C.c_size_t],
 }
+RESTYPES = {"a2v_query_workspace": C.c_size_t}      # everything else returns int
 
 _lib = None
 
@@ -94,7 +97,7 @@ def load() -> C.CDLL:
         except AttributeError as e:
             raise A2VError(f"liba2v_hip.so does not export {name}") from e
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = RESTYPES.get(name, C.c_int)
     # A2V_DEBUG_SET="key=value,key=value": A/B switches of a2v_debug_set for whole test / bench runs (experiments only).
     # Applied BEFORE the handle is cached: a malformed or unknown entry fails every load(), never half of the switches silently.
     for kv in filter(None, os.environ.get("A2V_DEBUG_SET", "").split(",")):

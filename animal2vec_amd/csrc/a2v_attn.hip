@@ -1007,8 +1007,7 @@ int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 // Ingredients of the bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i|^2 and max_j |k_j|^2 (Cauchy-Schwarz in
 // the attention kernel).  8 lanes share a row (16 B each); reads q and k once: 65 MB at 32 x 2000 x 16 heads.
-#define A2V_QKB_MAX 65536
-__device__ float g_qk_bound_all[A2V_MAX_STREAMS][A2V_QKB_MAX];
+#define A2V_QKB_MAX (A2V_WS_QKB_BYTES / 4)              // the bounds live at A2V_WS_QKB of the stream's workspace
 template <int HD>
 __global__ __launch_bounds__(256) void attn_qk_bound_kernel(const bf16* __restrict__ qkv, float* __restrict__ bound, int S, int H) {
   static_assert(HD == 64, "8 lanes x 8 elements per head row");
@@ -1068,11 +1067,9 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
     const long long nqb = (a.S + 127) / 128, heads8 = ((long long)a.N * a.H + 7) / 8 * 8;
     a.qk_bound = nullptr;
     if constexpr (HD == 64) {
-      const int ws = (g_a2v_attn_band && !a.pos && (long long)a.N * a.H * 2 * A2V_QKB_SPLIT <= A2V_QKB_MAX) ? a2v_stream_slot(st) : -1;
-      if (ws >= 0) {
-        static float* bp0_dev[A2V_MAX_DEVICES]; float*& bp0 = bp0_dev[a2v_device()];   // (device address of the scratch: looked up once per device)
-        if (!bp0) (void)hipGetSymbolAddress((void**)&bp0, HIP_SYMBOL(g_qk_bound_all));
-        float* const bp = bp0 + (long long)ws * A2V_QKB_MAX;
+      char* const ws = (g_a2v_attn_band && !a.pos && (long long)a.N * a.H * 2 * A2V_QKB_SPLIT <= A2V_QKB_MAX) ? a2v_stream_ws(st) : nullptr;
+      if (ws) {
+        float* const bp = (float*)(ws + A2V_WS_QKB);
         hipLaunchKernelGGL((attn_qk_bound_kernel<64>), dim3(A2V_QKB_SPLIT, a.N), dim3(256), 0, st, (const bf16*)a.qkv, bp, a.S, a.H);
         a.qk_bound = bp;
       }
@@ -1119,9 +1116,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const T* __restrict__ o
 // launch at N*H = 1536 workgroups; a "last workgroup folds" counter has the same problem).  Each workgroup instead
 // stores its partial sum to its own slot of a device scratch and a one-block-per-head kernel folds them afterwards:
 // no contention, and the sum order is fixed (deterministic gradient).
-#define A2V_DAL_PART_MAX 65536
-__device__ float g_dal_part_all[A2V_MAX_STREAMS][A2V_DAL_PART_MAX];     // one set per stream (a2v_stream_slot)
-__device__ __forceinline__ void dalibi_finish(float dal_wave, float* dalibi, int h, int use_part, float slope, float asc) {
+#define A2V_DAL_PART_MAX (A2V_WS_DAL_BYTES / 4)        // the partial sums live at A2V_WS_DAL of the stream's workspace
+__device__ __forceinline__ void dalibi_finish(float dal_wave, float* dalibi, int h, float* use_part, float slope, float asc) {
   __shared__ float red[4];
   const int tid = threadIdx.x;
   if (!use_part) {                                      // too many workgroups for the scratch: direct atomics
@@ -1134,11 +1130,10 @@ __device__ __forceinline__ void dalibi_finish(float dal_wave, float* dalibi, int
     float sum = 0.f;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) sum += red[w];
     const float v = asc >= 0.f ? sum * slope : 0.f;
-    g_dal_part_all[use_part - 1][((long long)h * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = v;      // blockIdx.y = head
+    use_part[((long long)h * gridDim.z + blockIdx.z) * gridDim.x + blockIdx.x] = v;      // blockIdx.y = head
   }
 }
-__global__ __launch_bounds__(256) void dalibi_fold_kernel(float* __restrict__ dalibi, int per_head, int slot) {
-  const float* const g_dal_part = g_dal_part_all[slot];
+__global__ __launch_bounds__(256) void dalibi_fold_kernel(float* __restrict__ dalibi, int per_head, const float* __restrict__ g_dal_part) {
   __shared__ float red[4];
   const int h = blockIdx.x, tid = threadIdx.x;
   float s = 0.f;
@@ -1158,7 +1153,7 @@ struct AttnBwdArgs {
   int N, S, H;
   float scale;
   Drop drop;
-  int dal_part;             // s + 1: per-workgroup partial sums of d alibi_scale go to the stream's scratch set s (folded by dalibi_fold_kernel); 0: atomics
+  float* dal_part;          // per-workgroup partial sums of d alibi_scale go here (the stream's workspace; folded by dalibi_fold_kernel); NULL: atomics
   float* bias_sum;          // (3, H, HD) fp32 or NULL: column sums of dqkv (the qkv Linear's bias gradient), whole-sequence kernel only
   // (N,H,S) or NULL: c_i = sum_j P_ij |pos_i - pos_j| from the forward.  d alibi_scale_h = -slope_h sum_ij dS_ij |pos_i - pos_j|, and
   // sum_j dS_ij = 0 exactly, so any per-row constant may be subtracted from the distance.  What is computed is dS_ij = P_ij (dP_ij -
@@ -2726,12 +2721,12 @@ template <typename T, int HD>
 static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delta, hipStream_t st) {
   AttnBwdArgs a = a_in;
   // d alibi_scale: per-workgroup partials + fold kernel whenever the launch's workgroups fit the scratch
-  const int ws = a.dalibi ? a2v_stream_slot(st) : -1;     // (no set left for this stream: direct atomics)
+  char* const ws = a.dalibi ? a2v_stream_ws(st) : nullptr;     // (no workspace left for this stream: direct atomics)
   auto set_part = [&](const dim3& grid) {
-    a.dal_part = (a.dalibi && ws >= 0 && (long long)grid.x * grid.y * grid.z <= A2V_DAL_PART_MAX) ? ws + 1 : 0;
+    a.dal_part = (a.dalibi && ws && (long long)grid.x * grid.y * grid.z <= A2V_DAL_PART_MAX) ? (float*)(ws + A2V_WS_DAL) : nullptr;
   };
   auto fold = [&](const dim3& grid) {
-    if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(a.H), dim3(256), 0, st, a.dalibi, (int)(grid.x * grid.z), ws);
+    if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(a.H), dim3(256), 0, st, a.dalibi, (int)(grid.x * grid.z), a.dal_part);
   };
   const long long total = (long long)a.N * a.S * a.H;
   int g = (int)((total + 255) / 256);
@@ -2842,9 +2837,9 @@ extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, co
   }
   if (dtype == A2V_BF16X3) {          // fp32 storage; S <= 160 at HD = 64: split products on the bf16 matrix cores, else the fp32 kernels
     if (HD == 64 && S <= AB48_ROWS) {
-      const int ws = a.dalibi ? a2v_stream_slot(stream) : -1;
+      char* const ws = a.dalibi ? a2v_stream_ws(stream) : nullptr;
       const dim3 grid(1, H, N);
-      a.dal_part = (a.dalibi && ws >= 0 && (long long)grid.y * grid.z <= A2V_DAL_PART_MAX) ? ws + 1 : 0;
+      a.dal_part = (a.dalibi && ws && (long long)grid.y * grid.z <= A2V_DAL_PART_MAX) ? (float*)(ws + A2V_WS_DAL) : nullptr;
       const bool dr = a.drop.thresh != 0;
       const bool four = (S + 63) / 64 < (S + 47) / 48;
 #define AX3_GO(D_, W_)                                                                                                       \
@@ -2854,7 +2849,7 @@ extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, co
   }
       if (four) { if (dr) AX3_GO(true, 4) else AX3_GO(false, 4) } else { if (dr) AX3_GO(true, 3) else AX3_GO(false, 3) }
 #undef AX3_GO
-      if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(H), dim3(256), 0, stream, a.dalibi, (int)(grid.x * grid.z), ws);
+      if (a.dal_part) hipLaunchKernelGGL(dalibi_fold_kernel, dim3(H), dim3(256), 0, stream, a.dalibi, (int)(grid.x * grid.z), a.dal_part);
       A2V_CHECK_LAUNCH();
       return A2V_OK;
     }

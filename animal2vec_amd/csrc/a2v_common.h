@@ -316,10 +316,24 @@ static inline int a2v_device() {
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// Library-owned device scratch (tile counters of the persistent GEMM, column-sum partial rows, d alibi_scale partial
-// sums) exists once per STREAM: the stream argument every entry point takes selects the set, so launches on different
-// streams never share scratch (re-entrant across streams) while launches on one stream are ordered anyway.  Static device
-// arrays, assigned to streams in order of first use: nothing is allocated, ever.  a2v_stream_slot returns -1 when more
-// than A2V_MAX_STREAMS distinct streams are live (a2v_stream_release gives a set back).
+// Device scratch of the library (tile counters of the persistent GEMM, column-sum partial rows and self-cleaning column-sum copies,
+// d alibi_scale partial sums, the |q.k| bounds of the long-sequence attention) exists once per STREAM: the stream argument every
+// entry point takes selects the workspace, so launches on different streams never share scratch (re-entrant across streams) while
+// launches on one stream are ordered anyway.  A workspace is ONE blob of A2V_WS_BYTES with the fixed layout below, either
+//   * caller-owned: a2v_bind_workspace(stream, ptr, bytes) (include/a2v.h, ABI 10: a2v_query_workspace() bytes of zeroed device
+//     memory) -- any number of streams, nothing static is used for them; or
+//   * one of A2V_MAX_STREAMS library-owned static sets, handed to unbound streams in order of first use (a2v_stream_release gives
+//     a set back); a fifth unbound stream gets nullptr and its calls take the kernels that need no scratch.
+// Nothing is ever allocated by the library.
 #define A2V_MAX_STREAMS 4
-int a2v_stream_slot(hipStream_t stream);
+#define A2V_WS_CTR 0                                   /* 16 x u32: tile counters of the persistent NT GEMM (self-resetting) */
+#define A2V_WS_SPREAD 256                              /* [64][3][4096] fp32: self-cleaning copies of column sums (a2v_norm.hip) */
+#define A2V_WS_SPREAD_BYTES (64 * 3 * 4096 * 4)
+#define A2V_WS_QKB (A2V_WS_SPREAD + A2V_WS_SPREAD_BYTES) /* 64 Ki fp32: max |q|^2, |k|^2 per (row range, n, h) (attn_qk_bound_kernel) */
+#define A2V_WS_QKB_BYTES (65536 * 4)
+#define A2V_WS_DAL (A2V_WS_QKB + A2V_WS_QKB_BYTES)     /* 64 Ki fp32: per-workgroup partial sums of d alibi_scale */
+#define A2V_WS_DAL_BYTES (65536 * 4)
+#define A2V_WS_CSPART (A2V_WS_DAL + A2V_WS_DAL_BYTES)  /* 4 Mi fp32: column-sum partial rows of the persistent NT GEMM's epilogue */
+#define A2V_WS_CSPART_BYTES ((1 << 22) * 4)
+#define A2V_WS_BYTES (A2V_WS_CSPART + A2V_WS_CSPART_BYTES)
+char* a2v_stream_ws(hipStream_t stream);               // the stream's workspace (bound or static), nullptr if none is left

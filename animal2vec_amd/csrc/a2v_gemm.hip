@@ -619,24 +619,49 @@ extern "C" int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long
   return conv_wgrad_impl(nullptr, dtype, xb, ldb_, 0, 0, M, M, 1, 0, 1, Kb, 0, nullptr, 1, dyb, ldpb, 0, gwb, ldwb, 0, M, Nb, Kb, 1, stream);
 }
 
-// ---- per-stream scratch sets (a2v_common.h)
+// ---- per-stream workspaces (a2v_common.h)
 #include <mutex>
+#include <vector>
+__device__ char g_ws_static[A2V_MAX_STREAMS][A2V_WS_BYTES];      // the library-owned sets: zero at load, self-cleaning afterwards
 static std::mutex g_ws_mu;
 static hipStream_t g_ws_stream[A2V_MAX_STREAMS];
 static bool g_ws_used[A2V_MAX_STREAMS];
-int a2v_stream_slot(hipStream_t stream) {
+struct WsBound { hipStream_t stream; int device; char* ptr; };
+static std::vector<WsBound> g_ws_bound;                           // caller-owned workspaces (a2v_bind_workspace)
+char* a2v_stream_ws(hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
+  const int dev = a2v_device();
+  for (const WsBound& b : g_ws_bound)
+    if (b.stream == stream && b.device == dev) return b.ptr;
+  static char* base_dev[A2V_MAX_DEVICES]; char*& base = base_dev[dev];        // address of the device symbol: looked up once per device
+  if (!base && hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_ws_static)) != hipSuccess) return nullptr;
   for (int i = 0; i < A2V_MAX_STREAMS; ++i)
-    if (g_ws_used[i] && g_ws_stream[i] == stream) return i;
+    if (g_ws_used[i] && g_ws_stream[i] == stream) return base + (size_t)i * A2V_WS_BYTES;
   for (int i = 0; i < A2V_MAX_STREAMS; ++i)
-    if (!g_ws_used[i]) { g_ws_used[i] = true; g_ws_stream[i] = stream; return i; }
-  return -1;
+    if (!g_ws_used[i]) { g_ws_used[i] = true; g_ws_stream[i] = stream; return base + (size_t)i * A2V_WS_BYTES; }
+  return nullptr;
 }
 extern "C" int a2v_stream_release(hipStream_t stream) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   for (int i = 0; i < A2V_MAX_STREAMS; ++i)
     if (g_ws_used[i] && g_ws_stream[i] == stream) { g_ws_used[i] = false; return A2V_OK; }
   return A2V_ERR_ARG;
+}
+extern "C" size_t a2v_query_workspace(void) { return (size_t)A2V_WS_BYTES; }
+extern "C" int a2v_bind_workspace(hipStream_t stream, void* ws, size_t bytes) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  const int dev = a2v_device();
+  for (size_t i = 0; i < g_ws_bound.size(); ++i)
+    if (g_ws_bound[i].stream == stream && g_ws_bound[i].device == dev) {
+      if (!ws) { g_ws_bound.erase(g_ws_bound.begin() + (long)i); return A2V_OK; }
+      if (bytes < (size_t)A2V_WS_BYTES || (((uintptr_t)ws) & 255)) return A2V_ERR_ARG;
+      g_ws_bound[i].ptr = (char*)ws;
+      return A2V_OK;
+    }
+  if (!ws) return A2V_ERR_ARG;                                   // nothing bound to this stream
+  if (bytes < (size_t)A2V_WS_BYTES || (((uintptr_t)ws) & 255)) return A2V_ERR_ARG;
+  g_ws_bound.push_back(WsBound{stream, dev, (char*)ws});
+  return A2V_OK;
 }
 
 // debugging / A-B benchmarking knob: key 0 = bf16 NT kernel variant (0 register-staged, 1 LDS-DMA)

@@ -51,10 +51,9 @@ __device__ __forceinline__ void p8_glds16(const char* gsrc, char* lds_dst) {
 // of this scratch and a small kernel folds them.  As atomics on the N addresses of the final buffer they sat in vmcnt
 // ahead of the next tile's first counted wait (stores and atomics share that counter on gfx9) and, contended 120-fold
 // per address, held the K loop back: +23 us on a 144 us GEMM.
-#define P8_CS_PART_MAX (1 << 22)
-__device__ float g_p8_cs_part_all[A2V_MAX_STREAMS][P8_CS_PART_MAX];     // one set per stream (a2v_stream_slot)
-__global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__ colsum, int N, int parts, int slot) {
-  const float* const g_p8_cs_part = g_p8_cs_part_all[slot];
+#define P8_CS_PART_MAX (A2V_WS_CSPART_BYTES / 4)
+__global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__ colsum, int N, int parts, const char* __restrict__ ws) {
+  const float* const g_p8_cs_part = (const float*)(ws + A2V_WS_CSPART);
   const int n = blockIdx.x * 256 + threadIdx.x;        // blockIdx.y: one of 16 interleaved slices of the partial rows
   if (n >= N) return;
   float s0 = 0.f, s1 = 0.f;
@@ -67,7 +66,7 @@ __global__ __launch_bounds__(256) void p8_colsum_fold_kernel(float* __restrict__
   atomicAdd(colsum + n, s0 + s1);
 }
 
-__device__ unsigned g_p8_ctr_all[A2V_MAX_STREAMS][9];      // one counter set per stream (a2v_stream_slot)
+// (tile counters: 9 x u32 at A2V_WS_CTR of the stream's workspace)
 #ifdef P8_STAMP
 // Diagnostic build only (MI355X_MICROARCH.md, DVFS give-back item 6; tools/inkernel_clock.py): wave 0 of every workgroup stamps
 // s_memtime (shader cycles) and s_memrealtime (100 MHz) around its whole tile loop into this buffer, which nothing else reads:
@@ -120,10 +119,10 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 // outputs at a third of the bf16 MFMA rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.  With K three times as long the
 // epilogue is a small share of a tile, so it is plain C++ here (compiler-placed waits), not the hand-counted form below.
 template <int IH, bool DS, int FX = 0, bool O32 = false>
-__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, int ctr_slot, int cs_part) {
+__global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int stagger, int dyn_tiles, char* wsp, int cs_part) {
   static_assert(!O32 || (DS && FX == 0), "fp32 outputs: direct-store form, generic flags");
-  unsigned* const g_p8_ctr = g_p8_ctr_all[ctr_slot];
-  float* const g_p8_cs_part = g_p8_cs_part_all[ctr_slot];
+  unsigned* const g_p8_ctr = (unsigned*)(wsp + A2V_WS_CTR);
+  float* const g_p8_cs_part = (float*)(wsp + A2V_WS_CSPART);
   constexpr int BM = 128 + 32 * IH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -915,8 +914,8 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
                       ((g_a2v_p8_tmode && tiles_n_ > 4 && tiles_n_ % 4 == 0) ? 2 : 0);      // bit 1: tile order
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);
-  const int ws = a2v_stream_slot(stream);
-  if (ws < 0) return false;                  // no scratch set left for this stream: the 128 x 128 kernel needs none
+  char* const ws = a2v_stream_ws(stream);
+  if (!ws) return false;                     // no workspace left for this stream: the 128 x 128 kernel needs none
   const int cs_part = ((g.flags & F_COLSUM) && g.G == 1 && (long long)parts * g.N <= P8_CS_PART_MAX) ? 1 : 0;
 #define P8_GO(IH_, DS_) hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<IH_, DS_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part)
   if (out32) {

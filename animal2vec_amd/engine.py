@@ -33,9 +33,21 @@ class Engine:
         every plain Linear product (forward, input gradient, weight gradient) runs as three exact bf16 products on the bf16
         matrix cores over split operands (ops.split_bf16, include/a2v.h: A2V_BF16X3); everything else is the fp32 mode."""
         self.tstream = None      # (first: __del__ -> close() must find it even when the constructor raises below)
+        self._ws_keys = []
         self.cfg, self.store, self.dtype = cfg, store, dtype
         self.x3 = bool(x3)
         self.k_cap = {}          # (sequences, frames) -> kept-frame capacity of the student's allocations (ops.set_row_cap)
+        dev = store.device
+        # the EMA teacher's forward runs on a side stream, concurrently with the student's forward (A2V_TEACHER_STREAM=0: off)
+        self.tstream = torch.cuda.Stream(dev) if (os.environ.get("A2V_TEACHER_STREAM", "1") == "1" and dev.type == "cuda") else None
+        # caller-owned scratch (include/a2v.h, ABI 10), before the first library call: one workspace for the stream the engine is built
+        # on and one for the teacher's side stream; the library keeps nothing of its own for them (another stream a caller switches to
+        # later falls back to the library's static sets)
+        if dev.type == "cuda":
+            with torch.cuda.device(dev):
+                self._ws_keys.append(ops.bind_workspace())
+                if self.tstream is not None:
+                    self._ws_keys.append(ops.bind_workspace(self.tstream))
         self.sp = Packs(store, dtype, teacher=False, need_grad=True, x3=self.x3)
         self.tp = Packs(store, dtype, teacher=True, need_grad=False, x3=self.x3)
         self.sp.refresh()
@@ -43,29 +55,29 @@ class Engine:
         self.layers = cfg.conv_layers
         self.sv: Dict[str, object] = {}
         self.on_grad_ready: Optional[Callable[[str], None]] = None
-        dev = store.device
         self.stats = torch.zeros(4 * cfg.embed_dim + 2, dtype=torch.float64, device=dev)
         c0 = self.layers[0][0]
         k0 = self.layers[0][1]
         self.dfilt = torch.zeros(c0, k0, dtype=torch.float32, device=dev)
-        # the EMA teacher's forward runs on a side stream, concurrently with the student's forward (A2V_TEACHER_STREAM=0: off)
-        self.tstream = torch.cuda.Stream(dev) if (os.environ.get("A2V_TEACHER_STREAM", "1") == "1" and dev.type == "cuda") else None
         self.sinc_cp = ops.sinc_out_channels(c0, k0)      # channel pitch of the SincConv output (128, or 320 for the blocked kernels)
         self.dpar = torch.zeros(4, self.sinc_cp, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ helpers
     def close(self):
-        """Gives the side stream's scratch set back to the library (a2v_stream_release; at most 4 streams hold one)."""
+        """Hands the caller-owned workspaces back (drains the streams first: a persistent GEMM queued there may still use the tile
+        counters); a side stream that picked up one of the library's static sets before it was bound returns it too."""
         ts, self.tstream = getattr(self, "tstream", None), None
-        if ts is not None:
-            try:
-                from . import _lib
-                # the set (tile counters, column-sum partials) may still be in use by a persistent GEMM queued on that stream: a new
-                # Engine's stream could be handed the same set -- drain the stream before the set goes back to the pool
+        keys, self._ws_keys = getattr(self, "_ws_keys", []), []
+        try:
+            if ts is not None:
                 ts.synchronize()
+            for k in keys:
+                ops.release_workspace(k)
+            if ts is not None:
+                from . import _lib
                 _lib.load().a2v_stream_release(ts.cuda_stream)
-            except Exception:
-                pass
+        except Exception:
+            pass
 
     def __del__(self):
         self.close()

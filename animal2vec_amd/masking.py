@@ -2,8 +2,9 @@
 
 In the step the masks come from the DEVICE sampler (`DeviceMaskSampler` -> a2v_span_mask, csrc/a2v_mask.hip): one launch
 pair per micro-batch on a side stream, one step ahead of its use, K read back through pinned memory -- no host loop, no
-pageable copy, no argsort.  `compute_mask_indices` below is the host statement of the same law (the finetune path's
-small time / channel masks still use it); `make_maskinfo` serves caller-supplied masks (`precomputed_mask`)."""
+pageable copy, no argsort.  The finetune path's time / channel masks (finetune.make_aug, model._features_only) are drawn by
+the same kernel (ops.span_mask; round 4).  `compute_mask_indices` below is the host statement of the same law, kept for the
+CPU tests of the host logic only -- no step path calls it; `make_maskinfo` serves caller-supplied masks (`precomputed_mask`)."""
 from __future__ import annotations
 
 from collections import deque
@@ -81,6 +82,22 @@ def mask_seed(base_seed: int, update: int, micro_batch: int, rank: int) -> int:
     return (x * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
 
 
+def check_span_law(*, mask_length: int, add_masks: bool = False, **other) -> None:
+    """The device sampler implements ONE law: static spans of length >= 2, require_same_masks (rows cut down to the batch's smallest
+    masked count), optional mask_dropout -- what every shipped recipe uses.  The reference switches to other laws for
+    mask_length == 1 (random_masking, base.py:395-396) and add_masks (rows topped up instead of cut down, base.py:409), and
+    has inverse_mask / keep_masked_pct / mask_prob_min / mask_prob_adjust on top: those are refused here instead of being
+    sampled with the wrong law silently (there is no host path in the step any more)."""
+    if add_masks:
+        raise NotImplementedError("add_masks=True (base.py:409) is not implemented by the device span-mask sampler")
+    if int(mask_length) == 1:
+        raise NotImplementedError("mask_length == 1 selects random_masking in the reference (base.py:395-396); the device sampler "
+                                  "implements the span law only")
+    for k in ("inverse_mask", "keep_masked_pct", "mask_prob_min", "mask_prob_adjust"):
+        if other.get(k):
+            raise NotImplementedError(f"{k} is not implemented by the device span-mask sampler")
+
+
 class DeviceMaskSampler:
     """Span masks + maskinfo on the device, one request ahead of their use.
 
@@ -91,7 +108,9 @@ class DeviceMaskSampler:
     caller's stream waits for the sampler (event); a reused slot's launch waits for what the caller's stream held at
     request time, so a slot is never overwritten under a kernel that still reads it."""
 
-    def __init__(self, device, *, mask_prob: float, mask_length: int, mask_dropout: float = 0.0, min_masks: int = 1):
+    def __init__(self, device, *, mask_prob: float, mask_length: int, mask_dropout: float = 0.0, min_masks: int = 1,
+                 add_masks: bool = False):
+        check_span_law(mask_length=mask_length, add_masks=add_masks)
         self.device = torch.device(device)
         self.law = dict(mask_prob=float(mask_prob), mask_length=int(mask_length), mask_dropout=float(mask_dropout),
                         min_masks=int(min_masks))

@@ -14,7 +14,7 @@ import torch.nn as tnn
 from . import ops
 from .config import Data2VecMultiConfig
 from .engine import Engine
-from .masking import DeviceMaskSampler, make_maskinfo, mask_seed
+from .masking import DeviceMaskSampler, check_span_law, make_maskinfo, mask_seed
 from .params import P, ParamStore
 from .registry import register_model
 from .trainer import get_annealed_rate
@@ -168,7 +168,7 @@ class Data2VecMultiModel(tnn.Module):
         a = self.cfg.audio
         if self._mask_sampler is None:
             self._mask_sampler = DeviceMaskSampler(self.store.device, mask_prob=a.mask_prob, mask_length=a.mask_length,
-                                                   mask_dropout=a.mask_dropout)
+                                                   mask_dropout=a.mask_dropout, add_masks=a.add_masks)
         if getattr(self, "_mask_release_pending", False):        # the previous forward's backward has been enqueued by now
             self._mask_sampler.end_step()
             self._mask_release_pending = False
@@ -273,6 +273,7 @@ class Data2VecMultiModel(tnn.Module):
             if precomputed_mask is not None:
                 m = precomputed_mask.to(source.device).to(torch.uint8)
             elif a.mask_prob > 0:
+                check_span_law(mask_length=a.mask_length, add_masks=a.add_masks)
                 self._mask_draws += 1
                 m = ops.span_mask(B, T, mask_prob=a.mask_prob, mask_length=a.mask_length, min_masks=1, mask_dropout=a.mask_dropout,
                                   seed=mask_seed(cfg.seed, self.num_updates, 2 * self._mask_draws, self._dist_rank()),

@@ -783,5 +783,44 @@ def mask_frames(x, mask_t=None, mask_c=None, *, noise_std=0.0, seed=0, backward=
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+#                                  caller-owned scratch (include/a2v.h, ABI 10)
+# ----------------------------------------------------------------------------------------------
+_WORKSPACES = {}          # (device index, stream handle) -> [zeroed uint8 tensor, users]
+
+
+def bind_workspace(stream_=None):
+    """Gives the library a caller-owned workspace for `stream_` (default: the current stream): a2v_query_workspace() bytes of
+    zeroed device memory, bound with a2v_bind_workspace -- the library then keeps no scratch of its own for that stream and
+    none of its four static sets is taken.  Counted per stream: every bind_workspace needs one release_workspace."""
+    st = stream_ if stream_ is not None else torch.cuda.current_stream()
+    key = (st.device.index, st.cuda_stream)
+    ent = _WORKSPACES.get(key)
+    if ent is None:
+        lib = _L()
+        n = int(lib.a2v_query_workspace())
+        with torch.cuda.stream(st):                      # the zero fill is ordered before every later call on that stream
+            t = torch.zeros(n + 256, dtype=torch.uint8, device=st.device)
+        off = (-t.data_ptr()) % 256
+        with torch.cuda.device(st.device):
+            check(lib.a2v_bind_workspace(st.cuda_stream, t.data_ptr() + off, n), "a2v_bind_workspace")
+        ent = _WORKSPACES[key] = [t, 0]
+    ent[1] += 1
+    return key
+
+
+def release_workspace(key) -> None:
+    ent = _WORKSPACES.get(key)
+    if ent is None:
+        return
+    ent[1] -= 1
+    if ent[1] <= 0:
+        del _WORKSPACES[key]
+        dev, handle = key
+        with torch.cuda.device(dev):
+            torch.cuda.synchronize(dev)                  # kernels queued on the stream may still use the workspace
+            _L().a2v_bind_workspace(handle, None, 0)
+
+
 def debug_set(key: int, value: int):
     check(_L().a2v_debug_set(int(key), int(value)), "a2v_debug_set")

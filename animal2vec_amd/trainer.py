@@ -71,7 +71,7 @@ class PretrainTrainer:
         self.mask_sampler = None
         if self.store.device.type == "cuda":
             self.mask_sampler = DeviceMaskSampler(self.store.device, mask_prob=a.mask_prob, mask_length=a.mask_length,
-                                                  mask_dropout=a.mask_dropout)
+                                                  mask_dropout=a.mask_dropout, add_masks=a.add_masks)
         self.sync = GradSync(self.store.grad, self._make_buckets(), process_group, wire_dtype=grad_wire)     # (ddp.GradSync: wire dtype)
         self.engine.on_grad_ready = self.sync.on_ready
         dev = self.store.device

@@ -160,8 +160,8 @@ class GemmRecorder:
         return out
 
 
-PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")
-PMC_MFMA = os.path.join("profiles", "r02_mfma_util.json")
+PMC_TRAFFIC = None          # set by select_pmc_files(): the newest committed profiles/rNN_pmc_traffic[_<model>].json
+PMC_MFMA = None             # ... / rNN_mfma_util[_<model>].json
 
 
 def select_pmc_files(model):
@@ -183,6 +183,8 @@ def select_pmc_files(model):
 
 
 def _pmc_doc(rel):
+    if rel is None:
+        return None
     try:
         with open(os.path.join(ROOT, rel)) as f:
             return json.load(f)
@@ -501,6 +503,15 @@ def main():
     use_dist = world > 1 or os.environ.get("A2V_BENCH_FORCE_DIST") == "1"   # the latter: RCCL path on a one-GPU box
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                         # A2V_BENCH_FORCE_DIST without a launcher: a one-rank group on this host
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                import socket
+                with socket.socket() as s_:
+                    s_.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
         dist.init_process_group("nccl", device_id=dev)
 
     from animal2vec_amd import ops
@@ -589,7 +600,7 @@ def main():
                     launches_per_microbatch=nt["launches"], avg_launch_us=round(nt["avg_us"], 2),
                     wgrad_kernel=dict(tflops=round(s["tn"]["tflops"], 2), launches=s["tn"]["launches"],
                                       avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None,
-                    # rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES share of the kernels' cycles (profiles/r02_mfma_util.json)
+                    # rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES share of the kernels' cycles (the file select_pmc_files() picked, named in `source`)
                     mfma_busy_share={"gemm_nt_bf16_p8_kernel": pmc_mfma("gemm_nt_bf16_p8_kernel"), "conv_nt_slab2_kernel": pmc_mfma("conv_nt_slab"), "conv_dec_kernel": pmc_mfma("conv_dec_kernel"),
                                      "gemm_tn_bf16_p8_kernel": pmc_mfma("gemm_tn_bf16_p8_kernel"), "attn_fwd_bf16_kernel": pmc_mfma("attn_fwd_bf16_kernel"),
                                      "source": PMC_MFMA} if dtype == torch.bfloat16 else None,
@@ -623,7 +634,9 @@ def main():
                        "kept_frames_mean": round(k_mean, 2), "allocator_primed_at_kept_frames": k_primed,
                        "global_batch_note": "strong scaling at a fixed global batch; 128 clips ~ the reference recipe's update "
                                             "(4 GPUs x 5 clips x update_freq 5 ~ 102 clips, a2v_large_pretrain_best.yaml:34-36,45-47,62)",
-                       "observed_world_size": dist.get_world_size() if use_dist else 1},
+                       "observed_world_size": dist.get_world_size() if use_dist else 1,
+                       "collectives": ("on (RCCL process group, forced at world size 1)" if world == 1 else "on (RCCL)") if (use_dist and tr.sync.active)
+                       else "off (one rank, no process group)"},
             "model_tflops_per_s": round(gf_fb * args.global_batch * args.steps / dt / 1e3, 2),
             "mfu_vs_bf16_dense_peak": round(gf_fb * args.global_batch * args.steps / dt / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
             "loss_per_sample": round(met["loss"], 5), "pred_var": round(met["pred_var"], 5),

@@ -15,10 +15,13 @@
  *  - ownership: the caller owns every buffer (incl. workspaces and tensors saved for backward);
  *    kernels never allocate, free or retain pointers.
  *  - every call is asynchronous on `stream` and graph-capturable (no sync, no alloc) and re-entrant across streams:
- *    the little device scratch the library owns itself (tile counters of the persistent GEMM, column-sum partial rows,
- *    d alibi_scale partial sums) exists once per stream -- static device arrays, a set is bound to a stream the first
- *    time the stream is passed in (at most 4 live streams; a2v_stream_release returns a set; a fifth stream still
- *    works, through the kernels that need no scratch).  Calls on ONE stream are ordered by the stream as usual.
+ *    the device scratch the kernels need besides their arguments (tile counters of the persistent GEMM, column-sum partial
+ *    rows, d alibi_scale partial sums, |q.k| bounds) is ONE workspace per stream.  ABI 10: the caller owns it --
+ *    a2v_query_workspace() bytes of zeroed device memory handed over with a2v_bind_workspace(stream, ptr, bytes), any
+ *    number of streams, the library keeps no state of its own for them (caller-owned scratch).  A stream that
+ *    was never bound falls back to one of 4 library-owned static sets (first use binds one, a2v_stream_release returns it;
+ *    a fifth unbound stream still works, through the kernels that need no scratch) -- the ABI <= 9 behaviour, kept so that
+ *    existing hosts run unchanged.  Calls on ONE stream are ordered by the stream as usual.
  *  - return value: 0 on success, <0 on error (-1 bad argument, -2 bad dtype, -(1000+hipError_t) on a
  *    launch failure).  No exceptions cross the ABI.
  */
@@ -271,12 +274,26 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   20 fixed-flavour instantiations of the NT kernel's 256-row tile for the eight hottest epilogue flag sets (1, default) / the generic epilogue (0)
  *   21 dense strided convs of the feature extractor on the 8-phase GEMMs + edge-frame kernels (1, default) / implicit-im2col 128 x 128 kernels (0)
  *   22 persistent NT kernel: the rows of a nearly empty last round of tiles go to the 128 x 128 kernel (1, default) / stay (0)
+ *   23 persistent NT kernel tile order: 0 (default) 8 m-tiles x all n-tiles per group; 1 "W-stationary" groups of four n-tiles
+ *      (round-4 experiment: +8.6 % fabric reads, 0.6 - 4 % slower -- profiles/r04_nt_tile_ab.txt)
  * No launch state goes through here (ABI 5's key 9, the tile-counter set, is gone: the stream argument selects it). */
 int a2v_debug_set(int key, int value);
 
-/* Gives the per-stream scratch set bound to `stream` back to the pool (see "re-entrant across streams" above); only needed
- * by hosts that create and destroy many streams.  -1 if the stream holds no set. */
+/* Gives the library-owned static scratch set an UNBOUND stream picked up back to the pool (see "re-entrant across streams"
+ * above); only needed by hosts that create and destroy many streams without binding workspaces.  -1 if the stream holds no set. */
 int a2v_stream_release(a2v_stream_t stream);
+
+/* ---------------------------------------------------------------- caller-owned scratch (ABI 10)
+ * a2v_query_workspace: bytes of device scratch the calls on ONE stream need (a constant of the build, about 19.5 MiB: shapes
+ * whose partial results would not fit take kernels that need none).
+ * a2v_bind_workspace: `ws` = at least that many bytes of device memory on the current device, 256-byte aligned, ZERO when
+ * handed over (the kernels leave it zero / self-consistent between calls), alive until every call queued on `stream` has
+ * finished or another workspace is bound.  From then on the library uses nothing of its own for `stream` (and no static
+ * set is consumed: any number of streams).  ws = NULL unbinds (the stream falls back to the static sets).  Binding is host
+ * state only -- no launch, no synchronisation; do it before the first call on the stream, not between dependent calls.
+ * Returns -1 for a short / misaligned workspace or an unbind of a stream that was never bound. */
+size_t a2v_query_workspace(void);
+int a2v_bind_workspace(a2v_stream_t stream, void* ws, size_t bytes);
 
 /* library version / build info */
 /* ---------------------------------------------------------------- finetune path
@@ -338,7 +355,8 @@ int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx,
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 9: + dtype A2V_BF16X3S and epilogue flag A2V_EPI_X3IMG of a2v_conv_gemm; a2v_attention_bwd takes dtype A2V_BF16X3 (signatures unchanged).
+/* 10: + a2v_query_workspace / a2v_bind_workspace (caller-owned scratch; every other signature unchanged); a2v_debug_set keys 23.
+ * 9: + dtype A2V_BF16X3S and epilogue flag A2V_EPI_X3IMG of a2v_conv_gemm; a2v_attention_bwd takes dtype A2V_BF16X3 (signatures unchanged).
  * 8: + a2v_split_bf16 and dtype A2V_BF16X3 of a2v_conv_gemm; + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
  * arithmetic).  7 added a2v_decoder_input_rng and A2V_EPI_DACT over 6. */
 int a2v_abi_version(void);

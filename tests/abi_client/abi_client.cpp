@@ -4,11 +4,14 @@
 //   2. a2v_layernorm_fwd (fp32) against a double-precision CPU LayerNorm
 //   3. a2v_conv_gemm as a Linear with bias + GELU (fp32 parity mode) against a CPU reference
 //   4. a2v_attention_fwd (fp32, ALiBi from explicit positions) against a CPU softmax attention
+//   5. caller-owned scratch (ABI 10): a2v_query_workspace / a2v_bind_workspace on SIX streams at once (the library's own static
+//      sets stop at four), a bf16 Linear with column sums on the persistent kernel on each, against a CPU reference
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "a2v.h"
@@ -133,6 +136,62 @@ int main() {
     const double e = relerr(out, ref);
     std::printf("attention_fwd rel err %.2e\n", e);
     if (!(e < 1e-5)) return 12;
+  }
+  // ---- caller-owned workspaces, more streams than the library has static sets
+  {
+    if (a2v_abi_version() < 10) { std::printf("abi version %d has no a2v_bind_workspace\n", a2v_abi_version()); return 13; }
+    const size_t wsb = a2v_query_workspace();
+    if (wsb == 0 || wsb > (size_t)1 << 30) { std::printf("a2v_query_workspace: %zu\n", wsb); return 13; }
+    const int NS = 6, M = 2048, N = 256, K = 256;
+    std::vector<unsigned short> x((size_t)M * K), w((size_t)N * K);
+    auto tobf = [](float f) { unsigned u; std::memcpy(&u, &f, 4); return (unsigned short)((u + 0x7FFF + ((u >> 16) & 1)) >> 16); };
+    auto frombf = [](unsigned short h) { unsigned u = (unsigned)h << 16; float f; std::memcpy(&f, &u, 4); return f; };
+    for (auto& v : x) v = tobf(rnd());
+    for (auto& v : w) v = tobf(rnd() * 0.0625f);
+    std::vector<double> ref((size_t)M * N), refcs(N, 0.0);
+    for (int m = 0; m < M; ++m)
+      for (int n = 0; n < N; ++n) {
+        double s_ = 0;
+        for (int k = 0; k < K; ++k) s_ += (double)frombf(x[(size_t)m * K + k]) * frombf(w[(size_t)n * K + k]);
+        ref[(size_t)m * N + n] = s_;
+      }
+    unsigned short *dx = dev(x), *dw = dev(w);
+    hipStream_t ss[NS];
+    void* wsp[NS];
+    unsigned short* dy[NS];
+    float* dcs[NS];
+    if (a2v_bind_workspace(st, nullptr, 0) == 0) { std::printf("unbinding a stream that was never bound must fail\n"); return 13; }
+    for (int i = 0; i < NS; ++i) {
+      CK(hipStreamCreate(&ss[i]));
+      CK(hipMalloc(&wsp[i], wsb));
+      CK(hipMemset(wsp[i], 0, wsb));
+      CK(hipMalloc((void**)&dy[i], (size_t)M * N * 2));
+      CK(hipMalloc((void**)&dcs[i], N * 4));
+      CK(hipMemset(dcs[i], 0, N * 4));
+      if (a2v_bind_workspace(ss[i], wsp[i], wsb - 1) == 0) { std::printf("a short workspace must be refused\n"); return 13; }
+      A2V(a2v_bind_workspace(ss[i], wsp[i], wsb));
+    }
+    CK(hipDeviceSynchronize());
+    for (int rep = 0; rep < 2; ++rep)          // twice: the workspace must come back self-consistent (counters reset, copies cleared)
+      for (int i = 0; i < NS; ++i)
+        A2V(a2v_conv_gemm(A2V_BF16, dx, K, 0, 0, M, M, 1, 0, 1, K, K, nullptr, 1, dw, K, 0, dy[i], N, 0, nullptr, nullptr, 0, nullptr, dcs[i],
+                          M, N, K, 1, A2V_EPI_COLSUM, 0.f, 0u, ss[i]));
+    CK(hipDeviceSynchronize());
+    for (int i = 0; i < NS; ++i) {
+      std::vector<unsigned short> y((size_t)M * N);
+      std::vector<float> cs(N), yf((size_t)M * N);
+      CK(hipMemcpy(y.data(), dy[i], y.size() * 2, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(cs.data(), dcs[i], N * 4, hipMemcpyDeviceToHost));
+      for (size_t j = 0; j < y.size(); ++j) yf[j] = frombf(y[j]);
+      if (i == 0) {                              // column sums of the bf16-ROUNDED outputs, summed over the two launches
+        for (int n = 0; n < N; ++n) { refcs[n] = 0; for (int m = 0; m < M; ++m) refcs[n] += 2.0 * yf[(size_t)m * N + n]; }
+      }
+      const double e = relerr(yf, ref), ec = relerr(cs, refcs);
+      std::printf("workspace stream %d: linear rel err %.2e, column sums rel err %.2e\n", i, e, ec);
+      if (!(e < 5e-3) || !(ec < 1e-3)) return 14;
+      A2V(a2v_bind_workspace(ss[i], nullptr, 0));                      // unbind
+      CK(hipFree(wsp[i]));
+    }
   }
   std::printf("ABI_CLIENT_OK\n");
   return 0;

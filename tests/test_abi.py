@@ -11,7 +11,7 @@ def header_decls():
     txt = open(os.path.join(ROOT, "include", "a2v.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\bint\s+(a2v_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t)\s+(a2v_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         decls[m.group(1)] = n
@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
         assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
     assert set(_lib.SIGNATURES) == set(decls)
-    assert lib.a2v_abi_version() == 9
+    assert lib.a2v_abi_version() == 10
 
 
 def test_ops_refuse_cpu_tensors():

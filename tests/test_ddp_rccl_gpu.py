@@ -73,3 +73,34 @@ def test_trainer_over_rccl_one_rank(tmp_path):
     f.write_text(_SCRIPT)
     r = subprocess.run([sys.executable, str(f)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_PATH_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_itself_runs_its_rccl_path_on_one_gpu():
+    """the RCCL code path of bench.py itself (process-group set-up from the launcher's environment, GradSync's
+    bucketed asynchronous all-reduces inside the timed steps, the packed statistics all-reduce, max-over-ranks timing) with one
+    rank on the one GPU of the test box: `A2V_BENCH_FORCE_DIST=1 A2V_DDP_FORCE=1 python bench.py --gpus 1 --steps 2`.  The JSON
+    line must keep the driver's contract and say that the gradients went through the collectives."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(A2V_BENCH_FORCE_DIST="1", A2V_DDP_FORCE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--global-batch", "8",
+                        "--cpu-baseline", "skip", "--no-roofline", "--parity-leg", "skip"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["unit"] == "audio-s/s" and j["dtype"] == "bf16"
+    assert j["config"]["global_batch"] == 8 and j["config"]["observed_world_size"] == 1
+    assert abs(j["value"] - 80.0 / (j["ms_per_step"] / 1e3)) / j["value"] < 1e-3
+    assert "overlapped with backward" in j["config"]["grad_all_reduce"]
+    assert j["config"].get("collectives") == "on (RCCL process group, forced at world size 1)", j["config"]
+    assert 0 < j["loss_per_sample"] < 1e4

@@ -149,29 +149,27 @@ def test_finetune_schedule_and_layer_decay():
 
 
 def test_finetune_aug_draws():
-    """make_aug: span masks with equal counts per row, channel spans, layerdrop frequencies, dropout settings"""
+    """make_aug on the host: layerdrop frequencies, dropout settings (the span masks come from the device sampler:
+    tests/test_masks_gpu.py::test_finetune_make_aug_draws_on_the_device_and_repeats_per_seed)"""
     import numpy as np
     from animal2vec_amd.finetune import FinetuneConfig, make_aug
-    f = FinetuneConfig()
+    f = FinetuneConfig(apply_mask=False)
     rng = np.random.default_rng(0)
     B, T, D = 8, 2000, 1024
     drops = np.zeros(24)
     for _ in range(40):
         a = make_aug(f, B, T, D, 8, 24, rng, 0.01, device="cpu")
-        mt, mc = a["mask_t"].numpy(), a["mask_c"].numpy()
-        assert mt.shape == (B, T) and mc.shape == (B, D)
-        assert len(set(mt.sum(1).tolist())) == 1                        # require_same_masks
-        assert 0.5 < mt.mean() < 0.9                                     # mask_prob 0.825 with overlapping spans of 4
-        assert 0.2 < mc.mean() < 0.5                                     # 0.5 with overlapping spans of 64
-        runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], mc[0], [0]]))))[::2]
-        assert runs.mean() > 2.0          # spans (thinned by require_same_masks' equalisation), not isolated channels
-        assert a["noise_std"] == 0.01 and a["p_att"] == 0.2 and a["p_drop"] == 0.1 and a["p_act"] == 0.1
+        assert "mask_t" not in a and "mask_c" not in a
+        assert a["p_att"] == 0.2 and a["p_drop"] == 0.1 and a["p_act"] == 0.1
         assert any(a["active"][8:])
         drops += 1 - np.asarray(a["active"], dtype=float)
     assert 0.03 < drops.mean() / 40 < 0.2                                # layerdrop 0.1
     f0 = FinetuneConfig(apply_mask=False, layerdrop=0.0, dropout=0.0, activation_dropout=0.0, attention_dropout=0.0)
     a = make_aug(f0, B, T, D, 8, 24, rng, 0.01, device="cpu")
     assert "mask_t" not in a and "mask_c" not in a and all(a["active"]) and "drop_seed" not in a
+    # with masks asked for and no GPU library call possible on CPU tensors, the product path fails loudly (no host fallback)
+    with pytest.raises(Exception):
+        make_aug(FinetuneConfig(), B, T, D, 8, 24, rng, 0.01, device="cpu")
 
 
 def test_checkpoint_wire_format_roundtrip(tmp_path):
@@ -453,3 +451,21 @@ def test_mask_seed_is_a_distinct_function_of_every_counter():
     seen = {mask_seed(s, u, j, r) for s in (0, 1) for u in range(50) for j in range(8) for r in range(8)}
     assert len(seen) == 2 * 50 * 8 * 8
     assert all(0 <= v < 2 ** 64 for v in seen)
+
+
+def test_device_sampler_refuses_laws_it_does_not_implement():
+    """add_masks / mask_length == 1 select other sampling laws in the reference (base.py:395-396, 409); with no host
+    path left in the step they must be rejected, not sampled with the span law silently."""
+    from animal2vec_amd.masking import check_span_law
+    check_span_law(mask_length=2, add_masks=False)
+    for kw in (dict(mask_length=1), dict(mask_length=2, add_masks=True), dict(mask_length=4, inverse_mask=True),
+               dict(mask_length=4, keep_masked_pct=0.1)):
+        with pytest.raises(NotImplementedError):
+            check_span_law(**kw)
+
+
+def test_mask_seed_is_a_pure_function_of_the_counters():
+    from animal2vec_amd.masking import mask_seed
+    a = mask_seed(1, 10, 0, 0)
+    assert a == mask_seed(1, 10, 0, 0)
+    assert len({a, mask_seed(1, 11, 0, 0), mask_seed(1, 10, 1, 0), mask_seed(1, 10, 0, 1), mask_seed(2, 10, 0, 0)}) == 5

@@ -49,6 +49,47 @@ def test_span_mask_bit_exact_vs_oracle(ops, N, T, prob, length, drop, seed):
     assert bool((mask.sum(1) == T - K).all())
 
 
+@pytest.mark.parametrize("N,T,prob,length,min_masks,seed", [
+    (64, 2000, 0.825, 4, 1, 99),                    # finetune time masks of one 64-clip micro-batch (finetune_mixup_100.yaml: 0.825 / 4)
+    (64, 1024, 0.5, 64, 0, 100),                    # finetune channel masks over D = 1024 (0.5 / 64, min_masks 0: base.py:471-484)
+    (8, 768, 0.5, 64, 0, 101),                      # base model's D
+    (4, 1024, 0.01, 64, 0, 102),                    # 0.16 spans per row: rows that draw NO span (min_masks 0) -> nothing is masked anywhere
+])
+def test_finetune_mask_shapes_bit_exact_vs_oracle(ops, N, T, prob, length, min_masks, seed):
+    """the finetune path's apply_mask draws (reference nn/modalities/base.py:370-425) come from the same device
+    sampler as the pretraining masks; time masks with min_masks 1, channel masks with min_masks 0."""
+    mask = ops.span_mask(N, T, mask_prob=prob, mask_length=length, min_masks=min_masks, seed=seed)[0]
+    torch.cuda.synchronize()
+    ref = O.span_mask(N, T, prob, length, seed, min_masks=min_masks)
+    assert torch.equal(mask.cpu().bool(), torch.from_numpy(ref))
+    cnt = mask.sum(1)
+    assert bool((cnt == cnt[0]).all())              # require_same_masks
+
+
+def test_finetune_make_aug_draws_on_the_device_and_repeats_per_seed(ops):
+    from animal2vec_amd.finetune import FinetuneConfig, make_aug
+    from animal2vec_amd.masking import mask_seed
+    f = FinetuneConfig()
+    B, T, D = 8, 500, 1024
+    seeds = (mask_seed(3, 17, 0, 1), mask_seed(3, 17, 1, 1))
+    a1 = make_aug(f, B, T, D, 8, 24, np.random.default_rng(0), 0.01, mask_seeds=seeds)
+    a2 = make_aug(f, B, T, D, 8, 24, np.random.default_rng(5), 0.01, mask_seeds=seeds)        # another host RNG, the same mask seeds
+    a3 = make_aug(f, B, T, D, 8, 24, np.random.default_rng(0), 0.01, mask_seeds=(mask_seed(3, 18, 0, 1), mask_seed(3, 18, 1, 1)))
+    for k, n in (("mask_t", T), ("mask_c", D)):
+        assert a1[k].is_cuda and a1[k].dtype == torch.uint8 and tuple(a1[k].shape) == (B, n)
+        assert torch.equal(a1[k], a2[k]) and not torch.equal(a1[k], a3[k])
+    assert torch.equal(a1["mask_t"].cpu().bool(), torch.from_numpy(O.span_mask(B, T, f.mask_prob, f.mask_length, seeds[0], min_masks=1)))
+    assert torch.equal(a1["mask_c"].cpu().bool(),
+                       torch.from_numpy(O.span_mask(B, D, f.mask_channel_prob, f.mask_channel_length, seeds[1], min_masks=0)))
+    frac = float(a1["mask_t"].float().mean())
+    assert 0.4 < frac < 0.7, frac                    # 0.825 / 4 with overlaps: 1 - exp(-0.825) = 0.56 of the frames
+    mc = a1["mask_c"].cpu().numpy()
+    assert 0.2 < mc.mean() < 0.5                     # 0.5 / 64 with overlapping spans
+    runs = np.diff(np.flatnonzero(np.diff(np.concatenate([[0], mc[0], [0]]))))[::2]
+    assert runs.mean() > 2.0                         # spans (thinned by require_same_masks' equalisation), not isolated channels
+    assert a1["noise_std"] == 0.01
+
+
 def test_same_seed_same_masks_other_seed_other_masks(ops):
     a = _sample(ops, 24, 2000, mask_prob=1.5, mask_length=2, seed=42)
     b = _sample(ops, 24, 2000, mask_prob=1.5, mask_length=2, seed=42)

@@ -20,7 +20,12 @@ AL_KEY = "modality_encoders.AUDIO.alibi_scale"
 # unit roundoff of the storage type (fp32: 2^-24 = 6e-8, bound 2e-7; bf16: 2^-9 = 2e-3).  Measured (profiles/r03_parity_report.jsonl):
 # fp32 1.4e-8 .. 4.9e-8, bf16 6.9e-5 .. 6.9e-4, over condition numbers A / |g| of 20 (D = 128, 8 kHz), 452 (the large model at 8 kHz),
 # 326 (base*), 99 / 673 (T = 5513 / 11 025) -- the relative errors of round 2 (5.7e-2, 2.8e-1) are exactly condition number x this.
-ALIBI_BACK = {torch.float32: 2e-7, torch.bfloat16: 2e-3, "bf16x3": 3e-5}     # (bf16x3: products exact to 2^-16 = 1.5e-5)
+# Round 4: the bf16 bound is 1e-3 (measured 4.0e-5 .. 6.9e-4, so at most 1.5x slack at the worst config), and
+# every mode also keeps a RELATIVE ceiling of 0.5 -- a sign or scale error of the kernel (relative error >= 1) cannot hide behind A.
+# What the relative error itself is when the sum does NOT cancel is pinned at full dims by
+# tests/test_ops_gpu.py::test_alibi_scale_gradient_well_conditioned_full_dims (bf16: 5e-2, condition number <= 30).
+ALIBI_BACK = {torch.float32: 2e-7, torch.bfloat16: 1e-3, "bf16x3": 3e-5}     # (bf16x3: products exact to 2^-16 = 1.5e-5)
+ALIBI_REL_CEILING = 0.5
 
 
 X3 = "bf16x3"        # parity mode on the bf16 matrix cores: fp32 storage, the Linears as three exact bf16 products (Engine(x3=True))
@@ -58,6 +63,7 @@ class alibi_term_scale:
         err = (g_hip.detach().float().cpu().reshape(-1) - g_ref.reshape(-1)).norm()
         rel, cond, back = float(err / g_ref.norm()), float(A.norm() / g_ref.norm()), float(err / A.norm())
         assert back < rel_bound, (rel, cond, back)
+        assert rel < ALIBI_REL_CEILING, (rel, cond, back)
         return rel, cond, back
 
 
