@@ -1093,6 +1093,8 @@ def test_alibi_scale_gradient_well_conditioned_full_dims(ops, dtype, N, S, arang
     assert rel_err(dqkv.double().cpu(), x.grad) < tol(dtype, 3)
     # per head too: no head may be off by more than 2.5 x the bound (the steep heads attend to 2 - 3 frames)
     worst = float(((dal.double().cpu() - sc.grad).abs() / sc.grad.abs()).max())
+    from conftest import parity_report
+    parity_report(f"alibi_well_conditioned_N{N}_S{S}", dtype, [(rel, "d_alibi_scale"), (worst, "d_alibi_scale_worst_head")], alibi_cond=cond)
     assert worst < 2.5 * bound, worst
 
 
