@@ -695,6 +695,9 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 21) { g_a2v_conv_strided = value; return A2V_OK; }
   if (key == 22) { g_a2v_p8_tail = value; return A2V_OK; }        // persistent NT kernel: nearly empty last round -> 128 x 128 kernel   // dense strided convs on the 8-phase GEMMs on / off
   if (key == 23) { g_a2v_p8_tmode = value; return A2V_OK; }   // persistent NT kernel: tile order (0: 8 m-tiles x all n-tiles, 1: W-stationary n-groups)
+#ifdef P8_SKEW
+  { extern int g_a2v_p8_skew; if (key == 24) { g_a2v_p8_skew = value; return A2V_OK; } }
+#endif
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off

@@ -76,6 +76,26 @@ extern "C" int a2v_diag_p8_stamps(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p8_stamp), sizeof(unsigned long long) * 256 * 4) == hipSuccess ? 0 : -1;
 }
 #endif
+#ifdef P8_STAMP2
+// Diagnostic build only (tools/p8_probe.py): wave 0 of every workgroup keeps, per output tile, five stamps in the unused part of
+// its epilogue staging area (LDS: no vector-memory operation is added to the kernel's in-order vmcnt stream) and copies them out
+// when the tile list is done: [A] s_memrealtime and [1] s_memtime at the top of the epilogue, [2] s_memtime at its end (last store
+// issued), [3] / [4] after the first / second K-tile of the NEXT tile.
+#define P8_ST2_MAX 96
+__device__ unsigned long long g_p8_stamp2[256][P8_ST2_MAX][5];
+__device__ int g_p8_stamp2_n[256];
+extern "C" int a2v_diag_p8_stamps2(unsigned long long* host_out, int* n_out) {
+  if (hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_p8_stamp2), sizeof(unsigned long long) * 256 * P8_ST2_MAX * 5) != hipSuccess) return -1;
+  return hipMemcpyFromSymbol(n_out, HIP_SYMBOL(g_p8_stamp2_n), sizeof(int) * 256) == hipSuccess ? 0 : -1;
+}
+#define P8_ST2(slot_) if (tid == 0 && st2_i < P8_ST2_MAX) { const unsigned long long v_ = __builtin_amdgcn_s_memtime(); \
+    asm volatile("ds_write_b64 %0, %1" :: "v"(lds0 + P8_STG + 256 + (st2_i * 5 + (slot_)) * 8), "v"(v_) : "memory"); }
+#define P8_ST2R(slot_) if (tid == 0 && st2_i < P8_ST2_MAX) { const unsigned long long v_ = __builtin_amdgcn_s_memrealtime(); \
+    asm volatile("ds_write_b64 %0, %1" :: "v"(lds0 + P8_STG + 256 + (st2_i * 5 + (slot_)) * 8), "v"(v_) : "memory"); }
+#else
+#define P8_ST2(slot_)
+#define P8_ST2R(slot_)
+#endif
 
 struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
@@ -310,6 +330,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   } else if (dynamic && tid == 0) {
     *slot = gridDim.x + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;
   }
+#ifdef P8_SKEW
+  // Experiment build: the workgroups of an XCD start in 8 groups (blockIdx.x >> 3) & 7 that are ((stagger >> 4) & 255) x ~0.5 us apart,
+  // so that the CUs' output bursts do not coincide (tools/p8_probe.py)
+  for (int i = ((stagger >> 4) & 255) * (int)((blockIdx.x >> 3) & 7u); i > 0; --i) __builtin_amdgcn_s_sleep(16);
+#endif
   P8Tile T = make_tile(seq);
   // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
   {
@@ -334,6 +359,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   if (wid == 0) { st_c0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 #endif
   int seq_next = 0;
+#ifdef P8_STAMP2
+  int st2_i = -1;           // the tile whose epilogue came last (its [3] / [4] stamps are taken in the next tile's K loop)
+#endif
   for (; seq < ntiles; seq = seq_next) {
     // (at the end of the list the "next tile" is this tile again: harmless re-fetches of valid data into dead
     // buffers keep the vmcnt accounting uniform)
@@ -344,8 +372,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 
     for (int kt = 0; kt < nk - 2; kt += 2) {
       { P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2) }
+#ifdef P8_STAMP2
+      if (kt == 0 && st2_i >= 0) { P8_ST2(3) }
+#endif
       { P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3) }
+#ifdef P8_STAMP2
+      if (kt == 0 && st2_i >= 0) { P8_ST2(4) }
+#endif
     }
+#ifdef P8_STAMP2
+    ++st2_i;
+#endif
     // last two K-tiles: the stream continues with K-tiles 0 / 1 of the next tile (its offsets are formed here, not
     // at the top of the tile, so that they are not live -- and spilled -- across the main loop)
     // (an LDS-typed read: through a generic pointer this was a flat_load, whose s_waitcnt vmcnt(0) lgkmcnt(0) drained
@@ -420,6 +457,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // K-loop barrier and the trailer's with the leader's first barrier of the next tile: both epilogues run at the same time,
       // two latency-bound waves per SIMD.  (Every wave executes exactly one of the two: the counts stay equal.)
       if (!(stagger & 1) || wr == 0) __builtin_amdgcn_s_barrier();
+      P8_ST2R(0) P8_ST2(1)
       if constexpr (O32) {
         // fp32 outputs: lane (fq, fr) holds row i*16 + fr, columns hb*128 + wc*32 + 8 fq + [0, 8) = two 16-B stores
         const int fre = le & 15, fqe = le >> 4;
@@ -511,8 +549,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // Addresses: a uniform 64-bit tile base (SGPRs) + a 32-bit per-lane element offset inside the tile's rows.
       const int fre = le & 15, fqe = le >> 4;
       const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
+#ifdef P8_L2STORE
+      bf16* const Ct = C + (int)(blockIdx.x * 8 + wid) * 1024;
+      bf16* const C2t = C2 + (int)(blockIdx.x * 8 + wid) * 1024;
+#else
       bf16* const Ct = C + tile_off;
       bf16* const C2t = C2 + tile_off;
+#endif
       // (made uniform explicitly: the raw-asm loads below take it as an SGPR pair, and hipcc does not always prove that itself)
       const unsigned long long rt_ = (unsigned long long)(R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0));
       const bf16* const Rt = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rt_ >> 32)) << 32) |
@@ -582,7 +625,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * hb][r]; v[4 + r] = acc[i][2 * hb + 1][r]; }
+#ifdef P8_L2STORE
+          // Experiment build (timing only, wrong results): every wave's output stores land in two fixed 1-KiB blocks at the head of C /
+          // C2 -- same instructions, same data path up to L2, but no write stream beyond it (tools/p8_probe.py)
+          const unsigned eo = (unsigned)((i & 1) * 512 + le * 8);
+#else
           const unsigned eo = (unsigned)(row * (int)g.ldc + cl);
+#endif
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += bias8[q];
           // (not at the 256-row tile: its register allocation has no room for this branch -- 8 spills, reloaded inside the tile
@@ -671,6 +720,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #undef P8_RLOAD
 #undef P8_RN
       }      // !O32
+      P8_ST2(2)
       if ((stagger & 1) && wr == 1) __builtin_amdgcn_s_barrier();     // the trailing group's half of the epilogue barrier (see above)
     } else {
     const int fre = le & 15, fqe = le >> 4;            // staging writes: MFMA layout (rows 4 fq + r, column fr)
@@ -797,6 +847,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     g_p8_stamp[blockIdx.x][0] = st_c0; g_p8_stamp[blockIdx.x][1] = c1; g_p8_stamp[blockIdx.x][2] = st_r0; g_p8_stamp[blockIdx.x][3] = r1;
   }
 #endif
+#ifdef P8_STAMP2
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 256) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const int n = st2_i + 1 < P8_ST2_MAX ? st2_i + 1 : P8_ST2_MAX;
+    g_p8_stamp2_n[blockIdx.x] = n;
+    const unsigned long long* src = (const unsigned long long*)(smem + P8_STG + 256);
+    for (int i = 0; i < n * 5; ++i) g_p8_stamp2[blockIdx.x][i / 5][i % 5] = src[i];
+  }
+#endif
   if (dynamic && tid == 0) {
     if (atomicAdd(&g_p8_ctr[8], 1u) == gridDim.x - 1) {
 #pragma unroll
@@ -813,6 +872,9 @@ int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swappe
 int g_a2v_p8_fx = 1;      // a2v_debug_set(20, v): 0 = every flavour takes the generic epilogue (A/B)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 int g_a2v_p8_tmode = 0;   // a2v_debug_set(23, v): tile order of the persistent NT kernel: 0 = 8 m-tiles x all n-tiles, 1 = W-stationary groups of four n-tiles (N >= 2048)
+#ifdef P8_SKEW
+int g_a2v_p8_skew = 0;    // a2v_debug_set(24, v), experiment build only: start skew of the workgroups (units of ~0.5 us x 8 groups)
+#endif
 int g_a2v_p8_tail = 1;    // a2v_debug_set(22, v): a nearly empty last round of tiles goes to the 128 x 128 kernel (1) / stays here (0)
 static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bool allow_tail = true);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, false); }
@@ -912,6 +974,11 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   const int tiles_n_ = g.N / 256;
   const int stagger = ((g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048)) ? 1 : 0) |
                       ((g_a2v_p8_tmode && tiles_n_ > 4 && tiles_n_ % 4 == 0) ? 2 : 0);      // bit 1: tile order
+#ifdef P8_SKEW
+  extern int g_a2v_p8_skew;
+  const int stagger_ = stagger | ((g_a2v_p8_skew & 255) << 4);
+#define stagger stagger_
+#endif
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);
   char* const ws = a2v_stream_ws(stream);
