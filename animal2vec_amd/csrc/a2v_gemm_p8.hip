@@ -279,14 +279,16 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #define P8_AH1(T_) ((DS && IH == 4) ? T_.ah0 + d64a_ : T_.ah1)
 #define P8_BL1(T_) (DS ? T_.bl0 + d64b_ : T_.bl1)
 #define P8_BH1(T_) (DS ? T_.bh0 + d64b_ : T_.bh1)
-#define P8_KTILE(cur, oth, T1, k1, T2, k2)                                                             \
+// PH1 = the phase-1 stage of A_hi(T1, k1) (absent in a tile's first K-tile: staged before the seam, below), PH4X = an extra stage in
+// phase 4 (the seam's last K-tile), WAITN = the counted wait of phase 4.
+#define P8_KTILE_X(cur, oth, T1, k1, T2, k2, PH1, PH4X, WAITN)                                          \
   unsigned d64a_ = d64a, d64b_ = d64b;                                                                 \
   asm volatile("" : "+s"(d64a_), "+s"(d64b_));                                                         \
   /* phase 1: quadrant lo/lo */                                                                        \
   P8_READ_B(fbl, cur, P8_BLO)                                                                          \
   __builtin_amdgcn_sched_barrier(0);                                                                   \
   P8_READ_A(cur, P8_ALO)                                                                               \
-  P8_STAGE2(abase, T1.ah0, P8_AH1(T1), k1, (oth) + P8_AHI, ah_second)                                      \
+  PH1                                                                                                  \
   P8_MFMA(0, 0, fbl, 4)                                                                                  \
   /* phase 2: lo/hi */                                                                                 \
   P8_READ_B(fbh, cur, P8_BHI)                                                                          \
@@ -298,8 +300,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   P8_MFMA(4, 2, fbh, IH)                                                                                  \
   /* phase 4: hi/lo (B_lo fragments kept from phase 1) */                                              \
   P8_STAGE(bbase, T2.bh0, P8_BH1(T2), k2, (cur) + P8_BHI)                                                  \
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                     \
+  PH4X                                                                                                 \
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");                                        \
   P8_MFMA(4, 0, fbl, IH)
+#define P8_KTILE(cur, oth, T1, k1, T2, k2) \
+  P8_KTILE_X(cur, oth, T1, k1, T2, k2, P8_STAGE2(abase, T1.ah0, P8_AH1(T1), k1, (oth) + P8_AHI, ah_second), , 6)
+// The tile seam and vmcnt.  Loads, stores, atomics and LDS-DMA retire through ONE in-order counter, so a counted wait for a DMA
+// issued AFTER the epilogue's output stores is also a wait for those stores' acknowledgements -- and a store into lines that are
+// not in L2 is acknowledged ~3.5 us after it was issued (tools/p8_probe.py, per-tile stamps: the first K-tile after an epilogue took
+// 3.9 us against 1.35 us for every other one; with the same stores aimed at L2-resident lines the whole launch is 12-13 % shorter).
+// The first K-tile of a tile used to stage A_hi of K-tile 1 in its phase 1, i.e. behind the stores, and wait for it in phase 4.  Now
+// that half-tile is staged in phase 4 of the PREVIOUS tile's last K-tile (its buffer was last read in that K-tile's phase 3), all
+// of K-tile 1 is older than the epilogue, and the first K-tile's wait may leave the epilogue's operations in flight: vmcnt(6 + E),
+// E = the number of vector-memory operations every wave certainly issues in the epilogue (fewer than the real count only makes the
+// wait stronger than needed).  The stores then have until the end of the tile's SECOND K-tile to be acknowledged.
+#define P8_KTILE_FIRST(cur, oth, T2, k2) P8_KTILE_X(cur, oth, T2, 0, T2, k2, , , P8_WAIT0)
+#define P8_KTILE_LAST(cur, oth, T1, k1, T2, k2)                                                          \
+  P8_KTILE_X(cur, oth, T1, k1, T2, k2, P8_STAGE2(abase, T1.ah0, P8_AH1(T1), k1, (oth) + P8_AHI, ah_second), \
+             P8_STAGE2(abase, T2.ah0, P8_AH1(T2), k2, (cur) + P8_AHI, ah_second), 8)
 
   // (a single round -- ntiles == gridDim.x -- keeps the static first tile: handing it out gains nothing there, and the
   // claim-one-ahead scheme would give half of the workgroups two tiles and the rest none)
@@ -336,7 +354,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   for (int i = ((stagger >> 4) & 255) * (int)((blockIdx.x >> 3) & 7u); i > 0; --i) __builtin_amdgcn_s_sleep(16);
 #endif
   P8Tile T = make_tile(seq);
-  // ---- prologue: K-tile 0 complete, three half-tiles of K-tile 1 in flight
+  // ---- prologue: K-tiles 0 and 1 complete
   {
     const unsigned d64a_ = d64a, d64b_ = d64b;
     P8_STAGE(abase, T.al0, P8_AL1(T), 0, P8_ALO)
@@ -346,8 +364,9 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     P8_STAGE(abase, T.al0, P8_AL1(T), 1, P8_BUF + P8_ALO)
     P8_STAGE(bbase, T.bl0, P8_BL1(T), 1, P8_BUF + P8_BLO)
     P8_STAGE(bbase, T.bh0, P8_BH1(T), 1, P8_BUF + P8_BHI)
+    P8_STAGE2(abase, T.ah0, P8_AH1(T), 1, P8_BUF + P8_AHI, ah_second)
   }
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (both K-tiles: the first K-tile's wait assumes K-tile 1 was complete before "the epilogue")
   __builtin_amdgcn_s_barrier();
   // The two waves that share a SIMD (w and w + 4, i.e. wr = 0 / 1) run half a phase apart from here on: one extra
   // barrier for the wr = 1 group pairs its "reads done" barrier with the other group's "MFMAs done" barrier, so one
@@ -370,15 +389,23 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int kt = 0; kt < nk - 2; kt += 2) {
+    // epilogue operations every wave issues for certain (see P8_KTILE_FIRST): the C stores, with fixed flags also the second output's
+    // stores, the bias vectors and the residual rows; the staged epilogue's stores are conditional (E = 0)
+    constexpr int P8_E_ = !DS ? 0
+                          : 2 * (4 + IH) * (((FX & 0xFF) & (F_STORE_PRE)) && FX > 0 ? 2 : 1) + ((FX > 0 && ((FX & 0xFF) & F_BIAS)) ? 4 : 0) +
+                                ((FX > 0 && ((FX & 0xFF) & (F_RES | F_GELU_BWD)) && !O32) ? 2 * (4 + IH) : 0);
+    constexpr int P8_WAIT0 = 6 + (P8_E_ > 48 ? 48 : P8_E_);
+    { P8_KTILE_FIRST(0, P8_BUF, T, 2) }
+#ifdef P8_STAMP2
+    if (st2_i >= 0) { P8_ST2(3) }
+#endif
+    { P8_KTILE(P8_BUF, 0, T, 2, T, 3) }          // (nk is even and >= 4: the launcher asks for K % 128 == 0, K >= 256)
+#ifdef P8_STAMP2
+    if (st2_i >= 0) { P8_ST2(4) }
+#endif
+    for (int kt = 2; kt < nk - 2; kt += 2) {
       { P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2) }
-#ifdef P8_STAMP2
-      if (kt == 0 && st2_i >= 0) { P8_ST2(3) }
-#endif
       { P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3) }
-#ifdef P8_STAMP2
-      if (kt == 0 && st2_i >= 0) { P8_ST2(4) }
-#endif
     }
 #ifdef P8_STAMP2
     ++st2_i;
@@ -417,7 +444,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     }
     const int kn0 = has_next ? 0 : nk - 2, kn1 = has_next ? 1 : nk - 1;
     { P8_KTILE(0, P8_BUF, T, nk - 1, Tn, kn0) }
-    { P8_KTILE(P8_BUF, 0, Tn, kn0, Tn, kn1) }
+    { P8_KTILE_LAST(P8_BUF, 0, Tn, kn0, Tn, kn1) }
     // the "+v" ties of P8_LGKM0 make every fragment register look live from one phase to the next, and so across the
     // epilogue into the next tile's first phase: redefine them (no instruction) so that the epilogue may use them
 #define P8_KILL4(x) "=v"(x[0][0]), "=v"(x[0][1]), "=v"(x[1][0]), "=v"(x[1][1])
@@ -549,9 +576,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // Addresses: a uniform 64-bit tile base (SGPRs) + a 32-bit per-lane element offset inside the tile's rows.
       const int fre = le & 15, fqe = le >> 4;
       const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
-#ifdef P8_L2STORE
-      bf16* const Ct = C + (int)(blockIdx.x * 8 + wid) * 1024;
+#if defined(P8_L2STORE) && P8_L2STORE == 1
+      bf16* const Ct = C + (int)(blockIdx.x * 8 + wid) * 1024;       // two fixed 1-KiB blocks per wave, contiguous 1-KiB stores
       bf16* const C2t = C2 + (int)(blockIdx.x * 8 + wid) * 1024;
+#elif defined(P8_L2STORE) && P8_L2STORE == 2
+      bf16* const Ct = C;                                            // the real access pattern (16 rows x 64 B per store), every tile onto tile (0, 0)
+      bf16* const C2t = C2;
+#elif defined(P8_L2STORE) && P8_L2STORE == 3
+      bf16* const Ct = C + ((long long)seq * 8 + wid) * (2 * (4 + IH)) * 512;   // contiguous 1-KiB stores, every one to fresh memory
+      bf16* const C2t = C2 + ((long long)seq * 8 + wid) * (2 * (4 + IH)) * 512;
 #else
       bf16* const Ct = C + tile_off;
       bf16* const C2t = C2 + tile_off;
@@ -625,10 +658,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * hb][r]; v[4 + r] = acc[i][2 * hb + 1][r]; }
-#ifdef P8_L2STORE
-          // Experiment build (timing only, wrong results): every wave's output stores land in two fixed 1-KiB blocks at the head of C /
-          // C2 -- same instructions, same data path up to L2, but no write stream beyond it (tools/p8_probe.py)
+#if defined(P8_L2STORE) && P8_L2STORE == 1
+          // Experiment builds (timing only, wrong results; tools/p8_probe.py): the output stores re-aimed, same instructions
           const unsigned eo = (unsigned)((i & 1) * 512 + le * 8);
+#elif defined(P8_L2STORE) && P8_L2STORE == 3
+          const unsigned eo = (unsigned)((hb * (4 + IH) + i) * 512 + le * 8);
 #else
           const unsigned eo = (unsigned)(row * (int)g.ldc + cl);
 #endif
