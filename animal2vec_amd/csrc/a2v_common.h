@@ -200,6 +200,26 @@ __device__ __forceinline__ float gelu_with_grad(float x, float& grad) {
   grad = fmaf(x * 0.39894228040143268f, e, 0.5f + copysignf(q, x));
   return fmaf(fabsf(x), q, 0.5f * x);
 }
+// The same for a PAIR of values in packed fp32 arithmetic (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of
+// FMAs per issue slot; only v_rcp / v_exp and the sign / magnitude bit operations stay per component).  Same formulas, same
+// constants, same operation order as gelu_with_grad: bit-identical results.
+typedef float a2v_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ a2v_f32x2 gelu_with_grad2(a2v_f32x2 x, a2v_f32x2& grad) {
+  a2v_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const a2v_f32x2 axs = ax * 0.70710678118654752f;
+  const a2v_f32x2 den = __builtin_elementwise_fma((a2v_f32x2){0.3275911f, 0.3275911f}, axs, (a2v_f32x2){1.f, 1.f});
+  const a2v_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  a2v_f32x2 p = __builtin_elementwise_fma((a2v_f32x2){0.5f * 1.061405429f, 0.5f * 1.061405429f}, t, (a2v_f32x2){0.5f * -1.453152027f, 0.5f * -1.453152027f});
+  p = __builtin_elementwise_fma(p, t, (a2v_f32x2){0.5f * 1.421413741f, 0.5f * 1.421413741f});
+  p = __builtin_elementwise_fma(p, t, (a2v_f32x2){0.5f * -0.284496736f, 0.5f * -0.284496736f});
+  p = __builtin_elementwise_fma(p, t, (a2v_f32x2){0.5f * 0.254829592f, 0.5f * 0.254829592f});
+  const a2v_f32x2 xx = x * x * -0.72134752044448170f;
+  const a2v_f32x2 e = {__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};
+  const a2v_f32x2 q = __builtin_elementwise_fma(-(p * t), e, (a2v_f32x2){0.5f, 0.5f});
+  const a2v_f32x2 cq = {copysignf(q[0], x[0]), copysignf(q[1], x[1])};
+  grad = __builtin_elementwise_fma(x * 0.39894228040143268f, e, (a2v_f32x2){0.5f, 0.5f} + cq);
+  return __builtin_elementwise_fma(ax, q, x * 0.5f);
+}
 __device__ __forceinline__ float gelu_f(float x) { return gelu_t<false>(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<false>(x); }
 

@@ -674,10 +674,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
             p8_u32x4 gr;                             // gelu and gelu' from one evaluation; the derivative is what is kept,
 #pragma unroll                                       // packed pair by pair, the order pinned (interleaved, the eight
             for (int q = 0; q < 4; ++q) {            // evaluations' temporaries spill at the 256-row tile)
-              float d0, d1;
-              v[2 * q] = gelu_with_grad(v[2 * q], d0);
-              v[2 * q + 1] = gelu_with_grad(v[2 * q + 1], d1);
-              const bf16 b0 = (bf16)d0, b1 = (bf16)d1;
+              a2v_f32x2 dd;
+              const a2v_f32x2 hh = gelu_with_grad2((a2v_f32x2){v[2 * q], v[2 * q + 1]}, dd);
+              v[2 * q] = hh[0];
+              v[2 * q + 1] = hh[1];
+              const bf16 b0 = (bf16)dd[0], b1 = (bf16)dd[1];
               gr[q] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
               asm volatile("" : "+v"(v[2 * q]), "+v"(v[2 * q + 1]), "+v"(gr[q]));
             }
@@ -909,7 +910,7 @@ int g_a2v_p8_tmode = 0;   // a2v_debug_set(23, v): tile order of the persistent 
 #ifdef P8_SKEW
 int g_a2v_p8_skew = 0;    // a2v_debug_set(24, v), experiment build only: start skew of the workgroups (units of ~0.5 us x 8 groups)
 #endif
-int g_a2v_p8_tail = 1;    // a2v_debug_set(22, v): a nearly empty last round of tiles goes to the 128 x 128 kernel (1) / stays here (0)
+int g_a2v_p8_tail = 1;    // a2v_debug_set(22, v): a last round of tiles that fills at most v quarters of the CUs goes to the 128 x 128 kernel (0: stays here)
 static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bool allow_tail = true);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, false); }
 // bf16 (split) operands, fp32 C / C2 / R (dtype A2V_BF16X3): only the direct-store form exists
@@ -980,7 +981,7 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
     const int tiles_n = g.N / 256;
     const long long nt_all = (long long)cdiv(g.M, bm) * tiles_n;
     const long long full = nt_all / cus, rem = nt_all % cus;
-    if (full >= 2 && rem > 0 && rem * 4 <= cus) {
+    if (full >= 2 && rem > 0 && rem * 4 <= (long long)cus * g_a2v_p8_tail) {
       const long long rows_main = (full * cus / tiles_n) * bm;
       if (rows_main >= 1024 && rows_main < g.M && g.M - rows_main >= 64 && a.Cg % 64 == 0 && g.K % 64 == 0) {
         GemmArgs gm = g;
