@@ -171,6 +171,7 @@ __device__ __forceinline__ int tn_off(int r, int col) {   // byte offset of elem
 // launchers implemented in a2v_gemm_fast.hip; return false when the shape is not eligible
 bool a2v_launch_nt_bf16_fast(const GemmArgs& g, hipStream_t stream);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream);
+bool a2v_launch_nt_bf16_w2(const GemmArgs& g, hipStream_t stream);   // a2v_gemm_w2.hip: 256 x 128 tiles, two workgroups per CU
 bool a2v_launch_conv_slab3(const GemmArgs& g, long long a_lo, long long b_lo, hipStream_t stream);   // A2V_BF16X3S
 bool a2v_launch_nt_x3_p8(const GemmArgs& g, hipStream_t stream);      // bf16 split operands, fp32 C / C2 / R (A2V_BF16X3)
 bool a2v_launch_nt_x3_fast(const GemmArgs& g, hipStream_t stream);    // the same for convolutions / shapes the 8-phase kernel refuses

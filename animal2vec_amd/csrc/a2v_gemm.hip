@@ -485,6 +485,10 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+  if (dtype == A2V_BF16 && !rowidx && g_a2v_gemm_p8 && a2v_launch_nt_bf16_w2(g, stream)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if (dtype == A2V_BF16 && !rowidx && g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
@@ -698,6 +702,7 @@ extern "C" int a2v_debug_set(int key, int value) {
 #ifdef P8_SKEW
   { extern int g_a2v_p8_skew; if (key == 24) { g_a2v_p8_skew = value; return A2V_OK; } }
 #endif
+  { extern int g_a2v_gemm_w2; if (key == 25) { g_a2v_gemm_w2 = value; return A2V_OK; } }   // 256 x 128 two-per-CU NT kernel: 0 off, 1 K <= 1024, 2 all
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off
