@@ -25,8 +25,11 @@
 
 typedef __attribute__((address_space(3))) void p8_lds_void_t;
 typedef __attribute__((address_space(1))) const void p8_gbl_cvoid_t;
+#ifndef P8_DMA_AUX
+#define P8_DMA_AUX 0      /* cache-policy bits of the LDS-DMA loads (experiment builds): 1 sc0, 2 sc1, 4 nt */
+#endif
 __device__ __forceinline__ void p8_glds16(const char* gsrc, char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((p8_gbl_cvoid_t*)gsrc, (p8_lds_void_t*)lds_dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((p8_gbl_cvoid_t*)gsrc, (p8_lds_void_t*)lds_dst, 16, 0, P8_DMA_AUX);
 }
 
 // LDS map (16 KiB half-tiles): [A_lo0 A_hi0 A_lo1 A_hi1 | B_lo0 B_hi0 B_lo1 B_hi1]: the A region and the B region are
@@ -207,8 +210,11 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   const int nk = g.K / 64;
   const unsigned d64a = (unsigned)(a.pitch * 128), d64b = (unsigned)(g.ldb * 128);   // bytes of 64 rows of A / of B
   // stage one half-tile: 2 LDS-DMA per thread
+#ifndef P8_EXP
+#define P8_EXP 0          /* timing experiments (wrong results): 1 no MFMA, 2 no LDS-DMA in the K loop */
+#endif
 #define P8_STAGE2(base, o0, o1, kt, lds_off, second)            \
-  {                                                            \
+  if (!(P8_EXP & 2)) {                                         \
     const unsigned ko_ = (unsigned)(kt) * 128u;                \
     p8_glds16(base + (o0 + ko_), dst0 + (lds_off));            \
     p8_glds16(base + (o1 + ko_), dst0 + (lds_off) + (second)); \
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
   _Pragma("unroll") for (int i = 0; i < (NI); ++i)                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-    acc[(ibase) + i][(jbase) + j] = DS                                                                 \
+    if (!(P8_EXP & 1)) acc[(ibase) + i][(jbase) + j] = DS                                              \
         ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0) \
         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                       \

@@ -30,8 +30,11 @@
 
 typedef __attribute__((address_space(3))) void w2_lds_void_t;
 typedef __attribute__((address_space(1))) const void w2_gbl_cvoid_t;
+#ifndef W2_DMA_AUX
+#define W2_DMA_AUX 0      /* cache-policy bits of the LDS-DMA loads (experiment builds): 1 sc0, 2 sc1, 4 nt */
+#endif
 __device__ __forceinline__ void w2_glds16(const char* gsrc, char* lds_dst) {
-  __builtin_amdgcn_global_load_lds((w2_gbl_cvoid_t*)gsrc, (w2_lds_void_t*)lds_dst, 16, 0, 0);
+  __builtin_amdgcn_global_load_lds((w2_gbl_cvoid_t*)gsrc, (w2_lds_void_t*)lds_dst, 16, 0, W2_DMA_AUX);
 }
 #define W2_STAGE 24576                 // A 256 rows x 64 B, then B 128 rows x 64 B
 #define W2_BOFF 16384
