@@ -288,9 +288,35 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnArgs a) {
   float m_run = -INFINITY, l_run = 0.f, a_run = 0.f;
 
   const int ntile = (S + 63) / 64;
-  for (int kt = 0; kt < ntile; ++kt) {
+  // ALiBi band limit, as the bf16 long-sequence forward's (positions = arange, a.qk_bound given): key tiles wholly beyond
+  // d_cut = (2B + 32) / (slope * alibi_scale) of every query row of this workgroup carry softmax weights below e^-32 of the row sum --
+  // 3e-11 over 2000 keys, three orders below an fp32 ulp of the sums -- and are not visited.  B from the exact fp32 row norms.
+  int kt_lo = 0, kt_end = ntile;
+  if (!a.pos && a.qk_bound) {
+    const float c_nat = a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f);
+    if (c_nat > 0.f) {
+      float q2 = 0.f, k2 = 0.f;
+#pragma unroll
+      for (int z = 0; z < A2V_QKB_SPLIT; ++z) {
+        const float* const bz = a.qk_bound + (((long long)z * a.N + n) * H + h) * 2;
+        q2 = fmaxf(q2, bz[0]);
+        k2 = fmaxf(k2, bz[1]);
+      }
+      const float dcut = (2.f * sqrtf(q2 * k2) * a.scale * 1.01f + 32.f) / c_nat;
+      if (dcut < 1.0e6f) {
+        const int dc = (int)dcut + 1;
+        kt_lo = max(0, (q0 - dc) / 64);
+        kt_end = min(ntile, (q0 + 63 + dc) / 64 + 1);
+        kt_lo = min(kt_lo, min(q0 / 64, ntile - 1));          // (the tile that holds the query rows is always visited)
+        kt_end = max(kt_end, min(q0 / 64 + 1, ntile));
+      }
+    }
+  }
+  for (int kt = kt_lo; kt < kt_end; ++kt) {
     const int kv0 = kt * 64;
     __syncthreads();
+    // (fetching the next tile's rows into registers under this tile's math was measured: +54 registers, three -> two waves per SIMD,
+    //  197 against 195 ms per 8-clip step: not kept)
     for (int c = tid; c < 64 * NCH; c += 256) {
       const int r = c / NCH, ch = c % NCH;
       float kv_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, vv_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -1008,8 +1034,8 @@ int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward take
 // Ingredients of the bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i|^2 and max_j |k_j|^2 (Cauchy-Schwarz in
 // the attention kernel).  8 lanes share a row (16 B each); reads q and k once: 65 MB at 32 x 2000 x 16 heads.
 #define A2V_QKB_MAX (A2V_WS_QKB_BYTES / 4)              // the bounds live at A2V_WS_QKB of the stream's workspace
-template <int HD>
-__global__ __launch_bounds__(256) void attn_qk_bound_kernel(const bf16* __restrict__ qkv, float* __restrict__ bound, int S, int H) {
+template <int HD, typename T = bf16>
+__global__ __launch_bounds__(256) void attn_qk_bound_kernel(const T* __restrict__ qkv, float* __restrict__ bound, int S, int H) {
   static_assert(HD == 64, "8 lanes x 8 elements per head row");
   // One workgroup = one clip (blockIdx.y) x one of A2V_QKB_SPLIT row ranges (blockIdx.x); a thread owns one 16-B chunk of the
   // [q | k] part of a row -- 2 x H x 8 chunks, read as one contiguous 4-KB piece per row at H = 16 (per-head workgroups read
@@ -1020,17 +1046,18 @@ __global__ __launch_bounds__(256) void attn_qk_bound_kernel(const bf16* __restri
   const int rbeg = blockIdx.x * rows_z, rend = min(S, rbeg + rows_z);
   const long long rowstride = 3LL * H * HD;
   for (int c = tid; c < nch; c += 256) {
-    const bf16* base = qkv + (long long)n * S * rowstride + c * 8;      // q chunks 0 .. 8H-1, k chunks 8H .. 16H-1: contiguous
+    const T* base = qkv + (long long)n * S * rowstride + c * 8;         // q chunks 0 .. 8H-1, k chunks 8H .. 16H-1: contiguous
     float mx = 0.f;
     for (int r0 = rbeg; r0 < rend; r0 += 8) {              // eight rows' loads in flight (rows past the range repeat its last row)
-      bf16x8 v[8];
+      Raw8<T> v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = *(const bf16x8*)(base + (long long)min(r0 + u, rend - 1) * rowstride);
+      for (int u = 0; u < 8; ++u) v[u].load(base + (long long)min(r0 + u, rend - 1) * rowstride);
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-        float sq = 0.f;
+        float sq = 0.f, e8[8];
+        v[u].unpack(e8);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { const float a_ = (float)v[u][i]; sq += a_ * a_; }
+        for (int i = 0; i < 8; ++i) sq += e8[i] * e8[i];
         // sum over the 8 lanes of the head row on the VALU (DPP: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror)
 #define QKB_DPP_ADD(ctrl) sq += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq), ctrl, 0xF, 0xF, true))
         QKB_DPP_ADD(0xB1);
@@ -1505,6 +1532,15 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
   }
   if (dtype == A2V_BF16X3) {          // fp32 storage, split products on the bf16 matrix cores
     const dim3 grid((a.S + 63) / 64, a.H, a.N);
+    a.qk_bound = nullptr;
+    if (HD == 64 && a.S >= 512 && g_a2v_attn_band && !a.pos && (long long)a.N * a.H * 2 * A2V_QKB_SPLIT <= A2V_QKB_MAX) {
+      char* const ws = a2v_stream_ws(stream);
+      if (ws) {
+        float* const bp = (float*)(ws + A2V_WS_QKB);
+        hipLaunchKernelGGL((attn_qk_bound_kernel<64, float>), dim3(A2V_QKB_SPLIT, a.N), dim3(256), 0, stream, (const float*)a.qkv, bp, a.S, a.H);
+        a.qk_bound = bp;
+      }
+    }
     if (HD == 64) hipLaunchKernelGGL((attn_fwd_x3_kernel<64>), grid, dim3(256), 0, stream, a);
     else if (HD == 32) hipLaunchKernelGGL((attn_fwd_x3_kernel<32>), grid, dim3(256), 0, stream, a);
     else return A2V_ERR_UNSUPPORTED;

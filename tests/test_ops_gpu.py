@@ -636,6 +636,31 @@ def test_attention_alibi_band_limit_changes_nothing(ops, S):
         assert (l1 - l0).abs().max() < 1e-5, sc
 
 
+@pytest.mark.parametrize("S", [700, 2000])
+def test_attention_x3_alibi_band_limit_changes_nothing(ops, S):
+    """The bf16x3 forward's ALiBi band limit (round 4; the bf16 kernel's rule with exact fp32 row norms): positions = arange, S >= 512;
+    against the all-tiles run (a2v_debug_set(19, 0)) output, LSE and mean attended distance agree to fp32 round-off, whatever the
+    slopes (steep: most key tiles skipped; flat / zero / negative scale: none)."""
+    N, H, hd = 2, 4, 64
+    qkv = dev(rnd(N, S, 3 * H * hd, dtype=torch.float32, seed=12) * 1.5, torch.float32)
+    slopes = torch.tensor(O.alibi_slopes(H)).cuda()
+    ops.X3_WGRAD = True
+    try:
+        for sc in ([1.0, 1.0, 1.0, 1.0], [40.0, 3.0, 0.0, -1.0], [0.02, 0.2, 8.0, 1.0]):
+            scd = torch.tensor(sc).cuda()
+            ops.debug_set(19, 1)
+            o1, l1 = ops.attention_fwd(qkv, None, slopes, scd, H, need_lse=True)
+            ops.debug_set(19, 0)
+            o0, l0 = ops.attention_fwd(qkv, None, slopes, scd, H, need_lse=True)
+            ops.debug_set(19, 1)
+            assert rel_err(o1, o0) < 1e-6, sc
+            assert (l1[0] - l0[0]).abs().max() < 1e-5, sc
+            assert rel_err(l1[1], l0[1]) < 1e-5, sc
+    finally:
+        ops.debug_set(19, 1)
+        ops.X3_WGRAD = False
+
+
 # ------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C_,act,affine", [(64, 0, True), (512, 1, True), (1024, 0, True), (768, 1, False), (32, 1, True)])
