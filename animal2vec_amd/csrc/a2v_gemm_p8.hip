@@ -147,6 +147,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   unsigned* const g_p8_ctr = (unsigned*)(wsp + A2V_WS_CTR);
   float* const g_p8_cs_part = (float*)(wsp + A2V_WS_CSPART);
   constexpr int BM = 128 + 32 * IH;
+  // the round-4 tile seam (P8_KTILE_FIRST / P8_KTILE_LAST below) for the fixed-flavour instantiations only: in the generic kernels its
+  // two extra live offsets do not fit (12-49 spilled registers at the 256-row tile, one of them the tile claim's destination, stored
+  // before the atomic had returned: repeating tile ids, a launch that never ends -- tests/test_abi.py's ISA check)
+  constexpr bool SEAM2 = DS && FX > 0;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 2, wc = wid & 3;
@@ -370,9 +374,10 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     P8_STAGE(abase, T.al0, P8_AL1(T), 1, P8_BUF + P8_ALO)
     P8_STAGE(bbase, T.bl0, P8_BL1(T), 1, P8_BUF + P8_BLO)
     P8_STAGE(bbase, T.bh0, P8_BH1(T), 1, P8_BUF + P8_BHI)
-    P8_STAGE2(abase, T.ah0, P8_AH1(T), 1, P8_BUF + P8_AHI, ah_second)
+    if constexpr (SEAM2) P8_STAGE2(abase, T.ah0, P8_AH1(T), 1, P8_BUF + P8_AHI, ah_second)
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (both K-tiles: the first K-tile's wait assumes K-tile 1 was complete before "the epilogue")
+  if constexpr (SEAM2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (both K-tiles: the first K-tile's wait assumes K-tile 1 was complete before "the epilogue")
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                      // (K-tile 0 complete, three half-tiles of K-tile 1 in flight)
   __builtin_amdgcn_s_barrier();
   // The two waves that share a SIMD (w and w + 4, i.e. wr = 0 / 1) run half a phase apart from here on: one extra
   // barrier for the wr = 1 group pairs its "reads done" barrier with the other group's "MFMAs done" barrier, so one
@@ -401,17 +406,24 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
                           : 2 * (4 + IH) * (((FX & 0xFF) & (F_STORE_PRE)) && FX > 0 ? 2 : 1) + ((FX > 0 && ((FX & 0xFF) & F_BIAS)) ? 4 : 0) +
                                 ((FX > 0 && ((FX & 0xFF) & (F_RES | F_GELU_BWD)) && !O32) ? 2 * (4 + IH) : 0);
     constexpr int P8_WAIT0 = 6 + (P8_E_ > 48 ? 48 : P8_E_);
-    { P8_KTILE_FIRST(0, P8_BUF, T, 2) }
+    if constexpr (SEAM2) {
+      { P8_KTILE_FIRST(0, P8_BUF, T, 2) }
 #ifdef P8_STAMP2
-    if (st2_i >= 0) { P8_ST2(3) }
+      if (st2_i >= 0) { P8_ST2(3) }
 #endif
-    { P8_KTILE(P8_BUF, 0, T, 2, T, 3) }          // (nk is even and >= 4: the launcher asks for K % 128 == 0, K >= 256)
+      { P8_KTILE(P8_BUF, 0, T, 2, T, 3) }          // (nk is even and >= 4: the launcher asks for K % 128 == 0, K >= 256)
 #ifdef P8_STAMP2
-    if (st2_i >= 0) { P8_ST2(4) }
+      if (st2_i >= 0) { P8_ST2(4) }
 #endif
-    for (int kt = 2; kt < nk - 2; kt += 2) {
-      { P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2) }
-      { P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3) }
+      for (int kt = 2; kt < nk - 2; kt += 2) {
+        { P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2) }
+        { P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3) }
+      }
+    } else {
+      for (int kt = 0; kt < nk - 2; kt += 2) {
+        { P8_KTILE(0, P8_BUF, T, kt + 1, T, kt + 2) }
+        { P8_KTILE(P8_BUF, 0, T, kt + 2, T, kt + 3) }
+      }
     }
 #ifdef P8_STAMP2
     ++st2_i;
@@ -450,7 +462,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     }
     const int kn0 = has_next ? 0 : nk - 2, kn1 = has_next ? 1 : nk - 1;
     { P8_KTILE(0, P8_BUF, T, nk - 1, Tn, kn0) }
-    { P8_KTILE_LAST(P8_BUF, 0, Tn, kn0, Tn, kn1) }
+    if constexpr (SEAM2) { P8_KTILE_LAST(P8_BUF, 0, Tn, kn0, Tn, kn1) } else { P8_KTILE(P8_BUF, 0, Tn, kn0, Tn, kn1) }
     // the "+v" ties of P8_LGKM0 make every fragment register look live from one phase to the next, and so across the
     // epilogue into the next tile's first phase: redefine them (no instruction) so that the epilogue may use them
 #define P8_KILL4(x) "=v"(x[0][0]), "=v"(x[0][1]), "=v"(x[1][0]), "=v"(x[1][1])

@@ -273,9 +273,13 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *      norms of q and k: weights below e^-32 of the row sum) (1, default) / visit every tile (0)
  *   20 fixed-flavour instantiations of the NT kernel's 256-row tile for the eight hottest epilogue flag sets (1, default) / the generic epilogue (0)
  *   21 dense strided convs of the feature extractor on the 8-phase GEMMs + edge-frame kernels (1, default) / implicit-im2col 128 x 128 kernels (0)
- *   22 persistent NT kernel: the rows of a nearly empty last round of tiles go to the 128 x 128 kernel (1, default) / stay (0)
+ *   22 persistent NT kernel: the rows of a last round of tiles that fills at most v quarters of the CUs go to the 128 x 128 kernel
+ *      (1, default; 2 / 3 measured in round 4: no gain) / stay (0)
  *   23 persistent NT kernel tile order: 0 (default) 8 m-tiles x all n-tiles per group; 1 "W-stationary" groups of four n-tiles
  *      (round-4 experiment: +8.6 % fabric reads, 0.6 - 4 % slower -- profiles/r04_nt_tile_ab.txt)
+ *   25 the 256 x 128 NT kernel with two workgroups per CU (a2v_gemm_w2.hip, round-4 experiment, profiles/r04_w2_experiment.txt):
+ *      0 off (default), 1 eligible Linears with K <= 1024, 2 every eligible Linear
+ *   (19 also switches the bf16x3 attention forward's band limit, round 4)
  * No launch state goes through here (ABI 5's key 9, the tile-counter set, is gone: the stream argument selects it). */
 int a2v_debug_set(int key, int value);
 
