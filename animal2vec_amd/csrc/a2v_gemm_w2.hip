@@ -369,7 +369,12 @@ bool a2v_launch_nt_bf16_w2(const GemmArgs& g, hipStream_t stream) {
   if (!ws) return false;
   const int cs_part = ((g.flags & F_COLSUM) && (long long)parts * g.N <= (A2V_WS_CSPART_BYTES / 4)) ? 1 : 0;
   // (experiment kernel: the generic epilogue and the bias-only flavour are enough to compare it with the 256 x 256 kernel)
-  if (g.flags == W2_FX_B) w2_go<W2_FX_B>(g, cs_part, ws, stream); else w2_go<0>(g, cs_part, ws, stream);
+  // (the generic epilogue of a 256-row tile has no room for the gelu + gelu' store: that flag set needs its fixed flavour)
+  const int eff = (g.flags & (F_STORE_PRE | F_GELU_BWD)) ? g.flags : (g.flags & ~F_DACT);
+  if (eff == W2_FX_B) w2_go<W2_FX_B>(g, cs_part, ws, stream);
+  else if (eff == W2_FX_FC1) w2_go<W2_FX_FC1>(g, cs_part, ws, stream);
+  else if (eff == W2_FX_FC2D) w2_go<W2_FX_FC2D>(g, cs_part, ws, stream);
+  else w2_go<0>(g, cs_part, ws, stream);
   if (cs_part) hipLaunchKernelGGL(w2_colsum_fold_kernel, dim3(cdiv(g.N, 256), 16), dim3(256), 0, stream, g.colsum, g.N, parts, ws);
   return true;
 }

@@ -166,6 +166,46 @@ def test_linear_p8_kernel(ops, M, N, K, ih, direct):
         assert torch.equal(new[k], old[k]) or rel_err(new[k].float(), old[k].float()) < 1e-5, k
 
 
+@pytest.mark.parametrize("M,N,K", [(2049, 768, 1024), (13440 + 100, 1024, 512), (1100, 512, 256)])
+def test_linear_w2_experiment_kernel(ops, M, N, K):
+    """a2v_gemm_w2.hip (round-4 experiment, off by default: a2v_debug_set(25, 2)): 256 x 128 tiles, two workgroups per CU, the
+    256 x 256 kernel's direct-store epilogue with a half width of 64.  Every epilogue against the 128 x 128 kernel: same arithmetic
+    order per output element, so bit-identical (column sums to 1e-5: their partials add in another order)."""
+    dtype = torch.bfloat16
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, seed=3)
+    r = rnd(M, N, dtype=dtype, seed=4)
+    xd, wd, bd, rd = dev(x, dtype), dev(w, dtype), dev(b, torch.float32), dev(r, dtype)
+
+    def run_all():
+        out = {}
+        out["plain"] = ops.linear(xd, wd, bd)
+        out["none"] = ops.linear(xd, wd, None)
+        out["res"] = ops.linear(xd, wd, bd, res=rd)
+        out["drop"] = ops.linear(xd, wd, bd, res=rd, drop=(0.25, 99))
+        keep = torch.empty(M, N, dtype=dtype, device="cuda")
+        out["gelu_dact"] = ops.linear(xd, wd, bd, gelu=True, pre_out=keep, dact=True)
+        out["dact"] = keep
+        cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+        out["gbwd_dact"] = ops.linear(xd, wd, None, gelu_bwd_aux=rd, colsum=cs, dact=True)
+        out["cs"] = cs
+        return out
+
+    ops.debug_set(25, 2)
+    try:
+        new = run_all()
+    finally:
+        ops.debug_set(25, 0)
+    ops.debug_set(1, 0)
+    try:
+        old = run_all()
+    finally:
+        ops.debug_set(1, 1)
+    assert rel_err(new["plain"].float(), x @ w.t() + b) < tol(dtype)
+    for k in new:
+        assert torch.equal(new[k], old[k]) or rel_err(new[k].float(), old[k].float()) < 1e-5, k
+
+
 @pytest.mark.parametrize("M,N,K", [(2100, 2048, 1024), (4096, 1024, 2048), (2048 + 64 * 3, 2048, 1024)])
 def test_linear_wgrad_p8_kernel(ops, M, N, K):
     """256x256 TN weight-gradient kernel (N, K % 256 == 0, >= 32 tiles): ragged M (rows past M come from the zero
