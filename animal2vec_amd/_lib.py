@@ -90,6 +90,11 @@ def load() -> C.CDLL:
         raise A2VError(
             f"{LIB_PATH} is missing: the HIP extension is mandatory (run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `python animal2vec_amd/build.py`). There is no CPU fallback.")
+    # torch first: its wheel carries its own HIP runtime (libamdhip64 under torch/lib).  Loaded before torch, this library pulls in
+    # /opt/rocm's copy instead and the process ends up with two runtimes -- torch's owns the devices and streams, ours reports
+    # "no device" at the first launch (seen with `python __graft_entry__.py --smoke`, where build() loads the library before anything
+    # has imported torch).  With torch already imported the loader resolves the same soname to the one runtime.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         try:
