@@ -946,7 +946,7 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   const bool c_r_overlap = g.R != nullptr && r0 < c1 && c0 < r1;
   const bool direct = (g_a2v_p8_direct || out32) && contiguous && !c_r_overlap && g.G == 1 && (long long)256 * g.ldc * 2 < (1LL << 31) && (long long)256 * g.ldr * 2 < (1LL << 31);
   if (out32 && !direct) return false;
-  if ((g.flags & F_X3IMG) && (!out32 || (g.flags & (F_RES | F_GELU_BWD | F_DROPOUT)) || g.ldc < 3LL * g.N || g.ldc % 8 || g.G != 1)) return false;
+  if ((g.flags & F_X3IMG) && (!out32 || (g.flags & (F_RES | F_DROPOUT)) || g.ldc < 3LL * g.N || g.ldc % 8 || g.G != 1)) return false;
   // 32-bit byte offsets inside one group's operands
   const long long a_span = ((long long)((g.M - 1) / a.T_out / a.bdiv) * a.bstride + (long long)a.T_out * a.pitch + g.K) * 2;
   const long long b_span = ((long long)g.N * g.ldb + g.K) * 2;

@@ -268,8 +268,9 @@ class Engine:
         elif dt2 is not None:
             ds2d = ops.mean_layers([ds2d, dt2], scale=1.0)
             ops.colsum(dt2, g[prefix + "mlp.fc2.bias"])          # dxsum above only saw the LN2 path
+        # (bf16x3: dh is read by fc1's input-gradient and weight-gradient products only: it leaves the epilogue as its split image)
         dh = ops.linear(ds2d, sp.wt[prefix + "mlp.fc2.weight"], gelu_bwd_aux=sv["hpre"], colsum=g[prefix + "mlp.fc1.bias"],
-                        drop=d_act1, dact=_DACT)
+                        drop=d_act1, dact=_DACT, out_image=self.x3 and d_act1 is None and ops.X3_DH_IMAGE)
         ops.linear_wgrad_pair(sv["g"], ds2d, g[prefix + "mlp.fc2.weight"], sv["x1"], dh, g[prefix + "mlp.fc1.weight"])
         dx1 = ops.linear(dh, sp.wt[prefix + "mlp.fc1.weight"], res=ds2)
         ds1, ds1d = ops.layernorm_bwd(dx1, sv["s1"], p[prefix + "norm1.weight"], p[prefix + "norm1.bias"], *sv["st1"],

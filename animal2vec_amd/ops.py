@@ -127,6 +127,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 # _a2v_x3), not in a table keyed by address: a freed weight's address is handed to the next allocation.
 X3_CONV_FUSED = os.environ.get("A2V_X3_CONV_FUSED", "1") != "0"     # 64 outputs per group: the three split products of a 64-wide grouped conv in one launch (A/B switch)
 X3_OUT_IMAGE = os.environ.get("A2V_X3_OUT_IMAGE", "1") != "0"         # the Mlp's hidden activation leaves fc1 as its split image only (A/B switch)
+X3_DH_IMAGE = os.environ.get("A2V_X3_DH_IMAGE", "1") != "0"           # the fc2 input gradient leaves its epilogue as a split image only (A/B switch)
 X3_ATTN_BWD = os.environ.get("A2V_X3_ATTN_BWD", "1") != "0"          # whole-sequence attention backward with split products (A/B switch)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
 X3_KEEP = False          # set by the engine during the student's saving forward: operand images stay on the activations for the backward
@@ -240,11 +241,14 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
     img = _x3_image(w, M) if x.dtype == torch.float32 else None
     if isinstance(x, X3Image) and img is None:
         raise RuntimeError("an image-only activation needs the split-product path (registered weight image, M >= 1024)")
-    if (out_image and img is not None and X3_WGRAD and X3_OUT_IMAGE and out is None and r is None and (drop is None or drop[0] <= 0)
+    if (out_image and img is not None and X3_WGRAD and X3_OUT_IMAGE and out is None and res is None and (drop is None or drop[0] <= 0)
             and M >= 2048 and N % 256 == 0):
+        # (round 4: also the fc2 input gradient -- GELU_BWD with its fp32 derivative tensor in R -- whose result nothing but fc1's
+        #  input-gradient and weight-gradient products reads)
         oimg = _E(M, 3 * N, dtype=torch.bfloat16, device=w.device)
         conv_gemm(_x3_m0(x), img, oimg, M=M, N=N, K=3 * K, T_in=M, T_out=M, Cg=3 * K, a_pitch=3 * K, a_bstride=0, ldb=3 * K,
-                  ldc=3 * N, bias=bias, gelu=gelu, pre_out=pre_out, colsum=colsum, dact=dact, x3=True, x3img=True)
+                  ldc=3 * N, bias=bias, res=r, ldr=r.stride(0) if r is not None else 0, gelu=gelu, gelu_bwd=gelu_bwd_aux is not None,
+                  pre_out=pre_out, colsum=colsum, dact=dact, x3=True, x3img=True)
         return X3Image(oimg, M, N)
     if out is None:
         out = _E(M, N, dtype=x.dtype, device=w.device)

@@ -54,7 +54,7 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
 #define A2V_EPI_STORE_PRE 16 /* also store the pre-activation (acc + bias) to C2 */
 #define A2V_EPI_COLSUM 32   /* atomically add column sums of the output to colsum (bias gradient) */
 #define A2V_EPI_DROPOUT 64  /* counter-based dropout(drop_p, drop_seed) of (acc+bias[gelu]) before the residual */
-#define A2V_EPI_X3IMG 256   /* dtype A2V_BF16X3 only (ABI 9), plain row-major products the persistent kernel takes, no RES / GELU_BWD / DROPOUT:
+#define A2V_EPI_X3IMG 256   /* dtype A2V_BF16X3 only (ABI 9), plain row-major products the persistent kernel takes, no RES / DROPOUT (GELU_BWD since round 4):
                              * C is written as the bf16 [hi | lo | hi] split image of the result (row pitch ldc >= 3 N bf16 elements; a
                              * pre-activation / derivative tensor C2 stays fp32 with row pitch N) instead of fp32 -- for a result that only further A2V_BF16X3 products read; else A2V_ERR_UNSUPPORTED */
 #define A2V_EPI_DACT 128    /* modifier.  With GELU | STORE_PRE: C2 receives gelu'(acc + bias) instead of the pre-activation (one

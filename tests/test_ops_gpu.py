@@ -1450,6 +1450,15 @@ def test_linear_bf16x3_image_only_output(ops):
         ops.linear_wgrad(h32, dy, ga)
         ops.linear_wgrad(himg, dy, gb)
         assert rel_err(ga, gb) < 1e-6
+        # round 4: the fc2 input gradient (GELU_BWD with the derivative tensor, column sums) as an image too
+        w2t = w2.t().contiguous()                                    # (N, K): dh = (dy @ w2t^T) * gelu'
+        ops.x3_register(w2t)
+        ca, cb = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+        dh32 = ops.linear(dy, w2t, gelu_bwd_aux=pre_a, colsum=ca, dact=True)
+        dhimg = ops.linear(dy, w2t, gelu_bwd_aux=pre_a, colsum=cb, dact=True, out_image=True)
+        assert isinstance(dhimg, ops.X3Image) and dhimg.shape == (M, N)
+        assert torch.equal(dhimg.img, ops.split_bf16(dh32, 0)) and rel_err(ca, cb) < 1e-6
+        del w2t._a2v_x3
         del w2._a2v_x3
         with pytest.raises(RuntimeError):
             ops.linear(himg, w2)
