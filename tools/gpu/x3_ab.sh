@@ -1,12 +1,16 @@
 #!/bin/bash
+# bf16x3 parity mode, same-box A/B of its switches / of two builds on tools/x3_bench.py (8-clip optimizer steps):
+#   bash tools/gpu/x3_ab.sh [rounds] "<env assignments of arm A>" "<env assignments of arm B>" ...   ("-" = none)  -> gpurun_out/x3_ab.txt
+#   e.g.  bash tools/gpu/x3_ab.sh 3 A2V_X3_DH_IMAGE=0 -        bash tools/gpu/x3_ab.sh 2 A2V_LIB_PATH=$PWD/animal2vec_amd/liba2v_hip_prev.so - A2V_DEBUG_SET=19=0
+rounds=$1; shift
 root=${GRAFT_REPO_ROOT:-/root/repo}
-out=$root/gpurun_out/r04_x3_ab.txt
+out=$root/gpurun_out/x3_ab.txt
 cd $root
-export PYTHONUNBUFFERED=1
 : > $out
-timeout 900 python3 -m pytest tests/test_ops_gpu.py -x -q -k "x3 or band" 2>&1 | tail -3 | tee -a $out
-for i in 1 2; do
-  A2V_LIB_PATH=$root/animal2vec_amd/liba2v_hip_prev.so timeout 300 python3 tools/x3_bench.py 2>&1 | grep "parity mode" | sed 's/^/prev /' | tee -a $out
-  timeout 300 python3 tools/x3_bench.py 2>&1 | grep "parity mode" | sed 's/^/new  /' | tee -a $out
-  A2V_DEBUG_SET=19=0 timeout 300 python3 tools/x3_bench.py 2>&1 | grep "parity mode" | sed 's/^/new, band limit off  /' | tee -a $out
+for i in $(seq 1 $rounds); do
+  for arm in "$@"; do
+    if [ "$arm" = "-" ]; then v=$(timeout 300 python3 tools/x3_bench.py 2>&1 | grep "parity mode")
+    else v=$(env $arm timeout 300 python3 tools/x3_bench.py 2>&1 | grep "parity mode"); fi
+    echo "[$arm] $v" | tee -a $out
+  done
 done
