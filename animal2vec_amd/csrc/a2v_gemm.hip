@@ -703,6 +703,13 @@ extern "C" int a2v_debug_set(int key, int value) {
   { extern int g_a2v_p8_skew; if (key == 24) { g_a2v_p8_skew = value; return A2V_OK; } }
 #endif
   { extern int g_a2v_gemm_w2; if (key == 25) { g_a2v_gemm_w2 = value; return A2V_OK; } }   // 256 x 128 two-per-CU NT kernel: 0 off, 1 K <= 1024, 2 all
+  { extern int g_a2v_ln_stream, g_a2v_ln_rows, g_a2v_ln_wpc;   // streaming LayerNorm (a2v_norm.hip): on / off bits, rows per batch, workgroups per CU
+    if (key == 30) { g_a2v_ln_stream = value; return A2V_OK; }
+    if (key == 31) { g_a2v_ln_rows = value; return A2V_OK; }
+    if (key == 32) { g_a2v_ln_wpc = value; return A2V_OK; }
+    extern int g_a2v_ln_bpw, g_a2v_ln_bpw_bwd;
+    if (key == 33) { g_a2v_ln_bpw = value; return A2V_OK; }
+    if (key == 34) { g_a2v_ln_bpw_bwd = value; return A2V_OK; } }
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off

@@ -308,6 +308,343 @@ __global__ __launch_bounds__(256, (ACT == 0 && NCH <= 2 && sizeof(T) == 2) ? 3 :
   (void)nvec;
 }
 
+// =============================================================================================
+//                      streaming LayerNorm (bf16, round 5): raw staging, in-order fronts
+// =============================================================================================
+// What bounds these kernels was measured first (tools/native/copy_bench.hip, profiles/r05_copy_bench.txt, 3 GiB buffers): a copy in
+// the LayerNorm's access shape (a wave moves whole 2-KB rows) runs at 5.9 TB/s when every workgroup moves ONE 8-KB piece and
+// retires -- workgroups are dispatched in order, so the chip walks the tensor as one narrow front -- and at 4.8-5.2 TB/s as a
+// persistent grid-stride loop, whatever its depth (1-8 rows in flight per wave, 2-32 workgroups per CU, hand-counted waits that
+// never wait for a store: all within 5 %); reads alone 6.4-6.8, writes alone 5.2 (persistent) / 6.8 (in order).  The row-per-wave
+// kernels above have the right launch shape but hold 64-160 registers per row in flight and spend ~1 us per row between the
+// last load and the first store (two dependent wave sums, GELU): 4.1-5.2 TB/s.  The kernels here keep the R rows of a wave's batch
+// PACKED (4 registers per 16-B chunk) until a row is worked on, pack the result back into the registers the row came in and store all
+// R rows at the end of the batch (every wait inside a batch is for loads only: hipcc turns a wait for a load into vmcnt(0) as soon
+// as a store is pending next to it); gamma / beta live in LDS.  Launch forms (`bpw`):
+//   front (bpw > 0)  a workgroup owns 4 bpw consecutive batches and retires: forward 5.5-5.6 TB/s (was 4.2-5.2); the backward of
+//                    the conv stacks (GELU', bias-gradient column sums kept in registers across the workgroup's rows) 5.1-5.4
+//   persistent (0)   batches wave, wave + nwaves, ...: the backward flavours with 32-48 column-sum registers per lane (blocks:
+//                    dgamma, dbeta, bias gradient), where one reduction per workgroup outweighs the launch order
+// profiles/r05_ln_front.txt has the sweep (rows per batch x bpw x flavour) the choices below come from.
+int g_a2v_ln_stream = 3;     // a2v_debug_set(30, v): bit 0 forward, bit 1 backward through the streaming kernels
+int g_a2v_ln_rows = 0;       // a2v_debug_set(31, v): rows per batch (0 = by shape)
+int g_a2v_ln_wpc = 0;        // a2v_debug_set(32, v): workgroups per CU of the persistent form (0 = by flavour)
+int g_a2v_ln_bpw = 0;        // a2v_debug_set(33, v): forward launch form: 0 by shape, v > 0 front with bpw = v, -1 persistent
+int g_a2v_ln_bpw_bwd = 0;    // a2v_debug_set(34, v): the same for the backward
+
+static int ln_cus() {
+  static int cus[A2V_MAX_DEVICES];
+  const int d = a2v_device();
+  if (!cus[d]) {
+    hipDeviceProp_t p;
+    cus[d] = (hipGetDeviceProperties(&p, d) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+  }
+  return cus[d];
+}
+template <typename K>
+static int ln_occupancy(K kernel, int* cache, int want) {
+  const int d = a2v_device();
+  if (!cache[d]) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, 256, 0) != hipSuccess || n < 1) n = 4;
+    cache[d] = n > 8 ? 8 : n;
+  }
+  const int w = g_a2v_ln_wpc > 0 ? g_a2v_ln_wpc : (want > 0 ? want : cache[d]);
+  return w < cache[d] ? w : cache[d];
+}
+// rows per batch: the shape's choice (want) or the forced one, never more than the flavour's registers allow (rmax)
+static int ln_pick_rows(int want, int rmax) {
+  int r = g_a2v_ln_rows > 0 ? g_a2v_ln_rows : want;
+  if (r > rmax) r = rmax;
+  return r == 3 ? 2 : (r > 4 && r < 8 ? 4 : r);
+}
+// (the empty asm pins the packed value where it is formed: the stores sit under "row < M" at the end of the batch and LLVM otherwise
+//  sinks the whole normalisation of every row down to them, keeping all R rows unpacked -- 220 registers instead of 80)
+__device__ __forceinline__ uint4 ln_pack8(const float* o) {
+  bf16x8 v;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+  uint4 u = __builtin_bit_cast(uint4, v);
+  asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w));
+  return u;
+}
+
+template <int NCH, int R, int ACT, bool AFFINE, bool POST, bool FULL>
+__global__ __launch_bounds__(256) void ln_fwd_stream_kernel(const bf16* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, bf16* __restrict__ y,
+                                                            float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                            const bf16* __restrict__ post, long long M, int C, float eps, int bpw) {
+  __shared__ __attribute__((aligned(16))) float sgb[AFFINE ? 2 * NCH * 512 : 4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (AFFINE) {
+    for (int k = threadIdx.x; k < NCH * 512; k += 256) {
+      sgb[k] = k < C ? gamma[k] : 1.f;
+      sgb[NCH * 512 + k] = k < C ? beta[k] : 0.f;
+    }
+    __syncthreads();
+  }
+  int col[NCH];
+  bool ok[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int cc = (c * 64 + lane) * 8;
+    ok[c] = FULL || cc < C;
+    col[c] = ok[c] ? cc : 0;                      // (idle lanes of a ragged last chunk re-read column 0: no load under a lane mask)
+  }
+  const long long nb = (M + R - 1) / R;
+  // bpw = 0: persistent, batches wave, wave + nwaves, ...; bpw > 0: the workgroup owns 4 bpw CONSECUTIVE batches and retires
+  // (workgroups are dispatched in order: the chip then walks the tensor as one narrow front -- tools/native/copy_bench.hip)
+  const long long nw = bpw ? 4 : (long long)gridDim.x * 4;
+  const long long bfirst = (bpw ? (long long)blockIdx.x * bpw * 4 : (long long)blockIdx.x * 4) + wid;
+  const long long bend = bpw ? ((long long)(blockIdx.x + 1) * bpw * 4 < nb ? (long long)(blockIdx.x + 1) * bpw * 4 : nb) : nb;
+  for (long long b = bfirst; b < bend; b += nw) {
+    const long long row0 = b * R;
+    Raw8<bf16> xr[R][NCH], pr[POST ? R : 1][POST ? NCH : 1];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long long row = row0 + r < M ? row0 + r : M - 1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        xr[r][c].load(x + row * C + col[c]);
+        if constexpr (POST) pr[r][c].load(post + row * C + col[c]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float mymean = 0.f, myrstd = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {               // (rows past M are copies of the last row: computed, never stored -- no branch in here)
+      float v[NCH][8];
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        xr[r][c].unpack(v[c]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (!FULL && !ok[c]) v[c][i] = 0.f;
+          s += v[c][i];
+        }
+      }
+      const float mean = wave_sum(s) / (float)C;
+      float q = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = (!FULL && !ok[c]) ? 0.f : v[c][i] - mean;
+          q += d * d;
+        }
+      const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+      if (lane == r) { mymean = mean; myrstd = rstd; }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float o[8], ga[8], be[8], pv[8];
+        if constexpr (AFFINE) {
+          const f32x4 g0 = *(const f32x4*)(sgb + col[c]), g1 = *(const f32x4*)(sgb + col[c] + 4);
+          const f32x4 b0 = *(const f32x4*)(sgb + NCH * 512 + col[c]), b1 = *(const f32x4*)(sgb + NCH * 512 + col[c] + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ga[i] = g0[i]; ga[4 + i] = g1[i]; be[i] = b0[i]; be[4 + i] = b1[i]; }
+        }
+        if constexpr (POST) pr[r][c].unpack(pv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float t = (v[c][i] - mean) * rstd;
+          if constexpr (AFFINE) t = t * ga[i] + be[i];
+          if constexpr (ACT == 1) t = gelu_f(t);
+          if constexpr (POST) t += pv[i];
+          o[i] = t;
+        }
+        xr[r][c].v = ln_pack8(o);
+      }
+      __builtin_amdgcn_sched_barrier(0);          // (rows one after the other: interleaved, their temporaries cost waves of occupancy)
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (row0 + r >= M) break;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (FULL || ok[c]) *(uint4*)(y + (row0 + r) * C + col[c]) = xr[r][c].v;
+    }
+    if (mean_out && lane < R && row0 + lane < M) { mean_out[row0 + lane] = mymean; rstd_out[row0 + lane] = myrstd; }
+  }
+}
+
+// waves per SIMD the backward is built for: 4 (<= 128 registers); the affine flavours at C > 512 carry 32-48 column-sum registers
+// per lane besides the row (3 waves, one row per batch)
+#define LN_BWD_WAVES ((AFFINE && NCH == 2) ? 3 : 4)
+// Backward of y = act(LN(x) gamma + beta) in the same form.  dx is packed into the registers dy came in, dropout(dx) (mode 2) into
+// x's; the column sums (dgamma / dbeta / dxsum) stay in registers over all batches of the wave and leave once per workgroup.
+template <int NCH, int R, int ACT, bool AFFINE, int DM, bool XS, bool FULL>
+__global__ __launch_bounds__(256, LN_BWD_WAVES) void ln_bwd_stream_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
+                                                            bf16* __restrict__ dx, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dxsum, long long M,
+                                                            int C, Drop drop, bf16* __restrict__ dx_drop,
+                                                            float* __restrict__ spread, int bpw) {
+  __shared__ float red[4][64 * 8];
+  __shared__ __attribute__((aligned(16))) float sgb[AFFINE ? (ACT ? 2 : 1) * NCH * 512 : 4];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if constexpr (AFFINE) {
+    for (int k = threadIdx.x; k < NCH * 512; k += 256) {
+      sgb[k] = k < C ? gamma[k] : 1.f;
+      if constexpr (ACT == 1) sgb[NCH * 512 + k] = k < C ? beta[k] : 0.f;
+    }
+    __syncthreads();
+  }
+  int col[NCH];
+  bool ok[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int cc = (c * 64 + lane) * 8;
+    ok[c] = FULL || cc < C;
+    col[c] = ok[c] ? cc : 0;
+  }
+  float ag[AFFINE ? NCH : 1][8], ab[AFFINE ? NCH : 1][8], as_[XS ? NCH : 1][8];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if constexpr (AFFINE) { ag[c][i] = 0.f; ab[c][i] = 0.f; }
+      if constexpr (XS) as_[c][i] = 0.f;
+    }
+  const long long nb = (M + R - 1) / R;
+  // bpw = 0: persistent, batches wave, wave + nwaves, ...; bpw > 0: the workgroup owns 4 bpw CONSECUTIVE batches and retires
+  // (workgroups are dispatched in order: the chip then walks the tensor as one narrow front -- tools/native/copy_bench.hip)
+  const long long nw = bpw ? 4 : (long long)gridDim.x * 4;
+  const long long bfirst = (bpw ? (long long)blockIdx.x * bpw * 4 : (long long)blockIdx.x * 4) + wid;
+  const long long bend = bpw ? ((long long)(blockIdx.x + 1) * bpw * 4 < nb ? (long long)(blockIdx.x + 1) * bpw * 4 : nb) : nb;
+  for (long long b = bfirst; b < bend; b += nw) {
+    const long long row0 = b * R;
+    Raw8<bf16> xr[R][NCH], dr[R][NCH];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const long long row = row0 + r < M ? row0 + r : M - 1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        xr[r][c].load(x + row * C + col[c]);
+        dr[r][c].load(dy + row * C + col[c]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {               // (rows past M are copies of the last row with dy = 0: no branch in here)
+      const bool live = row0 + r < M;
+      const long long row = live ? row0 + r : M - 1;
+      const float mean = mean_in[row], rstd = rstd_in[row];
+      // phase 1: the row's two sums (and the column sums of dgamma / dbeta).  Nothing per element survives it except, with an
+      // activation, d = dy gelu'(.) (16 registers): phase 2 unpacks x and dy again instead of keeping xhat and dy gamma (32 more)
+      float dk[ACT == 1 ? NCH : 1][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float xv[8], dv[8], ga8[8], bt8[8];
+        xr[r][c].unpack(xv);
+        dr[r][c].unpack(dv);
+        if constexpr (AFFINE) {
+          const f32x4 g0 = *(const f32x4*)(sgb + col[c]), g1 = *(const f32x4*)(sgb + col[c] + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ga8[i] = g0[i]; ga8[4 + i] = g1[i]; }
+          if constexpr (ACT == 1) {
+            const f32x4 b0 = *(const f32x4*)(sgb + NCH * 512 + col[c]), b1 = *(const f32x4*)(sgb + NCH * 512 + col[c] + 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { bt8[i] = b0[i]; bt8[4 + i] = b1[i]; }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float h = (xv[i] - mean) * rstd;
+          float d = ((!FULL && !ok[c]) || !live) ? 0.f : dv[i];
+          if constexpr (ACT == 1) {
+            d *= gelu_grad_f(AFFINE ? h * ga8[i] + bt8[i] : h);
+            dk[c][i] = d;
+          }
+          float dg = d;
+          if constexpr (AFFINE) {
+            ag[c][i] += d * h;
+            ab[c][i] += d;
+            dg = d * ga8[i];
+          }
+          s1 += dg;
+          s2 += dg * h;
+        }
+      }
+      s1 = wave_sum(s1) / (float)C;
+      s2 = wave_sum(s2) / (float)C;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {       // (opaque: otherwise the unpacked values of phase 1 are kept for phase 2 -- the point was not to)
+        asm volatile("" : "+v"(xr[r][c].v.x), "+v"(xr[r][c].v.y), "+v"(xr[r][c].v.z), "+v"(xr[r][c].v.w));
+        if constexpr (ACT == 0) asm volatile("" : "+v"(dr[r][c].v.x), "+v"(dr[r][c].v.y), "+v"(dr[r][c].v.z), "+v"(dr[r][c].v.w));
+      }
+      // phase 2: dx = rstd (dg - s1 - xhat s2) = d (rstd gamma) + (x - mean) (-rstd^2 s2) + (-rstd s1)
+      const float kb = -rstd * rstd * s2, kc = -rstd * s1;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        float xv[8], dv[8], ga8[8], o[8];
+        xr[r][c].unpack(xv);
+        if constexpr (ACT == 0) dr[r][c].unpack(dv);
+        if constexpr (AFFINE) {
+          const f32x4 g0 = *(const f32x4*)(sgb + col[c]), g1 = *(const f32x4*)(sgb + col[c] + 4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { ga8[i] = g0[i] * rstd; ga8[4 + i] = g1[i] * rstd; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float d = ACT == 1 ? dk[c][i] : dv[i];
+          o[i] = fmaf(d, AFFINE ? ga8[i] : rstd, fmaf(xv[i] - mean, kb, kc));
+        }
+        dr[r][c].v = ln_pack8(o);
+        if constexpr (DM == 2) {
+          drop_apply_n<8>(drop, (unsigned long long)row * C + col[c], o);
+          xr[r][c].v = ln_pack8(o);
+        }
+        if constexpr (XS) {
+          float q[8];
+          (DM == 2 ? xr[r][c] : dr[r][c]).unpack(q);               // the sum of what is stored (rounded to bf16)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) as_[c][i] += ((!FULL && !ok[c]) || !live) ? 0.f : q[i];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (row0 + r >= M) break;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (FULL || ok[c]) {
+          *(uint4*)(dx + (row0 + r) * C + col[c]) = dr[r][c].v;
+          if constexpr (DM == 2) *(uint4*)(dx_drop + (row0 + r) * C + col[c]) = xr[r][c].v;
+        }
+    }
+  }
+  // cross-wave reduction of the per-column partials, then one atomic per column and workgroup
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+    if (which < 2 && !(AFFINE && dgamma)) continue;
+    if (which == 2 && !(XS && dxsum)) continue;
+    float* dst = which == 0 ? dgamma : (which == 1 ? dbeta : dxsum);
+    if (spread) dst = spread + ((long long)(blockIdx.x % SPREAD) * 3 + which) * SPREAD_C;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float vv = 0.f;
+        if constexpr (AFFINE) { if (which == 0) vv = ag[c][i]; if (which == 1) vv = ab[c][i]; }
+        if constexpr (XS) { if (which == 2) vv = as_[c][i]; }
+        red[wid][lane * 8 + i] = vv;
+      }
+      __syncthreads();
+      for (int k = threadIdx.x; k < 512; k += 256) {
+        const int cc = c * 512 + k;
+        if (cc < C) atomicAdd(dst + cc, red[0][k] + red[1][k] + red[2][k] + red[3][k]);
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- instance norm
 // stats over T per (layer, batch, channel): mean and rstd (biased variance, eps) -- two passes over
 // the (L2-resident) column strip for accuracy.
@@ -492,10 +829,62 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
 }
 
 // =============================================================================================
+// ---- streaming forms: host side
+template <int NCH, int R, int ACT, bool AFFINE, bool POST, bool FULL>
+static void ln_fwd_stream_go(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                             const void* post, long long M, int C, float eps, hipStream_t st) {
+  static int occ[A2V_MAX_DEVICES];
+  auto kern = ln_fwd_stream_kernel<NCH, R, ACT, AFFINE, POST, FULL>;
+  const long long need = ((M + R - 1) / R + 3) / 4;
+  const long long cap = (long long)ln_occupancy(kern, occ, 0) * ln_cus();
+  const int bpw = g_a2v_ln_bpw == 0 ? 1 : (g_a2v_ln_bpw < 0 ? 0 : g_a2v_ln_bpw);       // forward: one batch per wave, in order
+  const long long grid = bpw > 0 ? (need + bpw - 1) / bpw : (need < cap ? need : cap);
+  hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), 0, st, (const bf16*)x, gamma, beta, (bf16*)y, mean,
+                     rstd, (const bf16*)post, M, C, eps, bpw);
+}
+template <int NCH, int ACT, bool AFFINE, bool POST>
+static void ln_fwd_stream_rows(int cpb, bool full, const void* x, const float* gamma, const float* beta, void* y, float* mean,
+                               float* rstd, const void* post, long long M, int C, float eps, hipStream_t st) {
+#define LN_GO(R_)                                                                                                   \
+  { if (full) ln_fwd_stream_go<NCH, R_, ACT, AFFINE, POST, true>(x, gamma, beta, y, mean, rstd, post, M, C, eps, st); \
+    else ln_fwd_stream_go<NCH, R_, ACT, AFFINE, POST, false>(x, gamma, beta, y, mean, rstd, post, M, C, eps, st); }
+  const int r = cpb / NCH;            // cpb: 16-B chunks of one tensor per lane and batch (2, 4 or 8)
+  if (r <= 1 * (2 / NCH)) LN_GO(1 * (2 / NCH))
+  else if (r <= 2 * (2 / NCH)) LN_GO(2 * (2 / NCH))
+  else LN_GO(4 * (2 / NCH))
+#undef LN_GO
+}
+// true when the call was taken
+static bool ln_fwd_stream(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out,
+                          float* mean, float* rstd, const void* post, long long M, int C, long long ldx, long long ldy, float eps,
+                          int act, Drop drop, hipStream_t st) {
+  if (!(g_a2v_ln_stream & 1) || res || sum_out || drop.thresh || ldx != C || ldy != C || C > 1024 || M < 2048) return false;
+  const bool aff = gamma != nullptr;
+  if (!act && (!aff || post)) return false;
+  if (act && aff && post) return false;
+  const int nch = (C + 511) / 512;
+  const bool full = C == nch * 512;
+  const int rmax = (post ? 4 : 8) / nch;                       // rows per batch the flavour's registers allow
+  // 4 chunks of 16 B per lane and batch (C = 1024: 2 rows, C = 512: 4 rows); one row for the longest C = 1024 tensors
+  const int cpb = ln_pick_rows((nch == 2 && full && M > 262144) ? 1 : 4 / nch, rmax) * nch;
+#define LN_FL(N)                                                                                                            \
+  { if (!act) ln_fwd_stream_rows<N, 0, true, false>(cpb, full, x, gamma, beta, y, mean, rstd, post, M, C, eps, st);          \
+    else if (aff) ln_fwd_stream_rows<N, 1, true, false>(cpb, full, x, gamma, beta, y, mean, rstd, post, M, C, eps, st);     \
+    else if (post) ln_fwd_stream_rows<N, 1, false, true>(cpb, full, x, gamma, beta, y, mean, rstd, post, M, C, eps, st);    \
+    else ln_fwd_stream_rows<N, 1, false, false>(cpb, full, x, gamma, beta, y, mean, rstd, post, M, C, eps, st); }
+  if (nch == 1) LN_FL(1) else LN_FL(2)
+#undef LN_FL
+  return true;
+}
+
 template <typename T>
 static int ln_fwd_launch(const void* x, const void* res, const float* gamma, const float* beta, void* y, void* sum_out,
                          float* mean, float* rstd, const void* post, long long M, int C, long long ldx, long long ldy, float eps, int act,
                          Drop drop, hipStream_t st) {
+  if (sizeof(T) == 2 && ln_fwd_stream(x, res, gamma, beta, y, sum_out, mean, rstd, post, M, C, ldx, ldy, eps, act, drop, st)) {
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   const int nch = (C + 511) / 512;
   const bool two = M <= 65536;
   dim3 grid((unsigned)((M + (two ? 8 : 4) - 1) / (two ? 8 : 4))), blk(256);
@@ -531,11 +920,86 @@ extern "C" int a2v_layernorm_fwd(int dtype, const void* x, const void* res, cons
   return A2V_ERR_DTYPE;
 }
 
+template <int NCH, int R, int ACT, bool AFFINE, int DM, bool XS, bool FULL>
+static int ln_bwd_stream_go(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                            const float* rstd, void* dx, float* dgamma, float* dbeta, float* dxsum, long long M, int C, Drop drop,
+                            void* dx_drop, hipStream_t st) {
+  static int occ[A2V_MAX_DEVICES];
+  auto kern = ln_bwd_stream_kernel<NCH, R, ACT, AFFINE, DM, XS, FULL>;
+  const long long need = ((M + R - 1) / R + 3) / 4;
+  // with an activation (conv stacks: GELU', at most 16 column-sum registers): front form, one batch per wave where the rows are
+  // full 512-column chunks, 8 where a ragged chunk leaves half a wave idle (C = 768) or the rows are short (C = 512);
+  // without (blocks, project_features: dgamma / dbeta / bias gradient): persistent, two workgroups per CU at C > 512
+  const int auto_bpw = ACT == 1 ? ((NCH == 2 && FULL) ? 1 : 8) : 0;
+  const int bpw = g_a2v_ln_bpw_bwd == 0 ? auto_bpw : (g_a2v_ln_bpw_bwd < 0 ? 0 : g_a2v_ln_bpw_bwd);
+  const long long cap = (long long)ln_occupancy(kern, occ, (ACT == 0 && NCH == 2) ? 2 : 0) * ln_cus();
+  const unsigned grid = (unsigned)(bpw > 0 ? (need + bpw - 1) / bpw : (need < cap ? need : cap));
+  float* spread = nullptr;
+  if (grid >= 4 * SPREAD && (dgamma || dxsum)) {
+    spread = spread_ws(st);
+    if (!spread) return A2V_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, (const bf16*)dy, (const bf16*)x, gamma, beta, mean, rstd, (bf16*)dx, dgamma,
+                     dbeta, dxsum, M, C, drop, (bf16*)dx_drop, spread, bpw);
+  if (spread) spread_fold(spread, dgamma, dbeta, dxsum, C, st);
+  return A2V_OK;
+}
+template <int NCH, int ACT, bool AFFINE, int DM, bool XS>
+static int ln_bwd_stream_rows(int cpb, bool full, const void* dy, const void* x, const float* gamma, const float* beta,
+                              const float* mean, const float* rstd, void* dx, float* dgamma, float* dbeta, float* dxsum,
+                              long long M, int C, Drop drop, void* dx_drop, hipStream_t st) {
+#define LN_GO(R_)                                                                                                                \
+  return full ? ln_bwd_stream_go<NCH, R_, ACT, AFFINE, DM, XS, true>(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, dxsum, M, C, \
+                                                                     drop, dx_drop, st)                                            \
+              : ln_bwd_stream_go<NCH, R_, ACT, AFFINE, DM, XS, false>(dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, dxsum, M, C, \
+                                                                      drop, dx_drop, st);
+  if (AFFINE || cpb / NCH <= 1 * (2 / NCH)) { LN_GO(1 * (2 / NCH)) }
+  if constexpr (!AFFINE) { LN_GO(2 * (2 / NCH)) }
+#undef LN_GO
+}
+// 1: not taken; otherwise the call's return code
+static int ln_bwd_stream(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
+                         const float* rstd, void* dx, const void* dres, float* dgamma, float* dbeta, float* dxsum, long long M,
+                         int C, long long ldx, long long lddy, int act, Drop drop, int drop_mode, void* dx_drop, hipStream_t st) {
+  if (!(g_a2v_ln_stream & 2) || dres || ldx != C || lddy != C || C > 1024 || M < 2048) return 1;
+  const bool aff = gamma != nullptr, xs = dxsum != nullptr;
+  int fl = -1;                                    // (ACT, AFFINE, DM, XS)
+  if (!act && aff && drop_mode == 2 && xs) fl = 0;
+  else if (!act && aff && drop_mode == 0) fl = xs ? 1 : 2;
+  else if (act && !aff && drop_mode == 0 && xs) fl = 3;
+  else if (act && aff && drop_mode == 0 && !xs) fl = 4;
+  if (fl < 0) return 1;
+  const int nch = (C + 511) / 512;
+  const bool full = C == nch * 512;
+  const int cpb = ln_pick_rows(4 / nch, 4 / nch) * nch;
+#define LN_A dy, x, gamma, beta, mean, rstd, dx, dgamma, dbeta, dxsum, M, C, drop, dx_drop, st
+#define LN_FL(N)                                                                    \
+  switch (fl) {                                                                     \
+    case 0: return ln_bwd_stream_rows<N, 0, true, 2, true>(cpb, full, LN_A);        \
+    case 1: return ln_bwd_stream_rows<N, 0, true, 0, true>(cpb, full, LN_A);        \
+    case 2: return ln_bwd_stream_rows<N, 0, true, 0, false>(cpb, full, LN_A);       \
+    case 3: return ln_bwd_stream_rows<N, 1, false, 0, true>(cpb, full, LN_A);       \
+    default: return ln_bwd_stream_rows<N, 1, true, 0, false>(cpb, full, LN_A);      \
+  }
+  if (nch == 1) LN_FL(1)
+  LN_FL(2)
+#undef LN_FL
+#undef LN_A
+}
+
 template <typename T>
 static int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const float* beta, const float* mean,
                          const float* rstd, void* dx, const void* dres, float* dgamma, float* dbeta, float* dxsum,
                          long long M, int C, long long ldx, long long lddy, int act, Drop drop, int drop_mode,
                          void* dx_drop, hipStream_t st) {
+  if (sizeof(T) == 2) {
+    const int rc = ln_bwd_stream(dy, x, gamma, beta, mean, rstd, dx, dres, dgamma, dbeta, dxsum, M, C, ldx, lddy, act, drop,
+                                 drop_mode, dx_drop, st);
+    if (rc != 1) {
+      if (rc == A2V_OK) A2V_CHECK_LAUNCH();
+      return rc;
+    }
+  }
   const int nch = (C + 511) / 512;
   const int rpw = LN_ROWS_PER_WAVE;     // 4 was measured slower for short tensors (dgamma atomics dominate)
   dim3 grid((unsigned)((M + 4 * rpw - 1) / (4 * rpw))), blk(256);

@@ -730,6 +730,87 @@ def test_layernorm_fwd_bwd(ops, dtype, C_, act, affine):
         assert rel_err(db, b.grad) < tol(dtype, 2)
 
 
+@pytest.mark.parametrize("C_,act,affine,post", [(1024, 0, True, False), (512, 1, True, False), (1024, 1, False, False),
+                                                (768, 1, False, True), (768, 1, False, False), (512, 0, True, False),
+                                                (256, 1, False, False)])
+@pytest.mark.parametrize("rows", [0, 1, 2, 4, 8])
+def test_layernorm_stream_fwd(ops, C_, act, affine, post, rows):
+    """The persistent streaming forward (bf16, a2v_norm.hip round 5) against torch and, bit for bit, against the row-per-wave
+    kernel it replaces; `rows` forces the rows per batch (ragged last batch: M is not a multiple of any of them)."""
+    dtype = torch.bfloat16
+    M = 3 * 2048 + 5
+    x = (rnd(M, C_, dtype=dtype, seed=1) * 1.5 + 0.3).to(dtype).float()
+    w = rnd(C_, dtype=torch.float32, seed=2) * 0.2 + 1 if affine else None
+    b = rnd(C_, dtype=torch.float32, seed=3) * 0.2 if affine else None
+    pz = rnd(M, C_, dtype=dtype, seed=5) if post else None
+    y = F.layer_norm(x.float(), (C_,), w, b, 1e-5)
+    if act:
+        y = F.gelu(y)
+    if post:
+        y = y + pz.float()
+    xd, wd, bd, pd = dev(x, dtype), (w.cuda() if affine else None), (b.cuda() if affine else None), (dev(pz, dtype) if post else None)
+    try:
+        ops.debug_set(31, rows)
+        y1, m1, r1 = ops.layernorm_fwd(xd, wd, bd, 1e-5, act=act, post=pd)
+        ops.debug_set(30, 0)
+        y0, m0, r0 = ops.layernorm_fwd(xd, wd, bd, 1e-5, act=act, post=pd)
+    finally:
+        ops.debug_set(30, 3)
+        ops.debug_set(31, 0)
+    assert rel_err(y1.float(), y) < tol(dtype)
+    assert torch.equal(m1, m0) and rel_err(r1, r0) < 1e-6       # (a ragged last chunk sums its zeros in another place: last-bit differences)
+    assert rel_err(y1.float(), y0.float()) < (1e-6 if C_ % 512 == 0 else 1e-4)
+
+
+@pytest.mark.parametrize("C_,act,affine,mode,xs", [(1024, 0, True, 2, True), (1024, 0, True, 0, True), (512, 0, True, 0, False),
+                                                   (1024, 1, False, 0, True), (768, 1, False, 0, True), (512, 1, True, 0, False),
+                                                   (768, 0, True, 2, True), (256, 1, False, 0, True)])
+@pytest.mark.parametrize("rows", [0, 1, 2, 4])
+def test_layernorm_stream_bwd(ops, C_, act, affine, mode, xs, rows):
+    """The streaming backward against autograd and against the row-per-wave kernel (same dropout mask, same column sums)."""
+    dtype = torch.bfloat16
+    M = 3 * 2048 + 3
+    x = (rnd(M, C_, dtype=dtype, seed=1) * 1.5 + 0.3).to(dtype).float().requires_grad_(True)
+    w = (rnd(C_, dtype=torch.float32, seed=2) * 0.2 + 1).requires_grad_(affine)
+    b = (rnd(C_, dtype=torch.float32, seed=3) * 0.2).requires_grad_(affine)
+    y = F.layer_norm(x, (C_,), w if affine else None, b if affine else None, 1e-5)
+    if act:
+        y = F.gelu(y)
+    dy = rnd(M, C_, dtype=dtype, seed=4)
+    y.backward(dy)
+    xd, dyd = dev(x.detach(), dtype), dev(dy, dtype)
+    wd, bd = (w.detach().cuda(), b.detach().cuda()) if affine else (None, None)
+    _, mean, rstd = ops.layernorm_fwd(xd, wd, bd, 1e-5, act=act)
+    kw = dict(drop=(0.1, 4242), drop_mode=2) if mode == 2 else {}
+    outs = []
+    try:
+        for stream in (3, 0):
+            ops.debug_set(30, stream)
+            ops.debug_set(31, rows)
+            dg = torch.zeros(C_, device="cuda") if affine else None
+            db = torch.zeros(C_, device="cuda") if affine else None
+            dxs = torch.zeros(C_, device="cuda") if xs else None
+            r = ops.layernorm_bwd(dyd, xd, wd, bd, mean, rstd, act=act, dgamma=dg, dbeta=db, dxsum=dxs, **kw)
+            dx, dxd = r if mode == 2 else (r, None)
+            outs.append((dx, dxd, dg, db, dxs))
+    finally:
+        ops.debug_set(30, 3)
+        ops.debug_set(31, 0)
+    (dx1, dxd1, dg1, db1, dxs1), (dx0, dxd0, dg0, db0, dxs0) = outs
+    assert rel_err(dx1.float(), x.grad.float()) < tol(dtype, 2)
+    assert rel_err(dx1.float(), dx0.float()) < 3e-3              # (another grouping of the same fp32 terms, then bf16 rounding)
+    if mode == 2:
+        keep = ops.dropout_mask(M * C_, 0.1, 4242).view(M, C_).float()
+        assert rel_err(dxd1.float(), dx1.float() * keep / 0.9) < tol(dtype)
+        assert rel_err(dxd1.float(), dxd0.float()) < 3e-3
+    if xs:
+        assert rel_err(dxs1, (dxd1 if mode == 2 else dx1).float().sum(0)) < 1e-4
+        assert rel_err(dxs1, dxs0) < 2e-2          # (sums of ~6 k bf16-rounded terms that differ in the last bit here and there)
+    if affine:
+        assert rel_err(dg1, w.grad.cuda()) < tol(dtype, 2) and rel_err(db1, b.grad.cuda()) < tol(dtype, 2)
+        assert rel_err(dg1, dg0) < 1e-4 and rel_err(db1, db0) < 1e-4
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_residual_in(ops, dtype):
     M, C_ = 100, 128
