@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("A2V_LIB_PATH") or os.path.join(_HERE, "liba2v_hip.so"
 
 F32, BF16, BF16X3, BF16X3S = 0, 1, 2, 3
 EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_X3IMG = 1, 2, 4, 8, 16, 32, 64, 128, 256
+EPI_DACT8 = 512
 
 _p, _i, _ll, _f, _u = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint
 

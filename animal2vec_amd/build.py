@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "liba2v_hip.so")
-SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_gemm_p8.hip", "a2v_gemm_w2.hip", "a2v_gemm_tn8.hip", "a2v_wgrad_slab.hip", "a2v_conv_slab.hip", "a2v_conv_dec.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip", "a2v_mixup.hip", "a2v_mask.hip", "a2v_conv_strided.hip", "a2v_split.hip"]
+SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_gemm_p8.hip", "a2v_gemm_tn8.hip", "a2v_wgrad_slab.hip", "a2v_conv_slab.hip", "a2v_conv_dec.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip", "a2v_mixup.hip", "a2v_mask.hip", "a2v_conv_strided.hip", "a2v_split.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in arch VGPRs (no kernel here needs > 256 registers), which removes the
 # v_accvgpr_read/write copies around every VALU use of an accumulator (softmax, epilogues: 96 of 417 VALU per attention step)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form"]
@@ -18,6 +18,10 @@ FLAGS += os.environ.get("A2V_HIPCC_FLAGS", "").split()      # extra -D switches 
 # a2v_attn.hip without the SLP vectoriser: paired into v_pk_fma_f32 the ALiBi term loses the |.| source modifier (one extra
 # v_and per score), and packed fp32 ops cost more issue time between MFMAs than two plain ones
 FILE_FLAGS = {"a2v_attn.hip": ["-fno-slp-vectorize"]}
+# sources that only experiment libraries carry, by the -D switch that asks for them (never part of the product build):
+#   python -m animal2vec_amd.build --variant w2 -DA2V_W2     -> liba2v_hip_w2.so with the 256 x 128 two-per-CU NT kernel (round 4's
+#   negative result, profiles/r04_w2_experiment.txt), switched on with a2v_debug_set(25, 2)
+VARIANT_SOURCES = {"-DA2V_W2": ["a2v_gemm_w2.hip"]}
 
 
 def _hipcc() -> str:
@@ -107,8 +111,9 @@ def build_variant(tag: str, defines, verbose: bool = False) -> str:
                 raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr}")
         return obj
 
+    sources = SOURCES + [f for d in defines for f in VARIANT_SOURCES.get(d, [])]
     with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(cc, SOURCES))
+        objs = list(ex.map(cc, sources))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs], capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(f"link failed:\n{r.stderr}")

@@ -220,6 +220,23 @@ __device__ __forceinline__ a2v_f32x2 gelu_with_grad2(a2v_f32x2 x, a2v_f32x2& gra
   grad = __builtin_elementwise_fma(x * 0.39894228040143268f, e, (a2v_f32x2){0.5f, 0.5f} + cq);
   return __builtin_elementwise_fma(ax, q, x * 0.5f);
 }
+// gelu'(x) in 8 bits (A2V_EPI_DACT8, bf16 throughput mode only): gelu' lies in [-0.129, 1.129]; q = round(200 g') + 26 in [0, 252],
+// g' ~ (q - 26) / 200 -- a grid of 1/200 on which 0 (dead units) and 1 (saturated units) are exact; |error| <= 0.0025, the size of the
+// bf16 rounding (2^-9 relative) of a derivative near 1/2.  What the fc1 epilogue keeps for the backward and the fc2 input-gradient
+// epilogue multiplies by: a quarter of the fc1 launch's output bytes and a third of that backward launch's extra input bytes less.
+// (v_cvt_pk_u8_f32 rounds to nearest even, saturates to [0, 255] and writes one byte of a dword: one FMA + one conversion per element)
+__device__ __forceinline__ unsigned dact8_put(unsigned w, unsigned byte, float d) {
+  return __builtin_amdgcn_cvt_pk_u8_f32(fmaf(d, 200.f, 26.f), byte, w);
+}
+__device__ __forceinline__ unsigned dact8_pack4(float a, float b, float c, float d) {
+  return dact8_put(dact8_put(dact8_put(dact8_put(0u, 0u, a), 1u, b), 2u, c), 3u, d);
+}
+__device__ __forceinline__ void dact8_unpack4(unsigned w, float* o) {
+  o[0] = fmaf((float)(w & 0xFFu), 0.005f, -0.13f);
+  o[1] = fmaf((float)((w >> 8) & 0xFFu), 0.005f, -0.13f);
+  o[2] = fmaf((float)((w >> 16) & 0xFFu), 0.005f, -0.13f);
+  o[3] = fmaf((float)(w >> 24), 0.005f, -0.13f);
+}
 __device__ __forceinline__ float gelu_f(float x) { return gelu_t<false>(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<false>(x); }
 

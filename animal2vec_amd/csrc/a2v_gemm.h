@@ -37,7 +37,8 @@ struct GemmArgs {
                                  // (the tail rows the persistent kernel hands to the 128 x 128 kernel) keeps the whole tensor's mask
 };
 
-enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64, F_DACT = 128, F_X3IMG = 256 };
+enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64, F_DACT = 128, F_X3IMG = 256,
+       F_DACT8 = 512 };    // F_DACT8 (bf16, with F_DACT): the derivative tensor (C2 when stored, R when multiplied) is uint8, a2v_common.h dact8_*
 // F_X3IMG (dtype A2V_BF16X3 on the persistent kernel only): C is written as the bf16 [hi | lo | hi] split image of the result (row pitch
 // ldc >= 3 N bf16 elements) instead of fp32 -- for a result that only further products read (the Mlp's hidden activation)
 // F_DACT (with F_GELU | F_STORE_PRE): C2 receives gelu'(acc + bias) instead of the pre-activation -- both come out of one
@@ -113,7 +114,8 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, i
         f32x4 gr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { float d_; v[i] = gelu_with_grad(v[i], d_); gr[i] = d_; }
-        Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, gr);
+        if (g.flags & F_DACT8) *(unsigned*)((unsigned char*)g.C2 + (long long)m * g.ldc + ccol) = dact8_pack4(gr[0], gr[1], gr[2], gr[3]);
+        else Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, gr);
       } else {
         if (g.flags & F_STORE_PRE) Vec4<T>::store(C2 + (long long)m * g.ldc + ccol, v);
         if (g.flags & F_GELU) {
@@ -127,7 +129,14 @@ __device__ __forceinline__ void wave_epilogue(const GemmArgs& g, float* stage, i
       }
       if (g.flags & F_RES) v += Vec4<T>::load(R + (long long)m * g.ldr + ccol);
       if (g.flags & F_GELU_BWD) {
-        f32x4 h = Vec4<T>::load(R + (long long)m * g.ldr + ccol);
+        f32x4 h;
+        if (g.flags & F_DACT8) {
+          float h4[4];
+          dact8_unpack4(*(const unsigned*)((const unsigned char*)g.R + (long long)m * g.ldr + ccol), h4);
+          h = (f32x4){h4[0], h4[1], h4[2], h4[3]};
+        } else {
+          h = Vec4<T>::load(R + (long long)m * g.ldr + ccol);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] *= (g.flags & F_DACT) ? h[i] : gelu_grad_f(h[i]);
       }

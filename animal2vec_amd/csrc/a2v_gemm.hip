@@ -461,6 +461,28 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+  if (flags & F_DACT8) {
+    // the 8-bit derivative tensor (include/a2v.h: A2V_EPI_DACT8): bf16 Linear products only, as the fc1 forward (gelu + stored
+    // derivative) or the fc2 input gradient (derivative multiplied in) -- the persistent kernel's fixed flavours, else the 128 x 128 kernels
+    const bool st = (flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE) && !(flags & F_GELU_BWD);
+    const bool mu = (flags & (F_DACT | F_GELU_BWD)) == (F_DACT | F_GELU_BWD) && !(flags & (F_STORE_PRE | F_RES));
+    if (dtype != A2V_BF16 || !(st || mu) || rowidx || rowmask || G != 1 || taps != 1 || stride != 1 || (st ? ldc % 8 : ldr % 8))
+      return A2V_ERR_UNSUPPORTED;
+    if (g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
+      A2V_CHECK_LAUNCH();
+      return A2V_OK;
+    }
+    if (!a2v_launch_nt_bf16_fast(g, stream)) {
+      static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];
+      if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES);
+        attr = true;
+      }
+      hipLaunchKernelGGL(gemm_nt_bf16_kernel, grid, dim3(NT_THREADS), NT_LDS_BYTES, stream, g);
+    }
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if ((flags & F_X3IMG) && (dtype != A2V_BF16X3 || rowidx || !a2v_launch_nt_x3_p8(g, stream))) return A2V_ERR_UNSUPPORTED;
   if (flags & F_X3IMG) {
     A2V_CHECK_LAUNCH();
@@ -485,10 +507,12 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+#ifdef A2V_W2
   if (dtype == A2V_BF16 && !rowidx && g_a2v_gemm_p8 && a2v_launch_nt_bf16_w2(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+#endif
   if (dtype == A2V_BF16 && !rowidx && g_a2v_gemm_p8 && a2v_launch_nt_bf16_p8(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
@@ -626,7 +650,10 @@ extern "C" int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long
 // ---- per-stream workspaces (a2v_common.h)
 #include <mutex>
 #include <vector>
-__device__ char g_ws_static[A2V_MAX_STREAMS][A2V_WS_BYTES];      // the library-owned sets: zero at load, self-cleaning afterwards
+// (256-byte aligned like the workspaces a caller binds: u32 atomic counters at offset 0, fp32 regions written as 16-B vectors behind them)
+static_assert(A2V_WS_BYTES % 256 == 0 && A2V_WS_SPREAD % 16 == 0 && A2V_WS_QKB % 16 == 0 && A2V_WS_DAL % 16 == 0 && A2V_WS_CSPART % 16 == 0,
+              "workspace layout: every region 16-byte aligned, the blob a multiple of 256 bytes");
+__device__ __attribute__((aligned(256))) char g_ws_static[A2V_MAX_STREAMS][A2V_WS_BYTES];      // the library-owned sets: zero at load, self-cleaning afterwards
 static std::mutex g_ws_mu;
 static hipStream_t g_ws_stream[A2V_MAX_STREAMS];
 static bool g_ws_used[A2V_MAX_STREAMS];
@@ -699,10 +726,9 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 21) { g_a2v_conv_strided = value; return A2V_OK; }
   if (key == 22) { g_a2v_p8_tail = value; return A2V_OK; }        // persistent NT kernel: nearly empty last round -> 128 x 128 kernel   // dense strided convs on the 8-phase GEMMs on / off
   if (key == 23) { g_a2v_p8_tmode = value; return A2V_OK; }   // persistent NT kernel: tile order (0: 8 m-tiles x all n-tiles, 1: W-stationary n-groups)
-#ifdef P8_SKEW
-  { extern int g_a2v_p8_skew; if (key == 24) { g_a2v_p8_skew = value; return A2V_OK; } }
-#endif
+#ifdef A2V_W2      // experiment library only (python -m animal2vec_amd.build --variant w2 -DA2V_W2): profiles/r04_w2_experiment.txt
   { extern int g_a2v_gemm_w2; if (key == 25) { g_a2v_gemm_w2 = value; return A2V_OK; } }   // 256 x 128 two-per-CU NT kernel: 0 off, 1 K <= 1024, 2 all
+#endif
   { extern int g_a2v_ln_stream, g_a2v_ln_rows, g_a2v_ln_wpc;   // streaming LayerNorm (a2v_norm.hip): on / off bits, rows per batch, workgroups per CU
     if (key == 30) { g_a2v_ln_stream = value; return A2V_OK; }
     if (key == 31) { g_a2v_ln_rows = value; return A2V_OK; }

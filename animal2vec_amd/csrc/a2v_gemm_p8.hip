@@ -136,6 +136,9 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 #define P8_FX_B (F_BIAS)                                        /* qkv, the teacher's upper fc2 */
 #define P8_FX_BG (F_BIAS | F_GELU)                              /* fc1, eval (teacher) */
 #define P8_FX_PLAIN 256                                         /* no flag at all (proj input gradient); bit 8 marks "fixed" */
+#define P8_FX_FC1_8 (P8_FX_FC1 | F_DACT8)                       /* fc1 forward, the kept derivative in 8 bits (a2v_common.h dact8_*) */
+#define P8_FX_FC2D_8 (P8_FX_FC2D | F_DACT8)                     /* fc2 input gradient reading it */
+#define P8_FXM 0x2FF                                            /* the epilogue flags a fixed flavour encodes (bit 8 is the marker above) */
 // O32 (dtype A2V_BF16X3 of the C ABI): bf16 operands, fp32 C / C2 / R.  The caller hands over SPLIT operand images --
 // A3 = [A_hi | A_lo | A_hi], B3 = [B_hi | B_hi | B_lo] along K (a2v_split_bf16), so that this ordinary bf16 product over 3 K
 // is A_hi B_hi + A_lo B_hi + A_hi B_lo: every product exact, fp32 accumulation, 2^-17-relative operands -- and gets fp32-grade
@@ -214,11 +217,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   const int nk = g.K / 64;
   const unsigned d64a = (unsigned)(a.pitch * 128), d64b = (unsigned)(g.ldb * 128);   // bytes of 64 rows of A / of B
   // stage one half-tile: 2 LDS-DMA per thread
-#ifndef P8_EXP
-#define P8_EXP 0          /* timing experiments (wrong results): 1 no MFMA, 2 no LDS-DMA in the K loop */
-#endif
 #define P8_STAGE2(base, o0, o1, kt, lds_off, second)            \
-  if (!(P8_EXP & 2)) {                                         \
+  {                                                            \
     const unsigned ko_ = (unsigned)(kt) * 128u;                \
     p8_glds16(base + (o0 + ko_), dst0 + (lds_off));            \
     p8_glds16(base + (o1 + ko_), dst0 + (lds_off) + (second)); \
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
   _Pragma("unroll") for (int i = 0; i < (NI); ++i)                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
-    if (!(P8_EXP & 1)) acc[(ibase) + i][(jbase) + j] = DS                                              \
+    acc[(ibase) + i][(jbase) + j] = DS                                                                 \
         ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0) \
         : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                       \
@@ -358,11 +358,6 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   } else if (dynamic && tid == 0) {
     *slot = gridDim.x + 8u * atomicAdd(&g_p8_ctr[xcd], 1u) + xcd;
   }
-#ifdef P8_SKEW
-  // Experiment build: the workgroups of an XCD start in 8 groups (blockIdx.x >> 3) & 7 that are ((stagger >> 4) & 255) x ~0.5 us apart,
-  // so that the CUs' output bursts do not coincide (tools/p8_probe.py)
-  for (int i = ((stagger >> 4) & 255) * (int)((blockIdx.x >> 3) & 7u); i > 0; --i) __builtin_amdgcn_s_sleep(16);
-#endif
   P8Tile T = make_tile(seq);
   // ---- prologue: K-tiles 0 and 1 complete
   {
@@ -403,8 +398,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
     // epilogue operations every wave issues for certain (see P8_KTILE_FIRST): the C stores, with fixed flags also the second output's
     // stores, the bias vectors and the residual rows; the staged epilogue's stores are conditional (E = 0)
     constexpr int P8_E_ = !DS ? 0
-                          : 2 * (4 + IH) * (((FX & 0xFF) & (F_STORE_PRE)) && FX > 0 ? 2 : 1) + ((FX > 0 && ((FX & 0xFF) & F_BIAS)) ? 4 : 0) +
-                                ((FX > 0 && ((FX & 0xFF) & (F_RES | F_GELU_BWD)) && !O32) ? 2 * (4 + IH) : 0);
+                          : 2 * (4 + IH) * (((FX & P8_FXM) & (F_STORE_PRE)) && FX > 0 ? 2 : 1) + ((FX > 0 && ((FX & P8_FXM) & F_BIAS)) ? 4 : 0) +
+                                ((FX > 0 && ((FX & P8_FXM) & (F_RES | F_GELU_BWD)) && !O32) ? 2 * (4 + IH) : 0);
     constexpr int P8_WAIT0 = 6 + (P8_E_ > 48 ? 48 : P8_E_);
     if constexpr (SEAM2) {
       { P8_KTILE_FIRST(0, P8_BUF, T, 2) }
@@ -486,12 +481,19 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // SGPR written by VALU needs 5 wait states, which the compiler only inserts around instructions it can see
       asm volatile("s_nop 4\n\tglobal_atomic_add %0, %1, %2, %3 sc0" : "=v"(fetched) : "v"(zoff), "v"(one), "s"(&g_p8_ctr[xcd]) : "memory");
     }
+    // lane-derived values are re-formed in the epilogue from an opaque copy of the lane id.  The 8-bit-derivative fc1 flavour needs
+    // one register more than the bf16 one at the 256-row tile (a second per-lane store offset): there `lane` itself was spilled
+    // across the K loop and reloaded behind a full vmcnt(0) -- the tile claim's round trip -- so that flavour re-reads the hardware
+    // lane id instead (volatile asm: as builtins the two instructions are loop invariant and hoisted in front of the tile loop)
     int le = lane;
-    asm volatile("" : "+v"(le));
+    if constexpr (FX > 0 && (FX & F_DACT8) != 0 && (FX & F_STORE_PRE) != 0)
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
+    else
+      asm volatile("" : "+v"(le));
     bf16* const C = (bf16*)g.C;
     bf16* const C2 = (bf16*)g.C2;
     const bf16* const R = (const bf16*)g.R;
-    const int flags = FX > 0 ? (FX & 0xFF) : g.flags;
+    const int flags = FX > 0 ? (FX & P8_FXM) : g.flags;
     const bool need_r = (flags & (F_RES | F_GELU_BWD)) != 0;
     if constexpr (DS) {
       // The two wave groups share ONE workgroup barrier and run one barrier apart.  Without a barrier inside the epilogue, the
@@ -594,21 +596,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // Addresses: a uniform 64-bit tile base (SGPRs) + a 32-bit per-lane element offset inside the tile's rows.
       const int fre = le & 15, fqe = le >> 4;
       const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
-#if defined(P8_L2STORE) && P8_L2STORE == 1
-      bf16* const Ct = C + (int)(blockIdx.x * 8 + wid) * 1024;       // two fixed 1-KiB blocks per wave, contiguous 1-KiB stores
-      bf16* const C2t = C2 + (int)(blockIdx.x * 8 + wid) * 1024;
-#elif defined(P8_L2STORE) && P8_L2STORE == 2
-      bf16* const Ct = C;                                            // the real access pattern (16 rows x 64 B per store), every tile onto tile (0, 0)
-      bf16* const C2t = C2;
-#elif defined(P8_L2STORE) && P8_L2STORE == 3
-      bf16* const Ct = C + ((long long)seq * 8 + wid) * (2 * (4 + IH)) * 512;   // contiguous 1-KiB stores, every one to fresh memory
-      bf16* const C2t = C2 + ((long long)seq * 8 + wid) * (2 * (4 + IH)) * 512;
-#else
       bf16* const Ct = C + tile_off;
       bf16* const C2t = C2 + tile_off;
-#endif
+      unsigned char* const C2t8 = (unsigned char*)g.C2 + tile_off;      // (F_DACT8: one byte per element)
       // (made uniform explicitly: the raw-asm loads below take it as an SGPR pair, and hipcc does not always prove that itself)
-      const unsigned long long rt_ = (unsigned long long)(R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0));
+      const unsigned long long rt_ = (FX > 0 && (FX & F_DACT8) != 0)
+          ? (unsigned long long)((const unsigned char*)g.R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0))
+          : (unsigned long long)(R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0));
       const bf16* const Rt = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(rt_ >> 32)) << 32) |
                                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rt_));
       const int rskip = T.m0 - T.mc;                        // the shifted last m-tile: rows below m0 belong to its neighbour
@@ -627,22 +621,20 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       constexpr int RQ = (IH == 4 && FX == 0) ? 2 : 4;    // residual row blocks in flight (4 VGPRs each; the generic 256-row tile has fewer to spare)
       constexpr int NB = 4 + IH, NT = 2 * NB;
       typedef unsigned p8_u32x4 __attribute__((ext_vector_type(4)));
-      p8_u32x4 rq[RQ];                       // (a native vector: asm operands cannot be members of the HIP uint4 struct)
+      typedef unsigned p8_u32x2 __attribute__((ext_vector_type(2)));
+      constexpr bool D8 = FX > 0 && (FX & F_DACT8) != 0;      // the derivative tensor (C2 / R) holds one byte per element
+      p8_u32x4 rq[D8 ? 1 : RQ];              // (a native vector: asm operands cannot be members of the HIP uint4 struct)
+      p8_u32x2 rq8[D8 ? RQ : 1];
 #define P8_DROW(i_) ((i_) < 4 ? rlo + (i_) * 16 : rhi + ((i_) - 4) * 16)
-#ifdef P8_STORE_SC1
-      // experiment build: write-through stores that do not stay in the XCD's L2 (MI355X_MICROARCH.md, store flavours); the data
-      // registers must survive until the store has read them (s_nop 1, cdna_hip_programming.md 5.7 item 1)
-      const unsigned long long ctb_ = (unsigned long long)Ct, c2b_ = (unsigned long long)C2t;
-      const bf16* const Ct_u = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(ctb_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ctb_));
-      const bf16* const C2t_u = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c2b_ >> 32)) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)c2b_));
-#define P8_ST16(base_, eo_, val_) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" :: "v"((eo_) * 2u), "v"(val_), "s"(base_##_u) : "memory")
-#else
 #define P8_ST16(base_, eo_, val_) *(p8_u32x4*)((base_) + (eo_)) = (val_)
-#endif
       // (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, as the compiler's own loads here; s_nop: the base may have
       //  just been written by v_readfirstlane / v_readlane, and a VMEM instruction reading such an SGPR needs 5 wait states)
 #define P8_ROFF(k_) ((unsigned)(P8_DROW((k_) % NB) * (int)g.ldr + ((k_) / NB) * 128 + wc * 32 + fqe * 8) * 2u)
-#define P8_RLOAD(k_) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(rq[(k_) % RQ]) : "v"(P8_ROFF(k_)), "s"(Rt) : "memory")
+#define P8_RLOAD(k_)                                                                                                             \
+  {                                                                                                                              \
+    if constexpr (D8) asm volatile("s_nop 4\n\tglobal_load_dwordx2 %0, %1, %2" : "=v"(rq8[(k_) % RQ]) : "v"(P8_ROFF(k_) >> 1), "s"(Rt) : "memory"); \
+    else asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(rq[(k_) % RQ]) : "v"(P8_ROFF(k_)), "s"(Rt) : "memory");   \
+  }
       // operations issued after residual load k and before its use in row block k (see above)
 #define P8_RN(k_) ((k_) < RQ ? (RQ - 1 - (k_)) + p8_later((k_) , 0, (k_), RQ, NT) : 1 + p8_later((k_), (k_) - RQ + 1, (k_), RQ, NT))
       if (need_r) {
@@ -676,19 +668,26 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * hb][r]; v[4 + r] = acc[i][2 * hb + 1][r]; }
-#if defined(P8_L2STORE) && P8_L2STORE == 1
-          // Experiment builds (timing only, wrong results; tools/p8_probe.py): the output stores re-aimed, same instructions
-          const unsigned eo = (unsigned)((i & 1) * 512 + le * 8);
-#elif defined(P8_L2STORE) && P8_L2STORE == 3
-          const unsigned eo = (unsigned)((hb * (4 + IH) + i) * 512 + le * 8);
-#else
           const unsigned eo = (unsigned)(row * (int)g.ldc + cl);
-#endif
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += bias8[q];
           // (not at the 256-row tile: its register allocation has no room for this branch -- 8 spills, reloaded inside the tile
           //  seam; the launcher gives the flavour 224- or 192-row tiles)
           if ((IH < 4 || FX > 0) && (flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
+            if constexpr (FX > 0 && (FX & F_DACT8) != 0) {
+              // the derivative in 8 bits (dact8_q): two dwords per 8 columns, one 8-B store -- the same store count (P8_E_), half the bytes
+              p8_u32x2 g8 = {0u, 0u};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                a2v_f32x2 dd;
+                const a2v_f32x2 hh = gelu_with_grad2((a2v_f32x2){v[2 * q], v[2 * q + 1]}, dd);
+                v[2 * q] = hh[0];
+                v[2 * q + 1] = hh[1];
+                g8[q >> 1] = dact8_put(dact8_put(g8[q >> 1], 2u * (q & 1), dd[0]), 2u * (q & 1) + 1u, dd[1]);
+                asm volatile("" : "+v"(v[2 * q]), "+v"(v[2 * q + 1]), "+v"(g8[q >> 1]));
+              }
+              *(p8_u32x2*)(C2t8 + eo) = g8;
+            } else {
             p8_u32x4 gr;                             // gelu and gelu' from one evaluation; the derivative is what is kept,
 #pragma unroll                                       // packed pair by pair, the order pinned (interleaved, the eight
             for (int q = 0; q < 4; ++q) {            // evaluations' temporaries spill at the 256-row tile)
@@ -701,6 +700,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               asm volatile("" : "+v"(v[2 * q]), "+v"(v[2 * q + 1]), "+v"(gr[q]));
             }
             P8_ST16(C2t, eo, gr);
+            }
           } else {
             if (flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
             if (flags & F_GELU) {
@@ -715,11 +715,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           if (need_r) {
             float h[8];
             const int k = hb * NB + i;
+            if constexpr (D8) {
+              asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rq8[k % RQ]) : "n"(P8_RN(k)) : "memory");
+              dact8_unpack4(rq8[k % RQ][0], h);
+              dact8_unpack4(rq8[k % RQ][1], h + 4);
+            } else {
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rq[k % RQ]) : "n"(P8_RN(k)) : "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               h[2 * q] = __uint_as_float(rq[k % RQ][q] << 16);
               h[2 * q + 1] = __uint_as_float(rq[k % RQ][q] & 0xffff0000u);
+            }
             }
             if (k + RQ < NT) P8_RLOAD(k + RQ);              // RQ row blocks ahead
             if (flags & F_RES) {
@@ -731,19 +737,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               for (int q = 0; q < 8; ++q) v[q] *= (flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
             }
           }
-#ifdef P8_STORE_SC1
-          {
-            p8_u32x4 ov;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const bf16 b0 = (bf16)v[2 * q], b1 = (bf16)v[2 * q + 1];
-              ov[q] = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
-            }
-            P8_ST16(Ct, eo, ov);
-          }
-#else
           Vec8<bf16>::store(Ct + eo, v);
-#endif
           if (flags & F_COLSUM) {
             const float own = row >= rskip ? 1.f : 0.f;        // rows of the shifted tile's neighbour are summed there
 #pragma unroll
@@ -925,9 +919,6 @@ int g_a2v_p8_direct = 1;  // a2v_debug_set(10, v): direct-store epilogue (swappe
 int g_a2v_p8_fx = 1;      // a2v_debug_set(20, v): 0 = every flavour takes the generic epilogue (A/B)
 int g_a2v_p8_ih = 0;      // a2v_debug_set(5, v): force the tile height (2 / 3 / 4), 0 = choose per shape
 int g_a2v_p8_tmode = 0;   // a2v_debug_set(23, v): tile order of the persistent NT kernel: 0 = 8 m-tiles x all n-tiles, 1 = W-stationary groups of four n-tiles (N >= 2048)
-#ifdef P8_SKEW
-int g_a2v_p8_skew = 0;    // a2v_debug_set(24, v), experiment build only: start skew of the workgroups (units of ~0.5 us x 8 groups)
-#endif
 int g_a2v_p8_tail = 1;    // a2v_debug_set(22, v): a last round of tiles that fills at most v quarters of the CUs goes to the 128 x 128 kernel (0: stays here)
 static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bool allow_tail = true);
 bool a2v_launch_nt_bf16_p8(const GemmArgs& g, hipStream_t stream) { return p8_launch_impl(g, stream, false); }
@@ -965,7 +956,7 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<2, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
 #define P8_ATTRF(F_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
   (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<3, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-    P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R) P8_ATTRF(P8_FX_B) P8_ATTRF(P8_FX_BG) P8_ATTRF(P8_FX_PLAIN)
+    P8_ATTRF(P8_FX_FC1_8) P8_ATTRF(P8_FX_FC2D_8) P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R) P8_ATTRF(P8_FX_B) P8_ATTRF(P8_FX_BG) P8_ATTRF(P8_FX_PLAIN)
 #undef P8_ATTRF
 #undef P8_ATTR
   }
@@ -977,10 +968,10 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   // (DACT only qualifies a pre-activation store or a GELU backward: alone it changes nothing)
   const int eff = (g.flags & (F_STORE_PRE | F_GELU_BWD)) ? g.flags : (g.flags & ~F_DACT);
   if (direct && g_a2v_p8_fx && !out32)
-    for (int f : {(int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R, (int)P8_FX_B, (int)P8_FX_BG})
+    for (int f : {(int)P8_FX_FC1_8, (int)P8_FX_FC2D_8, (int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R, (int)P8_FX_B, (int)P8_FX_BG})
       if (eff == f) fx = f;
   if (direct && g_a2v_p8_fx && eff == 0 && !out32) fx = P8_FX_PLAIN;
-  const bool fx1 = fx == P8_FX_FC1;
+  const bool fx1 = fx == P8_FX_FC1 || fx == P8_FX_FC1_8;
   for (int ih = (dact_store && direct && !fx1 && !out32) ? 3 : 4; ih >= 2; --ih) {
     if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && !fx1 && g_a2v_p8_ih == 4)) continue;
     const int bm = 128 + 32 * ih;
@@ -992,6 +983,9 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
     if (best < 0 || cost < best) { best = cost; best_ih = ih; }
   }
   const int bm = 128 + 32 * best_ih;
+  // the 8-bit derivative tensor exists in the two fixed flavours only (256- / 224-row tiles): anything else goes to the 128 x 128 kernels
+  const bool d8 = (g.flags & F_DACT8) != 0;
+  if (d8 && !((fx == P8_FX_FC1_8 || fx == P8_FX_FC2D_8) && best_ih >= 3)) return false;
   // A last round with few tiles leaves most CUs idle for a whole tile time (M = 768 x 151 kept frames, N = 1024: 7.08 rounds of
   // 256-row tiles -- 12 % of the launch for 1 % of the work).  The rows of that round go to the 128 x 128 LDS-DMA kernel instead: a
   // quarter of the work per tile, spread over four times as many CUs, issued right behind this launch.
@@ -1011,8 +1005,8 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
         gt.a.bstride = 0;
         gt.a.ptr = (const char*)a.ptr + rows_main * a.pitch * 2;
         gt.C = (char*)g.C + rows_main * g.ldc * 2;
-        if (g.C2) gt.C2 = (char*)g.C2 + rows_main * g.ldc * 2;
-        if (g.R) gt.R = (const char*)g.R + rows_main * g.ldr * 2;
+        if (g.C2) gt.C2 = (char*)g.C2 + rows_main * g.ldc * (d8 ? 1 : 2);
+        if (g.R) gt.R = (const char*)g.R + rows_main * g.ldr * ((d8 && (g.flags & F_GELU_BWD)) ? 1 : 2);
         gt.drop_base = g.drop_base + rows_main * g.ldc;
         const bool ok = p8_launch_impl(gm, stream, false, false);     // (the main part is a whole number of rounds by construction)
         if (ok && a2v_launch_nt_bf16_fast(gt, stream)) return true;
@@ -1027,11 +1021,6 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   const int tiles_n_ = g.N / 256;
   const int stagger = ((g_a2v_p8_stagger == 2 || (g_a2v_p8_stagger == 1 && g.K >= 2048)) ? 1 : 0) |
                       ((g_a2v_p8_tmode && tiles_n_ > 4 && tiles_n_ % 4 == 0) ? 2 : 0);      // bit 1: tile order
-#ifdef P8_SKEW
-  extern int g_a2v_p8_skew;
-  const int stagger_ = stagger | ((g_a2v_p8_skew & 255) << 4);
-#define stagger stagger_
-#endif
   dim3 grid(ntiles < cus ? ntiles : cus, g.G, 1);
   const int parts = 2 * cdiv(g.M, bm);
   char* const ws = a2v_stream_ws(stream);
@@ -1050,7 +1039,9 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
     else                                                                                                                  \
       hipLaunchKernelGGL((gemm_nt_bf16_p8_kernel<3, true, F_>), grid, dim3(512), P8_LDS, stream, g, stagger, g_a2v_p8_dynamic, ws, cs_part); \
   }
-    if (best_ih >= 3 && fx == P8_FX_FC1) P8_GOF(P8_FX_FC1)
+    if (best_ih >= 3 && fx == P8_FX_FC1_8) P8_GOF(P8_FX_FC1_8)
+    else if (best_ih >= 3 && fx == P8_FX_FC2D_8) P8_GOF(P8_FX_FC2D_8)
+    else if (best_ih >= 3 && fx == P8_FX_FC1) P8_GOF(P8_FX_FC1)
     else if (best_ih >= 3 && fx == P8_FX_FC2D) P8_GOF(P8_FX_FC2D)
     else if (best_ih >= 3 && fx == P8_FX_BR) P8_GOF(P8_FX_BR)
     else if (best_ih >= 3 && fx == P8_FX_BRD) P8_GOF(P8_FX_BRD)

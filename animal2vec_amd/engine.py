@@ -218,7 +218,9 @@ class Engine:
         x1, m1, r1 = ops.layernorm_fwd(s1, params[prefix + "norm1.weight"], params[prefix + "norm1.bias"], eps,
                                        save_stats=save is not None)
         hid = pk.w[prefix + "mlp.fc1.weight"].shape[0]
-        hpre = ops._E(N * S, hid, dtype=x.dtype, device=x.device) if save is not None else None
+        # (bf16 mode: gelu' is kept in 8 bits, A2V_EPI_DACT8 -- a quarter of fc1's output bytes; hid % 8 == 0 is the store's alignment)
+        d8 = _DACT and ops.DACT8 and x.dtype == torch.bfloat16 and hid % 8 == 0 and d_act1 is None
+        hpre = ops._E(N * S, hid, dtype=torch.uint8 if d8 else x.dtype, device=x.device) if save is not None else None
         # (dact: what is kept for the backward is gelu'(fc1 out), formed with gelu in one evaluation -- not the pre-activation)
         # (bf16x3: nothing but fc2's two products reads the hidden activation -- it leaves the epilogue as its split image, ops.X3Image)
         gact = ops.linear(x1, pk.w[prefix + "mlp.fc1.weight"], params[prefix + "mlp.fc1.bias"], gelu=True, pre_out=hpre,

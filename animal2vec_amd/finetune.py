@@ -157,6 +157,24 @@ def _to_device(arr: np.ndarray, device) -> torch.Tensor:
     return t.pin_memory().to(device, non_blocking=True)
 
 
+def span_lengths(fcfg, T: int, D: int):
+    """The time / channel span lengths the device sampler is asked for: both laws are checked -- span length 1 selects
+    another law in the reference (random_masking) and is refused, like the switches masking.check_span_law names -- and a span that
+    does not fit the axis (a clip shorter than mask_length frames, mask_channel_length >= embed_dim) is clamped to axis - 1 as
+    fairseq's compute_mask_indices does (`min(mask_length, sz - 1)` per row), instead of failing inside the kernel mid-training."""
+    from .masking import check_span_law
+    t_len, c_len = int(fcfg.mask_length), int(fcfg.mask_channel_length)
+    if fcfg.apply_mask and fcfg.mask_prob > 0:
+        check_span_law(mask_length=t_len)
+        if T < 3:
+            raise ValueError(f"time masking needs at least 3 frames (got T = {T})")
+        t_len = min(t_len, T - 1)
+    if fcfg.apply_mask and fcfg.mask_channel_prob > 0:
+        check_span_law(mask_length=c_len)
+        c_len = min(c_len, D - 1)
+    return t_len, c_len
+
+
 def make_aug(fcfg: FinetuneConfig, B: int, T: int, D: int, n_prenet: int, n_blocks: int, rng: np.random.Generator,
              noise_std: float, device="cuda", train_dropout: bool = True, mask_seeds=None) -> dict:
     """The per-micro-batch random draws of the train form (what Engine.finetune_forward takes as `aug`).
@@ -168,13 +186,14 @@ def make_aug(fcfg: FinetuneConfig, B: int, T: int, D: int, n_prenet: int, n_bloc
     aug: Dict[str, object] = {}
     if mask_seeds is None:
         mask_seeds = (int(rng.integers(0, 2 ** 62)), int(rng.integers(0, 2 ** 62)))
+    t_len, c_len = span_lengths(fcfg, T, D)
     if fcfg.apply_mask and fcfg.mask_prob > 0:
-        aug["mask_t"] = ops.span_mask(B, T, mask_prob=fcfg.mask_prob, mask_length=fcfg.mask_length, seed=mask_seeds[0],
+        aug["mask_t"] = ops.span_mask(B, T, mask_prob=fcfg.mask_prob, mask_length=t_len, seed=mask_seeds[0],
                                       min_masks=1, device=device)[0]
         aug["noise_std"] = 0.0 if fcfg.zero_mask else noise_std
         aug["noise_seed"] = int(rng.integers(0, 2 ** 31))
     if fcfg.apply_mask and fcfg.mask_channel_prob > 0:
-        aug["mask_c"] = ops.span_mask(B, D, mask_prob=fcfg.mask_channel_prob, mask_length=fcfg.mask_channel_length,
+        aug["mask_c"] = ops.span_mask(B, D, mask_prob=fcfg.mask_channel_prob, mask_length=c_len,
                                       seed=mask_seeds[1], min_masks=0, device=device)[0]
     aug["active"] = [bool(fcfg.layerdrop == 0 or rng.random() > fcfg.layerdrop) for _ in range(n_blocks)]
     if not any(aug["active"][n_prenet:]):          # the reference divides by zero layer results here; keep one block

@@ -275,7 +275,7 @@ class Data2VecMultiModel(tnn.Module):
             elif a.mask_prob > 0:
                 check_span_law(mask_length=a.mask_length, add_masks=a.add_masks)
                 self._mask_draws += 1
-                m = ops.span_mask(B, T, mask_prob=a.mask_prob, mask_length=a.mask_length, min_masks=1, mask_dropout=a.mask_dropout,
+                m = ops.span_mask(B, T, mask_prob=a.mask_prob, mask_length=min(a.mask_length, T - 1), min_masks=1, mask_dropout=a.mask_dropout,
                                   seed=mask_seed(cfg.seed, self.num_updates, 2 * self._mask_draws, self._dist_rank()),
                                   device=source.device)[0]
             else:
@@ -286,7 +286,9 @@ class Data2VecMultiModel(tnn.Module):
                 aug.update(mask_t=mu8, noise_std=0.0 if a.encoder_zero_mask else a.mask_noise_std,
                            noise_seed=int(self._rng.integers(0, 2 ** 31)))
             if a.mask_channel_prob > 0:                          # base.py:471-484
-                aug["mask_c"] = ops.span_mask(B, cfg.embed_dim, mask_prob=a.mask_channel_prob, mask_length=a.mask_channel_length,
+                check_span_law(mask_length=a.mask_channel_length)     # (the channel law too; spans clamped to the axis as fairseq does)
+                aug["mask_c"] = ops.span_mask(B, cfg.embed_dim, mask_prob=a.mask_channel_prob,
+                                              mask_length=min(a.mask_channel_length, cfg.embed_dim - 1),
                                               min_masks=0, device=source.device,
                                               seed=mask_seed(cfg.seed, self.num_updates, 2 * self._mask_draws + 1, self._dist_rank()))[0]
         if self.training:

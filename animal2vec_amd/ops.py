@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_X3IMG, check
+from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_DACT8, EPI_X3IMG, check
 
 
 def _L():
@@ -104,6 +104,10 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
         flags |= EPI_STORE_PRE
     if dact:
         flags |= EPI_DACT
+        # the derivative tensor in 8 bits (include/a2v.h: A2V_EPI_DACT8): the dtype of the tensor handed in says so
+        d8 = pre_out if pre_out is not None else (res if gelu_bwd else None)
+        if d8 is not None and d8.dtype == torch.uint8:
+            flags |= EPI_DACT8
     if colsum is not None:
         flags |= EPI_COLSUM
     if drop is not None and drop[0] > 0:
@@ -129,6 +133,7 @@ X3_CONV_FUSED = os.environ.get("A2V_X3_CONV_FUSED", "1") != "0"     # 64 outputs
 X3_OUT_IMAGE = os.environ.get("A2V_X3_OUT_IMAGE", "1") != "0"         # the Mlp's hidden activation leaves fc1 as its split image only (A/B switch)
 X3_DH_IMAGE = os.environ.get("A2V_X3_DH_IMAGE", "1") != "0"           # the fc2 input gradient leaves its epilogue as a split image only (A/B switch)
 X3_ATTN_BWD = os.environ.get("A2V_X3_ATTN_BWD", "1") != "0"          # whole-sequence attention backward with split products (A/B switch)
+DACT8 = os.environ.get("A2V_DACT8", "1") != "0"     # bf16 mode: the Mlp's kept gelu' in 8 bits (A/B switch; include/a2v.h: A2V_EPI_DACT8)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
 X3_KEEP = False          # set by the engine during the student's saving forward: operand images stay on the activations for the backward
 X3_BACKWARD = False      # set by the engine while it runs a backward: a gradient tensor is the left operand of its input-gradient product
@@ -323,8 +328,10 @@ def _x3_wgrad_ok(x, dy):
     N = dy.shape[1]
     ok = (X3_WGRAD and x.dtype == torch.float32 and dy.dtype == torch.float32 and M >= 2048 and N % 256 == 0 and K % 256 == 0
           and x.stride(1) == 1 and dy.stride(1) == 1)
-    if isinstance(x, X3Image) and not ok:
-        raise RuntimeError("an image-only activation needs the split-product weight-gradient path")
+    if (isinstance(x, X3Image) or isinstance(dy, X3Image)) and not ok:
+        # (dh leaves the fc2 input-gradient epilogue as an image only -- the plain path below would take ptr() of it)
+        raise RuntimeError(f"an image-only operand needs the split-product weight-gradient path (M={M} >= 2048, N={N} % 256, K={K} % 256, "
+                           "fp32 storage, ops.X3_WGRAD)")
     return ok
 
 

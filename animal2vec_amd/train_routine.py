@@ -27,7 +27,9 @@ def config_from_yaml(path: str):
     audio = D2vAudioConfig(decoder=dec, conv_feature_layers=t.get("conv_feature_layers", D2vAudioConfig().conv_feature_layers),
                            sample_rate=t.get("sample_rate", 8000), **au)
     mk = {k: v for k, v in m.items() if k in Data2VecMultiConfig.__dataclass_fields__ and k != "audio"}
-    cfg = Data2VecMultiConfig(audio=audio, **mk)
+    if "with_labels" in t:                         # (model.with_labels = II("task.with_labels"), data2vec2.py:146)
+        mk.setdefault("with_labels", bool(t["with_labels"]))
+    cfg = Data2VecMultiConfig(audio=audio, **mk)   # raises on reference switches that are not built (config.UNBUILT)
     g = y.get("optimizer", {}).get("groups", {}).get("default", {})
     oc = OptimConfig(lr=g.get("lr_float", 1e-4), adam_betas=tuple(g.get("optimizer", {}).get("adam_betas", (0.9, 0.98))),
                      adam_eps=float(g.get("optimizer", {}).get("adam_eps", 1e-6)),

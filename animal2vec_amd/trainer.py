@@ -49,6 +49,12 @@ class PretrainTrainer:
                  device="cuda", seed: int = 0, process_group=None, dropout: bool = True, mixup: bool = True, x3: bool = False,
                  grad_wire=None):
         self.cfg, self.optim = cfg, optim or OptimConfig()
+        if cfg.layerdrop > 0 or cfg.audio.prenet_layerdrop > 0:
+            # (the features-only / finetune paths draw layerdrop, model._features_only and finetune.make_aug; the pretraining
+            #  forward + hand-written backward schedule runs every block)
+            raise NotImplementedError(f"pretraining with layerdrop={cfg.layerdrop} / prenet_layerdrop={cfg.audio.prenet_layerdrop}: "
+                                      "block dropping in the pretraining step (data2vec2.py:651-655, modules.py:89-94) is not "
+                                      "built; every shipped pretraining recipe uses 0")
         self.store = ParamStore(cfg, device=device)
         self.store.init_reference(seed)
         self.engine = Engine(cfg, self.store, dtype=dtype, x3=x3)

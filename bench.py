@@ -273,78 +273,125 @@ def _cpu_leg(model_name, L, K, threads, budget_s):
     print(json.dumps(dict(threads=threads, warmup_s=round(warm, 3), runs_s=[round(t, 3) for t in times])), flush=True)
 
 
-def cpu_baseline(model_name, L, K, sample_rate=8000):
-    """The oracle timed on this box's host cores (SURVEY 8d / BASELINE.md 4: 1 warm-up + median of 3, core count
-    stated).  Two legs, each in its own child process so torch's thread pool is sized before anything runs and the
-    leg can be bounded: (a) min(cores, 16) threads -- this small-op-dominated graph runs SLOWER on every core of a
-    many-socket host (608 s on 256 threads vs 52 s on 8 in round 1); (b) all cores, bounded by a timeout.  `value`
-    is the faster leg; both are reported."""
+def cpu_baseline(model_name, L, K, sample_rate=8000, thread_legs=(16, 32, 64), procs=4, leg_timeout=90):
+    """The oracle timed on this box's host cores (SURVEY 8d / BASELINE.md 4: 1 warm-up + median of 3, thread counts stated).
+    Legs, each a child process so that torch's thread pool is sized before anything runs and the leg is bounded:
+      * one clip on 16 / 32 / 64 torch threads (this small-op-dominated graph does not scale: 608 s on 256 threads against 52 s on 8 in
+        round 1 -- the all-core leg of rounds 1-4 never finished a clip inside its 100 s and is gone);
+      * `procs` processes x 16 threads at the same time, one clip each (what a CPU user with a many-core host would run): the
+        aggregate rate is the sum of the processes' rates while they all run.
+    `value` is the best of these, `cores` the threads it used."""
     import subprocess
     ncpu = os.cpu_count() or 1
-    legs = []
-    for threads, timeout in ((min(ncpu, 16), 150), (ncpu, 100)):
-        if legs and threads == legs[0]["threads"]:
-            break
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--model", model_name,
-               "--samples", str(L), "--keep", str(K)]
-        env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    sec = L / sample_rate
+
+    def cmd(threads, budget=30.0):
+        # (timed work per leg is bounded: the 16-thread leg gets 3 runs, the wider ones stop earlier if they are slower)
+        return [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--model", model_name, "--samples", str(L),
+                "--keep", str(K), "--cpu-budget", str(budget)]
+
+    def env(threads):
+        return dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+
+    def parse(stdout, threads):
+        rec = json.loads(stdout.strip().splitlines()[-1])
+        ts = sorted(rec["runs_s"])
+        med = ts[len(ts) // 2]
+        return dict(threads=threads, audio_s_per_s=round(sec / med, 4), median_s=med, runs_s=rec["runs_s"], warmup_s=rec["warmup_s"])
+
+    legs, seen = [], set()
+    for threads in thread_legs:
+        threads = min(threads, ncpu)
+        if threads in seen:
+            continue
+        seen.add(threads)
         try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
-            rec = json.loads(out.stdout.strip().splitlines()[-1])
-            ts = sorted(rec["runs_s"])
-            med = ts[len(ts) // 2]
-            legs.append(dict(threads=threads, audio_s_per_s=round(L / sample_rate / med, 4), median_s=med,
-                             runs_s=rec["runs_s"], warmup_s=rec["warmup_s"]))
+            out = subprocess.run(cmd(threads, 30.0 if threads <= 16 else 20.0), capture_output=True, text=True, timeout=leg_timeout,
+                                 env=env(threads))
+            legs.append(parse(out.stdout, threads))
         except subprocess.TimeoutExpired:
-            legs.append(dict(threads=threads, audio_s_per_s=None, note=f"no timed run finished within {timeout} s"))
+            legs.append(dict(threads=threads, audio_s_per_s=None, note=f"no timed run finished within {leg_timeout} s"))
         except Exception as e:                                   # a failed leg must not lose the GPU measurement
             legs.append(dict(threads=threads, audio_s_per_s=None, note=f"leg failed: {type(e).__name__}: {e}"))
+    # ---- k processes x 16 threads, one clip each, at the same time
+    k = max(1, min(procs, ncpu // 16))
+    if k > 1:
+        try:
+            ps = [subprocess.Popen(cmd(16, 25.0), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env(16)) for _ in range(k)]
+            outs = []
+            t_end = time.time() + leg_timeout + 30
+            for p_ in ps:
+                try:
+                    outs.append(p_.communicate(timeout=max(1.0, t_end - time.time()))[0])
+                except subprocess.TimeoutExpired:
+                    p_.kill()                                    # (the exact child this process started)
+                    outs.append("")
+            recs = [parse(o, 16) for o in outs if o.strip()]
+            if len(recs) == k:
+                legs.append(dict(threads=16 * k, processes=k, threads_per_process=16,
+                                 audio_s_per_s=round(sum(r["audio_s_per_s"] for r in recs), 4),
+                                 median_s=[r["median_s"] for r in recs], note="aggregate of concurrent one-clip processes"))
+            else:
+                legs.append(dict(threads=16 * k, processes=k, audio_s_per_s=None, note=f"{k - len(recs)} of {k} processes did not finish"))
+        except Exception as e:
+            legs.append(dict(threads=16 * k, processes=k, audio_s_per_s=None, note=f"leg failed: {type(e).__name__}: {e}"))
     ok = [l for l in legs if l.get("audio_s_per_s")]
     if not ok:
         return dict(value=None, unit="audio-s/s", cores=legs[0]["threads"], kind="port", sample="cpu legs failed", legs=legs)
     best = max(ok, key=lambda l: l["audio_s_per_s"])
+    med = best["median_s"] if not isinstance(best["median_s"], list) else sorted(best["median_s"])[len(best["median_s"]) // 2]
     return dict(value=best["audio_s_per_s"], unit="audio-s/s", cores=best["threads"], kind="port", host_cores=ncpu,
-                sample=f"1 clip x {L / sample_rate:.1f}s, {model_name} model, fwd+bwd (teacher targets + student grads), fp32 "
-                       f"oracle on torch CPU; 1 warm-up + median of {len(best['runs_s'])} timed runs ({best['median_s']:.1f}s) on "
-                       f"{best['threads']} threads; legs = thread counts tried (min(cores,16) and all {ncpu} cores, bounded)",
+                sample=f"1 clip x {sec:.1f}s per process, {model_name} model, fwd+bwd (teacher targets + student grads), fp32 oracle on "
+                       f"torch CPU; per leg 1 warm-up + median of up to 3 timed runs ({med:.1f}s for the reported leg: "
+                       f"{best.get('processes', 1)} process(es) x {best['threads'] // best.get('processes', 1)} threads); legs = one clip on "
+                       f"{'/'.join(str(t) for t in sorted(seen))} threads and {k} concurrent processes x 16 threads, on a {ncpu}-core host",
                 legs=legs)
 
 
-def parity_mode_leg(cfg, L, dev, args, clips=16, steps=2):
-    """The parity mode of the same optimizer step on a bounded sample (1 warm-up + `steps` timed steps of `clips` clips, masks
-    sampled in the step like the headline): fp32 storage with the Linear products as three exact bf16 products over split operands
-    on the bf16 matrix cores (bf16x3, include/a2v.h: A2V_BF16X3) -- the mode `-m gpu` holds to 1e-3 against the oracle at BASELINE's
-    full size -- and, beside it, the older all-v_mfma_f32_16x16x4_f32 form of the same mode."""
+def parity_mode_leg(cfg, L, dev, args, micro=16, warmup=2, steps=5, f32_clips=16, f32_steps=2):
+    """The parity mode of the SAME optimizer step at the headline's protocol: `--global-batch` clips per step as
+    micro-batches of `micro` clips (fp32 storage: 64 clips do not fit), `warmup` untimed + `steps` timed steps, masks sampled in the
+    step: fp32 storage with every product as three exact bf16 products over split operands on the bf16 matrix cores (bf16x3,
+    include/a2v.h: A2V_BF16X3) -- the mode `-m gpu` holds to 1e-3 against the oracle at BASELINE's full size.  Beside it, on a
+    small sample, the older all-v_mfma_f32_16x16x4_f32 form of the same mode."""
     from animal2vec_amd.trainer import PretrainTrainer
 
-    def leg(x3):
+    def leg(x3, clips_step, micro_, warm, nsteps):
         tr = PretrainTrainer(cfg, dtype=torch.float32, device=dev, seed=0, x3=x3)
-        mbs = [make_microbatch(cfg, clips, L, 0, 4242, dev, masks="sampled")]
-        tr.prime_memory(clips, L)                 # untimed, as the headline: pools sized above the kept-frame counts the sampler draws
-        tr.train_step(mbs)
+        mbs = [make_microbatch(cfg, micro_, L, 0, 4242 + i, dev, masks="sampled") for i in range(clips_step // micro_)]
+        tr.prime_memory(micro_, L)                # untimed, as the headline: pools sized above the kept-frame counts the sampler draws
+        for _ in range(warm):
+            tr.train_step(mbs)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for _ in range(nsteps):
             tr.train_step(mbs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         tr.engine.close()
         del tr
         torch.cuda.empty_cache()
-        return clips * steps * L / cfg.audio.sample_rate / dt, 1e3 * dt / steps
+        return clips_step * nsteps * L / cfg.audio.sample_rate / dt, 1e3 * dt / nsteps
 
     try:
-        v3, ms3 = leg(True)
-        v1, ms1 = leg(False)
+        gb = int(args.global_batch)
+        micro = min(micro, gb)
+        while gb % micro:
+            micro -= 1
+        v3, ms3 = leg(True, gb, micro, warmup, steps)
+        v1, ms1 = leg(False, f32_clips, min(f32_clips, micro), 1, f32_steps)
         return dict(dtype="bf16x3 (fp32 storage; every Linear, convolution and attention product, forward and backward, = 3 exact "
                           "v_mfma_f32_16x16x32_bf16 products over split operands, fp32 accumulation; fp32 LayerNorm / softmax / GELU)",
-                    value=round(v3, 2), unit="audio-s/s", ms_per_step=round(ms3, 2),
+                    value=round(v3, 2), unit="audio-s/s", ms_per_step=round(ms3, 2), steps=steps, warmup=warmup,
+                    config=dict(global_batch=gb, micro_batch=micro, micro_batches_per_step=gb // micro,
+                                workload="the headline's optimizer step (same clips per step, sampled masks, dropout, mixup, clip + Adam, EMA)"),
                     tolerance="1e-3 relative L2 against the CPU oracle on targets, decoder output, loss and every parameter gradient "
                               "(tests/test_pretrain_gpu.py::test_large_full_size_vs_oracle[bf16x3])",
                     f32_mfma_mode=dict(value=round(v1, 2), ms_per_step=round(ms1, 2),
-                                       note="the same mode with every product on v_mfma_f32_16x16x4_f32 (round 2's parity mode)"),
-                    sample=f"{steps} optimizer steps of {clips} clips after 1 warm-up, same step as the headline (sampled masks, dropout, "
-                           f"mixup, clip + Adam, EMA)")
+                                       note=f"the same mode with every product on v_mfma_f32_16x16x4_f32 (round 2's parity mode); "
+                                            f"{f32_steps} steps of {f32_clips} clips after 1 warm-up"),
+                    sample=f"{steps} timed optimizer steps of {gb} clips ({gb // micro} micro-batches of {micro}) after {warmup} warm-ups: "
+                           f"the headline's protocol")
     except Exception as e:                                   # the leg must not lose the headline measurement
         return dict(value=None, note=f"parity leg failed: {type(e).__name__}: {e}")
 
@@ -477,10 +524,11 @@ def main():
                     help="host-only stand-in step (tiny flat gradient buffer through the trainer's GradSync on CPU tensors): "
                          "exercises spawn / rendezvous / barrier / max-over-ranks / the JSON line without a GPU")
     ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)      # internal: one cpu_baseline leg
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help=argparse.SUPPRESS)   # internal: seconds of timed work of that leg
     args = ap.parse_args()
 
     if args.cpu_leg:
-        _cpu_leg(args.model, args.samples, args.keep, args.cpu_leg, budget_s=45.0)
+        _cpu_leg(args.model, args.samples, args.keep, args.cpu_leg, budget_s=args.cpu_budget)
         return 0
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args.gpus)

@@ -62,6 +62,13 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
                              * as it is.  The Mlp's fc1 forward / fc2 input gradient pair (timm Mlp, modules.py:328-337) uses it:
                              * the backward epilogue then has no transcendental. */
 
+#define A2V_EPI_DACT8 512   /* modifier of A2V_EPI_DACT (ABI 11), dtype A2V_BF16, plain Linear products (G = 1, taps = 1, no row gather / mask): the
+                             * derivative tensor -- C2 with GELU | STORE_PRE, R with GELU_BWD -- holds ONE BYTE per element (row pitch ldc / ldr
+                             * in elements = bytes, % 8): q = round(200 gelu') + 26, gelu' ~ (q - 26) / 200, a grid of 1/200 on which 0 and 1
+                             * are exact (|error| <= 0.0025 -- what bf16 rounding does to a derivative near 1/2).  A quarter of the fc1 launch's
+                             * output bytes and a third of the fc2 input-gradient launch's extra input bytes less; the bf16 throughput mode's
+                             * default (A2V_DACT8=0 keeps bf16), never used by the fp32 / bf16x3 parity modes.  Other uses: A2V_ERR_UNSUPPORTED */
+
 /* ---------------------------------------------------------------- implicit-GEMM (MFMA) family
  * C[m][g*c_goff + n] = epi( sum_kk A_g[m][kk] * Bw[g][n][kk] ),  kk = tap*Cg + ci,
  * A_g[m=(b,t)][kk] = X[b / bdiv][t*stride - pad + tap][g*a_goff + ci]   (0 outside [0,T_in), 0 for
@@ -359,7 +366,8 @@ int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx,
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 10: + a2v_query_workspace / a2v_bind_workspace (caller-owned scratch; every other signature unchanged); a2v_debug_set keys 23.
+/* 11: + epilogue flag A2V_EPI_DACT8 of a2v_conv_gemm; a2v_debug_set keys 30-34 (LayerNorm launch forms); no signature changed.
+ * 10: + a2v_query_workspace / a2v_bind_workspace (caller-owned scratch; every other signature unchanged); a2v_debug_set keys 23.
  * 9: + dtype A2V_BF16X3S and epilogue flag A2V_EPI_X3IMG of a2v_conv_gemm; a2v_attention_bwd takes dtype A2V_BF16X3 (signatures unchanged).
  * 8: + a2v_split_bf16 and dtype A2V_BF16X3 of a2v_conv_gemm; + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7
  * arithmetic).  7 added a2v_decoder_input_rng and A2V_EPI_DACT over 6. */

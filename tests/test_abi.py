@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
         assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
     assert set(_lib.SIGNATURES) == set(decls)
-    assert lib.a2v_abi_version() == 10
+    assert lib.a2v_abi_version() == 11
 
 
 def test_ops_refuse_cpu_tensors():
@@ -158,11 +158,91 @@ def test_p8_tile_claim_register_is_untouched_until_its_wait(tmp_path):
         if "ELb1ELi" in m.group(1) and not o32:
             tail0 = [i for i in range(mfma[-1], len(lines)) if lines[i].startswith("s_waitcnt vmcnt(0)")]
             assert len(tail0) <= 5, (m.group(1), len(tail0))
-    assert checked == 25         # three tile heights x (two epilogue forms + the fp32-output form) + eight fixed flavours x two tile heights
+    assert checked == 29         # three tile heights x (two epilogue forms + the fp32-output form) + ten fixed flavours x two tile heights
     # the fixed-flavour instantiations exist because the generic 256-row epilogue has no registers to spare: none of them may spill
     for m in re.finditer(r"\.amdhsa_kernel (_Z\d+gemm_nt_bf16_p8_kernelILi[34]ELb1ELi([1-9]\d*)E\w*)(.*?)\.end_amdhsa_kernel", s, re.S):
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", m.group(3)).group(1))
         assert scratch == 0, (m.group(1), scratch)
+
+
+def _min_vmem_to_back_edge(lines, start):
+    """The smallest number of vector-memory instructions that are certain to issue (not under a lane mask) on any control-flow path from
+    lines[start] to a backward branch that re-enters the code in front of `start` (the tile loop's back edge).  Paths that leave the
+    loop do not count.  Shortest path over the instruction graph (fall-through + branch targets)."""
+    import heapq
+    labels = {m.group(1): i for i, l in enumerate(lines) for m in [re.match(r"(\.LBB\w+):", l)] if m}
+    # lane-mask state is tracked along the text (the epilogue's masked regions are properly nested if / endif pairs)
+    masked, m = [False] * len(lines), False
+    for i, l in enumerate(lines):
+        if re.match(r"s_(and|andn2|xor|or)_saveexec_b64|v_cmpx_", l) or re.match(r"s_(and|andn2)_b64 exec,", l):
+            m = True
+        elif re.match(r"s_or_b64 exec, exec|s_mov_b64 exec,", l):
+            m = False
+        masked[i] = m
+    cost = lambda i: 1 if (re.match(r"(global|buffer|flat)_(load|store|atomic)", lines[i]) and not masked[i]) else 0
+    best, dist, heap = None, {start: 0}, [(0, start)]
+    while heap:
+        d, i = heapq.heappop(heap)
+        if d > dist.get(i, 1 << 30) or i >= len(lines):
+            continue
+        d2 = d + cost(i)
+        mm = re.match(r"s_cbranch_\w+ (\.LBB\w+)|s_branch (\.LBB\w+)", lines[i])
+        succ = []
+        if mm:
+            t = labels[mm.group(1) or mm.group(2)]
+            if t < start:
+                best = d2 if best is None else min(best, d2)        # the back edge: this path is complete
+            else:
+                succ.append(t)
+            if mm.group(1):
+                succ.append(i + 1)
+        else:
+            succ.append(i + 1)
+        for j in succ:
+            if j < len(lines) and d2 < dist.get(j, 1 << 30):
+                dist[j] = d2
+                heapq.heappush(heap, (d2, j))
+    return best
+
+
+def test_p8_fixed_flavour_seam_wait_is_covered_by_the_epilogue(tmp_path):
+    """ADVICE r4 (medium).  In the fixed-flavour instantiations the first K-tile of a tile waits with vmcnt(6 + E) (P8_KTILE_FIRST): the
+    six LDS-DMA operations of its own phases 2-4 plus E operations of the epilogue in front of it may stay in flight, everything older
+    -- K-tile 1 of the tile, staged before the epilogue -- must be complete.  E is derived by hand from the epilogue's source (C / C2
+    stores, bias loads, residual loads); if hipcc ever emitted FEWER vector-memory operations than that on some path (merged or
+    predicated stores, another lowering of the 16-B vectors), the wait would let K-tile 1's DMA be in flight when its buffer is read:
+    wrong GEMM output, silently.  So the ISA is counted: between the seam's last counted wait (vmcnt(8), P8_KTILE_LAST) and the end
+    of the tile loop's body, at least min(E, 48) vector-memory instructions must be issued unconditionally, and the first K-tile's wait
+    must be exactly vmcnt(6 + min(E, 48))."""
+    import shutil
+    import subprocess
+    import pytest
+    from animal2vec_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = "a2v_gemm_p8.hip"
+    out = tmp_path / (src + ".s")
+    cmd = [hipcc, *B.FLAGS, *B.FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = out.read_text()
+    F_BIAS, F_RES, F_GELU_BWD, F_STORE_PRE = 1, 4, 8, 16
+    seen = 0
+    for m in re.finditer(r"^(_Z\d+gemm_nt_bf16_p8_kernelILi([34])ELb1ELi([1-9]\d*)ELb0EE\w*):", s, re.M):
+        ih, fx = int(m.group(2)), int(m.group(3)) & 0xFF
+        e = 2 * (4 + ih) * (2 if fx & F_STORE_PRE else 1) + (4 if fx & F_BIAS else 0) + (2 * (4 + ih) if fx & (F_RES | F_GELU_BWD) else 0)
+        e = min(e, 48)
+        body = s[m.end():s.index("s_endpgm", m.end())]
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        w8 = [i for i, l in enumerate(lines) if l == "s_waitcnt vmcnt(8)"]
+        w0 = [i for i, l in enumerate(lines) if l == f"s_waitcnt vmcnt({6 + e})"]
+        assert len(w8) == 1, (m.group(1), w8)
+        assert w0, (m.group(1), 6 + e, sorted({l for l in lines if l.startswith("s_waitcnt vmcnt")}))
+        n = _min_vmem_to_back_edge(lines, w8[0])
+        assert n is not None and n >= e, (m.group(1), "epilogue issues", n, "certain vector-memory operations, the seam wait assumes", e)
+        seen += 1
+    assert seen == 20            # ten fixed flavours x two tile heights
 
 
 def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):

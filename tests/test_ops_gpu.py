@@ -166,6 +166,96 @@ def test_linear_p8_kernel(ops, M, N, K, ih, direct):
         assert torch.equal(new[k], old[k]) or rel_err(new[k].float(), old[k].float()) < 1e-5, k
 
 
+@pytest.mark.parametrize("K", [256, 1024])
+def test_linear_p8_fixed_flavours_multi_round(ops, K):
+    """the fixed-flavour instantiations' tile seam lets the first K-tile of a tile wait with vmcnt(6 + E), E = the vector-memory
+    operations every wave certainly issues in the epilogue before it -- a hand-derived count.  If it were too high, K-tile 1's LDS-DMA
+    could still be in flight when its buffer is read: wrong products from the SECOND tile of a workgroup on, silently.  So every
+    fixed flavour runs a launch of more than two rounds of tiles (561 tiles > 2 x 256 CUs; K = 256: the shortest K loop, two K-tiles
+    between seams; K = 1024: the step's) against the generic kernel (a2v_debug_set(20, 0)), bit for bit.  tests/test_abi.py counts
+    the operations in the ISA."""
+    dtype = torch.bfloat16
+    M, N = 256 * 140 + 77, 1024
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b, r = rnd(N, dtype=torch.float32, seed=3), rnd(M, N, dtype=dtype, seed=4)
+    xd, wd, bd, rd = dev(x, dtype), dev(w, dtype), dev(b, torch.float32), dev(r, dtype)
+
+    def run_all():
+        out = {}
+        out["bias"] = ops.linear(xd, wd, bd)
+        out["none"] = ops.linear(xd, wd, None)
+        out["bias_res"] = ops.linear(xd, wd, bd, res=rd)
+        out["res"] = ops.linear(xd, wd, None, res=rd)
+        out["bias_res_drop"] = ops.linear(xd, wd, bd, res=rd, drop=(0.1, 99))
+        out["bias_gelu"] = ops.linear(xd, wd, bd, gelu=True)
+        keep = torch.empty(M, N, dtype=dtype, device="cuda")
+        out["fc1"] = ops.linear(xd, wd, bd, gelu=True, pre_out=keep, dact=True)
+        out["fc1_keep"] = keep
+        cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+        out["fc2d"] = ops.linear(xd, wd, None, gelu_bwd_aux=rd, colsum=cs, dact=True)
+        out["fc2d_cs"] = cs
+        return out
+
+    fixed = run_all()
+    again = run_all()
+    ops.debug_set(20, 0)
+    try:
+        generic = run_all()
+    finally:
+        ops.debug_set(20, 1)
+    ref = x @ w.t()
+    assert rel_err(fixed["none"].float(), ref) < tol(dtype)
+    for k in fixed:
+        if k.endswith("_cs"):
+            assert rel_err(fixed[k], generic[k]) < 1e-5 and rel_err(fixed[k], again[k]) < 1e-5, k
+        else:
+            assert torch.equal(fixed[k], generic[k]), (k, rel_err(fixed[k].float(), generic[k].float()))
+            assert torch.equal(fixed[k], again[k]), k
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 140 + 77, 1024, 256), (13440 + 100, 1024, 512), (2049, 768, 1024), (300, 200, 136)])
+def test_linear_dact8(ops, M, N, K):
+    """A2V_EPI_DACT8 (include/a2v.h, ABI 11): the Mlp's kept gelu' in 8 bits.  fc1 form: the activation is bit-identical to the bf16
+    form's, the byte tensor decodes to gelu'(pre) within half a grid step (1/400) + the rounding of pre; fc2-input-gradient form:
+    (dy W^T) * decode(bytes) and its column sums.  Shapes: more than two rounds of tiles of the persistent kernel's fixed
+    flavours (561 tiles), one round with an M tail (the tail rows go to the 128 x 128 kernel), N = 768 and a ragged shape
+    (128 x 128 kernels only); every one also against the 128 x 128 kernel alone (a2v_debug_set(1, 0)), bit for bit."""
+    dtype = torch.bfloat16
+    x, w = rnd(M, K, dtype=dtype, seed=1), rnd(N, K, dtype=dtype, seed=2, scale=K ** -0.5)
+    b = rnd(N, dtype=torch.float32, seed=3)
+    dy, w2 = rnd(M, K, dtype=dtype, seed=4), rnd(N, K, dtype=dtype, seed=5, scale=K ** -0.5)
+    xd, wd, bd, dyd, w2d = dev(x, dtype), dev(w, dtype), dev(b, torch.float32), dev(dy, dtype), dev(w2, dtype)
+
+    def run():
+        keep16 = torch.empty(M, N, dtype=dtype, device="cuda")
+        h16 = ops.linear(xd, wd, bd, gelu=True, pre_out=keep16, dact=True)
+        keep8 = torch.empty(M, N, dtype=torch.uint8, device="cuda")
+        h8 = ops.linear(xd, wd, bd, gelu=True, pre_out=keep8, dact=True)
+        cs = torch.zeros(N, dtype=torch.float32, device="cuda")
+        dh = ops.linear(dyd, w2d, None, gelu_bwd_aux=keep8, colsum=cs, dact=True)
+        return h16, keep16, h8, keep8, dh, cs
+
+    h16, keep16, h8, keep8, dh, cs = run()
+    assert torch.equal(h8, h16)
+    dec = (keep8.float() - 26.0) / 200.0
+    pre = (x @ w.t() + b).requires_grad_(True)
+    F.gelu(pre).sum().backward()
+    assert float((dec.cpu() - pre.grad).abs().max()) < 0.0025 + 0.008        # half a grid step + gelu' of a pre-activation rounded in bf16 products
+    assert float((dec - keep16.float()).abs().max()) < 0.0025 + 0.005          # against the bf16 form of the same derivative
+    assert int(keep8.max()) <= 252 and int(keep8.min()) >= 0
+    ref = (dy @ w2.t()) * dec.cpu()
+    assert rel_err(dh.float(), ref) < tol(dtype)
+    assert rel_err(cs, dh.float().sum(0)) < 5e-3
+    ops.debug_set(1, 0)
+    try:
+        o = run()
+    finally:
+        ops.debug_set(1, 1)
+    assert torch.equal(o[2], h8) and torch.equal(o[3], keep8) and torch.equal(o[4], dh) and rel_err(o[5], cs) < 1e-5
+    with pytest.raises(Exception):          # the byte tensor exists for the bf16 Linear pair only
+        ops.linear(xd.float(), wd.float(), bd, gelu=True, pre_out=keep8, dact=True)
+
+
 @pytest.mark.parametrize("M,N,K", [(2049, 768, 1024), (13440 + 100, 1024, 512), (1100, 512, 256)])
 def test_linear_w2_experiment_kernel(ops, M, N, K):
     """a2v_gemm_w2.hip (round-4 experiment, off by default: a2v_debug_set(25, 2)): 256 x 128 tiles, two workgroups per CU, the
@@ -191,7 +281,11 @@ def test_linear_w2_experiment_kernel(ops, M, N, K):
         out["cs"] = cs
         return out
 
-    ops.debug_set(25, 2)
+    try:
+        ops.debug_set(25, 2)
+    except Exception:
+        pytest.skip("the product library does not carry the experiment kernel (python -m animal2vec_amd.build --variant w2 -DA2V_W2, "
+                    "A2V_LIB_PATH=.../liba2v_hip_w2.so)")
     try:
         new = run_all()
     finally:
