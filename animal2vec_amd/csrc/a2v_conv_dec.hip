@@ -43,7 +43,7 @@ struct CdGeom {
 };
 
 template <int CI, int CO, int GPW>
-__global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_per_wg) {
+__global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_per_wg, int y_fastest) {
   using GM = CdGeom<CI, CO, GPW>;
   constexpr int CD_GW = GM::GW, CD_PITCH = GM::PITCH, CD_SLAB_BYTES = GM::SLAB_BYTES, CD_CHUNKS = GM::CHUNKS, CD_NLD = GM::NLD;
   constexpr int CD_KSTEPS = GM::KSTEPS, TCH = GM::TCH, KCH = GM::KCH, NJ = GM::NJ, RCH = GM::RCH;
@@ -54,11 +54,15 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
   const int T = a.T_out;
   const int rows_per_wg = blocks_per_wg * CD_ROWS;
   const int cpc = (T + rows_per_wg - 1) / rows_per_wg;           // row chunks per clip
-  const int clip = blockIdx.x / cpc;
-  const int t_begin = (blockIdx.x - clip * cpc) * rows_per_wg;
+  // (y_fastest: 1-D grid, the workgroups that share a row chunk -- one per 8 (4) groups -- are dispatched together)
+  const int ny = g.G / CD_GW;
+  const int bx = y_fastest ? (int)(blockIdx.x / (unsigned)ny) : (int)blockIdx.x;
+  const int by = y_fastest ? (int)(blockIdx.x % (unsigned)ny) : (int)blockIdx.y;
+  const int clip = bx / cpc;
+  const int t_begin = (bx - clip * cpc) * rows_per_wg;
   const int t_end = min(T, t_begin + rows_per_wg);
   const int nblk = (t_end - t_begin + CD_ROWS - 1) / CD_ROWS;
-  const int g0 = blockIdx.y * CD_GW;                              // first group of this workgroup
+  const int g0 = by * CD_GW;                                      // first group of this workgroup
 
   // ---- weights of this wave's two groups as MFMA fragments.  K-chunk q = 4 s + fq of step s is channels [8 (q % 6), +8)
   // of tap q / 6 (chunks 42, 43 of the last step: zero); fragment row fr of column block j is output channel
@@ -219,8 +223,12 @@ static void conv_dec_go(const GemmArgs& g, hipStream_t stream) {
   // enough for a few rounds over the CUs
   int bpw = 16;
   while (bpw > 4 && (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS) * (g.G / GM::GW) < 512) bpw >>= 1;
-  dim3 grid(nclips * cdiv(a.T_out, bpw * CD_ROWS), g.G / GM::GW, 1);
-  hipLaunchKernelGGL((conv_dec_kernel<CI, CO, GPW>), grid, dim3(256), GM::LDS, stream, g, bpw);
+  extern int g_a2v_slab_order;
+  const long long nx = (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS);
+  const int ny = g.G / GM::GW;
+  const int yf = (g_a2v_slab_order & 2) && nx * ny < (1ll << 31) ? 1 : 0;
+  dim3 grid(yf ? (unsigned)(nx * ny) : (unsigned)nx, yf ? 1 : ny, 1);
+  hipLaunchKernelGGL((conv_dec_kernel<CI, CO, GPW>), grid, dim3(256), GM::LDS, stream, g, bpw, yf);
 }
 bool a2v_launch_conv_dec48(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;

@@ -151,16 +151,20 @@ __global__ __launch_bounds__(512) void conv_nt_slab_kernel(GemmArgs g) {
 #define CS2_LDS (CS2_SLAB_BYTES + 2 * CS_B_BYTES)    // 68608: two per CU
 #define CS2_NLD ((CS2_SLAB_ROWS * 8 + 511) / 512)    // 7
 
-__global__ __launch_bounds__(512, 2) void conv_nt_slab2_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512, 2) void conv_nt_slab2_kernel(GemmArgs g, int group_fastest) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const sB = smem + CS2_SLAB_BYTES;
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const ConvA& a = g.a;
-  const int grp = blockIdx.y;
+  // launch order (a2v_debug_set(35)): 0 = one group after the other (grid (row blocks, G): every pass over the tensor touches one
+  // 128-B segment of every 2-KB row); 1 = 1-D grid, group fastest: the G workgroups of one row block are dispatched together, so a
+  // row's segments are read -- and its output segments written -- close in time (whole DRAM pages)
+  const int grp = group_fastest ? (int)(blockIdx.x % (unsigned)g.G) : (int)blockIdx.y;
+  const int bx = group_fastest ? (int)(blockIdx.x / (unsigned)g.G) : (int)blockIdx.x;
   const int T = a.T_out;
   const int bpc = (T + CS2_BM - 1) / CS2_BM;
-  const int clip = blockIdx.x / bpc;
-  const int t_base = (blockIdx.x - clip * bpc) * CS2_BM;
+  const int clip = bx / bpc;
+  const int t_base = (bx - clip * bpc) * CS2_BM;
   const int taps = a.taps;
   const int rows_here = min(CS2_BM, T - t_base);
   const int rows_needed = rows_here + taps - 1;
@@ -456,6 +460,7 @@ bool a2v_launch_conv_slab3(const GemmArgs& g, long long a_lo, long long b_lo, hi
   return true;
 }
 
+int g_a2v_slab_order = 0;    // a2v_debug_set(35, v): bit 0: conv_nt_slab2 launches group-fastest, bit 1: conv_dec launches group-half-fastest
 int g_a2v_conv_slab2 = 1;    // a2v_debug_set(14, v): 384-row two-per-CU form of the slab kernel on / off
 bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
@@ -472,8 +477,10 @@ bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream) {
   const int nclips = g.M / a.T_out;
   if (g_a2v_conv_slab2 && g.N == 64 && !(g.flags & ~(F_BIAS | F_RES)) && g.ldc % 8 == 0 && g.c_goff % 8 == 0 &&
       (!(g.flags & F_RES) || g.ldr % 8 == 0)) {
-    dim3 grid2(nclips * cdiv(a.T_out, CS2_BM), g.G, 1);
-    hipLaunchKernelGGL(conv_nt_slab2_kernel, grid2, dim3(512), CS2_LDS, stream, g);
+    const long long nb2 = (long long)nclips * cdiv(a.T_out, CS2_BM);
+    const int gf = (g_a2v_slab_order & 1) && nb2 * g.G < (1ll << 31) ? 1 : 0;
+    dim3 grid2(gf ? (unsigned)(nb2 * g.G) : (unsigned)nb2, gf ? 1 : g.G, 1);
+    hipLaunchKernelGGL(conv_nt_slab2_kernel, grid2, dim3(512), CS2_LDS, stream, g, gf);
     return true;
   }
   dim3 grid(nclips * cdiv(a.T_out, CS_BM), g.G, 1);

@@ -736,6 +736,7 @@ extern "C" int a2v_debug_set(int key, int value) {
     extern int g_a2v_ln_bpw, g_a2v_ln_bpw_bwd;
     if (key == 33) { g_a2v_ln_bpw = value; return A2V_OK; }
     if (key == 34) { g_a2v_ln_bpw_bwd = value; return A2V_OK; } }
+  { extern int g_a2v_slab_order; if (key == 35) { g_a2v_slab_order = value; return A2V_OK; } }   // grouped-conv launch orders (a2v_conv_slab.hip)
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off

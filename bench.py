@@ -201,8 +201,9 @@ def pmc_traffic(kernel_substr):
     if doc is None:
         return None, None, None
     n = b = us = 0
+    subs = (kernel_substr,) if isinstance(kernel_substr, str) else tuple(kernel_substr)
     for name, v in doc["kernels"].items():
-        if kernel_substr in name:
+        if any(s_ in name for s_ in subs):
             n += v["launches"]
             b += v["launches"] * v["hbm_bytes_per_launch"]
             us += v["launches"] * v["avg_us_under_pmc"]
@@ -637,7 +638,9 @@ def main():
             tr.engine.tstream = side
         nt = s["nt"]
         traffic, _, traffic_src = pmc_traffic("gemm_nt_bf16_p8_kernel") if dtype == torch.bfloat16 else (None, None, None)
-        for name, sub in (("layernorm_fwd", "layernorm_fwd_kernel"), ("layernorm_bwd", "layernorm_bwd_kernel"),
+        # (round 5: the bf16 LayerNorms run in ln_fwd_stream_kernel / ln_bwd_stream_kernel; the row-per-wave kernels keep the rest)
+        for name, sub in (("layernorm_fwd", ("layernorm_fwd_kernel", "ln_fwd_stream_kernel")),
+                          ("layernorm_bwd", ("layernorm_bwd_kernel", "ln_bwd_stream_kernel")),
                           ("sinc_fused_fwd", "sinc_fused_fwd_kernel"), ("sinc_fused_bwd", "sinc_fused_bwd_kernel")):
             if name in hbm:      # the same kernels' fabric bytes / duration from the PMC passes (not an algorithmic count)
                 hbm[name]["pmc_bytes_per_launch"], hbm[name]["pmc_GBps"], _ = pmc_traffic(sub)

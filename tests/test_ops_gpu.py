@@ -1633,6 +1633,22 @@ def test_linear_bf16x3_image_only_output(ops):
         dhimg = ops.linear(dy, w2t, gelu_bwd_aux=pre_a, colsum=cb, dact=True, out_image=True)
         assert isinstance(dhimg, ops.X3Image) and dhimg.shape == (M, N)
         assert torch.equal(dhimg.img, ops.split_bf16(dh32, 0)) and rel_err(ca, cb) < 1e-6
+        # what reads that image -- the paired weight-gradient launch (dh as the dy operand of fc1's product) and fc1's input
+        # gradient -- against the same calls on the fp32 tensor; an image where the split-product path cannot take it is an error
+        xin = torch.randn(M, K, generator=torch.Generator().manual_seed(9)).cuda()
+        g1a, g2a, g1b, g2b = (torch.zeros(K, N, device="cuda"), torch.zeros(N, K, device="cuda"),
+                              torch.zeros(K, N, device="cuda"), torch.zeros(N, K, device="cuda"))
+        ops.linear_wgrad_pair(h32, dy, g1a, xin, dh32, g2a)
+        ops.linear_wgrad_pair(himg, dy, g1b, xin, dhimg, g2b)
+        assert rel_err(g1a, g1b) < 1e-6 and rel_err(g2a, g2b) < 1e-6
+        w1t = w1.t().contiguous()                                    # (K, N): dx = dh @ w1t^T
+        ops.x3_register(w1t)
+        assert torch.equal(ops.linear(dh32, w1t), ops.linear(dhimg, w1t))
+        del w1t._a2v_x3
+        ops.X3_WGRAD = False
+        with pytest.raises(RuntimeError):
+            ops.linear_wgrad_pair(h32, dy, g1b, xin, dhimg, g2b)
+        ops.X3_WGRAD = True
         del w2t._a2v_x3
         del w2._a2v_x3
         with pytest.raises(RuntimeError):
