@@ -87,49 +87,71 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
       }
     }
   }
-  // per-lane K-chunk geometry of the X fragments (same q as above; the zero weight chunks read a valid address)
-  int xoff[CD_KSTEPS];
-#pragma unroll
-  for (int s = 0; s < CD_KSTEPS; ++s) {
-    int q = 4 * s + fq;
+  // per-lane K-chunk geometry of the X fragments (same q as above; the zero weight chunks read a valid address): formed where it is
+  // used, from an opaque copy of the lane's K-chunk index -- eleven offsets held across the block loop were eleven registers the
+  // counted fetch does not have (three spills at 512)
+  auto xoff_of = [&](int s_, int fq_, int fr_) {
+    int q = 4 * s_ + fq_;
     q = q < KCH ? q : KCH - 1;
     const int tap = q / TCH, c0 = (q - TCH * tap) * 8;
-    xoff[s] = (fr + tap) * CD_PITCH + c0 * 2;
-  }
-
+    return (fr_ + tap) * CD_PITCH + c0 * 2;
+  };
   const bf16* const xb = (const bf16*)a.ptr + (long long)(clip / a.bdiv) * a.bstride + (long long)g0 * a.goff;
-  uint4 rg[CD_NLD];
   // Every block is a full 64 rows: the last one of a chunk starts at t_end - 64 and recomputes rows its predecessor (or the
   // previous chunk's workgroup) also writes -- same operands, same order, same bits (the launcher refuses C overlapping R).
   auto block_t0 = [&](int blk) { return min(t_begin + blk * CD_ROWS, t_end - CD_ROWS); };
-  auto fetch = [&](int blk) {                        // slab rows block_t0 - pad + [0, 70): zero outside the clip
+  // The next slab is fetched by raw-asm loads from clamped addresses into AGPRs (slab rows block_t0 - pad + [0, 70); rows outside the
+  // clip and chunks past the slab are zeroed when the registers are stashed) and waited for by hand: vmcnt(N), N = the vector-memory
+  // operations certainly issued after the fetch -- the block's unconditional stores and, with a residual, its residual loads.  As
+  // compiler-visible loads the wait in front of the stash was vmcnt(0) (the block's output stores are pending beside them), and the 56
+  // staging registers + 64-bit per-lane addresses left no room for the fragment ring below.  (The wait itself turned out not to be what
+  // bounded the kernel -- profiles/r05_dec_bench.txt; tests/test_abi.py checks that nothing names the AGPRs before the wait.)
+  typedef unsigned cd_u32x4 __attribute__((ext_vector_type(4)));
+  cd_u32x4 rga[CD_NLD];
+  const unsigned long long xb64_ = (unsigned long long)xb;       // made uniform explicitly (the asm takes it as an SGPR pair); formed here,
+  const bf16* const xb_u = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb64_ >> 32)) << 32) |   // far from its first use
+                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb64_));
+  const unsigned xpitch_b = (unsigned)a.pitch * 2u;              // (a slab row of a 10 s clip is < 4 MiB from the clip's base)
+  auto fetch_asm = [&](int blk) {
+    const int t0 = block_t0(blk) - a.pad;
+#pragma unroll
+    for (int u = 0; u < CD_NLD; ++u) {
+      int idx = tid + 256 * u;
+      idx = idx < CD_CHUNKS ? idx : CD_CHUNKS - 1;
+      const int row = idx / RCH, ch = idx - row * RCH;
+      int rs = t0 + row;
+      rs = rs < 0 ? 0 : (rs < a.T_in ? rs : a.T_in - 1);
+      // (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane: half the address registers of 64-bit per-lane pointers)
+      const unsigned off_ = (unsigned)rs * xpitch_b + (unsigned)ch * 16u;
+      asm volatile("global_load_dwordx4 %0, %1, %2" : "=a"(rga[u]) : "v"(off_), "s"(xb_u) : "memory");
+    }
+  };
+  auto stash_asm = [&](char* buf, int blk) {
     const int t0 = block_t0(blk) - a.pad;
 #pragma unroll
     for (int u = 0; u < CD_NLD; ++u) {
       const int idx = tid + 256 * u;
       const int row = idx / RCH, ch = idx - row * RCH;
-      const int rs = t0 + row;
-      rg[u] = make_uint4(0u, 0u, 0u, 0u);
-      if (idx < CD_CHUNKS && (unsigned)rs < (unsigned)a.T_in) rg[u] = *(const uint4*)(xb + (long long)rs * a.pitch + ch * 8);
+      const bool ok = (unsigned)(t0 + row) < (unsigned)a.T_in;
+      const cd_u32x4 z = {0u, 0u, 0u, 0u};
+      if (idx < CD_CHUNKS) *(cd_u32x4*)(buf + row * CD_PITCH + ch * 16) = ok ? rga[u] : z;
     }
   };
-  auto stash = [&](char* buf) {
-#pragma unroll
-    for (int u = 0; u < CD_NLD; ++u) {
-      const int idx = tid + 256 * u;
-      const int row = idx / RCH, ch = idx - row * RCH;
-      if (idx < CD_CHUNKS) *(uint4*)(buf + row * CD_PITCH + ch * 16) = rg[u];
-    }
-  };
-
+  // operations of one block behind its fetch: per group 4 row blocks x (one 16-B store per column-block pair + one 8-B store at CO = 48),
+  // and as many residual loads
+  constexpr int CD_ST = GPW * 4 * (NJ / 2 + (NJ == 3 ? 1 : 0));
   // bias of the workgroup's GW x CO output channels in LDS (zeros without F_BIAS): held in registers it cost 24 of the 256
   // arch VGPRs next to 264 weight registers (AGPRs), 56 of slab staging and 48 accumulators
   float* const sBias = (float*)(smem + 2 * CD_SLAB_BYTES);
   for (int i = tid; i < CD_GW * CO; i += 256) sBias[i] = (g.flags & F_BIAS) ? g.bias[(long long)g0 * g.N + i] : 0.f;
 
-  fetch(0);
-  stash(smem);
+  fetch_asm(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < CD_NLD; ++u) asm volatile("" : "+a"(rga[u]));
+  stash_asm(smem, 0);
   __syncthreads();
+  const bool res_ = (g.flags & F_RES) != 0;
   bf16* const C = (bf16*)g.C;
   const bf16* const R = (const bf16*)g.R;
   // One block = fetch the next slab (registers) -> per group: residual rows (registers), MFMAs, stores -> stash the next slab.
@@ -139,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
   // issued and waits for vmcnt(0), i.e. for every store of the block, before the next slab may be written to LDS.
   for (int blk = 0; blk < nblk; ++blk) {
     const char* const cur = smem + (blk & 1) * CD_SLAB_BYTES;
-    if (blk + 1 < nblk) fetch(blk + 1);               // in flight under this block's MFMAs
+    if (blk + 1 < nblk) fetch_asm(blk + 1);           // in flight under this block's MFMAs
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       const int grp = g0 + GPW * wid + gi;
@@ -160,16 +182,40 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const char* const xs = cur + (GPW * wid + gi) * (CI * 2);
+      // X fragments by raw-asm ds_read_b128 one K-step AHEAD of the MFMAs that use them, behind counted lgkmcnt waits.  Left to
+      // hipcc, every fragment read sat directly in front of its three MFMAs behind `s_waitcnt lgkmcnt(0)` (one wave per SIMD: nothing
+      // else to run): ~120 cycles of LDS latency per 48 cycles of matrix work, MFMA-busy 0.22 -- that, not HBM, bounded this kernel.
+      // Ring of two K-steps (4 row blocks each); LDS returns in order, so lgkmcnt(4) = "the older K-step's four reads are back".
+      const int xs_lds = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)(const_cast<char*>(cur)) + (GPW * wid + gi) * (CI * 2);
+      int fq_ = fq, fr_ = fr;
+      asm volatile("" : "+v"(fq_), "+v"(fr_));
+      // ring of five fragments, four reads in flight: fragment f = 4 s + i (row block i of K-step s) is requested while f - 4 is
+      // multiplied; LDS returns in order, so lgkmcnt(n) with n = the reads issued behind f says f is back
+      bf16x8 xr[5];
+      constexpr int NF = 4 * CD_KSTEPS;
+      int xa_ = 0;
+#define CD_XREAD(f_)                                                                                                   \
+  {                                                                                                                    \
+    if (((f_) & 3) == 0) xa_ = xs_lds + xoff_of((f_) >> 2, fq_, fr_);                                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xr[(f_) % 5]) : "v"(xa_), "n"(((f_) & 3) * 16 * CD_PITCH));   \
+  }
+      static_assert(48 * CD_PITCH < 65536, "ds_read offset field");
 #pragma unroll
-      for (int s = 0; s < CD_KSTEPS; ++s) {
+      for (int f = 0; f < 4; ++f) CD_XREAD(f)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bf16x8 xf = *(const bf16x8*)(xs + xoff[s] + i * 16 * CD_PITCH);
+      for (int f = 0; f < NF; ++f) {
+        if (f + 4 < NF) CD_XREAD(f + 4)
+        const int behind = NF - 1 - f < 4 ? NF - 1 - f : 4;
+        if (behind == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(xr[f % 5]));
+        else if (behind == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(xr[f % 5]));
+        else if (behind == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xr[f % 5]));
+        else if (behind == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(xr[f % 5]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[f % 5]));
 #pragma unroll
-          for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gi][s][j], xf, acc[i][j], 0, 0, 0);
-        }
+        for (int j = 0; j < NJ; ++j)
+          acc[f & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gi][f >> 2][j], xr[f % 5], acc[f & 3][j], 0, 0, 0);
       }
+#undef CD_XREAD
       // ---- epilogue of (this block, group): lane (fq, fr) holds row 16 i + fr, channels 32 p + 8 fq + [0, 8) per column-block
       // pair p (and 32 + 4 fq + [0, 4) of the single block at CO = 48)
 #pragma unroll
@@ -203,7 +249,15 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
         }
       }
     }
-    if (blk + 1 < nblk) stash(smem + ((blk + 1) & 1) * CD_SLAB_BYTES);   // its readers (block blk - 1) are behind the last barrier
+    if (blk + 1 < nblk) {                             // its readers (block blk - 1) are behind the last barrier
+      // (volatile asm statements keep their order: the wait, then one empty statement per register that re-defines it -- every use of
+      //  the loaded values sits behind the wait)
+      if (res_) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * CD_ST) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CD_ST) : "memory");
+#pragma unroll
+      for (int u = 0; u < CD_NLD; ++u) asm volatile("" : "+a"(rga[u]));
+      stash_asm(smem + ((blk + 1) & 1) * CD_SLAB_BYTES, blk + 1);
+    }
     __syncthreads();
   }
 }

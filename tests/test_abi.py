@@ -245,6 +245,50 @@ def test_p8_fixed_flavour_seam_wait_is_covered_by_the_epilogue(tmp_path):
     assert seen == 20            # ten fixed flavours x two tile heights
 
 
+def test_conv_dec_counted_fetch_registers_are_untouched_until_their_wait(tmp_path):
+    """a2v_conv_dec.hip (round 5): the next slab is fetched by raw-asm loads into AGPRs and waited for by a hand-counted
+    `s_waitcnt vmcnt(N)` in front of the stash, so that the wait does not sit out the acknowledgement of the block's output stores.
+    hipcc treats an asm output as available at once: with VGPR destinations it copied every loaded register into an AGPR right behind
+    the load (v_accvgpr_write of data that had not arrived).  With AGPR destinations there is no copy -- checked here for every
+    instantiation: no instruction between the first load of the block loop and the counted wait names a destination register."""
+    import shutil
+    import subprocess
+    import pytest
+    from animal2vec_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = "a2v_conv_dec.hip"
+    out = tmp_path / (src + ".s")
+    cmd = [hipcc, *B.FLAGS, *B.FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = out.read_text()
+    seen = 0
+    for m in re.finditer(r"^(_Z15conv_dec_kernelILi\d+ELi\d+ELi\d+EE\w*):", s, re.M):
+        body = s[m.end():s.index("s_endpgm", m.end())]
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        fb = [i for i, l in enumerate(lines) if l == "s_barrier"][0]
+        loads = [(i, re.match(r"global_load_dwordx4 a\[(\d+):(\d+)\]", l)) for i, l in enumerate(lines) if i > fb]
+        loads = [(i, int(mm.group(1)), int(mm.group(2))) for i, mm in loads if mm]
+        assert len(loads) in (7, 9, 14), (m.group(1), len(loads))
+        regs = set()
+        for _, a, b in loads:
+            regs |= set(range(a, b + 1))
+        waits = [i for i, l in enumerate(lines) if i > loads[-1][0] and re.fullmatch(r"s_waitcnt vmcnt\((8|12|16|24|32)\)", l)]
+        assert waits, m.group(1)
+        for i in range(loads[0][0], waits[0]):
+            l = lines[i]
+            if l.startswith("global_load_dwordx4 a["):
+                continue
+            named = set()
+            for mm in re.finditer(r"\ba(\d+)\b|a\[(\d+):(\d+)\]", l):
+                named |= {int(mm.group(1))} if mm.group(1) else set(range(int(mm.group(2)), int(mm.group(3)) + 1))
+            assert not (named & regs), (m.group(1), i, l)
+        seen += 1
+    assert seen == 3
+
+
 def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):
     """256 x 256 TN weight-gradient kernel: at the register limit (256) the lane constants of the staging addresses used to be
     spilled and reloaded at the start of every work unit behind `s_waitcnt vmcnt(0)` -- a drain of the previous unit's 128
