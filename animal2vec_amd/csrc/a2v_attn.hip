@@ -16,6 +16,8 @@
 #include <type_traits>
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void af_lds_void_t;
+typedef __attribute__((address_space(1))) const void af_gbl_cvoid_t;
 
 template <typename T> struct AT {   // LDS tile addressing for [64][HD] tiles
   // row-read image (ds_read_b128 of 8 contiguous d): XOR swizzle of 16-B chunks
@@ -51,6 +53,7 @@ struct AttnArgs {
   const float* qk_bound;          // (SPLIT, N, H, 2): max |q_i|^2 and max |k_j|^2 per (n, h) and row range, or nullptr: ALiBi band limit
   float* mdist;                   // (N,H,S) or nullptr: c_i = sum_j P_ij |pos_i - pos_j|, the row's mean attended distance (dropout-free P);
                                   // the backward centres |pos_i - pos_j| on it when it forms d alibi_scale (see AttnBwdArgs::mdist)
+  float band_nats;                // ALiBi band limit: keys whose softmax weight is provably below exp(-band_nats) of the row sum are not visited
 };
 
 #define FP32_PITCH(HD) ((HD) + 4)
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnArgs a) {
         q2 = fmaxf(q2, bz[0]);
         k2 = fmaxf(k2, bz[1]);
       }
-      const float dcut = (2.f * sqrtf(q2 * k2) * a.scale * 1.01f + 32.f) / c_nat;
+      const float dcut = (2.f * sqrtf(q2 * k2) * a.scale * 1.01f + a.band_nats) / c_nat;
       if (dcut < 1.0e6f) {
         const int dc = (int)dcut + 1;
         kt_lo = max(0, (q0 - dc) / 64);
@@ -537,9 +540,10 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_f
   const int kd1 = sorted ? min(q0 / 64 + QB, ntile) : ntile;
   // ---- ALiBi band limit (positions = arange, a.qk_bound given).  With B >= |q_i . k_j| scale for every pair of this (n, h) and
   // c = slope_h max(alibi_scale_h, 0), a key j at distance |i - j| > d scores s_ij <= B - c d while the row's own diagonal key
-  // scores s_ii >= -B: its softmax weight is below exp(2B - c d) of the row sum.  Beyond d_cut = (2B + 32) / c that is e^-32 per key,
-  // 3e-11 of the row sum over 2000 keys -- three orders below one fp32 ulp of the sums the reference forms -- so key tiles wholly beyond
-  // d_cut of every query row of this workgroup are not visited.  B comes from the row norms (attn_qk_bound_kernel), so the limit
+  // scores s_ii >= -B: its softmax weight is below exp(2B - c d) of the row sum.  Beyond d_cut = (2B + L) / c that is e^-L per key
+  // (AttnArgs::band_nats: L = 20 in the bf16 kernels -- 4e-6 of the row sum over 2000 keys, 500 times below the 2^-9 rounding of every
+  // P the kernel feeds to the matrix cores; L = 32 in the bf16x3 kernel -- 3e-11, below one fp32 ulp of the sums the reference
+  // forms), so key tiles wholly beyond d_cut of every query row of this workgroup are not visited.  B comes from the row norms (attn_qk_bound_kernel), so the limit
   // is a bound, not a heuristic: it follows the learned alibi_scale and the data (c -> 0 or large B: every tile is visited).
   int kt_lo = 0, kt_end = ntile;
   if (sorted && a.qk_bound) {
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_f
         k2 = fmaxf(k2, bz[1]);
       }
       const float bnd = sqrtf(q2 * k2) * a.scale * 1.01f;       // Cauchy-Schwarz, + 1 %
-      const float dcut = (2.f * bnd + 32.f) / c_nat;
+      const float dcut = (2.f * bnd + a.band_nats) / c_nat;
       if (dcut < 1.0e6f) {
         const int dc = (int)dcut + 1;
         kt_lo = max(0, (q0 - dc) / 64);
@@ -837,6 +841,393 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_f
 }
 
 // ---------------------------------------------------------------------------------------------
+// bf16, HD = 64, long sequences, round 5: the same kernel on 32 x 32 x 16 MFMAs.  attn_fwd_bf16_kernel<64, ., 2> is bound by the
+// SIMD's vector ISSUE port (SQ_ACTIVE_INST_VALU 68 %, SQ_WAIT_INST_ANY 40 % of the wave cycles): per 64-key tile a wave issues
+// 36 v_mfma_f32_16x16x32_bf16, each holding the port for 8 of its 16 cycles, next to ~180 VALU instructions.  A
+// v_mfma_f32_32x32x16_bf16 does twice the work for the same 8 issue cycles.  Here a wave owns 32 query rows as ONE 32-wide
+// column block: S^T = K Q^T as two 32 x 32 tiles per key tile (a lane holds 32 scores of ONE query: one permlane32 swap
+// finishes the row maximum instead of two swaps per 16-row block), O^T = V^T P^T as two 32-dim row blocks.  20 MFMA issues per
+// tile instead of 36, the running statistics once per lane instead of twice.  LDS images, tile fetch, phases (ALiBi as the C
+// operand outside the diagonal tiles), band limit and deferred maximum are the 16 x 16 kernel's.
+//   S^T accumulator (jj = 0, 1: keys 32 jj ..): element i of lane (l31, h2) = key 32 jj + 8 (i >> 2) + 4 h2 + (i & 3), query l31
+//   P^T as the next B operand: MFMA (jj, t) takes elements 8 t .. 8 t + 7: k-slot (h2, e) = key 32 jj + 16 t + 8 (e >> 2) + 4 h2 + (e & 3)
+//   V^T as its A operand: 16-lane group (h2, dhalf) reads keys 32 jj + 16 t + {0, 8} + 4 h2 + 0..3 at dims 16 dd + 32 dhalf + 0..15
+//   (the two groups of one 32-lane half read column blocks that differ by 2: with the image's XOR swizzle their banks are disjoint)
+//   O^T accumulator dd: element i = dim 16 dd + 32 (i >> 3) + 8 ((i >> 2) & 1) + 4 h2 + (i & 3), query l31
+#define A32_LDS (4 * 64 * 64 * 2 + 2 * 64 * 4)
+template <bool DROP, bool MSUM = false, bool MD = false>
+__global__ __launch_bounds__(256, (!DROP && !MD) ? 3 : 1) void attn_fwd32_bf16_kernel(AttnArgs a) {
+  typedef bf16 T;
+  constexpr int HD = 64;
+  constexpr bool VSUM = DROP || !MSUM;
+  constexpr int NCH = HD / 8;
+  constexpr int TILE_BYTES = 64 * HD * 2;
+  constexpr int CPT = 64 * NCH / 256;
+  extern __shared__ __attribute__((aligned(128))) char smem[];     // A32_LDS bytes (the fragment addresses XOR bits 5-6 of a row base)
+  char (*const sK)[TILE_BYTES] = (char (*)[TILE_BYTES])smem;
+  char (*const sV)[TILE_BYTES] = (char (*)[TILE_BYTES])(smem + 2 * TILE_BYTES);
+  float (*const sPos)[64] = (float (*)[64])(smem + 4 * TILE_BYTES);   // per-key term of key k of the tile at (k & 32) | 16 ((k >> 2) & 1) | 4 ((k >> 3) & 3) | (k & 3):
+                                                                       // the 16 keys of a lane's accumulator are 64 contiguous bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h2 = lane >> 5;
+  const int S = a.S, H = a.H;
+  int q0, h, n;
+  if (a.xcd_order) {
+    const int nqb = (S + 127) / 128;
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int hl = (k / nqb) * 8 + xcd;
+    if (hl >= a.N * H) return;
+    q0 = (k % nqb) * 128;
+    n = hl / H;
+    h = (hl % H + n) % H;
+  } else {
+    q0 = blockIdx.x * 128; h = blockIdx.y; n = blockIdx.z;
+  }
+  const long long rowstride = 3LL * H * HD;
+  const T* qkv = (const T*)a.qkv + (long long)n * S * rowstride + (long long)h * HD;
+  constexpr float LOG2E = 1.4426950408889634f;
+  const float scale2 = a.scale * LOG2E;
+  const float c_rel = -a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f) / a.scale;
+  const float thr_acc = 4.f / scale2;
+
+  const int q = q0 + wid * 32 + l31;
+  const int qc = q < S ? q : S - 1;
+  const float pos_q = a.pos ? (float)a.pos[(long long)n * S + qc] : (float)qc;
+  float m_run = -INFINITY, l_run = 0.f, a_run = 0.f;
+  bf16x8 qf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) qf[kk] = *(const bf16x8*)(qkv + (long long)qc * rowstride + kk * 16 + h2 * 8);
+  f32x16 o[2];
+#pragma unroll
+  for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dd][i] = 0.f;
+
+  const int ntile = (S + 63) / 64, nfull = S / 64;
+  const bool sorted = a.pos == nullptr;
+  const int kd0 = sorted ? min(q0 / 64, ntile) : 0;
+  const int kd1 = sorted ? min(q0 / 64 + 2, ntile) : ntile;
+  int kt_lo = 0, kt_end = ntile;
+  if (sorted && a.qk_bound) {                                    // ALiBi band limit: see attn_fwd_bf16_kernel
+    const float c_nat = a.slopes[h] * fmaxf(a.alibi_scale[h], 0.f);
+    if (c_nat > 0.f) {
+      float q2 = 0.f, k2 = 0.f;
+#pragma unroll
+      for (int z = 0; z < A2V_QKB_SPLIT; ++z) {
+        const float* const bz = a.qk_bound + (((long long)z * a.N + n) * H + h) * 2;
+        q2 = fmaxf(q2, bz[0]);
+        k2 = fmaxf(k2, bz[1]);
+      }
+      const float bnd = sqrtf(q2 * k2) * a.scale * 1.01f;
+      const float dcut = (2.f * bnd + a.band_nats) / c_nat;
+      if (dcut < 1.0e6f) {
+        const int dc = (int)dcut + 1;
+        kt_lo = max(0, (q0 - dc) / 64);
+        kt_end = min(ntile, (q0 + 127 + dc) / 64 + 1);
+        kt_lo = min(kt_lo, kd0);
+        kt_end = max(kt_end, kd1);
+      }
+    }
+  }
+  const float qref = (float)q0;
+  float pmul = 1.f, padd = 0.f;
+  auto pos_form = [&](int kt_) {
+    if (kt_ < kd0) { pmul = -c_rel; padd = c_rel * qref; }
+    else if (kt_ < kd1) { pmul = 1.f; padd = 0.f; }
+    else { pmul = c_rel; padd = -c_rel * qref; }
+  };
+
+  // Tile fetch by LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at consecutive LDS addresses): wave w, instruction u
+  // fills LDS rows 8 (2 w + u) .. + 8 of the K and of the V image; the images' XOR swizzles are applied on the GLOBAL side (lane l
+  // fetches the chunk that belongs at position l & 7 of its row).  No staging registers, no ds_write, no per-tile address VALU:
+  // the tile's base is scalar arithmetic, the lane's offsets are loop-invariant.
+  unsigned koff[CPT], voff[CPT];
+#pragma unroll
+  for (int u = 0; u < CPT; ++u) {
+    const int r = (wid * CPT + u) * 8 + (lane >> 3), p_ = lane & 7;
+    const int kc = (p_ ^ (r >> 1)) & 7;                                   // rowimg_off: position = chunk ^ ((r >> 1) & 7)
+    const int vc = ((((p_ >> 1) ^ (r >> 1)) & 3) << 1) | (p_ & 1);        // trimg_off: 32-B block = (col >> 4) ^ ((r >> 1) & 3)
+    koff[u] = (unsigned)((r * (int)rowstride + kc * 8) * 2);
+    voff[u] = (unsigned)((r * (int)rowstride + vc * 8) * 2);
+  }
+  const int widu = __builtin_amdgcn_readfirstlane(wid);
+  int praw = 0;
+#define A32_LOAD(kt_)                                                                             \
+  {                                                                                               \
+    const int kv0_ = (kt_) * 64;                                                                  \
+    const int buf_ = (kt_) & 1;                                                                   \
+    const char* const kb_ = (const char*)(qkv + (long long)kv0_ * rowstride + H * HD);            \
+    const char* const vb_ = kb_ + H * HD * 2;                                                     \
+    unsigned ko_[CPT], vo_[CPT];                                                                  \
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) { ko_[u] = koff[u]; vo_[u] = voff[u]; }       \
+    if ((kt_) >= nfull) {                            /* uniform, rare: ragged last tile */        \
+      _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                           \
+        const int r = (wid * CPT + u) * 8 + (lane >> 3), rc = min(r, S - 1 - kv0_);               \
+        ko_[u] = koff[u] - (unsigned)((r - rc) * (int)rowstride * 2);                             \
+        vo_[u] = voff[u] - (unsigned)((r - rc) * (int)rowstride * 2);                             \
+      }                                                                                           \
+    }                                                                                             \
+    _Pragma("unroll") for (int u = 0; u < CPT; ++u) {                                             \
+      __builtin_amdgcn_global_load_lds((af_gbl_cvoid_t*)(kb_ + ko_[u]), (af_lds_void_t*)(sK[0] + buf_ * TILE_BYTES + (widu * CPT + u) * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((af_gbl_cvoid_t*)(vb_ + vo_[u]), (af_lds_void_t*)(sV[0] + buf_ * TILE_BYTES + (widu * CPT + u) * 1024), 16, 0, 0); \
+    }                                                                                             \
+    if (a.pos && tid < 64) praw = a.pos[(long long)n * S + min(kv0_ + tid, S - 1)];               \
+  }
+#define A32_STORE(kt_)                                                                            \
+  {                                                                                               \
+    const int buf_ = (kt_) & 1;                                                                   \
+    if (tid < 64) {                                                                               \
+      const int kv = (kt_) * 64 + tid;                                                            \
+      pos_form(kt_);                                                                              \
+      sPos[buf_][(tid & 32) | ((tid & 4) << 2) | ((tid >> 1) & 12) | (tid & 3)] = fmaf(a.pos ? (float)praw : (float)kv, pmul, padd); \
+    }                                                                                             \
+  }
+  A32_LOAD(kt_lo);
+  A32_STORE(kt_lo);
+  __syncthreads();
+
+  f32x16 lacc;
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) lacc[i] = 0.f;
+  const unsigned rt = DROP ? drop_row_term(a.drop.seed, (unsigned)(((long long)n * H + h) * S + qc)) : 0u;
+  const int qq = (lane & 15) >> 2, pp = lane & 3, dhalf = (lane >> 4) & 1;
+  // lane parts of the LDS addresses.  K fragment (kk, jj): row 32 jj + l31, chunk (2 kk + h2) ^ ((l31 >> 1) & 7) = (2 kk) ^ y:
+  // byte offset l31 * 128 + 16 y, XOR 32 kk (row bases are multiples of 128), + 4096 jj as the immediate.
+  const unsigned krow_off = (unsigned)(l31 * 128 + ((h2 ^ ((l31 >> 1) & 7)) << 4));
+  const unsigned kxor[4] = {0u, 32u, 64u, 96u};
+  // V^T fragment (step, dd, lo / hi): row 16 step + 4 h2 + qq (+ 8), 32-B block (dd + 2 dhalf) ^ ((2 h2 + (qq >> 1)) & 3), + 8 pp bytes;
+  // dd flips bit 5, step and lo / hi are immediates.
+  const unsigned vrow_off = (unsigned)((4 * h2 + qq) * 128 + ((((2 * dhalf) ^ (2 * h2 + (qq >> 1))) & 3) << 5) + 8 * pp);
+
+  auto key_tile = [&](int kt, auto ph_tag, auto tail_tag) {
+    constexpr int PH = decltype(ph_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const int buf = kt & 1;
+    const int kv0 = kt * 64;
+    const bool more = kt + 1 < kt_end;
+    if (more) A32_LOAD(kt + 1);
+    const char* const bK = sK[buf];
+    const char* const bV = sV[buf];
+
+    // ---- S^T tiles in accumulator units
+    f32x16 s[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      if constexpr (PH == 1) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {                 // the per-key bias IS the accumulator's initial value.  (Four 16-B loads: as ONE
+          // 64-B vector load hipcc puts s_waitcnt vmcnt(0) -- the tile DMA issued a moment ago -- in front of it.)
+          const f32x4 pk = *(const f32x4*)(&sPos[buf][32 * jj + 16 * h2 + 4 * ii]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[jj][4 * ii + r] = pk[r];
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[jj][i] = 0.f;
+      }
+    }
+    // K fragments by raw-asm ds_read_b128 THREE ahead of their MFMAs behind counted lgkmcnt waits (left to the compiler every
+    // read sits directly in front of its MFMA behind lgkmcnt(0): eight exposed LDS round trips per tile); fragment i = (kk, jj) =
+    // (i >> 1, i & 1): the two accumulator chains alternate.  An LDS operation the compiler issues in between only makes a
+    // counted wait stricter (LDS returns in order), never weaker.
+    {
+      const unsigned kb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(const_cast<char*>(bK)) + krow_off;
+      bf16x8 kr[5];
+#define A32_KREAD(i_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(i_) % 5]) : "v"(kb_lds ^ kxor[(i_) >> 1]), "n"(((i_) & 1) * 4096))
+      A32_KREAD(0); A32_KREAD(1); A32_KREAD(2); A32_KREAD(3);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        // fragment i + 4 goes out AFTER MFMA i: in the per-key form the first MFMA's C operand comes from the compiler's own sPos
+        // reads, whose lgkmcnt(0) would otherwise wait for a fragment issued a moment ago
+        if (i < 5) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(kr[i % 5]));
+        else if (i == 5) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kr[i % 5]));
+        else if (i == 6) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kr[i % 5]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[i % 5]));
+        s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i % 5], qf[i >> 1], s[i & 1], 0, 0, 0);
+        if (i + 4 < 8) A32_KREAD(i + 4);
+      }
+#undef A32_KREAD
+    }
+    // V^T fragments: vr[step & 1][2 dd + {lo, hi}]; step 0's reads go out here, under the softmax
+    const unsigned vb_lds = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(const_cast<char*>(bV)) + vrow_off;
+    s16x4 vr[2][4];
+#define A32_VREAD(st_)                                                                                                              \
+  {                                                                                                                                 \
+    _Pragma("unroll") for (int dd_ = 0; dd_ < 2; ++dd_) {                                                                           \
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[(st_) & 1][2 * dd_]) : "v"(vb_lds ^ (dd_ << 5)), "n"((st_) * 2048));        \
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[(st_) & 1][2 * dd_ + 1]) : "v"(vb_lds ^ (dd_ << 5)), "n"((st_) * 2048 + 1024)); \
+    }                                                                                                                               \
+  }
+    A32_VREAD(0);
+    if constexpr (PH == 0) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const f32x4 pk = *(const f32x4*)(&sPos[buf][32 * jj + 16 * h2 + 4 * ii]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[jj][4 * ii + r] = __builtin_fmaf(__builtin_fabsf(pos_q - pk[r]), c_rel, s[jj][4 * ii + r]);
+        }
+    } else {
+      // the inline-asm v_max3 below reads MFMA results the compiler cannot see a hazard for (see attn_fwd_bf16_kernel): a 16-pass
+      // MFMA needs 18 wait states before a VALU read of its result
+      asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(s[0]), "+v"(s[1]));
+    }
+    if (TAIL) {
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (kv0 + 32 * jj + 8 * (i >> 2) + 4 * h2 + (i & 3) >= S) s[jj][i] = -INFINITY;
+    }
+    float mx;
+    {
+      float v0 = max3f(s[0][0], s[0][1], s[0][2]);
+      float v1 = max3f(s[1][0], s[1][1], s[1][2]);
+      v0 = max3f(v0, s[0][3], s[0][4]);
+      v1 = max3f(v1, s[1][3], s[1][4]);
+      v0 = max3f(v0, s[0][5], s[0][6]);
+      v1 = max3f(v1, s[1][5], s[1][6]);
+      v0 = max3f(v0, s[0][7], s[0][8]);
+      v1 = max3f(v1, s[1][7], s[1][8]);
+      v0 = max3f(v0, s[0][9], s[0][10]);
+      v1 = max3f(v1, s[1][9], s[1][10]);
+      v0 = max3f(v0, s[0][11], s[0][12]);
+      v1 = max3f(v1, s[1][11], s[1][12]);
+      v0 = max3f(v0, s[0][13], s[0][14]);
+      v1 = max3f(v1, s[1][13], s[1][14]);
+      v0 = max3f(v0, s[0][15], s[1][15]);
+      const float v = max2f(v0, v1);
+      const unsigned u = __float_as_uint(v);
+      auto rr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+      mx = max2f(__uint_as_float(rr[0]), __uint_as_float(rr[1]));
+    }
+    const bool grow = mx > m_run + thr_acc;
+    if (__any(grow)) {                                   // deferred maximum, one wave-uniform decision
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale2);
+      m_run = m_new;
+      if constexpr (VSUM) l_run *= alpha; else lacc *= alpha;
+      if constexpr (MD) a_run *= alpha;
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) o[dd] *= alpha;
+    }
+    {
+      const float nm = -m_run * scale2;
+      float ps = 0.f, pa = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+          const int kbase = kv0 + 32 * jj + 8 * ii + 4 * h2;
+          f32x4 kp = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (MD) {
+            if constexpr (PH == 1) {
+              const float k0 = (float)kbase;
+              kp = (f32x4){k0, k0 + 1.f, k0 + 2.f, k0 + 3.f};
+            } else {
+              kp = *(const f32x4*)(&sPos[buf][32 * jj + 16 * h2 + 4 * ii]);
+            }
+          }
+          unsigned hp[2] = {0u, 0u};
+          if (DROP) {
+            hp[0] = drop_hash_pair(rt, (unsigned)kbase);
+            hp[1] = drop_hash_pair(rt, (unsigned)(kbase + 2));
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float p = __builtin_amdgcn_exp2f(fmaf(s[jj][4 * ii + r], scale2, nm));
+            if (VSUM && DROP) ps += p;                 // (the normaliser is dropout-free; without dropout the sums are formed beside the PV MFMAs)
+            if constexpr (MD) pa = __builtin_fmaf(__builtin_fabsf(pos_q - kp[r]), p, pa);
+            if (DROP) {
+              const unsigned h16 = (r & 1) ? (hp[r >> 1] >> 16) : (hp[r >> 1] & 0xFFFFu);
+              p = h16 >= (a.drop.thresh >> 16) ? p * a.drop.scale : 0.f;
+            }
+            s[jj][4 * ii + r] = p;
+          }
+        }
+      if (VSUM && DROP) l_run += ps;
+      if constexpr (MD) a_run += pa;
+    }
+
+    // ---- O^T += V^T P^T: step st = (jj, t) = (st >> 1, st & 1); its four transposing reads (two fragments) are issued one step
+    // ahead by raw asm (the ds_read_tr builtin makes hipcc wait for the tile DMA, vmcnt(0), in front of the first of them)
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      if (st + 1 < 4) A32_VREAD(st + 1);
+      bf16x8 pf;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pf[e] = (bf16)s[st >> 1][8 * (st & 1) + e];
+      if constexpr (VSUM && !DROP) {                     // this step's eight weights into the row sum, next to its MFMAs
+        const int j_ = st >> 1, e_ = 8 * (st & 1);
+        l_run += ((s[j_][e_] + s[j_][e_ + 1]) + (s[j_][e_ + 2] + s[j_][e_ + 3])) + ((s[j_][e_ + 4] + s[j_][e_ + 5]) + (s[j_][e_ + 6] + s[j_][e_ + 7]));
+      }
+      // (l_run rides along: the eight adds above stay in this step, beside its MFMAs, instead of sinking to the end of the tile)
+      if (st + 1 < 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vr[st & 1][0]), "+v"(vr[st & 1][1]), "+v"(vr[st & 1][2]), "+v"(vr[st & 1][3]), "+v"(l_run));
+      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vr[st & 1][0]), "+v"(vr[st & 1][1]), "+v"(vr[st & 1][2]), "+v"(vr[st & 1][3]), "+v"(l_run));
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd) {
+        union { struct { s16x4 a, b; } h; bf16x8 v; } vf;
+        vf.h.a = vr[st & 1][2 * dd]; vf.h.b = vr[st & 1][2 * dd + 1];
+        o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf, o[dd], 0, 0, 0);
+      }
+      if constexpr (!VSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+    }
+#undef A32_VREAD
+    if (more) A32_STORE(kt + 1);
+    __syncthreads();
+  };
+  typedef std::integral_constant<int, 0> PhAbs;
+  typedef std::integral_constant<int, 1> PhKey;
+  {
+    int kt = kt_lo;
+    for (; kt < kd0; ++kt) key_tile(kt, PhKey{}, std::false_type{});
+    if (kd0 > 0) m_run += c_rel * (pos_q - qref);
+    for (; kt < min(kd1, nfull); ++kt) key_tile(kt, PhAbs{}, std::false_type{});
+    if (kt < kd1) { key_tile(kt, PhAbs{}, std::true_type{}); ++kt; }
+    if (kt < kt_end) {
+      m_run += c_rel * (pos_q - qref);
+      for (; kt < min(nfull, kt_end); ++kt) key_tile(kt, PhKey{}, std::false_type{});
+      if (kt < kt_end) key_tile(kt, PhKey{}, std::true_type{});
+      m_run -= c_rel * (pos_q - qref);
+    }
+  }
+#undef A32_LOAD
+#undef A32_STORE
+  float l_tot;
+  if constexpr (VSUM) {
+    const unsigned u = __float_as_uint(l_run);
+    auto rr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    l_tot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+  } else {
+    l_tot = lacc[0];
+  }
+  const float inv = 1.f / l_tot;
+  if (q < S) {
+    T* orow = (T*)a.out + ((long long)n * S + q) * ((long long)H * HD) + (long long)h * HD;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        f32x4 v = {o[dd][4 * ii] * inv, o[dd][4 * ii + 1] * inv, o[dd][4 * ii + 2] * inv, o[dd][4 * ii + 3] * inv};
+        Vec4<T>::store(orow + 16 * dd + 32 * (ii >> 1) + 8 * (ii & 1) + 4 * h2, v);
+      }
+    if (h2 == 0 && a.lse)
+      a.lse[((long long)n * H + h) * S + q] = (m_run * scale2 + __builtin_amdgcn_logf(l_tot)) * 0.6931471805599453f;
+  }
+  if constexpr (MD) {
+    const unsigned u = __float_as_uint(a_run);
+    auto rr = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    const float a_tot = __uint_as_float(rr[0]) + __uint_as_float(rr[1]);
+    if (q < S && h2 == 0) a.mdist[((long long)n * H + h) * S + q] = a_tot * inv;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bf16, HD = 64, S <= 160 (the student's kept frames: 140 in round 2's seeded masks, 143 .. 155 as the sampler draws them at 96 ..
 // 768 rows): whole-sequence forward.  One workgroup of up to FOUR waves per (n, h) -- a wave without query rows leaves at once --;
 // K and V of all S keys are staged once (the tiled kernel above re-fetched them for each of its three 64-row query blocks
@@ -1030,6 +1421,7 @@ int g_a2v_attn_msum = 1;     // a2v_debug_set(18, v): forward-only long-sequence
                              // read as a loss of accuracy (d alibi_scale 0.16 -> 0.27 at T = 11 025) is that gradient's condition number (673)
                              // times rounding noise either way
 int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
+int g_a2v_attn_fwd32 = 1;    // a2v_debug_set(36, v): long-sequence bf16 forward on 32 x 32 x 16 MFMAs (0: the 16 x 16 x 32 kernel)
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 // Ingredients of the bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i|^2 and max_j |k_j|^2 (Cauchy-Schwarz in
 // the attention kernel).  8 lanes share a row (16 B each); reads q and k once: 65 MB at 32 x 2000 x 16 heads.
@@ -1076,7 +1468,9 @@ __global__ __launch_bounds__(256) void attn_qk_bound_kernel(const T* __restrict_
     }
   }
 }
-int g_a2v_attn_band = 1;     // a2v_debug_set(19, v): ALiBi band limit of the long-sequence forward (positions = arange) on / off
+int g_a2v_attn_band = 1;     // a2v_debug_set(19, v): ALiBi band limit of the long-sequence forward (positions = arange) on / off;
+                             // v >= 8: on, with exp(-v) as the bf16 kernel's weight bound (experiments)
+#define A2V_BAND_NATS_BF16 20.f  // bf16 kernels: 2000 keys x e^-20 = 4e-6 of the row sum, 500 times below the bf16 rounding of P itself (2^-9)
 
 template <int HD, bool DROP>
 static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
@@ -1104,6 +1498,16 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
     const bool xo = g_a2v_attn_xcd && heads8 * nqb < (1ll << 31);
     a.xcd_order = xo ? 1 : 0;
     const dim3 grid = xo ? dim3((unsigned)(heads8 * nqb)) : dim3((a.S + 127) / 128, a.H, a.N);
+    if constexpr (HD == 64) {
+      if (g_a2v_attn_fwd32) {                               // the 32 x 32 x 16 form (round 5)
+        if (a.mdist) hipLaunchKernelGGL((attn_fwd32_bf16_kernel<DROP, false, true>), grid, dim3(256), A32_LDS, st, a);
+        // (row sums on the matrix cores, a2v_debug_set(18, 2): four more 32 x 32 x 16 MFMAs per tile compute 32 identical rows; the
+        // kernel runs at the power cap, where their energy costs more clock than the 32 v_add they replace: 593 against 578 us)
+        else if (!DROP && !a.lse && g_a2v_attn_msum == 2) hipLaunchKernelGGL((attn_fwd32_bf16_kernel<DROP, !DROP>), grid, dim3(256), A32_LDS, st, a);
+        else hipLaunchKernelGGL((attn_fwd32_bf16_kernel<DROP, false>), grid, dim3(256), A32_LDS, st, a);
+        return;
+      }
+    }
     if (a.mdist) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, false, true>), grid, dim3(256), 0, st, a);
     else if (!DROP && !a.lse && g_a2v_attn_msum) hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, !DROP>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((attn_fwd_bf16_kernel<HD, DROP, 2, false>), grid, dim3(256), 0, st, a);
@@ -1519,8 +1923,9 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
                                  const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
                                  float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
-  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr, mdist};
+  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr, mdist, 32.f};
   if (dtype == A2V_BF16) {
+    a.band_nats = g_a2v_attn_band >= 8 ? (float)g_a2v_attn_band : A2V_BAND_NATS_BF16;
     const bool dr = a.drop.thresh != 0;
     if (HD == 64 && dr) attn_fwd_bf16_launch<64, true>(a, stream);
     else if (HD == 64) attn_fwd_bf16_launch<64, false>(a, stream);

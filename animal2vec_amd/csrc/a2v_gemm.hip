@@ -713,6 +713,7 @@ extern int g_a2v_attn_fwd48;
 extern int g_a2v_attn_xcd;
 extern int g_a2v_attn_msum;
 extern int g_a2v_attn_band;
+extern int g_a2v_attn_fwd32;
 extern "C" int a2v_debug_set(int key, int value) {
   if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
   if (key == 1) { g_a2v_gemm_p8 = value; return A2V_OK; }     // 256x256 8-phase kernel on / off
@@ -740,6 +741,7 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off
+  if (key == 36) { g_a2v_attn_fwd32 = value; return A2V_OK; }  // long-sequence attention forward: 32 x 32 x 16 kernel on / off
   if (key == 19) { g_a2v_attn_band = value; return A2V_OK; }  // long-sequence attention forward: ALiBi band limit on / off
   if (key == 18) { g_a2v_attn_msum = value; return A2V_OK; }  // forward-only long-sequence attention: P row sums on the matrix cores on / off
   if (key == 17) { g_a2v_attn_xcd = value; return A2V_OK; }   // long-sequence attention forward: XCD-aware workgroup order on / off

@@ -361,7 +361,8 @@ def linear_wgrad_pair(xa, dya, gwa, xb, dyb, gwb):
     Na, Nb, Kb = dya.shape[1], dyb.shape[1], xb.shape[1]
     assert xb.shape[0] == M and dya.shape[0] == M and dyb.shape[0] == M and xa.dtype == xb.dtype
     assert gwa.dtype == torch.float32 and gwb.dtype == torch.float32 and gwa.shape == (Na, Ka) and gwb.shape == (Nb, Kb)
-    if _x3_wgrad_ok(xa, dya) and _x3_wgrad_ok(xb, dyb):
+    ok_a, ok_b = _x3_wgrad_ok(xa, dya), _x3_wgrad_ok(xb, dyb)     # (both evaluated: each raises for an image-only operand it cannot take)
+    if ok_a and ok_b:
         for (xa_, da_), (xb_, db_) in zip(_x3_wgrad_terms(xa, dya), _x3_wgrad_terms(xb, dyb)):
             rc = _L().a2v_linear_wgrad_pair(BF16, M, ptr(xa_), 3 * Ka, ptr(da_), 3 * Na, ptr(gwa), gwa.stride(0), Na, Ka,
                                             ptr(xb_), 3 * Kb, ptr(db_), 3 * Nb, ptr(gwb), gwb.stride(0), Nb, Kb, stream())

@@ -275,9 +275,11 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   15 whole-sequence attention backward for S <= 160 (1: 48-row tiles on three waves; 0: 64-row tiles on four)
  *   16 attention forward for S <= 160 (1: whole-sequence kernel, 48 query rows per wave; 0: the tiled kernel)
  *   17 attention forward for S >= 512: 1-D launch that keeps the query blocks of one (n, h) on one XCD (1) / 3-D grid (0)
- *   18 forward-only attention for S >= 512: row sums of P from the bf16 P on the matrix cores (1, default since round 3) / fp32 sums (0)
+ *   18 forward-only attention for S >= 512: row sums of P from the bf16 P on the matrix cores (16 x 16 x 32 kernel: 1, default since
+ *      round 3; 32 x 32 x 16 kernel of round 5: only with 2 -- there the fp32 sums are faster) / fp32 sums (0)
  *   19 attention forward for S >= 512 with positions = arange: skip key tiles beyond the ALiBi band limit (a bound from the row
- *      norms of q and k: weights below e^-32 of the row sum) (1, default) / visit every tile (0)
+ *      norms of q and k: weights below e^-20 of the row sum in the bf16 kernels, e^-32 in the bf16x3 kernel) (1, default) / visit
+ *      every tile (0) / v >= 8: on, with e^-v in the bf16 kernels (experiments)
  *   20 fixed-flavour instantiations of the NT kernel's 256-row tile for the eight hottest epilogue flag sets (1, default) / the generic epilogue (0)
  *   21 dense strided convs of the feature extractor on the 8-phase GEMMs + edge-frame kernels (1, default) / implicit-im2col 128 x 128 kernels (0)
  *   22 persistent NT kernel: the rows of a last round of tiles that fills at most v quarters of the CUs go to the 128 x 128 kernel
@@ -286,6 +288,13 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *      (round-4 experiment: +8.6 % fabric reads, 0.6 - 4 % slower -- profiles/r04_nt_tile_ab.txt)
  *   25 the 256 x 128 NT kernel with two workgroups per CU (a2v_gemm_w2.hip, round-4 experiment, profiles/r04_w2_experiment.txt):
  *      0 off (default), 1 eligible Linears with K <= 1024, 2 every eligible Linear
+ *   30-34 streaming LayerNorm kernels (round 5; a2v_norm.hip): 30 bit mask of the directions that may take them (1 forward, 2
+ *      backward; default 3), 31 rows per batch (0 auto), 32 waves per CU of the persistent form (0 auto), 33 / 34 forward / backward
+ *      launch form (0 auto, > 0 batches per wave of the in-order front, -1 persistent)
+ *   35 launch order of the grouped-conv kernels: bit 0 conv_nt_slab2_kernel group-fastest, bit 2 conv_dec_kernel halves together
+ *      (round-5 experiment, no gain: profiles/r05_conv_order_ab.txt; default 0)
+ *   36 bf16 attention forward for S >= 512, head dimension 64: the 32 x 32 x 16 MFMA kernel of round 5 (1, default) / the
+ *      16 x 16 x 32 kernel (0)
  *   (19 also switches the bf16x3 attention forward's band limit, round 4)
  * No launch state goes through here (ABI 5's key 9, the tile-counter set, is gone: the stream argument selects it). */
 int a2v_debug_set(int key, int value);

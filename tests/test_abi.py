@@ -289,6 +289,56 @@ def test_conv_dec_counted_fetch_registers_are_untouched_until_their_wait(tmp_pat
     assert seen == 3
 
 
+def test_attn_fwd32_tile_dma_is_not_waited_for_before_the_tile_math(tmp_path):
+    """a2v_attn.hip, attn_fwd32_bf16_kernel (round 5): the next K / V tile is fetched by LDS-DMA at the top of a key tile and must
+    land UNDER that tile's math; the only wait for it belongs in front of the barrier at the tile's end.  hipcc inserts
+    `s_waitcnt vmcnt(0)` in front of LDS reads it believes may alias a pending LDS-DMA -- it did for static __shared__ arrays,
+    for the ds_read_tr builtin and for a 64-byte vector load, which parked every wave for the global latency once per tile.  The
+    kernel avoids those forms (dynamic LDS, raw-asm transposing reads, 16-byte loads); this test holds the result: in every key-tile
+    loop of every instantiation, no vmcnt wait between the tile's DMA instructions and its LAST MFMA, the raw reads' counted waits
+    present (lgkmcnt(3) for the K ring, lgkmcnt(4) for the V steps), and no spill."""
+    import shutil
+    import subprocess
+    import pytest
+    from animal2vec_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = "a2v_attn.hip"
+    out = tmp_path / (src + ".s")
+    cmd = [hipcc, *B.FLAGS, *B.FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = out.read_text()
+    seen = loops = 0
+    for m in re.finditer(r"^(_Z22attn_fwd32_bf16_kernelILb[01]ELb[01]ELb[01]EE\w*):", s, re.M):
+        name = m.group(1)
+        body = s[m.end():s.index("s_endpgm", m.end())]
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        meta = s[s.index(".name:           " + name):]
+        assert int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1)) == 0, name
+        dma = [i for i, l in enumerate(lines) if l.startswith("global_load_lds_dwordx4")]
+        bars = [i for i, l in enumerate(lines) if l == "s_barrier"]
+        # groups of four DMA instructions; the prologue's group is followed by a barrier before any MFMA
+        groups = [dma[i:i + 4] for i in range(0, len(dma), 4)]
+        assert all(len(g) == 4 and g[3] - g[0] < 40 for g in groups), (name, dma)
+        for g in groups:
+            nb = min(b for b in bars if b > g[3])
+            seg = lines[g[3]:nb]
+            mf = [i for i, l in enumerate(seg) if l.startswith("v_mfma_f32_32x32x16_bf16")]
+            if not mf:
+                continue                                   # the prologue's fetch
+            assert len(mf) in (16, 20), (name, len(mf))
+            for l in seg[:mf[-1]]:
+                assert "vmcnt" not in l, (name, l)
+            assert sum(1 for l in seg if l == "s_waitcnt lgkmcnt(3)") >= 5, name
+            assert sum(1 for l in seg if l == "s_waitcnt lgkmcnt(4)") == 3, name
+            assert sum(1 for l in seg if l.startswith("ds_read_b64_tr_b16")) == 16, name
+            loops += 1
+        seen += 1
+    assert seen == 5 and loops >= 15, (seen, loops)
+
+
 def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):
     """256 x 256 TN weight-gradient kernel: at the register limit (256) the lane constants of the staging addresses used to be
     spilled and reloaded at the start of every work unit behind `s_waitcnt vmcnt(0)` -- a drain of the previous unit's 128

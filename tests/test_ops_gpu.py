@@ -719,15 +719,21 @@ def test_alibi_scale_gradient_is_well_conditioned_in_bf16(ops, S, kind):
         assert e_u > e_c, (e_c, e_u)
 
 
+@pytest.mark.parametrize("kern", [1, 0])
 @pytest.mark.parametrize("S", [700, 64, 130, 257, 1000, 2000])
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_attention_teacher_arange_long(ops, dtype, S):
+def test_attention_teacher_arange_long(ops, dtype, S, kern, request):
     """positions = arange (the teacher): the bf16 kernel takes the per-key ALiBi form off the diagonal (bias as the MFMA's
     C operand, row constant dropped, running maximum re-based at the two phase changes) -- output AND log-sum-exp must come
-    out in true units whatever phase the last key tile was in (ragged last tile in either form: S = 700, 130, 257, 1000)."""
+    out in true units whatever phase the last key tile was in (ragged last tile in either form: S = 700, 130, 257, 1000).
+    kern: a2v_debug_set(36): the 32 x 32 x 16 kernel of round 5 (default) and the 16 x 16 x 32 one it replaced for S >= 512."""
     N, H, hd = 1, 2, 64
     if dtype == torch.float32 and S > 1000:
         pytest.skip("fp32 reference kernel: covered at S <= 1000")
+    if kern == 0 and (dtype != torch.bfloat16 or S < 512):
+        pytest.skip("the switch only exists for the bf16 long-sequence forward")
+    ops.debug_set(36, kern)
+    request.addfinalizer(lambda: ops.debug_set(36, 1))
     qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=4)
     slopes = torch.tensor(O.alibi_slopes(H))
     sc = torch.tensor([1.3, -0.2])          # negative learned scale is clamped to 0
@@ -752,10 +758,11 @@ def test_attention_teacher_arange_long(ops, dtype, S):
 
 @pytest.mark.parametrize("S", [700, 2000])
 def test_attention_alibi_band_limit_changes_nothing(ops, S):
-    """positions = arange, S >= 512: key tiles beyond d_cut = (2B + 32) / (slope * alibi_scale) of every query row of a workgroup are
-    skipped (B = bound of |q.k| scale from the row norms, attn_qk_bound_kernel).  The skipped softmax weights are below e^-32 of
-    the row sum, so the output and the lse must agree with the all-tiles run to fp32 round-off -- whatever the slopes (steep:
-    most tiles skipped; flat / zero scale: none)."""
+    """positions = arange, S >= 512: key tiles beyond d_cut = (2B + 20) / (slope * alibi_scale) of every query row of a workgroup are
+    skipped (B = bound of |q.k| scale from the row norms, attn_qk_bound_kernel).  The skipped softmax weights are below e^-20 of
+    the row sum EACH (the bound; 4e-6 over 2000 keys, 500 times below the 2^-9 rounding of the kernel's P), so the output must agree
+    with the all-tiles run bit for bit in bf16 and the lse to 1e-5 -- whatever the slopes (steep: most tiles skipped; flat / zero
+    scale: none)."""
     N, H, hd = 2, 4, 64
     qkv = dev(rnd(N, S, 3 * H * hd, dtype=torch.bfloat16, seed=11) * 1.5, torch.bfloat16)
     slopes = torch.tensor(O.alibi_slopes(H)).cuda()
@@ -768,6 +775,32 @@ def test_attention_alibi_band_limit_changes_nothing(ops, S):
         ops.debug_set(19, 1)
         assert torch.equal(o1, o0), sc                      # bf16 outputs: bit-identical
         assert (l1 - l0).abs().max() < 1e-5, sc
+
+
+@pytest.mark.parametrize("S,kind,drop", [(2000, "arange", None), (1100, "arange", None), (700, "kept", None), (700, "kept", (0.1, 77)),
+                                         (640, "arange", (0.1, 5))])
+def test_attention_fwd32_matches_the_16x16_kernel(ops, S, kind, drop):
+    """Round 5: for S >= 512 the bf16 forward runs on v_mfma_f32_32x32x16_bf16 (attn_fwd32_bf16_kernel: a wave owns 32 query rows as one
+    column block, K / V tiles arrive by LDS-DMA, fragments by counted raw LDS reads).  Same arithmetic as the 16 x 16 x 32 kernel up to the
+    order of the fp32 sums: output (bf16), log-sum-exp and mean attended distance of all its variants (forward only; with lse + mdist;
+    explicit positions = every tile in the |.| form; dropout: same mask, keyed by (row, key)) are held against that kernel."""
+    N, H, hd = 2, 4, 64
+    g = torch.Generator().manual_seed(3)
+    qkv = dev(rnd(N, S, 3 * H * hd, dtype=torch.bfloat16, seed=21) * 1.3, torch.bfloat16)
+    slopes = torch.tensor(O.alibi_slopes(H)).cuda()
+    sc = torch.tensor([1.0, 0.3, 6.0, 0.0]).cuda()
+    pos = None if kind == "arange" else torch.stack([torch.randperm(4000, generator=g)[:S].sort()[0] for _ in range(N)]).int().cuda()
+    res = {}
+    for kern in (1, 0):
+        ops.debug_set(36, kern)
+        o, lse = ops.attention_fwd(qkv, pos, slopes, sc, H, need_lse=True, drop=drop)
+        o2 = ops.attention_fwd(qkv, pos, slopes, sc, H, need_lse=False, drop=drop)[0] if drop is None else o
+        res[kern] = (o.float(), lse.clone(), o2.float())
+    ops.debug_set(36, 1)
+    assert rel_err(res[1][0], res[0][0]) < 4e-3                      # bf16 outputs of two summation orders
+    assert rel_err(res[1][2], res[0][2]) < 4e-3
+    assert (res[1][1][0] - res[0][1][0]).abs().max() < 1e-4          # lse
+    assert rel_err(res[1][1][1], res[0][1][1]) < 1e-4                # mean attended distance
 
 
 @pytest.mark.parametrize("S", [700, 2000])
