@@ -28,6 +28,8 @@ SIGNATURES = {
                            _p, _p, _i, _i, _i, _i, _i, _f, _u, _p],
     "a2v_conv_wgrad_rows": [_p, _i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                             _i, _p],
+    "a2v_conv_wgrad_kept": [_p, _i, _i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
+                            _i, _p],
     "a2v_linear_wgrad_pair": [_i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p],
     "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
     "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],

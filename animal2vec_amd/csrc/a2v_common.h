@@ -372,5 +372,7 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 #define A2V_WS_DAL_BYTES (65536 * 4)
 #define A2V_WS_CSPART (A2V_WS_DAL + A2V_WS_DAL_BYTES)  /* 4 Mi fp32: column-sum partial rows of the persistent NT GEMM's epilogue */
 #define A2V_WS_CSPART_BYTES ((1 << 22) * 4)
-#define A2V_WS_BYTES (A2V_WS_CSPART + A2V_WS_CSPART_BYTES)
+#define A2V_WS_SPTAB (A2V_WS_CSPART + A2V_WS_CSPART_BYTES) /* kept-row table of conv_wgrad_sparse_kernel (rewritten by every call that uses it) */
+#define A2V_WS_SPTAB_BYTES (4 << 20)
+#define A2V_WS_BYTES (A2V_WS_SPTAB + A2V_WS_SPTAB_BYTES)
 char* a2v_stream_ws(hipStream_t stream);               // the stream's workspace (bound or static), nullptr if none is left

@@ -50,6 +50,7 @@ struct WgradArgs {
   float* W; long long ldw; long long w_gstride;  // fp32 [G][N][ldw], accumulated with atomics
   int M, N, K, G;
   int m_chunk;                   // rows of M handled by one split (multiple of the M step)
+  const int* skip_if = nullptr;  // gemm_tn_bf16_fast_kernel: return at once if *skip_if != 0 (the fallback behind conv_wgrad_sparse_kernel)
 };
 
 // ----------------------------------------------------------------------------------------------
@@ -188,6 +189,7 @@ bool a2v_launch_conv_slab_o32(const GemmArgs& g, hipStream_t stream); // grouped
 bool a2v_launch_tn_bf16_p8(const WgradArgs& g, hipStream_t stream);   // a2v_gemm_tn8.hip: 256x256 weight gradients of the Linears
 bool a2v_launch_tn_bf16_p8_pair(const WgradArgs* ga, const WgradArgs* gb, hipStream_t stream);   // two of them in one launch
 bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream);
+int a2v_launch_wgrad_sparse(const WgradArgs& g, int n_seq, hipStream_t stream, const int** ok_flag);   // a2v_wgrad_sparse.hip
 bool a2v_launch_conv_dec48(const GemmArgs& g, hipStream_t stream);     // a2v_conv_dec.hip: decoder grouped conv (48 channels per group, HBM-bound)
 bool a2v_launch_conv_slab(const GemmArgs& g, hipStream_t stream);      // a2v_conv_slab.hip: grouped-conv forward / input grads    // a2v_wgrad_slab.hip: grouped-conv weight grads     // a2v_gemm_p8.hip: 256x256 8-phase kernel
 bool a2v_launch_tn_bf16_fast(const WgradArgs& g, int splits, hipStream_t stream);

@@ -558,7 +558,8 @@ extern "C" int a2v_conv_gemm_rows(const int* rowidx, int dtype, const void* A, l
   return conv_gemm_impl(rowidx, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, Bw, ldb, b_gstride, C, ldc, c_goff, C2, R, ldr, bias, colsum, M, N, K, G, flags, drop_p, drop_seed, stream);
 }
 
-static int conv_wgrad_impl(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+int g_a2v_wgrad_sparse = 1;   // a2v_debug_set(37, v): row-sparse weight gradients of the positional encoder (a2v_wgrad_sparse.hip) on / off
+static int conv_wgrad_impl(const int* rowidx, int n_seq, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
                               int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
                               const void* P, long long ldp,
                               int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
@@ -583,9 +584,27 @@ static int conv_wgrad_impl(const int* rowidx, int dtype, const void* A, long lon
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+  if (dtype == A2V_BF16 && !rowidx && rowmask && g_a2v_wgrad_sparse) {
+    // first pos-conv layer: X is zero at the masked frames.  (The kernel behind it runs only if the sparse kernel's table builder
+    // found a window it cannot take: WgradArgs::skip_if.)
+    const int* ok = nullptr;
+    if (a2v_launch_wgrad_sparse(g, 0, stream, &ok) == 1) {
+      A2V_CHECK_LAUNCH();
+      g.skip_if = ok;
+    }
+  }
   if (dtype == A2V_BF16 && !rowidx && g_a2v_wgrad_slab && a2v_launch_wgrad_slab(g, stream)) {
     A2V_CHECK_LAUNCH();
     return A2V_OK;
+  }
+  if (dtype == A2V_BF16 && rowidx && n_seq > 0 && g_a2v_wgrad_sparse) {
+    // last pos-conv layer: dY exists at the kept frames only.  The sparse kernel needs an ascending row list; its table builder
+    // checks that on the device, and the gathered TN kernel below runs only if the check failed.
+    const int* ok = nullptr;
+    if (a2v_launch_wgrad_sparse(g, n_seq, stream, &ok) == 2) {
+      A2V_CHECK_LAUNCH();
+      g.skip_if = ok;
+    }
   }
   const int tiles = dtype == A2V_BF16 ? a2v_tn_bf16_tiles(N, K) : cdiv(N, 128) * cdiv(K, 128);
   const int step = dtype == A2V_BF16 ? TN_MSTEP : 16;
@@ -613,14 +632,22 @@ extern "C" int a2v_conv_wgrad(int dtype, const void* A, long long a_pitch, long 
                               const void* P, long long ldp,
                               int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
                               hipStream_t stream) {
-  return conv_wgrad_impl(nullptr, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
+  return conv_wgrad_impl(nullptr, 0, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
 }
 extern "C" int a2v_conv_wgrad_rows(const int* rowidx, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
                               int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
                               const void* P, long long ldp,
                               int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
                               hipStream_t stream) {
-  return conv_wgrad_impl(rowidx, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
+  return conv_wgrad_impl(rowidx, 0, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
+}
+extern "C" int a2v_conv_wgrad_kept(const int* rowidx, int n_seq, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                              int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                              const void* P, long long ldp,
+                              int p_goff, float* W, long long ldw, long long w_gstride, int M, int N, int K, int G,
+                              hipStream_t stream) {
+  if (!rowidx || n_seq <= 0 || M % n_seq) return A2V_ERR_ARG;
+  return conv_wgrad_impl(rowidx, n_seq, dtype, A, a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv, rowmask, bdiv, P, ldp, p_goff, W, ldw, w_gstride, M, N, K, G, stream);
 }
 
 // Two Linear weight gradients over the same M rows (gw_a[Na,Ka] += dy_a^T x_a, gw_b[Nb,Kb] += dy_b^T x_b) in one launch
@@ -642,9 +669,9 @@ extern "C" int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long
       return A2V_OK;
     }
   }
-  int rc = conv_wgrad_impl(nullptr, dtype, xa, lda, 0, 0, M, M, 1, 0, 1, Ka, 0, nullptr, 1, dya, ldpa, 0, gwa, ldwa, 0, M, Na, Ka, 1, stream);
+  int rc = conv_wgrad_impl(nullptr, 0, dtype, xa, lda, 0, 0, M, M, 1, 0, 1, Ka, 0, nullptr, 1, dya, ldpa, 0, gwa, ldwa, 0, M, Na, Ka, 1, stream);
   if (rc) return rc;
-  return conv_wgrad_impl(nullptr, dtype, xb, ldb_, 0, 0, M, M, 1, 0, 1, Kb, 0, nullptr, 1, dyb, ldpb, 0, gwb, ldwb, 0, M, Nb, Kb, 1, stream);
+  return conv_wgrad_impl(nullptr, 0, dtype, xb, ldb_, 0, 0, M, M, 1, 0, 1, Kb, 0, nullptr, 1, dyb, ldpb, 0, gwb, ldwb, 0, M, Nb, Kb, 1, stream);
 }
 
 // ---- per-stream workspaces (a2v_common.h)
@@ -741,6 +768,7 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off
+  if (key == 37) { g_a2v_wgrad_sparse = value; return A2V_OK; }  // row-sparse pos-conv weight gradients on / off
   if (key == 36) { g_a2v_attn_fwd32 = value; return A2V_OK; }  // long-sequence attention forward: 32 x 32 x 16 kernel on / off
   if (key == 19) { g_a2v_attn_band = value; return A2V_OK; }  // long-sequence attention forward: ALiBi band limit on / off
   if (key == 18) { g_a2v_attn_msum = value; return A2V_OK; }  // forward-only long-sequence attention: P row sums on the matrix cores on / off

@@ -412,6 +412,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g, int
   constexpr int TI = WNN / 16;                         // 16-wide n tiles per wave
   static_assert(TNK == 128, "kk tile is 128");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (g.skip_if && *g.skip_if) return;                 // (launched behind conv_wgrad_sparse_kernel: only runs if that one could not)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wm = wid / WK, wn = wid % WK;
   const int tiles_k = (g.K + TNK - 1) / TNK;

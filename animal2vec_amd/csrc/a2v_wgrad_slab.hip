@@ -34,6 +34,7 @@ __device__ __forceinline__ bf16x8 ws_frag(const char* p) {      // rows r .. r+3
 template <int CPW, bool MASKED>
 __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int clips_per_unit) {
   __shared__ __attribute__((aligned(16))) char smem[2 * WS_STAGE];
+  if (g.skip_if && *g.skip_if) return;                   // (launched behind conv_wgrad_sparse_kernel: only runs if that one could not)
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const ConvA& a = g.a;
   const int grp = blockIdx.y;

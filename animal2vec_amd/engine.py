@@ -338,7 +338,7 @@ class Engine:
             gw = sp.gw[w]                          # cleared by the previous unpack_wgrad (zero at allocation)
             ops.conv1d_cl_wgrad(sv["x"], dc, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T,
                                 rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None,
-                                cv=m["Cg"], rowidx=rows if last else None)
+                                cv=m["Cg"], rowidx=rows if last else None, rows_kept=last)
             ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
             if last:                                   # the input gradient needs dc as a dense (N,T,D) operand
                 dc = ops.scatter_tokens(dc.view(N, K, D), ids_restore, T)

@@ -315,10 +315,17 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
 
 
 def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride, a_goff=0,
-               rowmask=None, bdiv=1, ldp, p_goff=0, ldw, w_gstride=0, rowidx=None):
+               rowmask=None, bdiv=1, ldp, p_goff=0, ldw, w_gstride=0, rowidx=None, n_seq=0):
+    """n_seq (with rowidx): the rows are the kept frames of n_seq sequences, M / n_seq each, ascending (masking.make_maskinfo) --
+    the kept-frame entry (include/a2v.h: a2v_conv_wgrad_kept), same result as the gathered one."""
     args = (dt(x), ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
             ptr(rowmask), bdiv, ptr(dy), ldp, p_goff, ptr(gw), ldw, w_gstride, M, N, K, G, stream())
-    rc = _L().a2v_conv_wgrad(*args) if rowidx is None else _L().a2v_conv_wgrad_rows(ptr(rowidx), *args)
+    if rowidx is None:
+        rc = _L().a2v_conv_wgrad(*args)
+    elif n_seq > 0 and M % n_seq == 0:
+        rc = _L().a2v_conv_wgrad_kept(ptr(rowidx), n_seq, *args)
+    else:
+        rc = _L().a2v_conv_wgrad_rows(ptr(rowidx), *args)
     check(rc, "a2v_conv_wgrad")
     return gw
 
@@ -374,8 +381,9 @@ def linear_wgrad_pair(xa, dya, gwa, xb, dyb, gwb):
 
 
 def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=None, bdiv=1, n_batch=None, cv=None,
-                    rowidx=None):
-    """gw_packed (G, N, k*Cg) fp32 += implicit-im2col(x)^T dy.  rowidx: dy holds only those rows (compact)."""
+                    rowidx=None, rows_kept=False):
+    """gw_packed (G, N, k*Cg) fp32 += implicit-im2col(x)^T dy.  rowidx: dy holds only those rows (compact); rows_kept: they are
+    the kept frames of the batch's sequences, equally many per sequence and ascending (conv_wgrad's n_seq)."""
     Bsrc, T_in, Cp = x.shape
     B = n_batch if n_batch is not None else Bsrc
     G = groups
@@ -399,7 +407,7 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
                        ldw=gw_packed.stride(-2), w_gstride=gw_packed.stride(0) if G > 1 else 0)
         return gw_packed
     return conv_wgrad(x, dy, gw_packed, M=B * T_out if rowidx is None else rowidx.numel(), N=N, K=k * Cg, G=G, T_in=T_in,
-                      T_out=T_out, stride=stride, pad=pad, rowidx=rowidx,
+                      T_out=T_out, stride=stride, pad=pad, rowidx=rowidx, n_seq=B if (rowidx is not None and rows_kept) else 0,
                       taps=k, Cg=Cg, Cv=cv, a_pitch=x.stride(1), a_bstride=x.stride(0), a_goff=cv if G > 1 else 0,
                       rowmask=rowmask, bdiv=bdiv, ldp=n_out, p_goff=N, ldw=gw_packed.stride(-2),
                       w_gstride=gw_packed.stride(0) if G > 1 else 0)

@@ -104,6 +104,17 @@ int a2v_conv_wgrad_rows(const int* rowidx, int dtype, const void* A, long long a
                         int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
                         const void* P, long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N,
                         int K, int G, a2v_stream_t stream);
+/* The kept-frame form of a2v_conv_wgrad_rows (ABI 12): rowidx holds the rows of n_seq sequences, M / n_seq each, strictly
+ * ascending -- what the reference's x[ids_keep] gather produces when the kept frames stay in frame order (base.py:300-314;
+ * animal2vec_amd/masking.py resolves the reference's unstable argsort that way).  Same result as a2v_conv_wgrad_rows; with 64
+ * channels per group, stride 1 and bf16 the product runs over the kept rows against time-contiguous slabs of the dense operand
+ * (a2v_wgrad_sparse.hip) instead of re-gathering a taps-row window per kept row.  The order is checked on the device: a list that
+ * is not ascending takes the a2v_conv_wgrad_rows kernel.  (a2v_conv_wgrad with a row mask -- the first layer, whose INPUT is zero
+ * at the masked frames -- takes the same kernel with the operands' roles exchanged; no new entry is needed there.) */
+int a2v_conv_wgrad_kept(const int* rowidx, int n_seq, int dtype, const void* A, long long a_pitch, long long a_bstride, int a_goff, int T_in,
+                        int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
+                        const void* P, long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N,
+                        int K, int G, a2v_stream_t stream);
 
 /* Two Linear weight gradients over the same M rows in one launch (gw_a[Na,Ka] += dy_a^T x_a, gw_b[Nb,Kb] += dy_b^T x_b;
  * torch.autograd's two separate addmm in the reference).  Sharing the launch lets the 256x256 TN kernel cut M into

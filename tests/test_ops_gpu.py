@@ -523,11 +523,11 @@ def test_conv_slab_kernels_masked_long(ops):
 
     y, dx, gw = run()
     lib = _lib.load()
-    lib.a2v_debug_set(2, 0); lib.a2v_debug_set(3, 0)
+    lib.a2v_debug_set(2, 0); lib.a2v_debug_set(3, 0); lib.a2v_debug_set(37, 0)
     try:
         y0, dx0, gw0 = run()
     finally:
-        lib.a2v_debug_set(2, 1); lib.a2v_debug_set(3, 1)
+        lib.a2v_debug_set(2, 1); lib.a2v_debug_set(3, 1); lib.a2v_debug_set(37, 1)
     assert rel_err(y.float(), ref.detach()) < tol(dtype)
     assert rel_err(dx.float(), xm.grad) < tol(dtype, 2)
     assert rel_err(gw, gw0) < 1e-4                              # fp32 atomics in a different order
@@ -571,6 +571,70 @@ def test_conv_row_gather(ops, dtype, D, G):
     gw_un = torch.zeros(D, Cg, k, dtype=torch.float32, device="cuda")
     ops.unpack_wgrad(gw, gw_un, GN=D, Cg=Cg, k=k, Cgp=cgp)
     assert rel_err(gw_un, wr.grad) < tol(dtype, 2)
+
+
+@pytest.mark.parametrize("T,keep_frac,k", [(700, 0.08, 19), (2000, 0.076, 19), (300, 0.6, 19), (128, 0.3, 7), (131, 1.0, 19)])
+def test_conv_wgrad_sparse_rows(ops, T, keep_frac, k):
+    """a2v_wgrad_sparse.hip (round 5): the positional encoder's weight gradients where one operand is row-sparse.
+    mode A -- a2v_conv_wgrad with a row mask (first layer: X = clone * (1 - mask) is zero at the masked frames),
+    mode B -- a2v_conv_wgrad_kept (last layer: dY only exists at the kept frames, ascending row list),
+    both against fp32 autograd of the dense convolution and against the kernels they replace (a2v_debug_set(37, 0): the masked slab
+    kernel / the gathered TN kernel); a row list that is NOT ascending must take the gathered kernel (checked on the device) and
+    still be right.  Ragged last window (T = 700, 300, 131), every frame kept (131), a window without kept frames (T = 2000 clone 0)."""
+    dtype = torch.bfloat16
+    B, cb, D, G = 2, 3, 128, 2
+    Cg = D // G
+    N = B * cb
+    gen = torch.Generator().manual_seed(7)
+    x = rnd(B, T, D, dtype=dtype, seed=1)
+    w = rnd(D, Cg, k, dtype=dtype, seed=2, scale=(Cg * k) ** -0.5)
+    K = max(1, int(round(T * keep_frac)))
+    keep = torch.stack([torch.randperm(T, generator=gen)[:K].sort().values for _ in range(N)])                     # (N, K) ascending
+    if T == 2000:
+        keep[0] = torch.cat([torch.arange(0, K // 2), torch.arange(1000, 1000 + K - K // 2)])                       # clone 0: empty windows
+    mask = torch.ones(N, T, dtype=torch.uint8)
+    mask.scatter_(1, keep, 0)
+    rowidx = (torch.arange(N).unsqueeze(1) * T + keep).reshape(-1).to(torch.int32)
+    xm = x.repeat_interleave(cb, 0) * (1 - mask.float().unsqueeze(-1))
+    xd, md, ri = dev(x, dtype), mask.cuda(), rowidx.cuda()
+
+    def unpacked(gw):
+        un = torch.zeros(D, Cg, k, dtype=torch.float32, device="cuda")
+        ops.unpack_wgrad(gw.clone(), un, GN=D, Cg=Cg, k=k, Cgp=Cg)
+        return un
+
+    # ---- mode A: dense dY, masked X
+    wr = w.clone().requires_grad_(True)
+    dy = rnd(N, T, D, dtype=dtype, seed=5)
+    F.conv1d(xm.transpose(1, 2), wr, None, padding=k // 2, groups=G).transpose(1, 2).backward(dy)
+    res = {}
+    for sw in (1, 0):
+        ops.debug_set(37, sw)
+        gw = torch.zeros(G, Cg, k * Cg, dtype=torch.float32, device="cuda")
+        ops.conv1d_cl_wgrad(xd, dev(dy, dtype), gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, rowmask=md, bdiv=cb, n_batch=N)
+        res[sw] = gw
+    ops.debug_set(37, 1)
+    assert rel_err(unpacked(res[1]), wr.grad) < tol(dtype, 2)
+    assert rel_err(res[1], res[0]) < 1e-4                                  # the same bf16 products, fp32 sums in another order
+
+    # ---- mode B: compact dY at the kept frames, dense X (no mask: a later layer's input)
+    wr = w.clone().requires_grad_(True)
+    xfull = rnd(N, T, D, dtype=dtype, seed=8)
+    ref = F.conv1d(xfull.transpose(1, 2), wr, None, padding=k // 2, groups=G).transpose(1, 2).reshape(N * T, D)
+    dyk = rnd(rowidx.numel(), D, dtype=dtype, seed=9)
+    ref[rowidx.long()].backward(dyk)
+    xf = dev(xfull, dtype)
+    perm = torch.randperm(rowidx.numel(), generator=gen)
+    cases = {"kept": (ri, dev(dyk, dtype), True), "rows": (ri, dev(dyk, dtype), False),
+             "not ascending": (ri[perm.cuda()].contiguous(), dev(dyk[perm], dtype), True)}
+    out = {}
+    for name, (rr, dd, kept) in cases.items():
+        gw = torch.zeros(G, Cg, k * Cg, dtype=torch.float32, device="cuda")
+        ops.conv1d_cl_wgrad(xf, dd, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, rowidx=rr, rows_kept=kept)
+        out[name] = gw
+        assert rel_err(unpacked(gw), wr.grad) < tol(dtype, 2), name
+    assert rel_err(out["kept"], out["rows"]) < 1e-4
+    assert rel_err(out["not ascending"], out["rows"]) < 1e-4
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
