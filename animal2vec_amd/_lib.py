@@ -28,6 +28,7 @@ SIGNATURES = {
                            _p, _p, _i, _i, _i, _i, _i, _f, _u, _p],
     "a2v_conv_wgrad_rows": [_p, _i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                             _i, _p],
+    "a2v_conv_sparse_in": [_i, _p, _ll, _ll, _i, _p, _i, _p, _i, _i, _i, _i, _i, _p, _ll, _ll, _p, _p, _ll, _i, _i, _p],
     "a2v_conv_wgrad_kept": [_p, _i, _i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                             _i, _p],
     "a2v_linear_wgrad_pair": [_i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p],

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "liba2v_hip.so")
-SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_gemm_p8.hip", "a2v_gemm_tn8.hip", "a2v_wgrad_slab.hip", "a2v_wgrad_sparse.hip", "a2v_conv_slab.hip", "a2v_conv_dec.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip", "a2v_mixup.hip", "a2v_mask.hip", "a2v_conv_strided.hip", "a2v_split.hip"]
+SOURCES = ["a2v_gemm.hip", "a2v_gemm_fast.hip", "a2v_gemm_p8.hip", "a2v_gemm_tn8.hip", "a2v_wgrad_slab.hip", "a2v_wgrad_sparse.hip", "a2v_conv_slab.hip", "a2v_conv_sparse.hip", "a2v_conv_dec.hip", "a2v_attn.hip", "a2v_norm.hip", "a2v_elem.hip", "a2v_sinc.hip", "a2v_mixup.hip", "a2v_mask.hip", "a2v_conv_strided.hip", "a2v_split.hip"]
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in arch VGPRs (no kernel here needs > 256 registers), which removes the
 # v_accvgpr_read/write copies around every VALU use of an accumulator (softmax, epilogues: 96 of 417 VALU per attention step)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form"]

@@ -306,9 +306,15 @@ class Engine:
             w = P + f"relative_positional_encoder.{i}.0.weight"
             first = i == 1 and mask_u8 is not None
             ri = rows if i == depth else None
-            c = ops.conv1d_cl(x, pk.w[w], params[P + f"relative_positional_encoder.{i}.0.bias"], k=k, stride=1, pad=k // 2,
-                              groups=a.conv_pos_groups, T_out=T, n_out=D, rowmask=mask_u8 if first else None,
-                              bdiv=cb if first else 1, n_batch=N if first else None, cv=pk.meta[w]["Cg"], rowidx=ri)
+            bias_i = params[P + f"relative_positional_encoder.{i}.0.bias"]
+            if first and ri is None and ops.conv_sparse_ok(x, pk.w[w], k=k, groups=a.conv_pos_groups, n_out=D):
+                # the masked clones are zero at 92 % of their frames: products per kept row, scatter-added into the output window
+                c = ops.conv1d_cl_sparse_in(x, pk.w[w], bias_i, k=k, pad=k // 2, groups=a.conv_pos_groups, T=T, n_out=D, n_seq=N,
+                                            rowmask=mask_u8, bdiv=cb)
+            else:
+                c = ops.conv1d_cl(x, pk.w[w], bias_i, k=k, stride=1, pad=k // 2,
+                                  groups=a.conv_pos_groups, T_out=T, n_out=D, rowmask=mask_u8 if first else None,
+                                  bdiv=cb if first else 1, n_batch=N if first else None, cv=pk.meta[w]["Cg"], rowidx=ri)
             y, mean, rstd = ops.layernorm_fwd(c, None, None, 1e-5, act=1, save_stats=save,
                                               post=post if ri is not None else None)
             if save:
@@ -340,6 +346,11 @@ class Engine:
                                 rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None,
                                 cv=m["Cg"], rowidx=rows if last else None, rows_kept=last)
             ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
+            if last and not first and ops.conv_sparse_ok(dc, sp.wt[w], k=k, groups=G, n_out=D):
+                # dc only exists at the kept frames: its products are scatter-added into the dense input gradient (no zero-filled copy)
+                dy = ops.conv1d_cl_sparse_in(dc.view(N * K, D), sp.wt[w], None, k=k, pad=k - 1 - k // 2, groups=G, T=T, n_out=D, n_seq=N,
+                                             rowidx=rows)
+                continue
             if last:                                   # the input gradient needs dc as a dense (N,T,D) operand
                 dc = ops.scatter_tokens(dc.view(N, K, D), ids_restore, T)
             if first:

@@ -314,6 +314,36 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
                      rowidx=rowidx)
 
 
+CONV_SPARSE = os.environ.get("A2V_CONV_SPARSE", "1") != "0"     # =0: the row-sparse pos-conv products (a2v_conv_sparse_in) off (A/B runs)
+
+
+def conv_sparse_ok(x, w_packed, *, k, groups, n_out):
+    """a2v_conv_sparse_in takes it: bf16, the positional encoder's shape (19 taps, 64 channels per group in and out)"""
+    return (CONV_SPARSE and x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and k == 19 and n_out == groups * 64
+            and w_packed.shape[-1] == k * 64 and w_packed.shape[-2] == 64 and x.stride(-1) == 1)
+
+
+def conv1d_cl_sparse_in(x, w_packed, bias, *, k, pad, groups, T, n_out, n_seq, rowmask=None, bdiv=1, rowidx=None, out=None):
+    """Channels-last grouped conv whose INPUT is row-sparse (include/a2v.h: a2v_conv_sparse_in) -> (n_seq, T, n_out).
+    rowmask (n_seq, T) u8: x (Bsrc, T, C) holds the sequences (clone c reads sequence c // bdiv), non-zero where the mask is 0;
+    rowidx (n_seq * K) int32: x (n_seq * K, C) is compact, row i belongs at flat frame rowidx[i]."""
+    G = groups
+    if out is None:
+        out = _E(n_seq, T, n_out, dtype=x.dtype, device=x.device)
+    if rowidx is not None:
+        K = rowidx.numel() // n_seq
+        assert x.dim() == 2 and x.shape[0] == rowidx.numel() and K * n_seq == rowidx.numel()
+        xp, xb = x.stride(0), 0
+    else:
+        K = 0
+        xp, xb = x.stride(1), x.stride(0)
+    rc = _L().a2v_conv_sparse_in(dt(x), ptr(x), xp, xb, 64 if G > 1 else 0, ptr(rowmask), bdiv, ptr(rowidx), K, n_seq, T, pad, k,
+                                 ptr(w_packed), w_packed.stride(-2), w_packed.stride(0) if G > 1 else 0, ptr(bias), ptr(out), n_out,
+                                 64, G, stream())
+    check(rc, "a2v_conv_sparse_in")
+    return out
+
+
 def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride, a_goff=0,
                rowmask=None, bdiv=1, ldp, p_goff=0, ldw, w_gstride=0, rowidx=None, n_seq=0):
     """n_seq (with rowidx): the rows are the kept frames of n_seq sequences, M / n_seq each, ascending (masking.make_maskinfo) --

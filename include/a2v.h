@@ -104,6 +104,20 @@ int a2v_conv_wgrad_rows(const int* rowidx, int dtype, const void* A, long long a
                         int T_out, int stride, int pad, int taps, int Cg, int Cv, const unsigned char* rowmask, int bdiv,
                         const void* P, long long ldp, int p_goff, float* W, long long ldw, long long w_gstride, int M, int N,
                         int K, int G, a2v_stream_t stream);
+/* Grouped convolution of a ROW-SPARSE input with a dense output (ABI 12; bf16, 64 channels per group in and out, stride 1,
+ * taps = 19: the positional encoder, audio.py:90-113):
+ *   Y[c][m][g*c_goff + n] = bias[g*c_goff + n] + sum_tap sum_ci W[g][n][tap*64 + ci] * X_c[m + tap - pad][g*x_goff + ci]
+ * for n_seq sequences of T frames, where X_c is zero outside a few rows given EITHER by rowmask (n_seq x T bytes; X_c = sequence
+ * c / bdiv of X (rows x_pitch apart, sequences x_bstride apart) at the frames whose mask byte is 0: the first layer's forward on
+ * clone * (1 - mask), base.py:292-314) OR by rowidx (n_seq x rows_per_seq flat indices c*T + t, any order; X compact: row i of X is
+ * frame rowidx[i]: the last layer's input gradient, whose output gradient only exists at the kept frames -- W is then the
+ * transposed / flipped pack and pad = taps - 1 - pad_forward).  Same result as a2v_conv_gemm on the dense (zero-filled) input up to
+ * the order of the fp32 sums; the products are formed per kept row and scatter-added into an fp32 tile of the output window
+ * (a2v_conv_sparse.hip).  W: (G, 64, taps*64) bf16, rows ldb apart, groups b_gstride apart; Y: (n_seq, T, ldc). */
+int a2v_conv_sparse_in(int dtype, const void* X, long long x_pitch, long long x_bstride, int x_goff, const unsigned char* rowmask,
+                       int bdiv, const int* rowidx, int rows_per_seq, int n_seq, int T, int pad, int taps, const void* W,
+                       long long ldb, long long b_gstride, const float* bias, void* Y, long long ldc, int c_goff, int G,
+                       a2v_stream_t stream);
 /* The kept-frame form of a2v_conv_wgrad_rows (ABI 12): rowidx holds the rows of n_seq sequences, M / n_seq each, strictly
  * ascending -- what the reference's x[ids_keep] gather produces when the kept frames stay in frame order (base.py:300-314;
  * animal2vec_amd/masking.py resolves the reference's unstable argsort that way).  Same result as a2v_conv_wgrad_rows; with 64

@@ -637,6 +637,59 @@ def test_conv_wgrad_sparse_rows(ops, T, keep_frac, k):
     assert rel_err(out["not ascending"], out["rows"]) < 1e-4
 
 
+@pytest.mark.parametrize("T,keep_frac", [(700, 0.08), (2000, 0.076), (300, 0.6), (160, 1.0), (95, 0.3)])
+def test_conv_sparse_in(ops, T, keep_frac):
+    """a2v_conv_sparse.hip (round 5): the positional encoder's two products whose INPUT is row-sparse and whose output is dense --
+    the first layer's forward on clone * (1 - mask) (rows from the mask bytes, bias) and the last layer's input gradient from the
+    compact output gradient (rows from the row list, the transposed / flipped pack, no bias) -- against fp32 torch and against the
+    dense kernels they replace (the zero-filled input through conv1d_cl).  Windows with more than 64 kept rows (several chunks),
+    a ragged last window, a window without kept rows, a row list that is not ascending (any order is taken)."""
+    dtype = torch.bfloat16
+    B, cb, D, G, k = 2, 3, 128, 2, 19
+    Cg = D // G
+    N = B * cb
+    gen = torch.Generator().manual_seed(11)
+    x = rnd(B, T, D, dtype=dtype, seed=1)
+    w = rnd(D, Cg, k, dtype=dtype, seed=2, scale=(Cg * k) ** -0.5)
+    bias = rnd(D, dtype=torch.float32, seed=4)
+    K = max(1, int(round(T * keep_frac)))
+    keep = torch.stack([torch.randperm(T, generator=gen)[:K].sort().values for _ in range(N)])
+    if T == 2000:
+        keep[0] = torch.cat([torch.arange(0, K // 2), torch.arange(1000, 1000 + K - K // 2)])
+    mask = torch.ones(N, T, dtype=torch.uint8)
+    mask.scatter_(1, keep, 0)
+    xd, md = dev(x, dtype), mask.cuda()
+    wp = dev(pack_ref(w, G, Cg), dtype)
+    # ---- forward of the first layer
+    xm = x.repeat_interleave(cb, 0) * (1 - mask.float().unsqueeze(-1))
+    ref = F.conv1d(xm.transpose(1, 2), w.float(), bias, padding=k // 2, groups=G).transpose(1, 2)
+    assert ops.conv_sparse_ok(xd, wp, k=k, groups=G, n_out=D)
+    y = ops.conv1d_cl_sparse_in(xd, wp, dev(bias, torch.float32), k=k, pad=k // 2, groups=G, T=T, n_out=D, n_seq=N, rowmask=md, bdiv=cb)
+    y0 = ops.conv1d_cl(xd, wp, dev(bias, torch.float32), k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, rowmask=md, bdiv=cb, n_batch=N)
+    assert rel_err(y.float(), ref) < tol(dtype)
+    assert rel_err(y.float(), y0.float()) < 3e-3                         # bf16 roundings of two summation orders
+    y_again = ops.conv1d_cl_sparse_in(xd, wp, dev(bias, torch.float32), k=k, pad=k // 2, groups=G, T=T, n_out=D, n_seq=N, rowmask=md, bdiv=cb)
+    assert torch.equal(y, y_again)                                       # a tile column is summed by one wave in program order
+    # ---- input gradient of the last layer: dY at the kept frames only
+    wt = torch.empty(G, Cg, k * Cg, dtype=dtype, device="cuda")
+    ops.pack_weight(dev(w, torch.float32), wt, G=G, N=Cg, Cg=Cg, k=k, mode=1)
+    dyk = rnd(N * K, D, dtype=dtype, seed=5)
+    rowidx = (torch.arange(N).unsqueeze(1) * T + keep).reshape(-1).to(torch.int32)
+    dyd = torch.zeros(N * T, D)
+    dyd[rowidx.long()] = dyk.float()
+    xin = torch.zeros(N, D, T, requires_grad=True)
+    F.conv1d(xin, w.float(), None, padding=k // 2, groups=G).backward(dyd.view(N, T, D).transpose(1, 2))
+    ref_dx = xin.grad.transpose(1, 2)
+    dx = ops.conv1d_cl_sparse_in(dev(dyk, dtype), wt, None, k=k, pad=k - 1 - k // 2, groups=G, T=T, n_out=D, n_seq=N, rowidx=rowidx.cuda())
+    dx0 = ops.conv1d_cl(dev(dyd.view(N, T, D), dtype), wt, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D)
+    assert rel_err(dx.float(), ref_dx) < tol(dtype, 2)
+    assert rel_err(dx.float(), dx0.float()) < 3e-3
+    perm = torch.cat([torch.randperm(K, generator=gen) + c * K for c in range(N)])       # any order inside a sequence's rows
+    dxp = ops.conv1d_cl_sparse_in(dev(dyk[perm], dtype), wt, None, k=k, pad=k - 1 - k // 2, groups=G, T=T, n_out=D, n_seq=N,
+                                  rowidx=rowidx[perm].cuda().contiguous())
+    assert rel_err(dxp.float(), ref_dx) < tol(dtype, 2)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_conv_dgrad_paths(ops, dtype):
     # stride-1 grouped conv: input gradient as a convolution with flipped/transposed weights (pack mode 1)
