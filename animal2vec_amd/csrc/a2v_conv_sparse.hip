@@ -29,7 +29,7 @@
 #define CSP_LIST 256                                      // list capacity per window (range = 178 frames)
 #define CSP_TILE_BYTES ((CSP_TROWS + 1) * CSP_TPITCH * 4)   // 53584: + one row, so that the slots past the list have 19 rows of their own
 #define CSP_XBUF_BYTES (CSP_CAP * CSP_XPITCH)             // 9216
-#define CSP_LDS (CSP_TILE_BYTES + 2 * CSP_XBUF_BYTES + 2 * (CSP_LIST * 4 + CSP_LIST) + 64)
+#define CSP_LDS (CSP_TILE_BYTES + 2 * CSP_XBUF_BYTES + 2 * (CSP_LIST * 4 + CSP_LIST) + 8 + 64)
 
 typedef __attribute__((address_space(3))) float csp_lds_float;
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
   int* const lsrc = (int*)(xbuf + 2 * CSP_XBUF_BYTES);                    // [2][CSP_LIST]
   unsigned char* const lrel = (unsigned char*)(lsrc + 2 * CSP_LIST);      // [2][CSP_LIST]
   int* const lcnt = (int*)(lrel + 2 * CSP_LIST);                          // [2]
-  int* const swc = lcnt + 2;                                              // [2 passes][4 waves]
+  int* const swc = lcnt + 2;                                              // [4 passes][4 waves]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = blockIdx.y, T = a.T, pad = a.pad;
   const int NW = (T + CSP_WIN - 1) / CSP_WIN;
@@ -76,11 +76,10 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
   for (int i = tid; i < (CSP_TROWS + 1) * CSP_TPITCH / 4; i += 256) ((f32x4*)tile)[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // ---- the kept rows of step s: frames lo .. lo + WIN + TAPS - 2 of clone c, lo = t0 - pad; entry = (source row, frame - lo)
-  constexpr int NP = ROWS ? 2 : 1;                         // scan passes (rows mode: K <= 512 list entries per clone)
-  int sflag[NP], ssrc[NP], srel[NP];
+  constexpr int NP = ROWS ? 4 : 1;                         // scan passes (rows mode: K <= 1024 list entries per sequence)
+  int sfl = 0, srl = 0;                                    // per pass p: bit p = entry in range; byte p = its frame - lo
   auto scan_load = [&](int s) {
-#pragma unroll
-    for (int p = 0; p < NP; ++p) { sflag[p] = 0; ssrc[p] = 0; srel[p] = 0; }
+    sfl = 0; srl = 0;
     if (s >= nsteps) return;
     const int c = c0 + s / NW, lo = (s - (s / NW) * NW) * CSP_WIN - pad;
     if constexpr (ROWS) {
@@ -89,27 +88,24 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
         const int i = tid + 256 * p;
         if (i < a.K) {
           const int f = a.rowidx[(long long)c * a.K + i] - c * T;
-          sflag[p] = (f >= max(lo, 0) && f < min(lo + CSP_WIN + TAPS - 1, T)) ? 1 : 0;
-          ssrc[p] = c * a.K + i;
-          srel[p] = f - lo;
+          if (f >= max(lo, 0) && f < min(lo + CSP_WIN + TAPS - 1, T)) { sfl |= 1 << p; srl |= (f - lo) << (8 * p); }
         }
       }
     } else {
       const int f = lo + tid;
-      if (tid < CSP_WIN + TAPS - 1 && f >= 0 && f < T) sflag[0] = a.rowmask[(long long)c * T + f] == 0 ? 1 : 0;
-      ssrc[0] = f;
-      srel[0] = tid;
+      if (tid < CSP_WIN + TAPS - 1 && f >= 0 && f < T && a.rowmask[(long long)c * T + f] == 0) { sfl = 1; srl = tid; }
     }
   };
   unsigned long long sbal[NP];
   auto list_count = [&]() {                                // before a barrier: every wave's number of kept entries, per pass
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      sbal[p] = __ballot(sflag[p] != 0);
+      sbal[p] = __ballot((sfl >> p) & 1);
       if (lane == 0) swc[p * 4 + wid] = __popcll(sbal[p]);
     }
   };
-  auto list_write = [&](int buf) {                         // behind that barrier: ordered compaction (pass, wave, lane)
+  auto list_write = [&](int buf, int s) {                  // behind that barrier: ordered compaction (pass, wave, lane) of step s's scan
+    const int c = c0 + s / NW, lo = (s - (s / NW) * NW) * CSP_WIN - pad;
     int before = 0, total = 0;
 #pragma unroll
     for (int p = 0; p < NP; ++p)
@@ -117,12 +113,16 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
       for (int v = 0; v < 4; ++v) total += swc[p * 4 + v];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-      int b = before;
+      int b_ = before;
 #pragma unroll
-      for (int v = 0; v < 4; ++v) { b += v < wid ? swc[p * 4 + v] : 0; before += swc[p * 4 + v]; }
-      if (sflag[p]) {
-        const int slot = b + __popcll(sbal[p] & ((1ull << lane) - 1ull));
-        if (slot < CSP_LIST) { lsrc[buf * CSP_LIST + slot] = ssrc[p]; lrel[buf * CSP_LIST + slot] = (unsigned char)srel[p]; }
+      for (int v = 0; v < 4; ++v) { b_ += v < wid ? swc[p * 4 + v] : 0; before += swc[p * 4 + v]; }
+      if ((sfl >> p) & 1) {
+        const int slot = b_ + __popcll(sbal[p] & ((1ull << lane) - 1ull));
+        const int rel = (srl >> (8 * p)) & 0xFF;
+        if (slot < CSP_LIST) {
+          lsrc[buf * CSP_LIST + slot] = ROWS ? c * a.K + tid + 256 * p : lo + rel;      // compact row / frame of the sequence
+          lrel[buf * CSP_LIST + slot] = (unsigned char)rel;
+        }
       }
     }
     if (tid == 0) lcnt[buf] = min(total, CSP_LIST);
@@ -189,14 +189,14 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
   scan_load(0);
   list_count();
   __syncthreads();
-  list_write(0);
+  list_write(0, 0);
   __syncthreads();
   scan_load(1);
   gather_load(0, 0, 0);
   list_count();
   gather_store(0);
   __syncthreads();
-  list_write(1);
+  list_write(1, 1);
   __syncthreads();
 
   for (int st = 0; st < nsteps; ++st) {
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
       }
     }
     gather_store(lb ^ 1);                                 // data of step st + 1
-    list_write(lb);                                       // list of step st + 2 (the list of step st has been consumed)
+    list_write(lb, st + 2);                               // list of step st + 2 (the list of step st has been consumed)
     __syncthreads();
   }
 }
@@ -264,7 +264,7 @@ extern "C" int a2v_conv_sparse_in(int dtype, const void* X, long long x_pitch, l
                                   hipStream_t stream) {
   if (dtype != A2V_BF16) return A2V_ERR_DTYPE;
   if (!X || !W || !Y || n_seq <= 0 || T <= 0 || G <= 0 || (!rowmask) == (!rowidx)) return A2V_ERR_ARG;
-  if (taps != CSP_TAPS || pad < 0 || pad >= taps || bdiv < 1 || (rowidx && (rows_per_seq <= 0 || rows_per_seq > 512))) return A2V_ERR_ARG;
+  if (taps != CSP_TAPS || pad < 0 || pad >= taps || bdiv < 1 || (rowidx && (rows_per_seq <= 0 || rows_per_seq > 1024))) return A2V_ERR_ARG;
   if ((x_pitch | ldb | ldc | b_gstride) % 8 || x_goff % 8 || c_goff % 8 || ((((uintptr_t)X) | ((uintptr_t)W) | ((uintptr_t)Y)) & 15)) return A2V_ERR_ARG;
   SpInArgs a{(const bf16*)X, x_pitch, x_bstride, x_goff, rowmask, bdiv, rowidx, rows_per_seq, T, pad, n_seq, (const bf16*)W, ldb, b_gstride,
              bias, (bf16*)Y, ldc, c_goff};

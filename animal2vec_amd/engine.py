@@ -346,7 +346,7 @@ class Engine:
                                 rowmask=mask_u8 if first else None, bdiv=cb if first else 1, n_batch=N if first else None,
                                 cv=m["Cg"], rowidx=rows if last else None, rows_kept=last)
             ops.unpack_wgrad(gw, g[w], GN=D, Cg=m["Cg"], k=k, Cgp=m["Cgp"])
-            if last and not first and ops.conv_sparse_ok(dc, sp.wt[w], k=k, groups=G, n_out=D):
+            if last and not first and ops.conv_sparse_ok(dc, sp.wt[w], k=k, groups=G, n_out=D, rows_per_seq=K):
                 # dc only exists at the kept frames: its products are scatter-added into the dense input gradient (no zero-filled copy)
                 dy = ops.conv1d_cl_sparse_in(dc.view(N * K, D), sp.wt[w], None, k=k, pad=k - 1 - k // 2, groups=G, T=T, n_out=D, n_seq=N,
                                              rowidx=rows)

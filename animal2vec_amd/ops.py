@@ -317,9 +317,10 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
 CONV_SPARSE = os.environ.get("A2V_CONV_SPARSE", "1") != "0"     # =0: the row-sparse pos-conv products (a2v_conv_sparse_in) off (A/B runs)
 
 
-def conv_sparse_ok(x, w_packed, *, k, groups, n_out):
-    """a2v_conv_sparse_in takes it: bf16, the positional encoder's shape (19 taps, 64 channels per group in and out)"""
-    return (CONV_SPARSE and x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and k == 19 and n_out == groups * 64
+def conv_sparse_ok(x, w_packed, *, k, groups, n_out, rows_per_seq=0):
+    """a2v_conv_sparse_in takes it: bf16, the positional encoder's shape (19 taps, 64 channels per group in and out); a row list
+    of at most 1024 rows per sequence"""
+    return (CONV_SPARSE and rows_per_seq <= 1024 and x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and k == 19 and n_out == groups * 64
             and w_packed.shape[-1] == k * 64 and w_packed.shape[-2] == 64 and x.stride(-1) == 1)
 
 

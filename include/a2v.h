@@ -329,7 +329,7 @@ int a2v_debug_set(int key, int value);
 int a2v_stream_release(a2v_stream_t stream);
 
 /* ---------------------------------------------------------------- caller-owned scratch (ABI 10)
- * a2v_query_workspace: bytes of device scratch the calls on ONE stream need (a constant of the build, about 19.5 MiB: shapes
+ * a2v_query_workspace: bytes of device scratch the calls on ONE stream need (a constant of the build, about 23.5 MiB: shapes
  * whose partial results would not fit take kernels that need none).
  * a2v_bind_workspace: `ws` = at least that many bytes of device memory on the current device, 256-byte aligned, ZERO when
  * handed over (the kernels leave it zero / self-consistent between calls), alive until every call queued on `stream` has

@@ -637,7 +637,7 @@ def test_conv_wgrad_sparse_rows(ops, T, keep_frac, k):
     assert rel_err(out["not ascending"], out["rows"]) < 1e-4
 
 
-@pytest.mark.parametrize("T,keep_frac", [(700, 0.08), (2000, 0.076), (300, 0.6), (160, 1.0), (95, 0.3)])
+@pytest.mark.parametrize("T,keep_frac", [(700, 0.08), (2000, 0.076), (300, 0.6), (160, 1.0), (95, 0.3), (1500, 0.45)])
 def test_conv_sparse_in(ops, T, keep_frac):
     """a2v_conv_sparse.hip (round 5): the positional encoder's two products whose INPUT is row-sparse and whose output is dense --
     the first layer's forward on clone * (1 - mask) (rows from the mask bytes, bias) and the last layer's input gradient from the
