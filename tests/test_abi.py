@@ -366,7 +366,7 @@ def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):
 
 
 HOT_KERNELS = {
-    "a2v_attn.hip": [r"attn_fwd_bf16_kernelILi64ELb0ELi2ELb[01]ELb0E", r"attn_fwd_seq48_kernel", r"attn_bwd_seq48_kernel"],
+    "a2v_attn.hip": [r"attn_fwd_bf16_kernelILi64ELb0ELi2ELb[01]ELb0E", r"attn_fwd32_bf16_kernel", r"attn_fwd_seq48_kernel", r"attn_bwd_seq48_kernel"],
     "a2v_mask.hip": [r"span_mask_rows_kernel", r"span_mask_finish_kernel"],
     "a2v_conv_slab.hip": [r"conv_nt_slab2_kernel"],
     "a2v_wgrad_slab.hip": [r"conv_wgrad_slab_kernel"],
@@ -376,6 +376,9 @@ HOT_KERNELS = {
     "a2v_elem.hip": [r"d2v_loss_kernel", r"decoder_input_kernel", r"col2im_kernel", r"adam_kernel", r"ema_kernel"],
     # (the four-wave form of sinc_fused_bwd needed 512 registers and spilled 7: 0.06 of its roofline)
     "a2v_sinc.hip": [r"sinc_fused_fwd_kernel", r"sinc_fused_bwd_kernel"],
+    # round 5: the row-sparse pos-conv products (232-246 registers each: accumulators / weight fragments fill the budget)
+    "a2v_wgrad_sparse.hip": [r"conv_wgrad_sparse_kernelILb1E", r"conv_wgrad_sparse_kernelILb0E"],
+    "a2v_conv_sparse.hip": [r"conv_sparse_in_kernelILb1E", r"conv_sparse_in_kernelILb0E"],
 }
 
 
