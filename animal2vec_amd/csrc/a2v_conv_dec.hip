@@ -263,6 +263,7 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
 }
 
 int g_a2v_conv_dec = 1;     // a2v_debug_set(13, v): decoder grouped conv through this kernel on / off
+int g_a2v_dec_bpw = 0;      // a2v_debug_set(38, v): 64-row blocks per workgroup (0: 32, fewer for small batches)
 template <int CI, int CO, int GPW>
 static void conv_dec_go(const GemmArgs& g, hipStream_t stream) {
   using GM = CdGeom<CI, CO, GPW>;
@@ -275,8 +276,9 @@ static void conv_dec_go(const GemmArgs& g, hipStream_t stream) {
   const int nclips = g.M / a.T_out;
   // rows per workgroup: long enough that the weight fragments a wave loads are a small share of its traffic, short
   // enough for a few rounds over the CUs
-  int bpw = 16;
+  int bpw = 32;                                        // (round 5 sweep, 768 clones x 2000 frames: 8 / 16 / 32 blocks = 1405 / 1331 / 1277 us)
   while (bpw > 4 && (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS) * (g.G / GM::GW) < 512) bpw >>= 1;
+  if (g_a2v_dec_bpw > 0) bpw = g_a2v_dec_bpw;
   extern int g_a2v_slab_order;
   const long long nx = (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS);
   const int ny = g.G / GM::GW;

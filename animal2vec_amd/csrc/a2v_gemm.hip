@@ -768,6 +768,7 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 5) { g_a2v_p8_ih = value; return A2V_OK; }       // force the p8 tile height (2 / 3 / 4; 0 = auto)
   if (key == 14) { g_a2v_conv_slab2 = value; return A2V_OK; } // 384-row two-per-CU slab kernel on / off
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off
+  { extern int g_a2v_dec_bpw; if (key == 38) { g_a2v_dec_bpw = value; return A2V_OK; } }   // conv_dec_kernel: 64-row blocks per workgroup (0 auto)
   if (key == 37) { g_a2v_wgrad_sparse = value; return A2V_OK; }  // row-sparse pos-conv weight gradients on / off
   if (key == 36) { g_a2v_attn_fwd32 = value; return A2V_OK; }  // long-sequence attention forward: 32 x 32 x 16 kernel on / off
   if (key == 19) { g_a2v_attn_band = value; return A2V_OK; }  // long-sequence attention forward: ALiBi band limit on / off

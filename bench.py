@@ -27,6 +27,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_BF16_TFLOPS = 2500.0      # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+SUSTAINED_BF16_TFLOPS = 1925.0   # measured: profiles/r05_mfma_power.txt (16 x 16 x 32 bf16 MFMA stream under the power cap)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -653,8 +654,13 @@ def main():
                                       avg_launch_us=round(s["tn"]["avg_us"], 2)) if "tn" in s else None,
                     # rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES share of the kernels' cycles (the file select_pmc_files() picked, named in `source`)
                     mfma_busy_share={"gemm_nt_bf16_p8_kernel": pmc_mfma("gemm_nt_bf16_p8_kernel"), "conv_nt_slab2_kernel": pmc_mfma("conv_nt_slab"), "conv_dec_kernel": pmc_mfma("conv_dec_kernel"),
-                                     "gemm_tn_bf16_p8_kernel": pmc_mfma("gemm_tn_bf16_p8_kernel"), "attn_fwd_bf16_kernel": pmc_mfma("attn_fwd_bf16_kernel"),
+                                     "gemm_tn_bf16_p8_kernel": pmc_mfma("gemm_tn_bf16_p8_kernel"), "attn_fwd32_bf16_kernel": pmc_mfma("attn_fwd32_bf16_kernel"),
                                      "source": PMC_MFMA} if dtype == torch.bfloat16 else None,
+                    # what the matrix pipe of this pool's boxes sustains under its power cap (tools/native/mfma_power.hip: independent
+                    # v_mfma_f32_16x16x32_bf16 on register operands, all CUs, seconds long -- a 1.85 GHz clock at a full pipe); `peak` above
+                    # stays the guide's nominal figure
+                    sustained_peak=dict(tflops=SUSTAINED_BF16_TFLOPS, frac=round(nt["tflops"] / SUSTAINED_BF16_TFLOPS, 4),
+                                        source="profiles/r05_mfma_power.txt") if dtype == torch.bfloat16 else None,
                     # the HBM-bound families of the same micro-batch (algorithmic bytes / HIP-event time, peak 8 TB/s)
                     hbm_kernels=hbm)
     if use_dist:
