@@ -16,8 +16,9 @@
 // the group and keeps ALL its weight fragments in registers (19 taps x 2 k-steps x 4 registers); the window's output lives as an
 // fp32 tile in LDS (160 + 2 x 18 rows, the halo rows are never written out), receives the scatter-adds as plain read-modify-write
 // -- a tile column belongs to one wave, so no atomics are needed and the order of the sums is the program's: deterministic --
-// and leaves as bf16 rows with the bias added.  The kept rows of a window (+- the taps' reach) are found by the workgroup itself two steps ahead (ordered compaction of the
-// mask bytes / of the clone's row list: any list, ascending or not), their data gathered one step ahead.  Two workgroups per CU.
+// and leaves as bf16 rows with the bias added.  The kept rows of a window (+- the taps' reach) are found by the workgroup itself (ordered compaction of the
+// mask bytes / of the clone's row list: any list, ascending or not) three steps ahead, their data gathered two steps ahead.
+// Two workgroups per CU.
 #include "a2v_gemm.h"
 
 #define CSP_WIN 160
@@ -25,11 +26,11 @@
 #define CSP_TROWS (CSP_WIN + 2 * (CSP_TAPS - 1))          // 196 tile rows
 #define CSP_TPITCH 68                                     // floats: a lane's four rows (slots 4 apart: frames >= 4 apart) land on different banks
 #define CSP_XPITCH 144                                    // bytes per staged kept row (128 + 16: conflict-free 16-B fragment reads)
-#define CSP_CAP 64                                        // kept rows staged per chunk (a window with more takes further chunks, synchronously)
+#define CSP_CAP 32                                        // kept rows staged per chunk (a window with more takes further chunks, synchronously)
 #define CSP_LIST 256                                      // list capacity per window (range = 178 frames)
 #define CSP_TILE_BYTES ((CSP_TROWS + 1) * CSP_TPITCH * 4)   // 53584: + one row, so that the slots past the list have 19 rows of their own
-#define CSP_XBUF_BYTES (CSP_CAP * CSP_XPITCH)             // 9216
-#define CSP_LDS (CSP_TILE_BYTES + 2 * CSP_XBUF_BYTES + 2 * (CSP_LIST * 4 + CSP_LIST) + 8 + 64)
+#define CSP_XBUF_BYTES (CSP_CAP * CSP_XPITCH)             // 4608
+#define CSP_LDS (CSP_TILE_BYTES + 2 * CSP_XBUF_BYTES + 3 * (CSP_LIST * 4 + CSP_LIST) + 16 + 64)
 
 typedef __attribute__((address_space(3))) float csp_lds_float;
 
@@ -49,10 +50,10 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const tile = (float*)smem;
   char* const xbuf = smem + CSP_TILE_BYTES;                               // [2][CSP_CAP][CSP_XPITCH]
-  int* const lsrc = (int*)(xbuf + 2 * CSP_XBUF_BYTES);                    // [2][CSP_LIST]
-  unsigned char* const lrel = (unsigned char*)(lsrc + 2 * CSP_LIST);      // [2][CSP_LIST]
-  int* const lcnt = (int*)(lrel + 2 * CSP_LIST);                          // [2]
-  int* const swc = lcnt + 2;                                              // [4 passes][4 waves]
+  int* const lsrc = (int*)(xbuf + 2 * CSP_XBUF_BYTES);                    // [3][CSP_LIST]: a ring -- the list of step s lives in buffer s % 3
+  unsigned char* const lrel = (unsigned char*)(lsrc + 3 * CSP_LIST);      // [3][CSP_LIST]
+  int* const lcnt = (int*)(lrel + 3 * CSP_LIST);                          // [3] (+ 1 pad)
+  int* const swc = lcnt + 4;                                              // [4 passes][4 waves]
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = blockIdx.y, T = a.T, pad = a.pad;
   const int NW = (T + CSP_WIN - 1) / CSP_WIN;
@@ -77,29 +78,43 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
 
   // ---- the kept rows of step s: frames lo .. lo + WIN + TAPS - 2 of clone c, lo = t0 - pad; entry = (source row, frame - lo)
   constexpr int NP = ROWS ? 4 : 1;                         // scan passes (rows mode: K <= 1024 list entries per sequence)
+  // scan_load only LOADS (the mask byte / the row-list entries of this thread, raw): anything that looks at the loaded value right
+  // away makes hipcc wait vmcnt(0) behind the load -- the full global round trip at the top of every step, and with it every
+  // other load and store in flight.  The values are interpreted in list_count, at the end of the step's math.
+  int sraw[NP];
   int sfl = 0, srl = 0;                                    // per pass p: bit p = entry in range; byte p = its frame - lo
+  int s_lo = 0, s_ok = 0;
   auto scan_load = [&](int s) {
-    sfl = 0; srl = 0;
-    if (s >= nsteps) return;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) sraw[p] = ROWS ? -(1 << 30) : 1;
+    s_ok = s < nsteps;
+    if (!s_ok) return;
     const int c = c0 + s / NW, lo = (s - (s / NW) * NW) * CSP_WIN - pad;
+    s_lo = lo;
     if constexpr (ROWS) {
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
         const int i = tid + 256 * p;
-        if (i < a.K) {
-          const int f = a.rowidx[(long long)c * a.K + i] - c * T;
-          if (f >= max(lo, 0) && f < min(lo + CSP_WIN + TAPS - 1, T)) { sfl |= 1 << p; srl |= (f - lo) << (8 * p); }
-        }
+        if (i < a.K) sraw[p] = a.rowidx[(long long)c * a.K + i] - c * T;
       }
     } else {
       const int f = lo + tid;
-      if (tid < CSP_WIN + TAPS - 1 && f >= 0 && f < T && a.rowmask[(long long)c * T + f] == 0) { sfl = 1; srl = tid; }
+      if (tid < CSP_WIN + TAPS - 1 && f >= 0 && f < T) sraw[0] = a.rowmask[(long long)c * T + f];
     }
   };
   unsigned long long sbal[NP];
   auto list_count = [&]() {                                // before a barrier: every wave's number of kept entries, per pass
+    sfl = 0; srl = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) asm volatile("" : "+v"(sraw[p]));      // (opaque: the comparison below is not formed next to the load)
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
+      if constexpr (ROWS) {
+        const int f = sraw[p];
+        if (s_ok && f >= max(s_lo, 0) && f < min(s_lo + CSP_WIN + TAPS - 1, T)) { sfl |= 1 << p; srl |= (f - s_lo) << (8 * p); }
+      } else {
+        if (s_ok && sraw[0] == 0) { sfl = 1; srl = tid; }
+      }
       sbal[p] = __ballot((sfl >> p) & 1);
       if (lane == 0) swc[p * 4 + wid] = __popcll(sbal[p]);
     }
@@ -127,24 +142,18 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
     }
     if (tid == 0) lcnt[buf] = min(total, CSP_LIST);
   };
-  // ---- the kept rows' data: chunk ch (slots 64 ch ..) of the list in buffer lb -> registers -> xbuf[xb]
-  uint4 xr[2];
-  auto gather_load = [&](int s, int lb, int ch) {
-    const uint4 z = {0u, 0u, 0u, 0u};
-    xr[0] = z; xr[1] = z;
+  // ---- the kept rows' data: chunk ch (slots 32 ch ..) of the list in buffer lb -> a register -> xbuf[xb]
+  auto gather_load = [&](int s, int lb, int ch, uint4& dst) {
+    dst = uint4{0u, 0u, 0u, 0u};
     if (s >= nsteps) return;
     const int c = c0 + s / NW;
     const int cnt = lcnt[lb];
     const bf16* xb = a.X + (long long)grp * a.x_goff + (tid & 7) * 8 + (ROWS ? 0ll : (long long)(c / a.bdiv) * a.x_bstride);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int slot = ch * CSP_CAP + (tid >> 3) + 32 * u;
-      if (slot < cnt) xr[u] = *(const uint4*)(xb + (long long)lsrc[lb * CSP_LIST + slot] * a.x_pitch);
-    }
+    const int slot = ch * CSP_CAP + (tid >> 3);
+    if (slot < cnt) dst = *(const uint4*)(xb + (long long)lsrc[lb * CSP_LIST + slot] * a.x_pitch);
   };
-  auto gather_store = [&](int xb) {
-#pragma unroll
-    for (int u = 0; u < 2; ++u) *(uint4*)(xbuf + xb * CSP_XBUF_BYTES + ((tid >> 3) + 32 * u) * CSP_XPITCH + (tid & 7) * 16) = xr[u];
+  auto gather_store = [&](int xb, const uint4& src) {
+    *(uint4*)(xbuf + xb * CSP_XBUF_BYTES + (tid >> 3) * CSP_XPITCH + (tid & 7) * 16) = src;
   };
   // ---- the products of one chunk (slots 64 ch .. of list lb, data in xbuf[xb]) into the tile
   auto chunk_math = [&](int lb, int xb, int ch) {
@@ -169,53 +178,65 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
       // slots of a lane are four different rows, and LDS operations of a wave execute in order -- but tap t of one slot and tap t + 1
       // of its neighbour CAN be the same cell (kept frames come in adjacent pairs), so the taps are not overlapped.  (As
       // ds_add_f32 the scatter ran at about one lane per three clocks per CU: 19.8 ms per call.)
+      f32x4 accn = {0.f, 0.f, 0.f, 0.f};                  // the products of tap t + 1 are formed under the read-modify-write of tap t
+      accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[0][0], accn, 0, 0, 0);
+      accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[0][1], accn, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[t][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[t][1], acc, 0, 0, 0);
+        const f32x4 acc = accn;
         float old[4];
         // (LDS-address-space pointers, not volatile generic ones: those became flat_load / flat_store, each behind its own vmcnt(0).
         // The order that matters is kept by the compiler itself: the four rows of a lane have unrelated bases -- may alias.)
 #pragma unroll
         for (int r = 0; r < 4; ++r) old[r] = *(trow[r] - t * CSP_TPITCH);                      // tile row rel - tap + TAPS - 1
+        if (t + 1 < TAPS) {
+          accn = (f32x4){0.f, 0.f, 0.f, 0.f};
+          accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[t + 1 < TAPS ? t + 1 : t][0], accn, 0, 0, 0);
+          accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[t + 1 < TAPS ? t + 1 : t][1], accn, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) *(trow[r] - t * CSP_TPITCH) = old[r] + acc[r];
       }
     }
   };
 
-  // ---- prologue: lists of steps 0 and 1, data of step 0
-  scan_load(0);
-  list_count();
-  __syncthreads();
-  list_write(0, 0);
-  __syncthreads();
-  scan_load(1);
-  gather_load(0, 0, 0);
-  list_count();
-  gather_store(0);
-  __syncthreads();
-  list_write(1, 1);
+  // ---- prologue: lists of steps 0, 1 and 2, data of step 0 in LDS, data of step 1 in flight
+  uint4 xnext, xnew;                                      // data of step st + 1 (loaded a step ago) / of step st + 2 (just requested)
+  for (int s0_ = 0; s0_ < 3; ++s0_) {
+    scan_load(s0_);
+    list_count();
+    __syncthreads();
+    list_write(s0_, s0_);
+    __syncthreads();
+  }
+  gather_load(0, 0, 0, xnext);
+  gather_store(0, xnext);
+  gather_load(1, 1, 0, xnext);
   __syncthreads();
 
-  for (int st = 0; st < nsteps; ++st) {
-    const int lb = st & 1;
-    scan_load(st + 2);                                    // lands under the math; compacted behind the first barrier
-    gather_load(st + 1, lb ^ 1, 0);                       // list of step st + 1 is complete (previous step / prologue)
+  // one step; xn: the data of step st + 1 (requested a step ago), xw: receives the data of step st + 2.  The loop below calls it with the
+  // two registers exchanged from step to step (no copy of a register whose load is in flight)
+  auto step = [&](int st, uint4& xn, uint4& xw) {
+    const int lb = st % 3, xb = st & 1;
+    // two steps of lead for the gathered rows (one step was not enough: the step is about as long as a global round trip, and
+    // with two workgroups per CU every wave sat in front of its gather_store), three for the scan of the mask / row list
+    scan_load(st + 3);
+    gather_load(st + 2, (st + 2) % 3, 0, xw);
     const int cnt = lcnt[lb];
-    chunk_math(lb, lb, 0);
-    for (int ch = 1; ch * CSP_CAP < cnt; ++ch) {          // a window that keeps more than 64 rows (not the pretraining masks): synchronous chunks
+    chunk_math(lb, xb, 0);
+    for (int ch = 1; ch * CSP_CAP < cnt; ++ch) {          // a window that keeps more than 32 rows (rare with the pretraining masks): synchronous chunks
       __syncthreads();
-      uint4 keep0 = xr[0], keep1 = xr[1];
-      gather_load(st, lb, ch);
-      gather_store(lb);
-      xr[0] = keep0; xr[1] = keep1;
+      uint4 xc;
+      gather_load(st, lb, ch, xc);
+      gather_store(xb, xc);
       __syncthreads();
-      chunk_math(lb, lb, ch);
+      chunk_math(lb, xb, ch);
     }
     list_count();
     __syncthreads();                                      // every scatter-add of the window is in the tile
+    // (before the write-out: the wait for the gathered rows is a vmcnt(0) -- the value crosses the loop's back edge -- and behind the
+    // write-out it would also wait for the stores just issued)
+    gather_store(xb ^ 1, xn);                             // data of step st + 1
     {
       const int c = c0 + st / NW, t0 = (st - (st / NW) * NW) * CSP_WIN;
       bf16* yb = a.Y + ((long long)c * T + t0) * a.ldc + (long long)grp * a.c_goff + (tid & 7) * 8;
@@ -234,9 +255,12 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
         }
       }
     }
-    gather_store(lb ^ 1);                                 // data of step st + 1
-    list_write(lb, st + 2);                               // list of step st + 2 (the list of step st has been consumed)
+    list_write(lb, st + 3);                               // list of step st + 3 (the list of step st has been consumed)
     __syncthreads();
+  };
+  for (int st = 0; st < nsteps; st += 2) {
+    step(st, xnext, xnew);
+    if (st + 1 < nsteps) step(st + 1, xnew, xnext);
   }
 }
 

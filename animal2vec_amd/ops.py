@@ -314,13 +314,18 @@ def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=No
                      rowidx=rowidx)
 
 
+def _has_entry(name):
+    """False only for an older build loaded through A2V_LIB_PATH (same-box A/B runs): _lib.load()"""
+    return hasattr(_L(), name)
+
+
 CONV_SPARSE = os.environ.get("A2V_CONV_SPARSE", "1") != "0"     # =0: the row-sparse pos-conv products (a2v_conv_sparse_in) off (A/B runs)
 
 
 def conv_sparse_ok(x, w_packed, *, k, groups, n_out, rows_per_seq=0):
     """a2v_conv_sparse_in takes it: bf16, the positional encoder's shape (19 taps, 64 channels per group in and out); a row list
     of at most 1024 rows per sequence"""
-    return (CONV_SPARSE and rows_per_seq <= 1024 and x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and k == 19 and n_out == groups * 64
+    return (CONV_SPARSE and rows_per_seq <= 1024 and _has_entry("a2v_conv_sparse_in") and x.dtype == torch.bfloat16 and w_packed.dtype == torch.bfloat16 and k == 19 and n_out == groups * 64
             and w_packed.shape[-1] == k * 64 and w_packed.shape[-2] == 64 and x.stride(-1) == 1)
 
 
@@ -353,7 +358,7 @@ def conv_wgrad(x, dy, gw, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1,
             ptr(rowmask), bdiv, ptr(dy), ldp, p_goff, ptr(gw), ldw, w_gstride, M, N, K, G, stream())
     if rowidx is None:
         rc = _L().a2v_conv_wgrad(*args)
-    elif n_seq > 0 and M % n_seq == 0:
+    elif n_seq > 0 and M % n_seq == 0 and _has_entry("a2v_conv_wgrad_kept"):
         rc = _L().a2v_conv_wgrad_kept(ptr(rowidx), n_seq, *args)
     else:
         rc = _L().a2v_conv_wgrad_rows(ptr(rowidx), *args)
