@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
 }
 
 static bool a2v_launch_conv_sparse_in(const SpInArgs& a, int G, hipStream_t stream) {
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_sparse_in_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, CSP_LDS);
     (void)hipFuncSetAttribute((const void*)conv_sparse_in_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, CSP_LDS);

@@ -278,7 +278,7 @@ int a2v_launch_wgrad_sparse(const WgradArgs& g_in, int n_seq, hipStream_t stream
   if (units > nclones) units = (int)nclones;
   const int cpu = cdiv((int)nclones, units);
   units = cdiv((int)nclones, cpu);
-  static bool attr = false;
+  static bool attr_dev[A2V_MAX_DEVICES]; bool& attr = attr_dev[a2v_device()];   // (function attributes are per device)
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)conv_wgrad_sparse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSP_STAGE);
     (void)hipFuncSetAttribute((const void*)conv_wgrad_sparse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSP_STAGE);
