@@ -1054,7 +1054,8 @@ def test_hd64_vs_oracle_after_200_updates(dtype, tol_y, tol_g):
         # fp32 / bf16x3: 1e-3 on everything.  bf16 (measured on two runs of the non-bit-reproducible bf16 trainer: median 2.4e-2 /
         # 2.7e-2, worst 6.7e-2 / 5.7e-2; stock autocast of the oracle on the same weights: median 1.8e-2, worst 9.2e-2): every tensor
         # within 1e-1, the median within twice the autocast's
-        if e > (0.1 if dtype == torch.bfloat16 else tol_g):
+        # (d alibi_scale in bf16 has its own, condition-scaled bound below: at cond 11.7 it read 3.0e-1 = 2.6e-2 x cond)
+        if e > (0.1 if dtype == torch.bfloat16 else tol_g) and not (k == AL_KEY and dtype == torch.bfloat16):
             bad.append((k, e, ac.get(k)))
     al_rel, al_cond, al_back = ats.check(store.g[AL_KEY], p[AL_KEY], po[AL_KEY].grad, None)
     extra = {}
