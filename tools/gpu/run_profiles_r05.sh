@@ -20,6 +20,6 @@ grep '^{' $out/${tag}_bench_default.log > $out/${tag}_bench_default.json
 # (the end-of-round pass, on the final build: GPU suite with the parity report + the bf16x3 mode's stats again)
 if [ "$2" = "final" ]; then
   rm -f $out/${tag}_parity_report.jsonl
-  A2V_PARITY_REPORT=$out/${tag}_parity_report.jsonl timeout 1200 python3 -m pytest tests -m gpu -x -q 2>&1 | tail -4 > $out/${tag}_final_gputest.log
+  A2V_PARITY_REPORT=$out/${tag}_parity_report.jsonl timeout 1500 python3 -m pytest tests -m gpu -q 2>&1 | tail -6 > $out/${tag}_final_gputest.log
   tail -2 $out/${tag}_final_gputest.log
 fi
