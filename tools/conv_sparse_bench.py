@@ -41,6 +41,11 @@ def main():
     res["sparse_mask_us"] = round(timed(lambda: ops.conv1d_cl_sparse_in(x, wp, bias, k=k, pad=k // 2, groups=G, T=T, n_out=D, n_seq=N, rowmask=md, bdiv=cb, out=out), a.iters), 1)
     res["sparse_rows_us"] = round(timed(lambda: ops.conv1d_cl_sparse_in(dyk, wp, None, k=k, pad=k // 2, groups=G, T=T, n_out=D, n_seq=N, rowidx=rows, out=out), a.iters), 1)
     res["dense_mask_us"] = round(timed(lambda: ops.conv1d_cl(x, wp, bias, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, rowmask=md, bdiv=cb, n_batch=N, out=out), a.iters), 1)
+    # the same layers' weight gradients (a2v_wgrad_sparse.hip): first layer (mask form), last layer (kept-row form)
+    gw = torch.zeros(G, 64, k * 64, dtype=torch.float32, device="cuda")
+    dy = torch.randn(N, T, D, generator=g).bfloat16().cuda()
+    res["wgrad_mask_us"] = round(timed(lambda: ops.conv1d_cl_wgrad(x, dy, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, rowmask=md, bdiv=cb, n_batch=N), a.iters), 1)
+    res["wgrad_kept_us"] = round(timed(lambda: ops.conv1d_cl_wgrad(dy, dyk, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, rowidx=rows, rows_kept=True), a.iters), 1)
     print(json.dumps(res))
 
 
