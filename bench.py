@@ -84,7 +84,7 @@ class GemmRecorder:
                                            ("gelu_bwd", kw.get("gelu_bwd")), ("pre", kw.get("pre_out") is not None),
                                            ("dact", kw.get("dact")), ("colsum", kw.get("colsum") is not None),
                                            ("drop", kw.get("drop") is not None and kw["drop"][0] > 0)) if on) or "plain"
-            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * G, e0, e1, (kw["M"], kw["N"], kw["K"], G, epi)))
+            rec.recs.append(("nt", 2.0 * kw["M"] * kw["N"] * kw["K"] * G, e0, e1, (kw["M"], kw["N"], kw["K"], G, epi), None))
             # algorithmic bytes: every operand element once (the im2col view re-uses each input element `taps` times)
             rec.bytes["nt"] = rec.bytes.get("nt", 0.0) + x.element_size() * G * (
                 kw["M"] * kw["K"] / kw.get("taps", 1) + kw["N"] * kw["K"] + kw["M"] * kw["N"])
@@ -95,8 +95,11 @@ class GemmRecorder:
             e0.record()
             r = rec._wg(x, dy, gw, **kw)
             e1.record()
+            # (a row-masked input -- the first pos-conv layer -- is multiplied over its non-zero rows only since round 5: its FLOPs are
+            #  counted over those rows, the fraction read from the mask at summary time; a row list already passes M = listed rows)
+            rm = kw.get("rowmask")
             rec.recs.append(("tn", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1,
-                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1), "wgrad")))
+                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1), "wgrad" if rm is None else "wgrad, masked input"), rm))
             return r
 
         ops.conv_gemm, ops.conv_wgrad = cg, wg
@@ -139,12 +142,17 @@ class GemmRecorder:
                              frac_of_8TBps=round(by / ms / 1e6 / 8000.0, 3))
         return out
 
+    @staticmethod
+    def _kept(rowmask):
+        """fraction of non-zero input rows of a row-masked product (1 without a mask)"""
+        return 1.0 if rowmask is None else 1.0 - float(rowmask.float().mean())
+
     def table(self):
         torch.cuda.synchronize()
         agg = {}
-        for k, f, e0, e1, shape in self.recs:
+        for k, f, e0, e1, shape, rm in self.recs:
             a = agg.setdefault((k,) + shape, [0, 0.0, 0.0])
-            a[0] += 1; a[1] += f; a[2] += e0.elapsed_time(e1)
+            a[0] += 1; a[1] += f * self._kept(rm); a[2] += e0.elapsed_time(e1)
         rows = sorted(agg.items(), key=lambda kv: -kv[1][2])
         return [dict(kind=k[0], M=k[1], N=k[2], K=k[3], G=k[4], epilogue=k[5], launches=v[0], ms=round(v[2], 3),
                      tflops=round(v[1] / v[2] / 1e9, 1)) for k, v in rows]
@@ -153,7 +161,7 @@ class GemmRecorder:
         torch.cuda.synchronize()
         out = {}
         for kind in ("nt", "tn"):
-            rs = [(f, e0.elapsed_time(e1)) for k, f, e0, e1, _ in self.recs if k == kind]
+            rs = [(f * self._kept(rm), e0.elapsed_time(e1)) for k, f, e0, e1, _, rm in self.recs if k == kind]
             if rs:
                 fl, ms = sum(f for f, _ in rs), sum(t for _, t in rs)
                 out[kind] = dict(launches=len(rs), flops=fl, ms=ms, avg_us=1e3 * ms / len(rs), tflops=fl / ms / 1e9,
@@ -696,6 +704,11 @@ def main():
                        else "off (one rank, no process group)"},
             "model_tflops_per_s": round(gf_fb * args.global_batch * args.steps / dt / 1e3, 2),
             "mfu_vs_bf16_dense_peak": round(gf_fb * args.global_batch * args.steps / dt / 1e3 / (PEAK_BF16_TFLOPS * world), 4),
+            # (model FLOPs = the reference's nominal count: every product dense over all T frames of every clone.  Six of the fifteen
+            #  positional-encoder products -- the first layer's, whose input is zero at the masked frames, and the last layer's, whose output
+            #  is only used at the kept frames -- are evaluated over the kept rows only: 5.6 % of the nominal FLOPs are not executed)
+            "model_flops_note": "nominal (the reference's dense count); 5.6 % of it -- the positional encoder's first / last layer on masked "
+                                "clones -- is evaluated over the kept rows only",
             "loss_per_sample": round(met["loss"], 5), "pred_var": round(met["pred_var"], 5),
             "target_var": round(met["target_var"], 5),
             "roofline": roof,
