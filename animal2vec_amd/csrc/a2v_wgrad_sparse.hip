@@ -208,7 +208,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_sparse_kernel(WgradArgs g, con
         const int off = (c >> 2) * WSP_PITCH + (c & 3) * 32;
         const bf16x8 fb = wsp_frag2(dlo + off, dhi + off);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i)                       // (mode A: operands exchanged, so that the LANES of a tile run along ci -- the contiguous
+                                                          //  index of dW -- in the atomics of the epilogue: 637 -> 159 MB of write traffic)
+          acc[i][j] = MODE_A ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
       }
     }
     WSP_STORE(buf ^ 1);
@@ -224,14 +227,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_sparse_kernel(WgradArgs g, con
   for (int j = 0; j < CPW; ++j) {
     const int c = wid * CPW + j;
     if (c >= taps * 4) continue;
-    const int tp = c >> 2, bidx = (c & 3) * 16 + fr;                      // dense-side channel
+    const int tp = c >> 2;
     const int tap = MODE_A ? taps - 1 - tp : tp;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int aidx = i * 16 + fq * 4 + r;                            // compact-side channel
-        const int n = MODE_A ? bidx : aidx, ci = MODE_A ? aidx : bidx;
+        // accumulator rows 4 fq + r belong to the MFMA's first operand, the lane's column fr to its second: mode B (compact, dense) =
+        // (n, ci), mode A (dense, compact) = (n, ci) as well -- ci on the lanes either way
+        const int n = MODE_A ? (c & 3) * 16 + fq * 4 + r : i * 16 + fq * 4 + r;
+        const int ci = MODE_A ? i * 16 + fr : (c & 3) * 16 + fr;
         atomicAdd(g.W + (long long)grp * g.w_gstride + (long long)n * g.ldw + tap * 64 + ci, acc[i][j][r]);
       }
   }
