@@ -30,8 +30,10 @@ def main():
         us1 = timed(lambda: ops.conv1d_cl(x, w, b, k=k, stride=1, pad=k // 2, groups=G, T_out=T, n_out=D, cv=C, out=y))
         us2 = timed(lambda: ops.conv1d_cl(x, w, None, k=k, stride=1, pad=k - 1 - k // 2, groups=G, T_out=T, n_out=D, cv=C, res=res, out=y))
         by = N * T * D * 2
+        gw = torch.zeros(G, C, k * 64, dtype=torch.float32, device="cuda")
+        us3 = timed(lambda: ops.conv1d_cl_wgrad(x, res, gw, k=k, stride=1, pad=k // 2, groups=G, T_out=T, cv=C))
         print(f"{os.environ.get('A2V_LIB_PATH', 'product library')[-24:]:24s}  bias {us1:8.1f} us ({2 * by / us1 / 1e6:5.2f} TB/s)   residual {us2:8.1f} us "
-              f"({3 * by / us2 / 1e6:5.2f} TB/s)", flush=True)
+              f"({3 * by / us2 / 1e6:5.2f} TB/s)   weight gradient {us3:8.1f} us ({2 * by / us3 / 1e6:5.2f} TB/s)", flush=True)
 
 
 if __name__ == "__main__":
