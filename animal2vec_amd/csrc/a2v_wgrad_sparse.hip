@@ -17,7 +17,7 @@
 // 160-B row pitch so that a tap is an immediate offset) with the reduction index running over the kept slots: the slab rows of
 // a fragment are GATHERED -- a transposing read takes its row from the lane's address, so that costs nothing -- and a window
 // with 20 kept rows issues one 32-deep k-step instead of eight.  (256-frame windows, not 128: one workgroup per CU (232
-// registers) has ONE step of loads in flight, and at 128 frames that was 19 KB per CU -- 1.82 / 1.34 ms against 1.30 / 0.84.)
+// registers) has ONE step of loads in flight, and at 128 frames that was 19 KB per CU -- 1.82 / 1.34 ms against 1.30 / 0.84 (0.89 / 0.84 with the mask form's epilogue atomics along ci).)
 //   mode A (first layer): C = X at the kept frames, D = dY, D row = pos + pad - tap      -> tap' = taps - 1 - tap, a = ci, b = n
 //   mode B (last layer):  C = dY (compact rows),    D = X,  D row = pos + tap - pad      -> tap' = tap,            a = n,  b = ci
 // The kept positions come from a table built by a small kernel in front (per (clone, window): count, first compact row, the
