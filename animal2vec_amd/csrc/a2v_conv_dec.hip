@@ -42,6 +42,18 @@ struct CdGeom {
   static constexpr int NJ = CO / 16;                       // 3 / 4
 };
 
+#ifdef CD_STAMP
+// Diagnostic build only (python -m animal2vec_amd.build --variant cdstamp -DCD_STAMP; tools/dec_probe.py): wave 0 of the first 256
+// workgroups stamps s_memtime at eight points of each of its first 24 blocks -- [0] block start, [4] the next slab requested, [5] / [6] the
+// first group multiplied / stored, [7] the second group multiplied, [1] ... stored, [2] the next slab's counted wait passed, [3] behind the
+// stash and the barrier.  The stamps stay in LDS until the workgroup ends (no vector-memory operation is added inside the loop).
+// -DCD_NOSTORE (with it): the output stores compiled out.  The product library contains none of this.
+#define CD_ST_BLK 24
+__device__ unsigned long long g_cd_stamp[256][CD_ST_BLK][8];
+extern "C" int a2v_diag_cd_stamps(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_cd_stamp), sizeof(g_cd_stamp)) == hipSuccess ? 0 : -1;
+}
+#endif
 template <int CI, int CO, int GPW>
 __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_per_wg, int y_fastest) {
   using GM = CdGeom<CI, CO, GPW>;
@@ -159,9 +171,17 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
   // its first store (a load issued behind a store cannot be waited for without that store's acknowledgement), and the stores
   // of a full 64-row block are unconditional so that the compiler can count them -- behind a branch it has to assume none was
   // issued and waits for vmcnt(0), i.e. for every store of the block, before the next slab may be written to LDS.
+#ifdef CD_STAMP
+  __shared__ unsigned long long s_st[CD_ST_BLK][8];
+#define CD_STAMP_AT(k_) if (tid == 0 && blk < CD_ST_BLK) s_st[blk][k_] = __builtin_amdgcn_s_memtime();
+#else
+#define CD_STAMP_AT(k_)
+#endif
   for (int blk = 0; blk < nblk; ++blk) {
     const char* const cur = smem + (blk & 1) * CD_SLAB_BYTES;
+    CD_STAMP_AT(0)
     if (blk + 1 < nblk) fetch_asm(blk + 1);           // in flight under this block's MFMAs
+    CD_STAMP_AT(4)
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       const int grp = g0 + GPW * wid + gi;
@@ -216,6 +236,7 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
           acc[f & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gi][f >> 2][j], xr[f % 5], acc[f & 3][j], 0, 0, 0);
       }
 #undef CD_XREAD
+      if (gi == 0) { CD_STAMP_AT(5) } else { CD_STAMP_AT(7) }
       // ---- epilogue of (this block, group): lane (fq, fr) holds row 16 i + fr, channels 32 p + 8 fq + [0, 8) per column-block
       // pair p (and 32 + 4 fq + [0, 4) of the single block at CO = 48)
 #pragma unroll
@@ -237,7 +258,11 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
 #pragma unroll
             for (int e = 0; e < 8; ++e) v8[e] += hh[e];
           }
+#ifdef CD_NOSTORE      /* timing builds only: what the block costs without its output stores (results kept alive, not written) */
+          asm volatile("" :: "v"(v8[0]), "v"(v8[1]), "v"(v8[2]), "v"(v8[3]), "v"(v8[4]), "v"(v8[5]), "v"(v8[6]), "v"(v8[7]));
+#else
           Vec8<bf16>::store(cp + 32 * p + 8 * fq, v8);
+#endif
         }
         if (NJ == 3) {
           f32x4 o4 = acc[i][2] + *(const f32x4*)(sBias + (GPW * wid + gi) * CO + 32 + 4 * fq);
@@ -245,10 +270,16 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
             o4[0] += __uint_as_float(h4[i].x << 16); o4[1] += __uint_as_float(h4[i].x & 0xffff0000u);
             o4[2] += __uint_as_float(h4[i].y << 16); o4[3] += __uint_as_float(h4[i].y & 0xffff0000u);
           }
+#ifdef CD_NOSTORE
+          asm volatile("" :: "v"(o4));
+#else
           Vec4<bf16>::store(cp + 32 + 4 * fq, o4);
+#endif
         }
       }
+      if (gi == 0) { CD_STAMP_AT(6) }
     }
+    CD_STAMP_AT(1)
     if (blk + 1 < nblk) {                             // its readers (block blk - 1) are behind the last barrier
       // (volatile asm statements keep their order: the wait, then one empty statement per register that re-defines it -- every use of
       //  the loaded values sits behind the wait)
@@ -256,10 +287,18 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
       else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(CD_ST) : "memory");
 #pragma unroll
       for (int u = 0; u < CD_NLD; ++u) asm volatile("" : "+a"(rga[u]));
+      CD_STAMP_AT(2)
       stash_asm(smem + ((blk + 1) & 1) * CD_SLAB_BYTES, blk + 1);
     }
     __syncthreads();
+    CD_STAMP_AT(3)
   }
+#ifdef CD_STAMP
+  if (tid == 0 && blockIdx.y == 0 && blockIdx.x < 256)
+    for (int b = 0; b < CD_ST_BLK; ++b)
+      for (int k_ = 0; k_ < 8; ++k_) g_cd_stamp[blockIdx.x][b][k_] = b < nblk ? s_st[b][k_] : 0ull;
+#endif
+#undef CD_STAMP_AT
 }
 
 int g_a2v_conv_dec = 1;     // a2v_debug_set(13, v): decoder grouped conv through this kernel on / off
