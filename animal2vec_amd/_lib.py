@@ -32,8 +32,9 @@ SIGNATURES = {
     "a2v_conv_wgrad_kept": [_p, _i, _i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                             _i, _p],
     "a2v_linear_wgrad_pair": [_i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p],
-    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
-    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_attention_dropmask_words": [_i, _i, _i],
+    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
     "a2v_attention_bwd_fused_bias": [_i, _i, _i],
     "a2v_layernorm_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _f, _i, _f, _u, _p],
     "a2v_layernorm_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _ll, _i, _ll, _ll, _i, _f, _u, _i, _p, _p],
@@ -77,6 +78,13 @@ SIGNATURES = {
     "a2v_bind_workspace": [_p, _p, C.c_size_t],
 }
 ABI12_ENTRIES = ("a2v_conv_sparse_in", "a2v_conv_wgrad_kept")
+# ABI 13: a2v_attention_fwd / a2v_attention_bwd take `dropmask` (one more pointer each, after mdist) + a2v_attention_dropmask_words.
+# An ABI-12 library loaded through A2V_LIB_PATH (same-box A/B against the previous round, tools/build_prev.sh) keeps its signatures:
+ABI13_ENTRIES = ("a2v_attention_dropmask_words",)
+ABI12_SIGNATURES = {
+    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+}
 RESTYPES = {"a2v_query_workspace": C.c_size_t}      # everything else returns int
 
 _lib = None
@@ -101,7 +109,14 @@ def load() -> C.CDLL:
     # has imported torch).  With torch already imported the loader resolves the same soname to the one runtime.
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    lib.a2v_abi_version.restype = C.c_int
+    abi = int(lib.a2v_abi_version())
+    lib._a2v_abi = abi
     for name, argtypes in SIGNATURES.items():
+        if abi < 13 and os.environ.get("A2V_LIB_PATH"):
+            if name in ABI13_ENTRIES:
+                continue
+            argtypes = ABI12_SIGNATURES.get(name, argtypes)
         try:
             fn = getattr(lib, name)
         except AttributeError as e:

@@ -41,7 +41,7 @@ def _stale(target: str, deps) -> bool:
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, "a2v_common.h"), os.path.join(CSRC, "a2v_gemm.h")]
+    hdrs = [os.path.join(CSRC, "a2v_common.h"), os.path.join(CSRC, "a2v_gemm.h"), os.path.join(CSRC, "a2v_attn_seq2.h")]
     jobs = []
     for s in SOURCES:
         src, obj = os.path.join(CSRC, s), os.path.join(OBJ, s.replace(".hip", ".o"))
@@ -98,7 +98,7 @@ def build_variant(tag: str, defines, verbose: bool = False) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     lib = os.path.join(HERE, f"liba2v_hip_{tag}.so")
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, "a2v_common.h"), os.path.join(CSRC, "a2v_gemm.h")]
+    hdrs = [os.path.join(CSRC, "a2v_common.h"), os.path.join(CSRC, "a2v_gemm.h"), os.path.join(CSRC, "a2v_attn_seq2.h")]
 
     def cc(s):
         src, obj = os.path.join(CSRC, s), os.path.join(obj_dir, s.replace(".hip", ".o"))

@@ -41,6 +41,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile_lo, const char* tile_
   return u.v;
 }
 
+__device__ __forceinline__ int dual_off(int r, int chunk) { return r * 128 + ((chunk ^ (r & 7)) << 4); }   // [rows][64] bf16
+
 struct AttnArgs {
   const void* qkv; void* out; float* lse;
   const int* pos;                 // (N,S) original frame index or nullptr (= arange)
@@ -54,6 +56,28 @@ struct AttnArgs {
   float* mdist;                   // (N,H,S) or nullptr: c_i = sum_j P_ij |pos_i - pos_j|, the row's mean attended distance (dropout-free P);
                                   // the backward centres |pos_i - pos_j| on it when it forms d alibi_scale (see AttnBwdArgs::mdist)
   float band_nats;                // ALiBi band limit: keys whose softmax weight is provably below exp(-band_nats) of the row sum are not visited
+  unsigned* dropmask;             // (N,H,160,4,2) u32 or nullptr: the whole-sequence forward (S <= 160, bf16, HD 64) writes its dropout decisions here (a2v_attn_seq2.h)
+};
+
+struct AttnBwdArgs {
+  const void* qkv; const void* d_out; const float* lse; const float* delta;
+  void* dqkv;               // (N,S,3,H,HD): k and v slots written here
+  float* dq32;              // (N,S,H,HD) fp32, zeroed by the caller, accumulated with atomics
+  float* dalibi;            // (H) fp32 accumulated: d loss / d alibi_scale_h
+  const int* pos; const float* slopes; const float* alibi_scale;
+  int N, S, H;
+  float scale;
+  Drop drop;
+  float* dal_part;          // per-workgroup partial sums of d alibi_scale go here (the stream's workspace; folded by dalibi_fold_kernel); NULL: atomics
+  float* bias_sum;          // (3, H, HD) fp32 or NULL: column sums of dqkv (the qkv Linear's bias gradient), whole-sequence kernel only
+  // (N,H,S) or NULL: c_i = sum_j P_ij |pos_i - pos_j| from the forward.  d alibi_scale_h = -slope_h sum_ij dS_ij |pos_i - pos_j|, and
+  // sum_j dS_ij = 0 exactly, so any per-row constant may be subtracted from the distance.  What is computed is dS_ij = P_ij (dP_ij -
+  // delta_i) with delta_i = dO_i . O_i from the ROUNDED forward output: it misses sum_j P_ij dP_ij by some e_i (bf16: 2^-9 relative),
+  // which puts -e_i P_ij into every dS_ij and -e_i c_i into the row's distance sum -- e_i times the mean attended distance, a
+  // systematic term as large as the (heavily cancelling) true sum at long sequences.  With the distance centred on c_i that term
+  // is -e_i sum_j P_ij (|.| - c_i) = 0: the gradient is as accurate as the dS values themselves.
+  const float* mdist;
+  const unsigned* dropmask;  // the forward's dropout decisions (AttnArgs::dropmask) or nullptr: re-hash
 };
 
 #define FP32_PITCH(HD) ((HD) + 4)
@@ -1245,6 +1269,8 @@ __device__ __forceinline__ float rows_sum(float v) {    // sum over the lanes l,
   return __uint_as_float(t[0]) + __uint_as_float(t[1]);
 }
 
+#include "a2v_attn_seq2.h"
+
 template <bool DROP, bool MD = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
   typedef bf16 T;
@@ -1422,6 +1448,8 @@ int g_a2v_attn_msum = 1;     // a2v_debug_set(18, v): forward-only long-sequence
                              // times rounding noise either way
 int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
 int g_a2v_attn_fwd32 = 1;    // a2v_debug_set(36, v): long-sequence bf16 forward on 32 x 32 x 16 MFMAs (0: the 16 x 16 x 32 kernel)
+int g_a2v_attn_dbg = 0;      // a2v_debug_set(40, flags): timing experiments on the round-6 forward (1 no output stores, 2 no mask store, 4 no math)
+int g_a2v_attn_seq2 = 1;     // a2v_debug_set(39, v): S <= 160 bf16 forward AND backward take the round-6 five-wave kernels (0: the round-5 ones)
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 // Ingredients of the bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i|^2 and max_j |k_j|^2 (Cauchy-Schwarz in
 // the attention kernel).  8 lanes share a row (16 B each); reads q and k once: 65 MB at 32 x 2000 x 16 heads.
@@ -1477,6 +1505,16 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = 0;
   if constexpr (HD == 64) {
+    if (a.S <= AS2_ROWS && g_a2v_attn_seq2) {              // round 6: five-wave workgroups, three per CU (a2v_attn_seq2.h)
+      const dim3 grid(1, a.H, a.N);
+      const bool wm = DROP && a.dropmask != nullptr;
+      a.xcd_order = g_a2v_attn_dbg;                         // (timing experiments only; 0 in every product run)
+#define AS2F_GO(MD_, WM_) hipLaunchKernelGGL((attn_seq2_fwd_kernel<DROP, MD_, WM_>), grid, dim3(AS2_NT), AS2F_LDS, st, a, a.dropmask)
+      if (a.mdist) { if (wm) AS2F_GO(true, DROP); else AS2F_GO(true, false); }
+      else { if (wm) AS2F_GO(false, DROP); else AS2F_GO(false, false); }
+#undef AS2F_GO
+      return;
+    }
     if (a.S <= AF48_MAXS && g_a2v_attn_fwd48) {
       const int nthr = a.S > 144 ? 256 : 192;             // 48 query rows per wave
       if (a.mdist) hipLaunchKernelGGL((attn_fwd_seq48_kernel<DROP, true>), dim3(1, a.H, a.N), dim3(nthr), AF48_LDS, st, a);
@@ -1575,25 +1613,6 @@ __global__ __launch_bounds__(256) void dalibi_fold_kernel(float* __restrict__ da
   if (tid == 0) dalibi[h] += red[0] + red[1] + red[2] + red[3];
 }
 
-struct AttnBwdArgs {
-  const void* qkv; const void* d_out; const float* lse; const float* delta;
-  void* dqkv;               // (N,S,3,H,HD): k and v slots written here
-  float* dq32;              // (N,S,H,HD) fp32, zeroed by the caller, accumulated with atomics
-  float* dalibi;            // (H) fp32 accumulated: d loss / d alibi_scale_h
-  const int* pos; const float* slopes; const float* alibi_scale;
-  int N, S, H;
-  float scale;
-  Drop drop;
-  float* dal_part;          // per-workgroup partial sums of d alibi_scale go here (the stream's workspace; folded by dalibi_fold_kernel); NULL: atomics
-  float* bias_sum;          // (3, H, HD) fp32 or NULL: column sums of dqkv (the qkv Linear's bias gradient), whole-sequence kernel only
-  // (N,H,S) or NULL: c_i = sum_j P_ij |pos_i - pos_j| from the forward.  d alibi_scale_h = -slope_h sum_ij dS_ij |pos_i - pos_j|, and
-  // sum_j dS_ij = 0 exactly, so any per-row constant may be subtracted from the distance.  What is computed is dS_ij = P_ij (dP_ij -
-  // delta_i) with delta_i = dO_i . O_i from the ROUNDED forward output: it misses sum_j P_ij dP_ij by some e_i (bf16: 2^-9 relative),
-  // which puts -e_i P_ij into every dS_ij and -e_i c_i into the row's distance sum -- e_i times the mean attended distance, a
-  // systematic term as large as the (heavily cancelling) true sum at long sequences.  With the distance centred on c_i that term
-  // is -e_i sum_j P_ij (|.| - c_i) = 0: the gradient is as accurate as the dS values themselves.
-  const float* mdist;
-};
 
 // NT = 0: one workgroup per 64-key block, dQ summed across key blocks with fp32 atomics into dq32 (any S).
 // NT > 0: S <= 64*NT; one workgroup per (n, h) walks every key block, dQ of all NT query tiles stays in
@@ -1919,11 +1938,18 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
   return A2V_OK;
 }
 
-extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, const int* pos,
+// Words (u32) per (n, h) of the dropout bit mask a2v_attention_fwd writes and a2v_attention_bwd reads for this (dtype, S, HD), or 0
+// where the kernels regenerate the decisions from the counter hash instead (the pointer is then ignored).
+extern "C" int a2v_attention_dropmask_words(int dtype, int S, int HD) {
+  return (dtype == A2V_BF16 && HD == 64 && S <= AS2_ROWS && g_a2v_attn_seq2) ? AS2_ROWS * 4 * 2 : 0;
+}
+
+extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, unsigned* dropmask, const int* pos,
                                  const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
                                  float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
-  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr, mdist, 32.f};
+  AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr, mdist, 32.f,
+             a2v_attention_dropmask_words(dtype, S, HD) ? dropmask : nullptr};
   if (dtype == A2V_BF16) {
     a.band_nats = g_a2v_attn_band >= 8 ? (float)g_a2v_attn_band : A2V_BAND_NATS_BF16;
     const bool dr = a.drop.thresh != 0;
@@ -1968,7 +1994,6 @@ extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* l
 // there is no global load and one barrier per (key block, query tile) step (dS double buffered), where the tiled
 // kernel above re-staged Q / dO for every key block and sat in s_waitcnt / s_barrier for 61 % of its cycles.
 // delta = rowsum(dO * O) is computed here too (no separate pass).
-__device__ __forceinline__ int dual_off(int r, int chunk) { return r * 128 + ((chunk ^ (r & 7)) << 4); }   // [rows][64] bf16
 
 #define ABS_ROWS 192
 #define ABS_LDS (2 * ABS_ROWS * 128 + 64 * 128 + 2 * 64 * 128 + 4 * ABS_ROWS * 4 + 3 * 64 * 4)
@@ -3194,6 +3219,21 @@ static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delt
       A2V_CHECK_LAUNCH();
       return A2V_OK;
     }
+    if (a.S <= AS2_ROWS && g_a2v_attn_seq2) {              // round 6: two barrier-free roles over one 40-KB LDS image pair (a2v_attn_seq2.h)
+      const bool dr = a.drop.thresh != 0;
+      const dim3 grid(1, a.H, a.N);
+      set_part(grid);
+#define AS2B_GO(DM_)                                                                                                                  \
+  {                                                                                                                                   \
+    (void)hipFuncSetAttribute((const void*)attn_seq2_bwd_kernel<DM_>, hipFuncAttributeMaxDynamicSharedMemorySize, AS2B_LDS);          \
+    hipLaunchKernelGGL((attn_seq2_bwd_kernel<DM_>), grid, dim3(AS2_NT), AS2B_LDS, st, a, (const bf16*)out, a.dropmask, g_a2v_attn_dbg >> 8);               \
+  }
+      if (!dr) AS2B_GO(0) else if (a.dropmask) AS2B_GO(2) else AS2B_GO(1)
+#undef AS2B_GO
+      fold(grid);
+      A2V_CHECK_LAUNCH();
+      return A2V_OK;
+    }
     if (a.S <= AB48_ROWS && g_a2v_attn_seq48) {
       const bool dr = a.drop.thresh != 0;
       (void)hipFuncSetAttribute((const void*)attn_bwd_seq48_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, AB48_LDS);
@@ -3263,14 +3303,15 @@ extern "C" int a2v_attention_bwd_fused_bias(int dtype, int S, int HD) {
 }
 
 extern "C" int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse,
-                                 const float* mdist, float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos,
+                                 const float* mdist, const unsigned* dropmask, float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos,
                                  const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
                                  float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (qkv_bias_grad && !a2v_attention_bwd_fused_bias(dtype, S, HD)) return A2V_ERR_ARG;
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || !lse || !delta || drop_p < 0.f || drop_p >= 1.f)
     return A2V_ERR_ARG;
   AttnBwdArgs a{qkv, d_out, lse, delta, dqkv, dq32, dalibi, pos, slopes, alibi_scale, N, S, H, scale,
-                make_drop(drop_p, drop_seed), 0, qkv_bias_grad, mdist};
+                make_drop(drop_p, drop_seed), 0, qkv_bias_grad, mdist,
+                a2v_attention_dropmask_words(dtype, S, HD) ? dropmask : nullptr};
   if (dtype == A2V_BF16) {
     if (HD == 64) return attn_bwd_launch<bf16, 64>(a, out, delta, stream);
     if (HD == 32) return attn_bwd_launch<bf16, 32>(a, out, delta, stream);

@@ -132,6 +132,7 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
 X3_CONV_FUSED = os.environ.get("A2V_X3_CONV_FUSED", "1") != "0"     # 64 outputs per group: the three split products of a 64-wide grouped conv in one launch (A/B switch)
 X3_OUT_IMAGE = os.environ.get("A2V_X3_OUT_IMAGE", "1") != "0"         # the Mlp's hidden activation leaves fc1 as its split image only (A/B switch)
 X3_DH_IMAGE = os.environ.get("A2V_X3_DH_IMAGE", "1") != "0"           # the fc2 input gradient leaves its epilogue as a split image only (A/B switch)
+DROPMASK = os.environ.get("A2V_DROPMASK", "1") != "0"                # attention dropout: forward writes a bit mask, backward reads it (0: both hash)
 X3_ATTN_BWD = os.environ.get("A2V_X3_ATTN_BWD", "1") != "0"          # whole-sequence attention backward with split products (A/B switch)
 DACT8 = os.environ.get("A2V_DACT8", "1") != "0"     # bf16 mode: the Mlp's kept gelu' in 8 bits (A/B switch; include/a2v.h: A2V_EPI_DACT8)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
@@ -461,9 +462,19 @@ def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None)
     lse = _E(2, N, H, S, dtype=torch.float32, device=qkv.device) if need_lse else None
     # bf16x3 run (fp32 storage): the forward's two products split on the bf16 matrix cores (the backward: attention_bwd below)
     code = BF16X3 if (X3_WGRAD and qkv.dtype == torch.float32 and HD in (32, 64)) else dt(qkv)
-    rc = _L().a2v_attention_fwd(code, ptr(qkv), ptr(out), ptr(lse), ptr(lse[1]) if need_lse else None, ptr(pos), ptr(slopes),
-                                ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)), stream())
+    # the whole-sequence kernels (bf16, HD 64, S <= 160) decide the dropout once, in the forward, and hand the backward a bit mask
+    # (csrc/a2v_attn_seq2.h); it rides on the lse tensor, the object callers keep for the backward
+    dm = None
+    abi13 = _L()._a2v_abi >= 13                      # (an ABI-12 library: A2V_LIB_PATH, same-box A/B against the previous round)
+    if abi13 and need_lse and drop is not None and drop[0] > 0 and DROPMASK:
+        words = _L().a2v_attention_dropmask_words(code, S, HD)
+        if words:
+            dm = _E(N * H * words, dtype=torch.int32, device=qkv.device)
+    rc = _L().a2v_attention_fwd(code, ptr(qkv), ptr(out), ptr(lse), ptr(lse[1]) if need_lse else None, *((ptr(dm),) if abi13 else ()),
+                                ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_fwd")
+    if dm is not None:
+        lse._a2v_dropmask = dm
     return out, lse
 
 
@@ -481,7 +492,9 @@ def attention_bwd(qkv, out, d_out, lse, pos, slopes, alibi_scale, H, dalibi, dro
     dq32 = None if direct else torch.zeros(N * S, H * HD, dtype=torch.float32, device=qkv.device)
     delta = _E(N, H, S, dtype=torch.float32, device=qkv.device)
     md = lse[1] if lse.dim() == 4 else None           # (a bare (N,H,S) lse: the uncentred arithmetic)
-    rc = _L().a2v_attention_bwd(code, ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(md), ptr(delta), ptr(dqkv), ptr(dq32),
+    dm = getattr(lse, "_a2v_dropmask", None) if (drop is not None and drop[0] > 0) else None
+    rc = _L().a2v_attention_bwd(code, ptr(qkv), ptr(out), ptr(d_out), ptr(lse), ptr(md), *((ptr(dm),) if _L()._a2v_abi >= 13 else ()),
+                                ptr(delta), ptr(dqkv), ptr(dq32),
                                 ptr(dalibi), ptr(bias_grad) if fused else None, ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H,
                                 HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_bwd")

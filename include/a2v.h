@@ -146,8 +146,14 @@ int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long lda, const
  * lse for a2v_attention_bwd pass it too: the backward centres the distance on it when it forms d alibi_scale, which makes
  * that gradient insensitive to the rounding of the saved output (sum_j dS_ij = 0 holds only up to dO.(O_rounded - O); see
  * AttnBwdArgs::mdist in csrc/a2v_attn.hip).  NULL in both calls is the uncentred ABI-7 arithmetic. */
-int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, const int* pos, const float* slopes,
-                      const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
+/* dropmask (ABI 13): where a2v_attention_dropmask_words(dtype, S, HD) is W > 0 (bf16, HD = 64, S <= 160: the student's kept
+ * frames) the forward makes the dropout decision of the softmax probabilities (modules.py:405) ONCE and writes it as a bit mask of
+ * W u32 words per (n, h) -- N*H*W words, caller-owned like every buffer -- which a2v_attention_bwd reads instead of re-hashing
+ * every score (layout: csrc/a2v_attn_seq2.h).  NULL in either call, or W = 0: both calls regenerate the same decisions from the
+ * counter hash of (drop_seed, row, key), so a mask-less backward after a masked forward (and vice versa) is still exact. */
+int a2v_attention_dropmask_words(int dtype, int S, int HD);
+int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, unsigned* dropmask, const int* pos,
+                      const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
                       unsigned drop_seed, a2v_stream_t stream);
 /* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dalibi (H) fp32 accumulates d loss / d alibi_scale.
  * dQ: when a2v_attention_bwd_direct_dq(dtype, S, HD) is 1 (bf16 with S <= 192 -- the student's kept-token sequences --
@@ -156,7 +162,7 @@ int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* 
  * otherwise dq32 (N,S,H,HD) fp32 must be zero on entry, receives dQ through atomics, and the caller casts it
  * into dqkv (a2v_cast2d). */
 int a2v_attention_bwd(int dtype, const void* qkv, const void* out, const void* d_out, const float* lse, const float* mdist,
-                      float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos, const float* slopes,
+                      const unsigned* dropmask, float* delta, void* dqkv, float* dq32, float* dalibi, float* qkv_bias_grad, const int* pos, const float* slopes,
                       const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p, unsigned drop_seed,
                       a2v_stream_t stream);
 /* qkv_bias_grad (3*H*HD fp32, accumulated) or NULL: the column sums of dqkv -- the qkv Linear's bias gradient -- formed
@@ -402,7 +408,10 @@ int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx,
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 11: + epilogue flag A2V_EPI_DACT8 of a2v_conv_gemm; a2v_debug_set keys 30-34 (LayerNorm launch forms); no signature changed.
+/* 13: a2v_attention_fwd / a2v_attention_bwd take `dropmask` (one more pointer each, after mdist; NULL = the ABI-12 arithmetic); + a2v_attention_dropmask_words;
+ *     a2v_debug_set key 39 (round-6 whole-sequence attention kernels on / off).
+ * 12: + a2v_conv_sparse_in, a2v_conv_wgrad_kept.
+ * 11: + epilogue flag A2V_EPI_DACT8 of a2v_conv_gemm; a2v_debug_set keys 30-34 (LayerNorm launch forms); no signature changed.
  * 10: + a2v_query_workspace / a2v_bind_workspace (caller-owned scratch; every other signature unchanged); a2v_debug_set keys 23.
  * 9: + dtype A2V_BF16X3S and epilogue flag A2V_EPI_X3IMG of a2v_conv_gemm; a2v_attention_bwd takes dtype A2V_BF16X3 (signatures unchanged).
  * 8: + a2v_split_bf16 and dtype A2V_BF16X3 of a2v_conv_gemm; + a2v_span_mask, a2v_maskinfo; a2v_attention_fwd / a2v_attention_bwd take `mdist` (one more pointer each, NULL = the ABI-7

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
         assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
     assert set(_lib.SIGNATURES) == set(decls)
-    assert lib.a2v_abi_version() == 12
+    assert lib.a2v_abi_version() == 13
 
 
 def test_ops_refuse_cpu_tensors():

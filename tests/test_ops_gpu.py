@@ -1373,6 +1373,72 @@ def test_attention_dropout(ops, dtype, hd):
     assert rel_err(dal, sc.grad) < max(tol(dtype, 3), 5e-4)
 
 
+def _unpack_dropmask(dm, N, H, S):
+    """keep[n, h, q, key] from the forward's bit mask (csrc/a2v_attn_seq2.h): word pair of lane quarter g of row q holds keys
+    16 j + 4 g + r at bit 31 - (4 j + r) of word 0 (j < 8) / bit 7 - (4 (j - 8) + r) of word 1 (j = 8, 9)."""
+    w = dm.view(N, H, 160, 4, 2).cpu().numpy().astype("uint32")
+    keep = torch.zeros(N, H, S, 160, dtype=torch.bool)
+    import numpy as np
+    for j in range(10):
+        for g in range(4):
+            for r in range(4):
+                word = w[:, :, :S, g, 0 if j < 8 else 1]
+                bit = (31 if j < 8 else 7) - (4 * (j & 7) + r)
+                keep[:, :, :, 16 * j + 4 * g + r] = torch.from_numpy(((word >> np.uint32(bit)) & np.uint32(1)).astype("bool"))
+    return keep[:, :, :, :S]
+
+
+@pytest.mark.parametrize("S", [37, 96, 140, 152, 155, 160])
+def test_attention_seq2_dropout_mask_path(ops, S):
+    """Round-6 whole-sequence kernels (bf16, HD 64, S <= 160): the forward's bit mask IS the counter hash's decision; a backward that
+    reads the mask, one that re-hashes, and the round-5 kernels agree; forward / backward against the fp32 reference with that mask."""
+    dtype, hd = torch.bfloat16, 64
+    N, H, p_, seed = 3, 4, 0.1, 4242
+    qkv = rnd(N, S, 3 * H * hd, dtype=dtype, seed=11).requires_grad_(True)
+    g = torch.Generator().manual_seed(5)
+    pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = (torch.rand(H, generator=g) + 0.5).requires_grad_(True)
+    keep = ops.dropout_mask2d(N * H * S, S, p_, seed).view(N, H, S, S).float().cpu()
+    q, k, v = qkv.reshape(N, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+    bias = O.alibi_bias_from_positions(pos.long(), H, sc.view(1, 1, H, 1, 1))
+    att = ((q * hd ** -0.5) @ k.transpose(-2, -1) + bias).softmax(-1) * keep / (1 - p_)
+    ref = (att @ v).transpose(1, 2).reshape(N, S, H * hd)
+    do = rnd(N, S, H * hd, dtype=dtype, seed=3)
+    ref.backward(do)
+    qd, dod = dev(qkv.detach(), dtype), dev(do, dtype)
+    args = (pos.cuda(), slopes.cuda(), sc.detach().cuda(), H)
+    out, lse = ops.attention_fwd(qd, *args, drop=(p_, seed))
+    dm = getattr(lse, "_a2v_dropmask", None)
+    assert dm is not None, "the whole-sequence forward did not return a dropout mask"
+    assert torch.equal(_unpack_dropmask(dm, N, H, S), keep.bool())
+    assert rel_err(out.float(), ref) < tol(dtype, 2)
+
+    def bwd(lse_):
+        dal = torch.zeros(H, device="cuda")
+        bg = torch.zeros(3 * H * hd, device="cuda")
+        d = ops.attention_bwd(qd, out, dod, lse_, *args, dal, drop=(p_, seed), bias_grad=bg)
+        return d, dal, bg
+    d_mask, dal_mask, bg_mask = bwd(lse)
+    lse_plain = lse.clone()                               # (no mask attribute: the backward re-hashes)
+    d_hash, dal_hash, _ = bwd(lse_plain)
+    assert torch.equal(d_mask, d_hash)
+    assert rel_err(dal_mask, dal_hash) < 1e-6
+    assert rel_err(d_mask.float(), qkv.grad) < tol(dtype, 3)
+    assert rel_err(bg_mask, d_mask.float().sum((0, 1))) < 1e-4
+    assert rel_err(dal_mask, sc.grad) < max(tol(dtype, 3), 5e-4)
+    ops.debug_set(39, 0)                                  # the round-5 kernels on the same inputs
+    try:
+        out5, lse5 = ops.attention_fwd(qd, *args, drop=(p_, seed))
+        assert getattr(lse5, "_a2v_dropmask", None) is None
+        d5, dal5, _ = bwd(lse5)
+    finally:
+        ops.debug_set(39, 1)
+    assert rel_err(out.float(), out5.float()) < 4e-3 and rel_err(lse[0], lse5[0]) < 1e-5 and rel_err(lse[1], lse5[1]) < 1e-4
+    assert rel_err(d_mask.float(), d5.float()) < 8e-3
+    assert rel_err(dal_mask, dal5) < 2e-2
+
+
 def test_attention_dropout_mask_statistics(ops):
     """2-D pair hash of the attention-probability site: keep rate 1 - p, no correlation inside a pair, between
     neighbouring pairs, between rows or between seeds."""
