@@ -1506,12 +1506,17 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   a.xcd_order = 0;
   if constexpr (HD == 64) {
     if (a.S <= AS2_ROWS && g_a2v_attn_seq2) {              // round 6: five-wave workgroups, three per CU (a2v_attn_seq2.h)
-      const dim3 grid(1, a.H, a.N);
+      const long long np = (long long)a.N * a.H;
+      const dim3 grid((unsigned)(np < 256 ? np : 256));     // persistent: one workgroup per CU walks the (n, h) sequences
       const bool wm = DROP && a.dropmask != nullptr;
       a.xcd_order = g_a2v_attn_dbg;                         // (timing experiments only; 0 in every product run)
-#define AS2F_GO(MD_, WM_) hipLaunchKernelGGL((attn_seq2_fwd_kernel<DROP, MD_, WM_>), grid, dim3(AS2_NT), AS2F_LDS, st, a, a.dropmask)
-      if (a.mdist) { if (wm) AS2F_GO(true, DROP); else AS2F_GO(true, false); }
-      else { if (wm) AS2F_GO(false, DROP); else AS2F_GO(false, false); }
+#define AS2F_GO(MD_, WM_)                                                                                                         \
+  {                                                                                                                               \
+    (void)hipFuncSetAttribute((const void*)attn_seq2_fwd_kernel<DROP, MD_, WM_>, hipFuncAttributeMaxDynamicSharedMemorySize, AS2F_LDS); \
+    hipLaunchKernelGGL((attn_seq2_fwd_kernel<DROP, MD_, WM_>), grid, dim3(AS2F_NT), AS2F_LDS, st, a, a.dropmask);                  \
+  }
+      if (a.mdist) { if (wm) AS2F_GO(true, DROP) else AS2F_GO(true, false) }
+      else AS2F_GO(false, false)                            // (no mask without the statistics a backward needs: forward-only call)
 #undef AS2F_GO
       return;
     }
@@ -3221,16 +3226,18 @@ static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delt
     }
     if (a.S <= AS2_ROWS && g_a2v_attn_seq2) {              // round 6: two barrier-free roles over one 40-KB LDS image pair (a2v_attn_seq2.h)
       const bool dr = a.drop.thresh != 0;
-      const dim3 grid(1, a.H, a.N);
-      set_part(grid);
+      const dim3 pgrid(1, a.H, a.N);                        // (the d alibi_scale partials: one slot per (n, h), as the one-shot kernels)
+      set_part(pgrid);
+      const long long np = (long long)a.N * a.H;
+      const dim3 grid((unsigned)(np < 256 ? np : 256));     // persistent: one workgroup per CU walks the (n, h) sequences
 #define AS2B_GO(DM_)                                                                                                                  \
   {                                                                                                                                   \
     (void)hipFuncSetAttribute((const void*)attn_seq2_bwd_kernel<DM_>, hipFuncAttributeMaxDynamicSharedMemorySize, AS2B_LDS);          \
-    hipLaunchKernelGGL((attn_seq2_bwd_kernel<DM_>), grid, dim3(AS2_NT), AS2B_LDS, st, a, (const bf16*)out, a.dropmask, g_a2v_attn_dbg >> 8);               \
+    hipLaunchKernelGGL((attn_seq2_bwd_kernel<DM_>), grid, dim3(AS2B_NT), AS2B_LDS, st, a, (const bf16*)out, a.dropmask);             \
   }
       if (!dr) AS2B_GO(0) else if (a.dropmask) AS2B_GO(2) else AS2B_GO(1)
 #undef AS2B_GO
-      fold(grid);
+      fold(pgrid);
       A2V_CHECK_LAUNCH();
       return A2V_OK;
     }

@@ -1374,15 +1374,15 @@ def test_attention_dropout(ops, dtype, hd):
 
 
 def _unpack_dropmask(dm, N, H, S):
-    """keep[n, h, q, key] from the forward's bit mask (csrc/a2v_attn_seq2.h): word pair of lane quarter g of row q holds keys
-    16 j + 4 g + r at bit 31 - (4 j + r) of word 0 (j < 8) / bit 7 - (4 (j - 8) + r) of word 1 (j = 8, 9)."""
-    w = dm.view(N, H, 160, 4, 2).cpu().numpy().astype("uint32")
-    keep = torch.zeros(N, H, S, 160, dtype=torch.bool)
+    """keep[n, h, q, key] from the forward's bit mask (csrc/a2v_attn_seq2.h): per (n, h) 1280 words [word][lane quarter g][row q];
+    the lane (q, g) holds keys 16 j + 4 g + r at bit 31 - (4 j + r) of word 0 (j < 8) / bit 7 - (4 (j - 8) + r) of word 1 (j = 8, 9)."""
     import numpy as np
+    w = dm.view(N, H, 2, 4, 160).cpu().numpy().astype("uint32")
+    keep = torch.zeros(N, H, S, 160, dtype=torch.bool)
     for j in range(10):
         for g in range(4):
             for r in range(4):
-                word = w[:, :, :S, g, 0 if j < 8 else 1]
+                word = w[:, :, 0 if j < 8 else 1, g, :S]
                 bit = (31 if j < 8 else 7) - (4 * (j & 7) + r)
                 keep[:, :, :, 16 * j + 4 * g + r] = torch.from_numpy(((word >> np.uint32(bit)) & np.uint32(1)).astype("bool"))
     return keep[:, :, :, :S]
