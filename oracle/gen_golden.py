@@ -16,6 +16,7 @@ What it does
 from __future__ import annotations
 
 import argparse
+import json
 import os
 import sys
 
@@ -507,8 +508,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also validate large dims at L=80000 (slow)")
     ap.add_argument("--no-write", action="store_true")
+    ap.add_argument("--trained", action="store_true",
+                    help="only tests/golden/tiny_trained.npz: a small hd-64 model 200 oracle updates from init (needs no reference)")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
+    if args.trained:
+        fx = trained_fixture()
+        if not args.no_write:
+            save("tiny_trained.npz", fx)
+        return
     refnn = ref_shims.install()
 
     sx = sinc_fixtures(refnn)
@@ -535,6 +543,87 @@ def main():
         save("tiny_finetune.npz", ftx)
         save("tiny_finetune_train.npz", fttx)
 
+
+
+TRAINED_DIMS = dict(embed_dim=64, num_heads=1, depth=2, prenet_depth=1, decoder_dim=32, decoder_layers=2, decoder_kernel=7,
+                    decoder_groups=4, clone_batch=2, conv_pos_groups=4, average_top_k_layers=2, ema_decay=0.99, ema_end_decay=0.999,
+                    ema_anneal_end_step=200)
+
+
+def _structured_clips(n, L, seed, f_lo=200.0, f_step=150.0):
+    """a corpus with structure to learn: band-limited noise bursts over a tone that drifts per clip (white noise trains nothing)"""
+    g = torch.Generator().manual_seed(seed)
+    t = torch.arange(L) / 8000.0
+    clips = []
+    for i in range(n):
+        f0 = f_lo + f_step * i
+        x = torch.sin(2 * torch.pi * (f0 + 40.0 * torch.sin(2 * torch.pi * 1.5 * t)) * t) + 0.3 * torch.randn(L, generator=g)
+        x = x * (0.3 + (torch.rand(L // 800, generator=g).repeat_interleave(800) > 0.5).float())
+        clips.append(x)
+    return torch.nn.functional.layer_norm(torch.stack(clips), (L,))
+
+
+def trained_fixture(steps=200):
+    """parity OFF init with fixed inputs.  A small model with head dimension 64 (the bf16 kernels' shape) is trained
+    `steps` updates by the CPU oracle alone -- Adam, gradient clipping, span masks of the oracle's counter stream, EMA teacher; every
+    seed fixed, eval-mode arithmetic (the oracle restates no dropout) -- then student, teacher, a held-out batch and the oracle's
+    outputs and gradients on it are stored.  The GPU test compares the HIP path on exactly these weights with FIXED bounds."""
+    dims = dict(TRAINED_DIMS)
+    ocfg = O.OracleConfig(conv_feature_layers=list(TINY_LAYERS), **dims)
+    torch.manual_seed(0)
+    p = {k: v.clone().requires_grad_(True) for k, v in O.init_params(ocfg, seed=5).items()}
+    ema = O.make_teacher(p)
+    L = 8000
+    T = O.frame_counts(L, ocfg.conv_feature_layers)[-1]
+    clips = _structured_clips(16, L, 21)
+    decay_keys = [k for k, v in p.items() if v.dim() > 1 and "alibi_scale" not in k and "p_swish" not in k]
+    opt = torch.optim.Adam([dict(params=[p[k] for k in decay_keys], weight_decay=0.01),
+                            dict(params=[v for k, v in p.items() if k not in decay_keys], weight_decay=0.0)],
+                           lr=1e-3, betas=(0.9, 0.98), eps=1e-6)
+    g = torch.Generator().manual_seed(77)
+    first = last = None
+    for step in range(steps):
+        lr = 1e-3 * min(1.0, (step + 1) / 10.0)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        src = clips[(step % 2) * 8:(step % 2) * 8 + 8]
+        mask = torch.from_numpy(O.span_mask(8 * ocfg.clone_batch, T, 1.5, 2, seed=1000 + step)).float()
+        keep = int(T - mask[0].sum())
+        noise = torch.randn(8 * ocfg.clone_batch, T - keep, ocfg.embed_dim, generator=g) * 0.01
+        opt.zero_grad(set_to_none=True)
+        res = O.pretrain_forward(p, ema, src, mask, noise, ocfg)
+        loss = res["losses"]["AUDIO_regression"].sum() / float(res["sample_size"])
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(list(p.values()), 1.0)
+        opt.step()
+        O.ema_step(p, ema, O.ema_decay_at(ocfg, step + 1))
+        if step == 4:
+            first = float(loss)
+        last = float(loss)
+        if step % 20 == 0:
+            print(f"trained fixture: step {step} loss {float(loss):.4f} kept {keep}", flush=True)
+    assert last < first, (first, last)
+    # held-out batch: other tones, a seeded mask with an equal count per row
+    B, keep = 2, 16
+    src = _structured_clips(B, L, 55, f_lo=300.0, f_step=700.0)
+    mask = O.seeded_mask(B * ocfg.clone_batch, T, keep, 12)
+    g2 = torch.Generator().manual_seed(56)
+    noise = torch.randn(B * ocfg.clone_batch, T - keep, ocfg.embed_dim, generator=g2) * 0.01
+    po = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    res = O.pretrain_forward(po, ema, src, mask, noise, ocfg)
+    res["losses"]["AUDIO_regression"].sum().backward()
+    fx = dict(source=src, mask=mask, noise=noise, loss_sum=res["losses"]["AUDIO_regression"].detach().sum(),
+              sample_size=torch.tensor(float(res["sample_size"])), loss_first=torch.tensor(first), loss_last=torch.tensor(last),
+              dims=np.frombuffer(json.dumps(dims).encode(), dtype=np.uint8), layers=np.asarray(TINY_LAYERS, dtype=np.int64))
+    for k in ("local_features", "targets", "decoder_out"):
+        fx["out." + k] = res["_dbg"][k].detach().float()
+    for k, v in po.items():
+        fx["p." + k] = v.detach()
+        fx["g." + k] = v.grad.detach()
+    for k, v in ema.items():
+        fx["ema." + k] = v.detach()
+    print(f"trained fixture: loss {first:.4f} -> {last:.4f}; held-out loss_sum {float(fx['loss_sum']):.4f}")
+    return fx
 
 
 def init_fixture(refnn):

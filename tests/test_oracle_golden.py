@@ -1,6 +1,7 @@
 """CPU: the oracle (oracle/a2v_oracle.py) against the golden vectors dumped from the LIVE reference
 by oracle/gen_golden.py.  These are the tests that pin the oracle."""
 import math
+import os
 
 import pytest
 import torch
@@ -190,3 +191,25 @@ def test_focal_loss_known_values():
     l = O.sigmoid_focal_loss(torch.zeros(2), torch.tensor([1.0, 0.0]))
     assert l[0].item() == pytest.approx(0.25 * 0.25 * math.log(2), rel=1e-6)
     assert l[1].item() == pytest.approx(0.75 * 0.25 * math.log(2), rel=1e-6)
+
+
+def test_trained_fixture_is_the_oracles(tmp_path):
+    """tests/golden/tiny_trained.npz (oracle/gen_golden.py --trained): the stored outputs and gradients are what the oracle computes
+    on the stored weights and batch -- the off-init GPU test compares the HIP path with exactly these numbers."""
+    import json
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tiny_trained.npz"))
+    dims = json.loads(bytes(z["dims"]).decode())
+    ocfg = O.OracleConfig(conv_feature_layers=[tuple(int(x) for x in r) for r in z["layers"]], **dims)
+    p = {k[2:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith("p.")}
+    ema = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("ema.")}
+    res = O.pretrain_forward(p, ema, torch.from_numpy(z["source"]), torch.from_numpy(z["mask"]), torch.from_numpy(z["noise"]), ocfg)
+    res["losses"]["AUDIO_regression"].sum().backward()
+    assert abs(float(res["losses"]["AUDIO_regression"].sum()) - float(z["loss_sum"])) < 1e-3 * float(z["loss_sum"])
+    for k in ("local_features", "targets", "decoder_out"):
+        a, b = res["_dbg"][k].detach().double(), torch.from_numpy(z["out." + k]).double()
+        assert float((a - b).norm() / b.norm()) < 1e-5, k
+    worst = max(float((p[k].grad.double() - torch.from_numpy(z["g." + k]).double()).norm() / (torch.from_numpy(z["g." + k]).double().norm() + 1e-30))
+                for k in p)
+    assert worst < 1e-4, worst
+    assert float(z["loss_last"]) < 0.25 * float(z["loss_first"])          # the state is far from init

@@ -1120,6 +1120,60 @@ def test_finetune_hd64_vs_oracle_after_200_updates(dtype, tol_y, tol_g):
     assert not bad, bad[:8]
 
 
+# bf16 bounds of the deterministic off-init fixture: FIXED numbers, set from the measured values of the fixture
+# (profiles/r06_parity_report.jsonl, rows "tiny_trained_golden") with about 1.5x slack -- not scaled by anything the run measures
+TRAINED_BOUNDS = {torch.float32: dict(y=1e-3, med=1e-3, worst=1e-3, ffn=1e-3),
+                  X3: dict(y=1e-3, med=1e-3, worst=1e-3, ffn=1e-3),
+                  torch.bfloat16: dict(y=2.5e-2, med=3.5e-2, worst=8e-2, ffn=5e-2)}
+
+
+def _trained_fixture():
+    import json
+    fx = load_golden("tiny_trained.npz")
+    dims = json.loads(bytes(fx["dims"].numpy().astype("uint8")).decode())
+    p = {k[2:]: v for k, v in fx.items() if k.startswith("p.")}
+    ema = {k[4:]: v for k, v in fx.items() if k.startswith("ema.")}
+    g = {k[2:]: v for k, v in fx.items() if k.startswith("g.")}
+    return fx, dims, p, ema, g
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, X3])
+def test_tiny_trained_golden(dtype):
+    """Parity OFF init on a committed state (tests/golden/tiny_trained.npz, oracle/gen_golden.py --trained: a head-dimension-64 model
+    200 oracle updates from init, loss 5.4 -> 0.75; student, EMA teacher, a held-out batch, the oracle's outputs and every
+    gradient).  The HIP path runs on exactly those weights: local features, teacher targets, decoder output, loss and all gradients
+    against FIXED bounds; the Mlp weights' gradients (whose backward operand is the 8-bit GELU' in the bf16 mode) are bounded and
+    reported separately."""
+    from animal2vec_amd.config import tiny_config
+    fx, dims, p, ema, gref = _trained_fixture()
+    cfg = tiny_config(embed_dim=dims["embed_dim"], num_heads=dims["num_heads"], ema_decay=dims["ema_decay"],
+                      ema_end_decay=dims["ema_end_decay"], ema_anneal_end_step=dims["ema_anneal_end_step"])
+    b = TRAINED_BOUNDS[dtype]
+    store, eng = build(cfg, p, ema, dtype)
+    dbg = run(eng, fx["source"], fx["mask"], fx["noise"])
+    D = cfg.embed_dim
+    ey = {k: rel_err(dbg[k].float(), fx["out." + k]) for k in ("local_features", "targets", "decoder_out")}
+    ls = float(fx["loss_sum"])
+    ey["loss"] = abs(float(eng.stats[4 * D]) - ls) / ls
+    allerr = sorted((rel_err(store.g[k], v), k) for k, v in gref.items())
+    med, worst = allerr[len(allerr) // 2][0], allerr[-1]
+    ffn = [(e, k) for e, k in allerr if ".mlp.fc1.weight" in k or ".mlp.fc2.weight" in k]
+    parity_report("tiny_trained_golden", dtype, allerr, targets=ey["targets"], decoder_out=ey["decoder_out"],
+                  local_features=ey["local_features"], loss=ey["loss"], ffn_weight_worst=max(ffn)[0],
+                  ffn_weight_median=sorted(ffn)[len(ffn) // 2][0], loss_first=float(fx["loss_first"]), loss_last=float(fx["loss_last"]))
+    eng.close()
+    for k, v in ey.items():
+        assert v < b["y"], (k, v)
+    assert med < b["med"], med
+    al = [e for e, k in allerr if k == AL_KEY][0]
+    rest = [(e, k) for e, k in allerr if k != AL_KEY]
+    assert rest[-1][0] < b["worst"], rest[-3:]
+    assert max(ffn)[0] < b["ffn"], sorted(ffn)[-3:]
+    # d alibi_scale off init is well conditioned (the heads have learnt to prefer near frames): the same ceiling as every tensor in
+    # fp32 / bf16x3, twice it in bf16 (one number per head)
+    assert al < (2 * b["worst"] if dtype == torch.bfloat16 else b["worst"]), al
+
+
 def test_exact_resume_from_checkpoint(tmp_path):
     """Stop after two updates, write the fairseq-style checkpoint with the optimizer state, resume in a fresh trainer and
     take two more: same parameters / teacher as four updates in one go (dropout seeds derive from num_updates, the mixup

@@ -123,8 +123,9 @@ def main():
     fx = os.path.join(ROOT, "tests", "golden", "tiny_trained.npz")
     if os.path.exists(fx):
         import numpy as np
+        import json as _json
         z = np.load(fx)
-        tcfg = O.OracleConfig(**O.TINY)
+        tcfg = O.OracleConfig(conv_feature_layers=[tuple(int(x) for x in r) for r in z["layers"]], **_json.loads(bytes(z["dims"]).decode()))
         tp = {k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("p.")}
         tema = {k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("ema.")}
         tsrc = torch.from_numpy(z["source"])
