@@ -491,13 +491,29 @@ class Engine:
         dxm = ops.linear(dlog, head.wt_op)                                       # (B*T, D)
         if c.get("d_fin") is not None:
             dxm = ops.add_drop(None, dxm, drop=c["d_fin"])
-        sel, active = c["sel"], c["active"]
+        sel = c["sel"]
         dt = ops.mean_layers([dxm], scale=1.0 / len(sel)).view(B, T, D)
-        # ---- blocks: the last executed block's output x feeds nothing; every selected block receives dt at its FFN output
-        dxe = torch.zeros(B, T, D, dtype=self.dtype, device=dlog.device)
+        # the last executed block's output x feeds nothing; every selected block receives dt at its FFN output
+        self.features_backward(c, None, {i: dt for i in sel})
+
+    def features_backward(self, c, dx, dts):
+        """Backward of encode_features(save=True): dx (B,T,D) or None = gradient arriving at the last block's output x, dts {block
+        index: (B,T,D)} = gradients arriving at the blocks' FFN outputs (layer_results, data2vec2.py:722-728).  Accumulates the
+        encoder's and project_features' gradients into store.grad; the conv feature extractor is frozen as in finetune_backward.
+        `c` is the context encode_features returned (with its per-block saves still in self.sv)."""
+        cfg, st = self.cfg, self.store
+        p, g = st.p, st.g
+        H, D = cfg.num_heads, cfg.embed_dim
+        a = cfg.audio
+        ops.X3_WGRAD = self.x3
+        B, T = c["B"], c["T"]
+        asc = p[P + "alibi_scale"].view(-1)
+        active = c["active"]
+        dev = st.grad.device
+        dxe = torch.zeros(B, T, D, dtype=self.dtype, device=dev) if dx is None else dx.to(self.dtype).contiguous()
         for i in reversed(range(cfg.depth)):
             if active[a.prenet_depth + i]:
-                dxe = self.block_bwd(dxe, f"blocks.{i}.", None, asc, H, f"fmb{i}", dt=dt if i in sel else None)
+                dxe = self.block_bwd(dxe, f"blocks.{i}.", None, asc, H, f"fmb{i}", dt=dts.get(i))
             self._ready(f"block{i}")
         if c.get("d_in") is not None:
             dxe = ops.add_drop(None, dxe.contiguous(), drop=c["d_in"])

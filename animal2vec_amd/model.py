@@ -303,16 +303,21 @@ class Data2VecMultiModel(tnn.Module):
                 aug.update(drop_seed=(cfg.seed * 7919 + self._fwd_count) & 0x7FFFFFFF, p_drop=cfg.encoder_dropout,
                            p_proj=cfg.encoder_dropout, p_mlp=cfg.post_mlp_drop, p_pre=a.prenet_dropout,
                            p_att=cfg.attention_dropout, p_in=cfg.dropout_input, p_act=0.0, p_final=0.0)
-        if self.training and torch.is_grad_enabled() and not getattr(self, "_warned_features_only", False):
-            import warnings
-            self._warned_features_only = True
-            warnings.warn("Data2VecMultiModel.forward(features_only=True) returns features WITHOUT an autograd graph: a wrapper "
-                          "that trains through this call (the reference's finetune model does, wav2vec2.py:433-445) would update "
-                          "only its own head.  The native finetune path is nn.Wav2VecCcasFinetune / Engine.finetune_forward_backward.")
+        if torch.is_grad_enabled() and any(prm.requires_grad for prm in self.parameters()):
+            # a wrapper that trains THROUGH this call (the reference's finetune model does, wav2vec2.py:433-463): the features carry
+            # an autograd node whose backward runs the hand-written encoder backward into the flat gradient buffer
+            outs = _FeaturesOnly.apply(self._features_anchor(source.device), self, source, aug or None)
+            x, ts = outs[0], list(outs[1:])
+            return {"x": x, "linear_eval_projection": None, "padding_mask": None, "layer_results": ts, "mask": minfo}
         with torch.no_grad():
             x, ts, _ = eng.encode_features(source, save=False, aug=aug or None)
         return {"x": x, "linear_eval_projection": None, "padding_mask": None, "layer_results": [t for _, t in ts],
                 "mask": minfo}
+
+    def _features_anchor(self, device):
+        if getattr(self, "_fanchor", None) is None or self._fanchor.device != torch.device(device):
+            self._fanchor = torch.zeros(1, device=device, requires_grad=True)
+        return self._fanchor
 
     def extract_features(self, source, mode=None, padding_mask=None, mask=False, remove_extra_tokens=True):
         """data2vec2.py:1112-1123"""
@@ -322,3 +327,30 @@ class Data2VecMultiModel(tnn.Module):
     def remove_pretraining_modules(self, modality=None, keep_decoder=False):
         """data2vec2.py:1125-1142: drops the teacher; the decoder weights stay allocated (flat buffer)."""
         self.skip_ema = True
+
+
+class _FeaturesOnly(torch.autograd.Function):
+    """autograd bridge of forward(features_only=True) (data2vec2.py:722-728): forward runs Engine.encode_features with its saves
+    kept in the engine; backward receives the cotangents of x and of every layer result from whatever sits on top (a finetune
+    head of another package, a probe ...) and runs Engine.features_backward into the flat gradient buffer the parameters' .grad
+    view.  One backward per forward (the saves are consumed), as Engine.finetune_backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, source, aug):
+        eng = model.engine
+        ctx.set_materialize_grads(False)                      # cotangents nobody supplied stay None (no zero tensors per layer)
+        x, ts, c = eng.encode_features(source, save=True, aug=aug)
+        c = dict(c)
+        c.pop("d_fin_spec", None)
+        ctx.model, ctx.c, ctx.idx = model, c, [i for i, _ in ts]
+        ctx.dev = anchor.device
+        return (x, *[t for _, t in ts])
+
+    @staticmethod
+    def backward(ctx, dx, *dts):
+        model = ctx.model
+        model.attach_grads()                                  # the optimizer may have set p.grad = None
+        eng = model.engine
+        given = {i: d.to(eng.dtype).contiguous() for i, d in zip(ctx.idx, dts) if d is not None}
+        eng.features_backward(ctx.c, dx, given)
+        return torch.zeros(1, device=ctx.dev), None, None, None

@@ -1129,6 +1129,7 @@ TRAINED_BOUNDS = {torch.float32: dict(y=1e-3, med=1e-3, worst=1e-3, ffn=1e-3),
 
 def _trained_fixture():
     import json
+    from conftest import load_golden
     fx = load_golden("tiny_trained.npz")
     dims = json.loads(bytes(fx["dims"].numpy().astype("uint8")).decode())
     p = {k[2:]: v for k, v in fx.items() if k.startswith("p.")}
