@@ -94,21 +94,17 @@ class A2VError(RuntimeError):
     pass
 
 
-def load() -> C.CDLL:
-    """Load liba2v_hip.so (never builds, never falls back)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def _load_path(path: str, what: str) -> C.CDLL:
+    if not os.path.exists(path):
         raise A2VError(
-            f"{LIB_PATH} is missing: the HIP extension is mandatory (run `python -c 'import __graft_entry__ as g; "
+            f"{path} is missing: the HIP extension{what} is mandatory (run `python -c 'import __graft_entry__ as g; "
             f"g.build()'` or `python animal2vec_amd/build.py`). There is no CPU fallback.")
     # torch first: its wheel carries its own HIP runtime (libamdhip64 under torch/lib).  Loaded before torch, this library pulls in
     # /opt/rocm's copy instead and the process ends up with two runtimes -- torch's owns the devices and streams, ours reports
     # "no device" at the first launch (seen with `python __graft_entry__.py --smoke`, where build() loads the library before anything
     # has imported torch).  With torch already imported the loader resolves the same soname to the one runtime.
     import torch  # noqa: F401
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.a2v_abi_version.restype = C.c_int
     abi = int(lib.a2v_abi_version())
     lib._a2v_abi = abi
@@ -124,7 +120,7 @@ def load() -> C.CDLL:
             # calls they replaced; the product library must export everything)
             if name in ABI12_ENTRIES and os.environ.get("A2V_LIB_PATH"):
                 continue
-            raise A2VError(f"liba2v_hip.so does not export {name}") from e
+            raise A2VError(f"{os.path.basename(path)} does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = RESTYPES.get(name, C.c_int)
     # A2V_DEBUG_SET="key=value,key=value": A/B switches of a2v_debug_set for whole test / bench runs (experiments only).
@@ -137,8 +133,32 @@ def load() -> C.CDLL:
             raise A2VError(f"A2V_DEBUG_SET: malformed entry {kv!r} (want key=value with integers)") from e
         if lib.a2v_debug_set(k, v) != 0:
             raise A2VError(f"A2V_DEBUG_SET: a2v_debug_set({k}, {v}) was refused (unknown key)")
-    _lib = lib
     return lib
+
+
+def load() -> C.CDLL:
+    """Load liba2v_hip.so (never builds, never falls back)."""
+    global _lib
+    if _lib is None:
+        _lib = _load_path(LIB_PATH, "")
+    return _lib
+
+
+_lib_f16 = None
+LIB_F16_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liba2v_hip_f16.so")
+
+
+def load_f16() -> C.CDLL:
+    """liba2v_hip_f16.so: the same sources and C ABI with IEEE half as the 16-bit type (csrc/a2v_common.h: A2V_ELT_F16) -- the EMA
+    teacher's forward.  Loaded RTLD_LOCAL like the product library, so the two sets of identical symbol names never meet."""
+    global _lib_f16
+    if _lib_f16 is None:
+        _lib_f16 = _load_path(LIB_F16_PATH, " (fp16 teacher build)")
+    return _lib_f16
+
+
+def have_f16() -> bool:
+    return os.path.exists(LIB_F16_PATH) and not os.environ.get("A2V_LIB_PATH")
 
 
 def check(rc: int, what: str) -> None:

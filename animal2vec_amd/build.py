@@ -69,6 +69,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if r.returncode:
             raise RuntimeError(f"link failed:\n{r.stderr}")
     build_abi_client(force=force or bool(jobs), verbose=verbose)
+    # the fp16 twin (csrc/a2v_common.h: A2V_ELT_F16): same sources, IEEE half as the 16-bit type -- the EMA teacher's forward
+    build_variant("f16", ["-DA2V_ELT_F16"], verbose=verbose)
     return LIB
 
 

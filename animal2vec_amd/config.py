@@ -95,7 +95,7 @@ class D2vAudioConfig:
                          ("keep_masked_pct", 0.0), ("remove_masks", False), ("num_extra_tokens", 0), ("start_drop_path_rate", 0.0),
                          ("end_drop_path_rate", 0.0), ("sinc_input", True), ("sinc_norm", "layer_norm"), ("use_pswish", True),
                          ("use_alibi_encoder", True), ("learned_alibi_scale", True), ("learned_alibi_scale_per_head", True),
-                         ("encoder_zero_mask", True), ("add_masks", False)):
+                         ("add_masks", False)):
             v = getattr(self, k)
             if (v is None) != (built is None) or (built is not None and type(built)(v) != built):
                 bad.append(f"{k}={v!r} (built: {built!r})")

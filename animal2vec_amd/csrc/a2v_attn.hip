@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int ks = 0; ks < HD / 32; ++ks) {
           const bf16x8 kf = *(const bf16x8*)(sK + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
-          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf_b[ks], acc, 0, 0, 0);
+          acc = A2V_MFMA_16x16x32(kf, qf_b[ks], acc, 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
           const bf16x8 vf = tr_frag(sV + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sV + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
-          o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, o[i], 0, 0, 0);
+          o[i] = A2V_MFMA_16x16x32(vf, pf, o[i], 0, 0, 0);
         }
       }
     } else {
@@ -374,9 +374,9 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnArgs a) {
       for (int ks = 0; ks < HD / 32; ++ks) {
         const bf16x8 kh_ = *(const bf16x8*)(sKh + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
         const bf16x8 kl_ = *(const bf16x8*)(sKl + rowimg_off<HD>(16 * j + fr, ks * 4 + g));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kl_, qh[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, ql[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kh_, qh[ks], acc, 0, 0, 0);
+        acc = A2V_MFMA_16x16x32(kl_, qh[ks], acc, 0, 0, 0);
+        acc = A2V_MFMA_16x16x32(kh_, ql[ks], acc, 0, 0, 0);
+        acc = A2V_MFMA_16x16x32(kh_, qh[ks], acc, 0, 0, 0);
       }
       s[j] = acc;
     }
@@ -430,9 +430,9 @@ __global__ __launch_bounds__(256) void attn_fwd_x3_kernel(AttnArgs a) {
       for (int i = 0; i < ND; ++i) {
         const bf16x8 vh_ = tr_frag(sVh + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sVh + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
         const bf16x8 vl_ = tr_frag(sVl + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sVl + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
-        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl_, ph, o[i], 0, 0, 0);
-        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh_, pl, o[i], 0, 0, 0);
-        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh_, ph, o[i], 0, 0, 0);
+        o[i] = A2V_MFMA_16x16x32(vl_, ph, o[i], 0, 0, 0);
+        o[i] = A2V_MFMA_16x16x32(vh_, pl, o[i], 0, 0, 0);
+        o[i] = A2V_MFMA_16x16x32(vh_, ph, o[i], 0, 0, 0);
       }
     }
   }
@@ -687,12 +687,12 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_f
         if constexpr (PH == 1) {
           f32x4 acc = pk;                            // the bias IS the accumulator's initial value
 #pragma unroll
-          for (int ks = 0; ks < HD / 32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+          for (int ks = 0; ks < HD / 32; ++ks) acc = A2V_MFMA_16x16x32(kf[ks], qf[b][ks], acc, 0, 0, 0);
           s[b][j] = acc;
         } else {
           f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < HD / 32; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+          for (int ks = 0; ks < HD / 32; ++ks) acc = A2V_MFMA_16x16x32(kf[ks], qf[b][ks], acc, 0, 0, 0);
           // acc + c_rel |pos_q - pos_k| = v_sub + one v_fma with the |.| source modifier.  This file is built with
           // -fno-slp-vectorize: paired into v_pk_fma_f32 (no modifiers) the abs costs a separate v_and per element and the
           // packed op more issue time next to MFMAs than two plain fmas (MI355X_MICROARCH.md cycle constants).
@@ -800,11 +800,11 @@ __global__ __launch_bounds__(256, (QB == 2 && !DROP && !MD) ? 3 : 1) void attn_f
       for (int i = 0; i < ND; ++i) {
         const bf16x8 vf = tr_frag(bV + trimg_off<HD>(r_lo, 16 * i + 4 * pp), bV + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
 #pragma unroll
-        for (int b = 0; b < QB; ++b) o[b][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b], o[b][i], 0, 0, 0);
+        for (int b = 0; b < QB; ++b) o[b][i] = A2V_MFMA_16x16x32(vf, pf[b], o[b][i], 0, 0, 0);
       }
       if constexpr (!VSUM) {
 #pragma unroll
-        for (int b = 0; b < QB; ++b) lacc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[b], lacc[b], 0, 0, 0);
+        for (int b = 0; b < QB; ++b) lacc[b] = A2V_MFMA_16x16x32(ones, pf[b], lacc[b], 0, 0, 0);
       }
     }
     // buffer buf^1 was last read in iteration kt-1; every wave has passed that iteration's barrier
@@ -1071,7 +1071,7 @@ __global__ __launch_bounds__(256, (!DROP && !MD) ? 3 : 1) void attn_fwd32_bf16_k
         else if (i == 5) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kr[i % 5]));
         else if (i == 6) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kr[i % 5]));
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[i % 5]));
-        s[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i % 5], qf[i >> 1], s[i & 1], 0, 0, 0);
+        s[i & 1] = A2V_MFMA_32x32x16(kr[i % 5], qf[i >> 1], s[i & 1], 0, 0, 0);
         if (i + 4 < 8) A32_KREAD(i + 4);
       }
 #undef A32_KREAD
@@ -1197,9 +1197,9 @@ __global__ __launch_bounds__(256, (!DROP && !MD) ? 3 : 1) void attn_fwd32_bf16_k
       for (int dd = 0; dd < 2; ++dd) {
         union { struct { s16x4 a, b; } h; bf16x8 v; } vf;
         vf.h.a = vr[st & 1][2 * dd]; vf.h.b = vr[st & 1][2 * dd + 1];
-        o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf, o[dd], 0, 0, 0);
+        o[dd] = A2V_MFMA_32x32x16(vf.v, pf, o[dd], 0, 0, 0);
       }
-      if constexpr (!VSUM) lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+      if constexpr (!VSUM) lacc = A2V_MFMA_32x32x16(ones, pf, lacc, 0, 0, 0);
     }
 #undef A32_VREAD
     if (more) A32_STORE(kt + 1);
@@ -1344,7 +1344,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
       for (int b = 0; b < QB; ++b) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[b][ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) acc = A2V_MFMA_16x16x32(kf[ks], qf[b][ks], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v = __builtin_fmaf(__builtin_fabsf(pos_q[b] - pk[r]), c_rel, acc[r]);
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_seq48_kernel(AttnArgs a) {
       for (int i = 0; i < ND; ++i) {
         const bf16x8 vf = tr_frag(sV + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sV + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
 #pragma unroll
-        for (int b = 0; b < QB; ++b) o[b][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[b], o[b][i], 0, 0, 0);
+        for (int b = 0; b < QB; ++b) o[b][i] = A2V_MFMA_16x16x32(vf, pf[b], o[b][i], 0, 0, 0);
       }
     }
   }
@@ -1763,8 +1763,8 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
         for (int ks = 0; ks < HD / 32; ++ks) {
           const bf16x8 qa = *(const bf16x8*)(sQ + rowimg_off<HD>(16 * i + fr, ks * 4 + g));
           const bf16x8 da = *(const bf16x8*)(sDO + rowimg_off<HD>(16 * i + fr, ks * 4 + g));
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf_b[ks], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf_b[ks], pacc, 0, 0, 0);
+          sacc = A2V_MFMA_16x16x32(qa, kf_b[ks], sacc, 0, 0, 0);
+          pacc = A2V_MFMA_16x16x32(da, vf_b[ks], pacc, 0, 0, 0);
         }
       } else {
 #pragma unroll
@@ -1827,8 +1827,8 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
         for (int i = 0; i < ND; ++i) {
           const bf16x8 dof = tr_frag(sDOt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sDOt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
           const bf16x8 qf = tr_frag(sQt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sQt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
-          dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[i], 0, 0, 0);
-          dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, df, dk[i], 0, 0, 0);
+          dv[i] = A2V_MFMA_16x16x32(dof, pf, dv[i], 0, 0, 0);
+          dk[i] = A2V_MFMA_16x16x32(qf, df, dk[i], 0, 0, 0);
         }
       }
     } else {
@@ -1869,7 +1869,7 @@ __global__ __launch_bounds__(256, NT > 0 ? 2 : 1) void attn_bwd_kernel(AttnBwdAr
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
           const bf16x8 kf = tr_frag(sKt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sKt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
-          dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, dq[i], 0, 0, 0);
+          dq[i] = A2V_MFMA_16x16x32(af, kf, dq[i], 0, 0, 0);
         }
       }
     } else {
@@ -2148,8 +2148,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 qa = *(const bf16x8*)(sQ + dual_off(q0 + 16 * i + fr, ks * 4 + g));
           const bf16x8 da = *(const bf16x8*)(sDO + dual_off(q0 + 16 * i + fr, ks * 4 + g));
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf_b[ks], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf_b[ks], pacc, 0, 0, 0);
+          sacc = A2V_MFMA_16x16x32(qa, kf_b[ks], sacc, 0, 0, 0);
+          pacc = A2V_MFMA_16x16x32(da, vf_b[ks], pacc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -2195,8 +2195,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
           const int chl = 2 * i + (pp >> 1), sub = (pp & 1) << 3;       // column 16 i + 4 pp: chunk, byte inside it
           const bf16x8 dof = tr_frag(sDO + dual_off(r_lo, chl) + sub, sDO + dual_off(r_hi, chl) + sub);
           const bf16x8 qf = tr_frag(sQ + dual_off(r_lo, chl) + sub, sQ + dual_off(r_hi, chl) + sub);
-          dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[i], 0, 0, 0);
-          dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, df, dk[i], 0, 0, 0);
+          dv[i] = A2V_MFMA_16x16x32(dof, pf, dv[i], 0, 0, 0);
+          dk[i] = A2V_MFMA_16x16x32(qf, df, dk[i], 0, 0, 0);
         }
       }
       __syncthreads();   // dS tile complete (and the other dS buffer's readers of step - 1 are past)
@@ -2217,7 +2217,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_seq_kernel(AttnBwdArgs a, con
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
           const bf16x8 kf = tr_frag(sKt + trimg_off<HD>(r_lo, 16 * i + 4 * pp), sKt + trimg_off<HD>(r_hi, 16 * i + 4 * pp));
-          dq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kf, dq[i], 0, 0, 0);
+          dq[i] = A2V_MFMA_16x16x32(af, kf, dq[i], 0, 0, 0);
         }
       }
 #pragma unroll
@@ -2459,8 +2459,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_seq48_kernel(AttnBwdArgs 
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 qa = *(const bf16x8*)(sQ + dual_off(rb + fr, ks * 4 + g));
         const bf16x8 da = *(const bf16x8*)(sDO + dual_off(rb + fr, ks * 4 + g));
-        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf_b[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf_b[ks], pacc, 0, 0, 0);
+        sacc = A2V_MFMA_16x16x32(qa, kf_b[ks], sacc, 0, 0, 0);
+        pacc = A2V_MFMA_16x16x32(da, vf_b[ks], pacc, 0, 0, 0);
       }
       const f32x4 lse4 = *(const f32x4*)(sLse + rb + 4 * g);
       const f32x4 del4 = *(const f32x4*)(sDelta + rb + 4 * g);
@@ -2497,8 +2497,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_seq48_kernel(AttnBwdArgs 
         const int chl = 2 * i + (pp >> 1), sub = (pp & 1) << 3;       // column 16 i + 4 pp: chunk, byte inside it
         const bf16x8 dof = tr_frag(sDO + dual_off(r_lo, chl) + sub, sDO + dual_off(r_hi, chl) + sub);
         const bf16x8 qf = tr_frag(sQ + dual_off(r_lo, chl) + sub, sQ + dual_off(r_hi, chl) + sub);
-        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dof, pf, dv[i], 0, 0, 0);
-        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf, df, dk[i], 0, 0, 0);
+        dv[i] = A2V_MFMA_16x16x32(dof, pf, dv[i], 0, 0, 0);
+        dk[i] = A2V_MFMA_16x16x32(qf, df, dk[i], 0, 0, 0);
       }
     };
 #pragma unroll 1
@@ -2558,7 +2558,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_seq48_kernel(AttnBwdArgs 
         const int ch = ks * 4 + g;
         const bf16x8 af = *(const bf16x8*)(sDS + rq * 128 + (((ch ^ ((rq >> 1) & 7)) & 7) << 4));
 #pragma unroll
-        for (int i = 0; i < ND; ++i) dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, kfr[i], dq[t][i], 0, 0, 0);
+        for (int i = 0; i < ND; ++i) dq[t][i] = A2V_MFMA_16x16x32(af, kfr[i], dq[t][i], 0, 0, 0);
       }
     }
     __syncthreads();           // the next key block overwrites sKt and sDS
@@ -2763,12 +2763,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_x3_kernel(AttnBwdArgs a, con
         const int o_ = dual_off(rb + fr, ks * 4 + g);
         const bf16x8 qh_ = *(const bf16x8*)(sQh + o_), ql_ = *(const bf16x8*)(sQl + o_);
         const bf16x8 dh_ = *(const bf16x8*)(sDOh + o_), dl_ = *(const bf16x8*)(sDOl + o_);
-        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql_, kfh[ks], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh_, kfl[ks], sacc, 0, 0, 0);
-        sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh_, kfh[ks], sacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl_, vfh[ks], pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh_, vfl[ks], pacc, 0, 0, 0);
-        pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh_, vfh[ks], pacc, 0, 0, 0);
+        sacc = A2V_MFMA_16x16x32(ql_, kfh[ks], sacc, 0, 0, 0);
+        sacc = A2V_MFMA_16x16x32(qh_, kfl[ks], sacc, 0, 0, 0);
+        sacc = A2V_MFMA_16x16x32(qh_, kfh[ks], sacc, 0, 0, 0);
+        pacc = A2V_MFMA_16x16x32(dl_, vfh[ks], pacc, 0, 0, 0);
+        pacc = A2V_MFMA_16x16x32(dh_, vfl[ks], pacc, 0, 0, 0);
+        pacc = A2V_MFMA_16x16x32(dh_, vfh[ks], pacc, 0, 0, 0);
       }
       const f32x4 lse4 = *(const f32x4*)(sLse + rb + 4 * g);
       const f32x4 del4 = *(const f32x4*)(sDelta + rb + 4 * g);
@@ -2806,12 +2806,12 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_x3_kernel(AttnBwdArgs a, con
         const int o_lo = dual_off(r_lo, chl) + sub, o_hi = dual_off(r_hi, chl) + sub;
         const bf16x8 doh = tr_frag(sDOh + o_lo, sDOh + o_hi), dol = tr_frag(sDOl + o_lo, sDOl + o_hi);
         const bf16x8 qfh = tr_frag(sQh + o_lo, sQh + o_hi), qfl = tr_frag(sQl + o_lo, sQl + o_hi);
-        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dol, pfh, dv[i], 0, 0, 0);
-        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doh, pfl, dv[i], 0, 0, 0);
-        dv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(doh, pfh, dv[i], 0, 0, 0);
-        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfl, dfh, dk[i], 0, 0, 0);
-        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfh, dfl, dk[i], 0, 0, 0);
-        dk[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qfh, dfh, dk[i], 0, 0, 0);
+        dv[i] = A2V_MFMA_16x16x32(dol, pfh, dv[i], 0, 0, 0);
+        dv[i] = A2V_MFMA_16x16x32(doh, pfl, dv[i], 0, 0, 0);
+        dv[i] = A2V_MFMA_16x16x32(doh, pfh, dv[i], 0, 0, 0);
+        dk[i] = A2V_MFMA_16x16x32(qfl, dfh, dk[i], 0, 0, 0);
+        dk[i] = A2V_MFMA_16x16x32(qfh, dfl, dk[i], 0, 0, 0);
+        dk[i] = A2V_MFMA_16x16x32(qfh, dfh, dk[i], 0, 0, 0);
       }
     };
 #pragma unroll 1
@@ -2873,9 +2873,9 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_x3_kernel(AttnBwdArgs a, con
         const bf16x8 ah_ = *(const bf16x8*)(sDSh + o_), al_ = *(const bf16x8*)(sDSl + o_);
 #pragma unroll
         for (int i = 0; i < ND; ++i) {
-          dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al_, kh_[i], dq[t][i], 0, 0, 0);
-          dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, kl_[i], dq[t][i], 0, 0, 0);
-          dq[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah_, kh_[i], dq[t][i], 0, 0, 0);
+          dq[t][i] = A2V_MFMA_16x16x32(al_, kh_[i], dq[t][i], 0, 0, 0);
+          dq[t][i] = A2V_MFMA_16x16x32(ah_, kl_[i], dq[t][i], 0, 0, 0);
+          dq[t][i] = A2V_MFMA_16x16x32(ah_, kh_[i], dq[t][i], 0, 0, 0);
         }
       }
     }
@@ -3098,8 +3098,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
           f32x4 sacc = {0.f, 0.f, 0.f, 0.f}, pacc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < 2; ++ks) {
-            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], own1[og][ks], sacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ks], own2[og][ks], pacc, 0, 0, 0);
+            sacc = A2V_MFMA_16x16x32(a1[ks], own1[og][ks], sacc, 0, 0, 0);
+            pacc = A2V_MFMA_16x16x32(a2[ks], own2[og][ks], pacc, 0, 0, 0);
           }
           f32x4 pcur, dcur;
 #pragma unroll
@@ -3144,12 +3144,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_long_kernel(AttnBwdArgs a) {
         const bf16x8 x1f = tr_frag(X1 + dual_off(r_lo, chl) + sub, X1 + dual_off(r_hi, chl) + sub);
 #pragma unroll
         for (int og = 0; og < 2; ++og)
-          accB[og][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1f, dk_[og], accB[og][i], 0, 0, 0);
+          accB[og][i] = A2V_MFMA_16x16x32(x1f, dk_[og], accB[og][i], 0, 0, 0);
         if (MODE == 0) {
           const bf16x8 x2f = tr_frag(X2 + dual_off(r_lo, chl) + sub, X2 + dual_off(r_hi, chl) + sub);
 #pragma unroll
           for (int og = 0; og < 2; ++og)
-            accA[og][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x2f, pk[og], accA[og][i], 0, 0, 0);
+            accA[og][i] = A2V_MFMA_16x16x32(x2f, pk[og], accA[og][i], 0, 0, 0);
         }
       }
     }

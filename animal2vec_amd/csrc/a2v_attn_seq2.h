@@ -68,7 +68,7 @@ __device__ __forceinline__ void as2_stagger(int sleeps) {
 
 __device__ __forceinline__ unsigned as2_pack2(float lo, float hi) {     // two fp32 -> packed bf16 pair (RNE), one instruction
   unsigned r;
-  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+  asm(A2V_ASM_CVT_PK " %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
   return r;
 }
 
@@ -89,79 +89,79 @@ __device__ __forceinline__ unsigned as2_pack2(float lo, float hi) {     // two f
     "ds_read_b64_tr_b16 v[164:165], v153 offset:0\n" \
     "ds_read_b64_tr_b16 v[166:167], v153 offset:2048\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %0, v[156:159], %4, %0\n" \
+    A2V_ASM_MFMA_16x16x32 " %0, v[156:159], %4, %0\n" \
     "ds_read_b64_tr_b16 v[156:157], v154 offset:0\n" \
     "ds_read_b64_tr_b16 v[158:159], v154 offset:2048\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %1, v[160:163], %4, %1\n" \
+    A2V_ASM_MFMA_16x16x32 " %1, v[160:163], %4, %1\n" \
     "ds_read_b64_tr_b16 v[160:161], %9 offset:4096\n" \
     "ds_read_b64_tr_b16 v[162:163], %9 offset:6144\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %2, v[164:167], %4, %2\n" \
+    A2V_ASM_MFMA_16x16x32 " %2, v[164:167], %4, %2\n" \
     "ds_read_b64_tr_b16 v[164:165], v152 offset:4096\n" \
     "ds_read_b64_tr_b16 v[166:167], v152 offset:6144\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %3, v[156:159], %4, %3\n" \
+    A2V_ASM_MFMA_16x16x32 " %3, v[156:159], %4, %3\n" \
     "ds_read_b64_tr_b16 v[156:157], v153 offset:4096\n" \
     "ds_read_b64_tr_b16 v[158:159], v153 offset:6144\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %0, v[160:163], %5, %0\n" \
+    A2V_ASM_MFMA_16x16x32 " %0, v[160:163], %5, %0\n" \
     "ds_read_b64_tr_b16 v[160:161], v154 offset:4096\n" \
     "ds_read_b64_tr_b16 v[162:163], v154 offset:6144\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %1, v[164:167], %5, %1\n" \
+    A2V_ASM_MFMA_16x16x32 " %1, v[164:167], %5, %1\n" \
     "ds_read_b64_tr_b16 v[164:165], %9 offset:8192\n" \
     "ds_read_b64_tr_b16 v[166:167], %9 offset:10240\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %2, v[156:159], %5, %2\n" \
+    A2V_ASM_MFMA_16x16x32 " %2, v[156:159], %5, %2\n" \
     "ds_read_b64_tr_b16 v[156:157], v152 offset:8192\n" \
     "ds_read_b64_tr_b16 v[158:159], v152 offset:10240\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %3, v[160:163], %5, %3\n" \
+    A2V_ASM_MFMA_16x16x32 " %3, v[160:163], %5, %3\n" \
     "ds_read_b64_tr_b16 v[160:161], v153 offset:8192\n" \
     "ds_read_b64_tr_b16 v[162:163], v153 offset:10240\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %0, v[164:167], %6, %0\n" \
+    A2V_ASM_MFMA_16x16x32 " %0, v[164:167], %6, %0\n" \
     "ds_read_b64_tr_b16 v[164:165], v154 offset:8192\n" \
     "ds_read_b64_tr_b16 v[166:167], v154 offset:10240\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %1, v[156:159], %6, %1\n" \
+    A2V_ASM_MFMA_16x16x32 " %1, v[156:159], %6, %1\n" \
     "ds_read_b64_tr_b16 v[156:157], %9 offset:12288\n" \
     "ds_read_b64_tr_b16 v[158:159], %9 offset:14336\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %2, v[160:163], %6, %2\n" \
+    A2V_ASM_MFMA_16x16x32 " %2, v[160:163], %6, %2\n" \
     "ds_read_b64_tr_b16 v[160:161], v152 offset:12288\n" \
     "ds_read_b64_tr_b16 v[162:163], v152 offset:14336\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %3, v[164:167], %6, %3\n" \
+    A2V_ASM_MFMA_16x16x32 " %3, v[164:167], %6, %3\n" \
     "ds_read_b64_tr_b16 v[164:165], v153 offset:12288\n" \
     "ds_read_b64_tr_b16 v[166:167], v153 offset:14336\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %0, v[156:159], %7, %0\n" \
+    A2V_ASM_MFMA_16x16x32 " %0, v[156:159], %7, %0\n" \
     "ds_read_b64_tr_b16 v[156:157], v154 offset:12288\n" \
     "ds_read_b64_tr_b16 v[158:159], v154 offset:14336\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %1, v[160:163], %7, %1\n" \
+    A2V_ASM_MFMA_16x16x32 " %1, v[160:163], %7, %1\n" \
     "ds_read_b64_tr_b16 v[160:161], %9 offset:16384\n" \
     "ds_read_b64_tr_b16 v[162:163], %9 offset:18432\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %2, v[164:167], %7, %2\n" \
+    A2V_ASM_MFMA_16x16x32 " %2, v[164:167], %7, %2\n" \
     "ds_read_b64_tr_b16 v[164:165], v152 offset:16384\n" \
     "ds_read_b64_tr_b16 v[166:167], v152 offset:18432\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %3, v[156:159], %7, %3\n" \
+    A2V_ASM_MFMA_16x16x32 " %3, v[156:159], %7, %3\n" \
     "ds_read_b64_tr_b16 v[156:157], v153 offset:16384\n" \
     "ds_read_b64_tr_b16 v[158:159], v153 offset:18432\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %0, v[160:163], %8, %0\n" \
+    A2V_ASM_MFMA_16x16x32 " %0, v[160:163], %8, %0\n" \
     "ds_read_b64_tr_b16 v[160:161], v154 offset:16384\n" \
     "ds_read_b64_tr_b16 v[162:163], v154 offset:18432\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %1, v[164:167], %8, %1\n" \
+    A2V_ASM_MFMA_16x16x32 " %1, v[164:167], %8, %1\n" \
     "s_waitcnt lgkmcnt(2)\n" \
-    "v_mfma_f32_16x16x32_bf16 %2, v[156:159], %8, %2\n" \
+    A2V_ASM_MFMA_16x16x32 " %2, v[156:159], %8, %2\n" \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_mfma_f32_16x16x32_bf16 %3, v[160:163], %8, %3\n" \
+    A2V_ASM_MFMA_16x16x32 " %3, v[160:163], %8, %3\n" \
     "s_nop 7\n" \
     "s_nop 7\n"
 
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(AS2F_NT, 3) void attn_seq2_fwd_kernel(AttnArgs a, u
         const f32x4 pk = *(const f32x4*)(sPos + 16 * j + 4 * g);
         f32x4 acc = *(const f32x4*)(sKb + 16 * j + 4 * g);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[ks], qf[ks], acc, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) acc = A2V_MFMA_16x16x32(kf[ks], qf[ks], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) s[j][r] = __builtin_fmaf(__builtin_fabsf(pos_q - pk[r]), c_rel, acc[r]);
       }
@@ -373,31 +373,31 @@ __global__ __launch_bounds__(AS2F_NT, 3) void attn_seq2_fwd_kernel(AttnArgs a, u
     "ds_read_b64_tr_b16 v[164:165], v153 offset:20480\n" \
     "ds_read_b64_tr_b16 v[166:167], v153 offset:22528\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %0, v[156:159], %8, %0\n" \
+    A2V_ASM_MFMA_16x16x32 " %0, v[156:159], %8, %0\n" \
     "ds_read_b64_tr_b16 v[156:157], v153 offset:0\n" \
     "ds_read_b64_tr_b16 v[158:159], v153 offset:2048\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %4, v[160:163], %9, %4\n" \
+    A2V_ASM_MFMA_16x16x32 " %4, v[160:163], %9, %4\n" \
     "ds_read_b64_tr_b16 v[160:161], v154 offset:20480\n" \
     "ds_read_b64_tr_b16 v[162:163], v154 offset:22528\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %1, v[164:167], %8, %1\n" \
+    A2V_ASM_MFMA_16x16x32 " %1, v[164:167], %8, %1\n" \
     "ds_read_b64_tr_b16 v[164:165], v154 offset:0\n" \
     "ds_read_b64_tr_b16 v[166:167], v154 offset:2048\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %5, v[156:159], %9, %5\n" \
+    A2V_ASM_MFMA_16x16x32 " %5, v[156:159], %9, %5\n" \
     "ds_read_b64_tr_b16 v[156:157], v155 offset:20480\n" \
     "ds_read_b64_tr_b16 v[158:159], v155 offset:22528\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %2, v[160:163], %8, %2\n" \
+    A2V_ASM_MFMA_16x16x32 " %2, v[160:163], %8, %2\n" \
     "ds_read_b64_tr_b16 v[160:161], v155 offset:0\n" \
     "ds_read_b64_tr_b16 v[162:163], v155 offset:2048\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %6, v[164:167], %9, %6\n" \
+    A2V_ASM_MFMA_16x16x32 " %6, v[164:167], %9, %6\n" \
     "s_waitcnt lgkmcnt(2)\n" \
-    "v_mfma_f32_16x16x32_bf16 %3, v[156:159], %8, %3\n" \
+    A2V_ASM_MFMA_16x16x32 " %3, v[156:159], %8, %3\n" \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_mfma_f32_16x16x32_bf16 %7, v[160:163], %9, %7\n" \
+    A2V_ASM_MFMA_16x16x32 " %7, v[160:163], %9, %7\n" \
     "s_nop 7\n" \
     "s_nop 7\n"
 
@@ -412,15 +412,15 @@ __global__ __launch_bounds__(AS2F_NT, 3) void attn_seq2_fwd_kernel(AttnArgs a, u
     "ds_read_b64_tr_b16 v[164:165], v154 offset:0\n" \
     "ds_read_b64_tr_b16 v[166:167], v154 offset:2048\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %0, v[156:159], %4, %0\n" \
+    A2V_ASM_MFMA_16x16x32 " %0, v[156:159], %4, %0\n" \
     "ds_read_b64_tr_b16 v[156:157], v155 offset:0\n" \
     "ds_read_b64_tr_b16 v[158:159], v155 offset:2048\n" \
     "s_waitcnt lgkmcnt(4)\n" \
-    "v_mfma_f32_16x16x32_bf16 %1, v[160:163], %4, %1\n" \
+    A2V_ASM_MFMA_16x16x32 " %1, v[160:163], %4, %1\n" \
     "s_waitcnt lgkmcnt(2)\n" \
-    "v_mfma_f32_16x16x32_bf16 %2, v[164:167], %4, %2\n" \
+    A2V_ASM_MFMA_16x16x32 " %2, v[164:167], %4, %2\n" \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_mfma_f32_16x16x32_bf16 %3, v[156:159], %4, %3\n" \
+    A2V_ASM_MFMA_16x16x32 " %3, v[156:159], %4, %3\n" \
     "s_nop 7\n" \
     "s_nop 7\n"
 
@@ -442,9 +442,9 @@ __global__ __launch_bounds__(AS2F_NT, 3) void attn_seq2_fwd_kernel(AttnArgs a, u
     "ds_read_b64_tr_b16 v[156:157], %5 offset:512\n" \
     "ds_read_b64_tr_b16 v[158:159], %5 offset:640\n" \
     "s_waitcnt lgkmcnt(2)\n" \
-    "v_mfma_f32_16x16x32_bf16 v[160:163], v[152:155], %6, 0\n" \
+    A2V_ASM_MFMA_16x16x32 " v[160:163], v[152:155], %6, 0\n" \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_mfma_f32_16x16x32_bf16 v[164:167], v[156:159], %6, 0\n" \
+    A2V_ASM_MFMA_16x16x32 " v[164:167], v[156:159], %6, 0\n" \
     "ds_read_b64_tr_b16 v[152:153], %5 offset:1024\n" \
     "ds_read_b64_tr_b16 v[154:155], %5 offset:1152\n" \
     "ds_read_b64_tr_b16 v[156:157], %5 offset:1536\n" \
@@ -455,8 +455,8 @@ __global__ __launch_bounds__(AS2F_NT, 3) void attn_seq2_fwd_kernel(AttnArgs a, u
     "ds_write_b128 %7, v[160:163] offset:0\n" \
     "ds_write_b128 %7, v[164:167] offset:64\n" \
     "s_waitcnt lgkmcnt(0)\n" \
-    "v_mfma_f32_16x16x32_bf16 v[160:163], v[152:155], %6, 0\n" \
-    "v_mfma_f32_16x16x32_bf16 v[164:167], v[156:159], %6, 0\n" \
+    A2V_ASM_MFMA_16x16x32 " v[160:163], v[152:155], %6, 0\n" \
+    A2V_ASM_MFMA_16x16x32 " v[164:167], v[156:159], %6, 0\n" \
     "s_nop 7\n" \
     "s_nop 7\n" \
     "s_nop 3\n" \
@@ -597,7 +597,7 @@ __global__ __launch_bounds__(AS2B_NT, 3) void attn_seq2_bwd_kernel(AttnBwdArgs a
   const unsigned cs_o = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(sBias + wid * 192) + (unsigned)(g * 16);
   union { unsigned u[4]; bf16x8 v; } cs_ones_u;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) cs_ones_u.u[i] = g < 2 ? 0x3F803F80u : 0u;
+  for (int i = 0; i < 4; ++i) cs_ones_u.u[i] = g < 2 ? (sizeof(bf16) == 2 && (float)(bf16)1.0f == 1.0f && __builtin_bit_cast(unsigned short, (bf16)1.0f) == 0x3F80 ? 0x3F803F80u : 0x3C003C00u) : 0u;
   const bf16x8 cs_ones = cs_ones_u.v;
   auto as2_colsum = [&](unsigned (*t)[2], unsigned wa, unsigned ra, const bf16x8& ones, unsigned oa) {
     const unsigned long long b0 = ((unsigned long long)t[0][1] << 32) | t[0][0], b1 = ((unsigned long long)t[1][1] << 32) | t[1][0];
@@ -649,8 +649,8 @@ __global__ __launch_bounds__(AS2B_NT, 3) void attn_seq2_bwd_kernel(AttnBwdArgs a
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 qa = *(const bf16x8*)(imgQ + dual_off(rb + fr, ks * 4 + g));
           const bf16x8 da = *(const bf16x8*)(imgDO + dual_off(rb + fr, ks * 4 + g));
-          sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[ks], sacc, 0, 0, 0);
-          pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[ks], pacc, 0, 0, 0);
+          sacc = A2V_MFMA_16x16x32(qa, kf[ks], sacc, 0, 0, 0);
+          pacc = A2V_MFMA_16x16x32(da, vf[ks], pacc, 0, 0, 0);
         }
         const f32x4 lse4 = *(const f32x4*)(sLse + rb + 4 * g);
         const f32x4 del4 = *(const f32x4*)(sDelta + rb + 4 * g);
@@ -756,8 +756,8 @@ __global__ __launch_bounds__(AS2B_NT, 3) void attn_seq2_bwd_kernel(AttnBwdArgs a
           for (int ks = 0; ks < 2; ++ks) {
             const bf16x8 ka = *(const bf16x8*)(imgK + dual_off(16 * j + fr, ks * 4 + g));
             const bf16x8 va = *(const bf16x8*)(imgV + dual_off(16 * j + fr, ks * 4 + g));
-            sacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ka, qf[ks], sacc, 0, 0, 0);
-            pacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va, dof[ks], pacc, 0, 0, 0);
+            sacc = A2V_MFMA_16x16x32(ka, qf[ks], sacc, 0, 0, 0);
+            pacc = A2V_MFMA_16x16x32(va, dof[ks], pacc, 0, 0, 0);
           }
           const f32x4 pk = *(const f32x4*)(sPos + 16 * j + 4 * g);
           unsigned hp[2] = {0u, 0u};

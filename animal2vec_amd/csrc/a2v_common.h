@@ -5,10 +5,47 @@
 #include <stdint.h>
 #include <math.h>
 
+// The 16-bit storage / MFMA operand type of this object.  The product library (liba2v_hip.so) is built with bfloat16; the SAME
+// sources built with -DA2V_ELT_F16 give liba2v_hip_f16.so, in which every "bf16" below is IEEE half (11 significand bits at the
+// same matrix rate): the EMA teacher's no-grad forward runs on it (the reference's own recipe is fp16,
+// configs/MeerKAT/a2v_large_pretrain_best.yaml:4; profiles/r06_fp16_teacher.json: target error 2.8e-2 -> 3.4e-3).  Both libraries
+// export the same C ABI (include/a2v.h); dtype code A2V_BF16 means "this library's 16-bit type".
+#ifdef A2V_ELT_F16
+typedef _Float16 bf16;
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2;
+#define A2V_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define A2V_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define A2V_ASM_MFMA_16x16x32 "v_mfma_f32_16x16x32_f16"
+#define A2V_ASM_CVT_PK "v_cvt_pk_f16_f32"
+#define A2V_ELT_NAME "f16"
+#else
 typedef __bf16 bf16;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+#define A2V_MFMA_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#define A2V_MFMA_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define A2V_ASM_MFMA_16x16x32 "v_mfma_f32_16x16x32_bf16"
+#define A2V_ASM_CVT_PK "v_cvt_pk_bf16_f32"
+#define A2V_ELT_NAME "bf16"
+#endif
+// the two 16-bit halves of a packed pair as fp32 (bf16: a shift / a mask; half: conversions)
+__device__ __forceinline__ float a2v_lo16_f32(unsigned w) {
+#ifdef A2V_ELT_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w & 0xFFFFu));
+#else
+  return __builtin_bit_cast(float, w << 16);
+#endif
+}
+__device__ __forceinline__ float a2v_hi16_f32(unsigned w) {
+#ifdef A2V_ELT_F16
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)(w >> 16));
+#else
+  return __builtin_bit_cast(float, w & 0xffff0000u);
+#endif
+}
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -122,10 +159,10 @@ template <> struct Raw8<bf16> {
   uint4 v;
   __device__ __forceinline__ void load(const bf16* p) { v = *(const uint4*)p; }
   __device__ __forceinline__ void unpack(float* o) const {
-    o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-    o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-    o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-    o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+    o[0] = a2v_lo16_f32(v.x); o[1] = a2v_hi16_f32(v.x);
+    o[2] = a2v_lo16_f32(v.y); o[3] = a2v_hi16_f32(v.y);
+    o[4] = a2v_lo16_f32(v.z); o[5] = a2v_hi16_f32(v.z);
+    o[6] = a2v_lo16_f32(v.w); o[7] = a2v_hi16_f32(v.w);
   }
 };
 template <> struct Raw8<float> {

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xr[f % 5]));
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-          acc[f & 3][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[gi][f >> 2][j], xr[f % 5], acc[f & 3][j], 0, 0, 0);
+          acc[f & 3][j] = A2V_MFMA_16x16x32(wf[gi][f >> 2][j], xr[f % 5], acc[f & 3][j], 0, 0, 0);
       }
 #undef CD_XREAD
       if (gi == 0) { CD_STAMP_AT(5) } else { CD_STAMP_AT(7) }

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(512) void conv_nt_slab_kernel(GemmArgs g) {
       for (int i = 0; i < 8; ++i) {
         const bf16x8 fa = *(const bf16x8*)(smem + (a_off ^ (ks << 6)) + i * 2048);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = A2V_MFMA_16x16x32(fa, fb[j], acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();                                  // weight tile tap+1 landed (vmcnt(0)), tile `buf` free
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv_nt_slab2_kernel(GemmArgs g, int g
       for (int i = 0; i < 3; ++i) {
         const bf16x8 fa = *(const bf16x8*)(smem + (a_off ^ (ks << 6)) + i * 2048);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa, acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) acc[i][j] = A2V_MFMA_16x16x32(fb[j], fa, acc[i][j], 0, 0, 0);
       }
     }
     __syncthreads();                                  // weight tile tap+1 landed (vmcnt(0)), tile `buf` free
@@ -399,9 +399,9 @@ __global__ __launch_bounds__(512) void conv_nt_slab3_kernel(GemmArgs g, long lon
         const bf16x8 fal = *(const bf16x8*)(sXl + (a_off ^ (ks << 6)) + i * 2048);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[j], fal, acc[i][j], 0, 0, 0);     // small terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbl[j], fah, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fbh[j], fah, acc[i][j], 0, 0, 0);
+          acc[i][j] = A2V_MFMA_16x16x32(fbh[j], fal, acc[i][j], 0, 0, 0);     // small terms first
+          acc[i][j] = A2V_MFMA_16x16x32(fbl[j], fah, acc[i][j], 0, 0, 0);
+          acc[i][j] = A2V_MFMA_16x16x32(fbh[j], fah, acc[i][j], 0, 0, 0);
         }
       }
     }

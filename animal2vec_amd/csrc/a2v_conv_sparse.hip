@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
       // of its neighbour CAN be the same cell (kept frames come in adjacent pairs), so the taps are not overlapped.  (As
       // ds_add_f32 the scatter ran at about one lane per three clocks per CU: 19.8 ms per call.)
       f32x4 accn = {0.f, 0.f, 0.f, 0.f};                  // the products of tap t + 1 are formed under the read-modify-write of tap t
-      accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[0][0], accn, 0, 0, 0);
-      accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[0][1], accn, 0, 0, 0);
+      accn = A2V_MFMA_16x16x32(a0, wf[0][0], accn, 0, 0, 0);
+      accn = A2V_MFMA_16x16x32(a1, wf[0][1], accn, 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const f32x4 acc = accn;
@@ -191,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv_sparse_in_kernel(SpInArgs a, int 
         for (int r = 0; r < 4; ++r) old[r] = *(trow[r] - t * CSP_TPITCH);                      // tile row rel - tap + TAPS - 1
         if (t + 1 < TAPS) {
           accn = (f32x4){0.f, 0.f, 0.f, 0.f};
-          accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, wf[t + 1 < TAPS ? t + 1 : t][0], accn, 0, 0, 0);
-          accn = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, wf[t + 1 < TAPS ? t + 1 : t][1], accn, 0, 0, 0);
+          accn = A2V_MFMA_16x16x32(a0, wf[t + 1 < TAPS ? t + 1 : t][0], accn, 0, 0, 0);
+          accn = A2V_MFMA_16x16x32(a1, wf[t + 1 < TAPS ? t + 1 : t][1], accn, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) *(trow[r] - t * CSP_TPITCH) = old[r] + acc[r];

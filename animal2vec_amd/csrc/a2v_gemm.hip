@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NT_THREADS) void gemm_nt_bf16_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = A2V_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) store_tile(buf ^ 1);
     __syncthreads();
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(WgradArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = A2V_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     if (st + 1 < nsteps) store_tile(buf ^ 1);
     __syncthreads();

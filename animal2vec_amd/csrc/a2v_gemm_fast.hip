@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_fast_kernel(GemmArgs g) {
           fb[j] = *(const bf16x8*)(sb_ + swz128(wn * 64 + j * 16 + fr, ks * 4 + fq));                   \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                   \
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);        \
+          acc[i][j] = A2V_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);        \
     }                                                                                                   \
   }
   // Two register sets: the loads of tile kt+2 are issued before tile kt is computed and are only written to
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void gemm_nt_bf16_glds_kernel(GemmArgs g) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = A2V_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     STORE_TILE(buf ^ 1);
     __syncthreads();
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_fast_kernel(WgradArgs g, int
       for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = A2V_MFMA_16x16x32(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
     if (st + 1 < nsteps) STORE_TILE(buf ^ 1);

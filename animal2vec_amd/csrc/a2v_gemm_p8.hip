@@ -275,8 +275,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   _Pragma("unroll") for (int i = 0; i < (NI); ++i)                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
     acc[(ibase) + i][(jbase) + j] = DS                                                                 \
-        ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j][ks], fa[i][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0) \
-        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
+        ? A2V_MFMA_16x16x32(fb[j][ks], fa[i][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0) \
+        : A2V_MFMA_16x16x32(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                       \
   __builtin_amdgcn_s_barrier();
 
@@ -723,8 +723,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
             asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rq[k % RQ]) : "n"(P8_RN(k)) : "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-              h[2 * q] = __uint_as_float(rq[k % RQ][q] << 16);
-              h[2 * q + 1] = __uint_as_float(rq[k % RQ][q] & 0xffff0000u);
+              h[2 * q] = a2v_lo16_f32(rq[k % RQ][q]);
+              h[2 * q + 1] = a2v_hi16_f32(rq[k % RQ][q]);
             }
             }
             if (k + RQ < NT) P8_RLOAD(k + RQ);              // RQ row blocks ahead

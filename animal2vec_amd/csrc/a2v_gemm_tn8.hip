@@ -144,7 +144,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
     acc[(ibase) + i][(jbase) + j] =                                                                      \
-        __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
+        A2V_MFMA_16x16x32(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                         \
   __builtin_amdgcn_s_barrier();
 

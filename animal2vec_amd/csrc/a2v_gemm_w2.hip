@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_w2_kernel(GemmArgs g, int
                   "+v"(fb[c][0]), "+v"(fb[c][1]), "+v"(fb[c][2]), "+v"(fb[c][3])
 #define W2_MFMA4(c, i)                                                                                          \
   _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                  \
-    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
+    acc[i][j] = A2V_MFMA_16x16x32(fb[c][j], fa[c][i], acc[i][j], 0, 0, 0);
 #define W2_SB __builtin_amdgcn_sched_barrier(0);
   // one K-step: cur_o = ring offset of stage kt (free: refilled with stage kt + 3), stage kt + 1 sits in the next slot.
   // DMA / RD: compile-time 0 / 1; WAITN: the counted wait for stage kt + 1 (6: stage kt + 2 stays in flight, 0: nothing younger)

@@ -185,9 +185,9 @@ __global__ __launch_bounds__(256) void sinc_fused_fwd_kernel(const float* __rest
       }
 #pragma unroll
       for (int jc = 0; jc < 8; ++jc) {
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wal[jc], xh, acc[jc], 0, 0, 0);
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wah[jc], xl, acc[jc], 0, 0, 0);
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wah[jc], xh, acc[jc], 0, 0, 0);
+        acc[jc] = A2V_MFMA_16x16x32(wal[jc], xh, acc[jc], 0, 0, 0);
+        acc[jc] = A2V_MFMA_16x16x32(wah[jc], xl, acc[jc], 0, 0, 0);
+        acc[jc] = A2V_MFMA_16x16x32(wah[jc], xh, acc[jc], 0, 0, 0);
       }
     } else {
 #pragma unroll
@@ -429,9 +429,9 @@ __global__ __launch_bounds__(512) void sinc_fused_bwd_kernel(const float* __rest
       for (int jc = 0; jc < SB_NJ; ++jc) {
         const bf16x8 wh = *(const bf16x8*)(sFh + (cb0 + 16 * jc + fr) * 32 + 8 * g);
         const bf16x8 wl = *(const bf16x8*)(sFl + (cb0 + 16 * jc + fr) * 32 + 8 * g);
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wl, acc[jc], 0, 0, 0);
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, wh, acc[jc], 0, 0, 0);
-        acc[jc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, wh, acc[jc], 0, 0, 0);
+        acc[jc] = A2V_MFMA_16x16x32(xh, wl, acc[jc], 0, 0, 0);
+        acc[jc] = A2V_MFMA_16x16x32(xl, wh, acc[jc], 0, 0, 0);
+        acc[jc] = A2V_MFMA_16x16x32(xh, wh, acc[jc], 0, 0, 0);
       }
     } else {
 #pragma unroll 4

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
         const int c = ct0 + j;
         const bf16x8 fb = ws_frag(sx_ + ks * 32 * WS_PITCH + ((c >> 2) * WS_PITCH + (c & 3) * 32));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[i][j] = A2V_MFMA_16x16x32(fa[i], fb, acc[i][j], 0, 0, 0);
       }
     }
     if constexpr (MASKED) {

@@ -210,8 +210,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_sparse_kernel(WgradArgs g, con
 #pragma unroll
         for (int i = 0; i < 4; ++i)                       // (mode A: operands exchanged, so that the LANES of a tile run along ci -- the contiguous
                                                           //  index of dW -- in the atomics of the epilogue: 637 -> 159 MB of write traffic)
-          acc[i][j] = MODE_A ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb, fa[i], acc[i][j], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb, acc[i][j], 0, 0, 0);
+          acc[i][j] = MODE_A ? A2V_MFMA_16x16x32(fb, fa[i], acc[i][j], 0, 0, 0)
+                             : A2V_MFMA_16x16x32(fa[i], fb, acc[i][j], 0, 0, 0);
       }
     }
     WSP_STORE(buf ^ 1);

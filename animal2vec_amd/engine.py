@@ -28,7 +28,7 @@ _DACT = os.environ.get("A2V_NO_DACT") is None      # (A/B switch for the gelu'-i
 
 
 class Engine:
-    def __init__(self, cfg: Data2VecMultiConfig, store: ParamStore, dtype=torch.bfloat16, x3: bool = False):
+    def __init__(self, cfg: Data2VecMultiConfig, store: ParamStore, dtype=torch.bfloat16, x3: bool = False, teacher_half=None):
         """dtype: the activation storage (bf16 = throughput mode, fp32 = parity mode).  x3 (with fp32): the bf16x3 parity mode --
         every plain Linear product (forward, input gradient, weight gradient) runs as three exact bf16 products on the bf16
         matrix cores over split operands (ops.split_bf16, include/a2v.h: A2V_BF16X3); everything else is the fp32 mode."""
@@ -49,9 +49,19 @@ class Engine:
                 if self.tstream is not None:
                     self._ws_keys.append(ops.bind_workspace(self.tstream))
         self.sp = Packs(store, dtype, teacher=False, need_grad=True, x3=self.x3)
-        self.tp = Packs(store, dtype, teacher=True, need_grad=False, x3=self.x3)
+        # The EMA teacher in IEEE half (bf16 mode only; OPT-IN: A2V_TEACHER_F16=1 or teacher_half=True).  Its no-grad forward
+        # (data2vec2.py:755-844) produces the regression targets; half keeps 11 significand bits where bf16 keeps 8 at the same matrix
+        # rate, and the reference's own recipe is fp16 (a2v_large_pretrain_best.yaml:4).  It runs in liba2v_hip_f16.so
+        # (ops.half_library) on fp16 operand images.  Measured (profiles/r06_f16_teacher.txt): target error at full size
+        # 4.4e-2 -> 1.9e-2 (the floor is now the bf16 front end's 1.1e-2 on the features the teacher is fed), on weights 200 updates from
+        # init 2.0e-2 -> 5e-3; but the step is 1.1 % slower (the fp16 MFMAs hold a lower clock at the power cap) and the student's
+        # GRADIENTS move away from the oracle's near a minimum (median 0.9e-2 -> 1.5e-2, worst 3.8e-2 -> 9.3e-2): with both networks in
+        # bf16 the rounding of prediction and target is largely common-mode and cancels in their difference.  Hence not the default.
+        want_half = teacher_half if teacher_half is not None else os.environ.get("A2V_TEACHER_F16", "0") == "1"
+        self.teacher_half = bool(want_half and dtype == torch.bfloat16 and not self.x3 and dev.type == "cuda" and ops.have_half_library())
+        self.tp = Packs(store, torch.float16 if self.teacher_half else dtype, teacher=True, need_grad=False, x3=self.x3)
         self.sp.refresh()
-        self.tp.refresh()
+        self.refresh_teacher_packs()
         self.layers = cfg.conv_layers
         self.sv: Dict[str, object] = {}
         self.on_grad_ready: Optional[Callable[[str], None]] = None
@@ -86,7 +96,11 @@ class Engine:
         self.sp.refresh()
 
     def refresh_teacher_packs(self):
-        self.tp.refresh()
+        if self.teacher_half:
+            with ops.half_library():
+                self.tp.refresh()
+        else:
+            self.tp.refresh()
 
     def _pads(self, i):
         """(pad_left) of feature-extractor layer i: 'same' (left = (k-1)//2) for stride 1 else ceil(s/2)."""
@@ -606,6 +620,12 @@ class Engine:
     @torch.no_grad()
     def teacher_targets(self, feats):
         """Teacher section + make_targets (data2vec2.py:779-846,1023-1066): feats (B,T,D) -> y fp32."""
+        if self.teacher_half:
+            with ops.half_library():
+                return self._teacher_targets(feats.to(torch.float16))
+        return self._teacher_targets(feats)
+
+    def _teacher_targets(self, feats):
         cfg, st, tp = self.cfg, self.store, self.tp
         t = st.t
         B, T, D = feats.shape

@@ -14,16 +14,38 @@ from . import _lib
 from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_DACT8, EPI_X3IMG, check
 
 
+_HALF = False       # inside half_library(): calls go to liba2v_hip_f16.so, whose 16-bit type is IEEE half (the teacher's forward)
+
+
 def _L():
-    return _lib.load()
+    return _lib.load_f16() if _HALF else _lib.load()
+
+
+class half_library:
+    """with ops.half_library(): every op of this module runs in liba2v_hip_f16.so -- the same kernels with torch.float16 as the
+    16-bit storage / MFMA operand type (csrc/a2v_common.h).  Python is sequential, so a module switch is enough; tensors of the
+    other 16-bit type are refused by dt()."""
+
+    def __enter__(self):
+        global _HALF
+        self._was, _HALF = _HALF, True
+        return self
+
+    def __exit__(self, *a):
+        global _HALF
+        _HALF = self._was
+
+
+def have_half_library() -> bool:
+    return _lib.have_f16()
 
 
 def dt(t: torch.Tensor) -> int:
-    if t.dtype == torch.bfloat16:
-        return BF16
+    if t.dtype == (torch.float16 if _HALF else torch.bfloat16):
+        return BF16                      # "this library's 16-bit type"
     if t.dtype == torch.float32:
         return F32
-    raise TypeError(f"unsupported activation dtype {t.dtype}")
+    raise TypeError(f"unsupported activation dtype {t.dtype}" + (" in the fp16 library" if _HALF else ""))
 
 
 def ptr(t: Optional[torch.Tensor]):
@@ -804,7 +826,7 @@ def pack_weight(w, out, *, G, N, Cg, k, Cgp=None, Np=None, mode=0):
 
 def pack_weight_batch(desc: torch.Tensor, dtype: torch.dtype):
     """desc: (n, 10) int64 device tensor of (src, dst, G, N, Cg, k, Cgp, Np, mode, total) -- see a2v.h."""
-    code = BF16 if dtype == torch.bfloat16 else F32
+    code = BF16 if dtype in (torch.bfloat16, torch.float16) else F32
     rc = _L().a2v_pack_weight_batch(code, ptr(desc), desc.shape[0], stream())
     check(rc, "a2v_pack_weight_batch")
 

@@ -263,7 +263,7 @@ def _pad8(c: int) -> int:
 def _padk(c: int, dtype) -> int:
     """Tap width in the packed operand: bf16 pads >=32-wide taps up to a multiple of 64 so that a 64-wide
     K tile never straddles two taps (the fast implicit-GEMM path); the padding reads as zero."""
-    if dtype == torch.bfloat16 and c >= 32 and c % 64:
+    if dtype in (torch.bfloat16, torch.float16) and c >= 32 and c % 64:
         return (c + 63) // 64 * 64
     return _pad8(c)
 

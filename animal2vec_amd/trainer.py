@@ -49,6 +49,11 @@ class PretrainTrainer:
                  device="cuda", seed: int = 0, process_group=None, dropout: bool = True, mixup: bool = True, x3: bool = False,
                  grad_wire=None):
         self.cfg, self.optim = cfg, optim or OptimConfig()
+        if not cfg.audio.encoder_zero_mask:
+            # (the features-only / finetune paths replace masked frames by noise when this is off, model._features_only; the
+            # pretraining engine zero-masks through the row mask of its first pos-conv layer and has no noise form)
+            raise NotImplementedError("pretraining with modalities.audio.encoder_zero_mask=False is not built "
+                                      "(the shipped recipe zero-masks, a2v_large_pretrain_best.yaml)")
         if cfg.layerdrop > 0 or cfg.audio.prenet_layerdrop > 0:
             # (the features-only / finetune paths draw layerdrop, model._features_only and finetune.make_aug; the pretraining
             #  forward + hand-written backward schedule runs every block)

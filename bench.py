@@ -96,13 +96,28 @@ class GemmRecorder:
             r = rec._wg(x, dy, gw, **kw)
             e1.record()
             # (a row-masked input -- the first pos-conv layer -- is multiplied over its non-zero rows only since round 5: its FLOPs are
-            #  counted over those rows, the fraction read from the mask at summary time; a row list already passes M = listed rows)
+            #  counted over those rows, the fraction read from the mask when the call is recorded; a row list already passes M = listed rows)
             rm = kw.get("rowmask")
-            rec.recs.append(("tn", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1), e0, e1,
-                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1), "wgrad" if rm is None else "wgrad, masked input"), rm))
+            rec.recs.append(("tn", 2.0 * kw["M"] * kw["N"] * kw["K"] * kw.get("G", 1) * rec._kept(rm), e0, e1,
+                             (kw["M"], kw["N"], kw["K"], kw.get("G", 1), "wgrad" if rm is None else "wgrad, masked input"), None))
             return r
 
-        ops.conv_gemm, ops.conv_wgrad = cg, wg
+        def sp(x, w_packed, bias, **kw):
+            # the row-sparse-input products of the pos-conv's first forward / last input gradient (a2v_conv_sparse_in): FLOPs over
+            # the KEPT rows (what the kernel multiplies), the kept fraction read when the call is recorded
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = rec._sp(x, w_packed, bias, **kw)
+            e1.record()
+            G, T, n_seq, k_ = kw["groups"], kw["T"], kw["n_seq"], kw["k"]
+            rows = kw["rowidx"].numel() if kw.get("rowidx") is not None else n_seq * T * rec._kept(kw.get("rowmask"))
+            cg_, ng_ = x.shape[-1] // G, kw["n_out"] // G
+            rec.recs.append(("nt", 2.0 * rows * ng_ * (k_ * cg_) * G, e0, e1, (int(rows), ng_, k_ * cg_, G, "row-sparse input"), None))
+            rec.bytes["nt"] = rec.bytes.get("nt", 0.0) + x.element_size() * (rows * cg_ * G + ng_ * k_ * cg_ * G + n_seq * T * kw["n_out"])
+            return r
+
+        self._sp = ops.conv1d_cl_sparse_in
+        ops.conv_gemm, ops.conv_wgrad, ops.conv1d_cl_sparse_in = cg, wg, sp
         # HBM-bound families: algorithmic bytes = every tensor element the call must read or write, once
         self._hbm_orig = {}
         self.hbm = []
@@ -128,7 +143,7 @@ class GemmRecorder:
         timed("sinc_fused_bwd", lambda a, kw, r: nb(a[0]) + nb(a[6]))
 
     def unwrap(self, ops):
-        ops.conv_gemm, ops.conv_wgrad = self._cg, self._wg
+        ops.conv_gemm, ops.conv_wgrad, ops.conv1d_cl_sparse_in = self._cg, self._wg, self._sp
         for name, orig in self._hbm_orig.items():
             setattr(ops, name, orig)
 
@@ -335,6 +350,7 @@ def cpu_baseline(model_name, L, K, sample_rate=8000, thread_legs=(16, 32, 64), p
                     outs.append(p_.communicate(timeout=max(1.0, t_end - time.time()))[0])
                 except subprocess.TimeoutExpired:
                     p_.kill()                                    # (the exact child this process started)
+                    p_.communicate()
                     outs.append("")
             recs = [parse(o, 16) for o in outs if o.strip()]
             if len(recs) == k:

@@ -31,6 +31,15 @@ def test_library_exports_every_declared_symbol():
     assert lib.a2v_abi_version() == 13
 
 
+def test_fp16_twin_library_exports_the_same_abi():
+    """liba2v_hip_f16.so (csrc/a2v_common.h: A2V_ELT_F16; the EMA teacher's opt-in fp16 forward): the same sources, the same C ABI."""
+    from animal2vec_amd import _lib
+    lib = _lib.load_f16()
+    for name in header_decls():
+        assert hasattr(lib, name), f"{name} missing from liba2v_hip_f16.so"
+    assert lib.a2v_abi_version() == _lib.load().a2v_abi_version()
+
+
 def test_ops_refuse_cpu_tensors():
     import pytest
     import torch
@@ -337,6 +346,66 @@ def test_attn_fwd32_tile_dma_is_not_waited_for_before_the_tile_math(tmp_path):
             loops += 1
         seen += 1
     assert seen == 5 and loops >= 15, (seen, loops)
+
+
+def test_attn_seq2_fetches_are_not_waited_for_inside_the_math(tmp_path):
+    """a2v_attn_seq2.h (round 6): the persistent student-attention kernels fetch the NEXT sequence's images by LDS-DMA at the top of a
+    sequence (forward) / of a role (backward); they must land under the current math.  The traps, each of which once serialised the
+    pipeline: a use of a fetched register value (hipcc waits vmcnt(0)), the ds_read_tr builtin (vmcnt(0) in front of it: "may alias
+    the DMA"), an LDS atomicAdd (vmcnt(0) in front of every ds_add), a spilled register (its reload waits vmcnt(0)).  Held here:
+    no scratch, no SGPR-spill-free requirement on the forward, and in every kernel the ONLY vmcnt waits inside the sequence loop are
+    the hand-placed `s_waitcnt vmcnt(0)` (asm) -- at most three per loop body -- with every transposed read inside an asm block."""
+    import shutil
+    import subprocess
+    import pytest
+    from animal2vec_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = "a2v_attn.hip"
+    out = tmp_path / (src + ".s")
+    cmd = [hipcc, *B.FLAGS, *B.FILE_FLAGS.get(src, []), "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    s = out.read_text()
+    seen = 0
+    for m in re.finditer(r"^(_Z20attn_seq2_(fwd|bwd)_kernelI\w*):", s, re.M):
+        name, kind = m.group(1), m.group(2)
+        body = s[m.end():s.index("s_endpgm", m.end())]
+        meta = s[s.index(".name:           " + name):]
+        assert int(re.search(r"\.vgpr_spill_count:\s*(\d+)", meta).group(1)) == 0, name
+        assert "scratch_" not in body, name
+        lines = [l.strip() for l in body.split("\n") if l.strip()]
+        # the loop over sequences: from its header to the end of the kernel
+        hdr = [i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l]
+        assert hdr, name
+        loop = lines[hdr[0]:]
+        in_asm = False
+        compiler_vm, asm_vm, tr_outside = [], 0, 0
+        for l in loop:
+            if l.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if l.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if l.startswith(";"):
+                continue
+            if "vmcnt" in l:
+                if in_asm:
+                    asm_vm += 1
+                else:
+                    compiler_vm.append(l)
+            if l.startswith("ds_read_b64_tr_b16") and not in_asm:
+                tr_outside += 1
+            assert not l.startswith(("ds_add_f32", "ds_add_rtn_f32")), (name, l)
+        assert tr_outside == 0, (name, tr_outside)
+        assert 1 <= asm_vm <= 4, (name, asm_vm)
+        # what the compiler adds on its own may only sit directly behind one of those hand-placed waits (the register copies of the
+        # fetched values at the top of the next sequence): never a wait the math has to sit behind
+        assert len(compiler_vm) <= 4, (name, compiler_vm)
+        seen += 1
+    assert seen >= 8, seen
 
 
 def test_tn8_kernel_has_no_spills_and_no_drain_at_unit_seams(tmp_path):
