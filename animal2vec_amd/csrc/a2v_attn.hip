@@ -1448,8 +1448,13 @@ int g_a2v_attn_msum = 1;     // a2v_debug_set(18, v): forward-only long-sequence
                              // times rounding noise either way
 int g_a2v_attn_xcd = 1;      // a2v_debug_set(17, v): long-sequence forward: XCD-aware 1-D workgroup order on / off
 int g_a2v_attn_fwd32 = 1;    // a2v_debug_set(36, v): long-sequence bf16 forward on 32 x 32 x 16 MFMAs (0: the 16 x 16 x 32 kernel)
-int g_a2v_attn_dbg = 0;      // a2v_debug_set(40, flags): timing experiments on the round-6 forward (1 no output stores, 2 no mask store, 4 no math)
+// The round-6 kernels always walk ten 16-row groups: they pay where the sequence HAS ten (145 .. 160 kept frames: what the sampler draws
+// at the shipped recipe, 143 .. 155); with nine or fewer the round-5 kernels (three waves, 48-row blocks) waste less -- measured at
+// S = 140: forward 320 against 333 us, backward 782 against 788 (profiles/r06_attn_bench.txt).  a2v_debug_set(39, 2) sends every
+// S <= 160 to the round-6 kernels (tests), 0 none.
+static inline bool as2_takes(int S);
 int g_a2v_attn_seq2 = 1;     // a2v_debug_set(39, v): S <= 160 bf16 forward AND backward take the round-6 five-wave kernels (0: the round-5 ones)
+static inline bool as2_takes(int S) { return S <= AS2_ROWS && (g_a2v_attn_seq2 == 2 || (g_a2v_attn_seq2 == 1 && S > 144)); }
 int g_a2v_attn_fwd48 = 1;    // a2v_debug_set(16, v): S <= 144 bf16 forward takes the whole-sequence three-wave kernel (0: the tiled one)
 // Ingredients of the bound of |q_i . k_j| * scale over all pairs of one (n, h): max_i |q_i|^2 and max_j |k_j|^2 (Cauchy-Schwarz in
 // the attention kernel).  8 lanes share a row (16 B each); reads q and k once: 65 MB at 32 x 2000 x 16 heads.
@@ -1505,11 +1510,10 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
   AttnArgs a = a_in;
   a.xcd_order = 0;
   if constexpr (HD == 64) {
-    if (a.S <= AS2_ROWS && g_a2v_attn_seq2) {              // round 6: five-wave workgroups, three per CU (a2v_attn_seq2.h)
+    if (as2_takes(a.S)) {                                   // round 6: persistent ten-wave kernels (a2v_attn_seq2.h)
       const long long np = (long long)a.N * a.H;
       const dim3 grid((unsigned)(np < 256 ? np : 256));     // persistent: one workgroup per CU walks the (n, h) sequences
       const bool wm = DROP && a.dropmask != nullptr;
-      a.xcd_order = g_a2v_attn_dbg;                         // (timing experiments only; 0 in every product run)
 #define AS2F_GO(MD_, WM_)                                                                                                         \
   {                                                                                                                               \
     (void)hipFuncSetAttribute((const void*)attn_seq2_fwd_kernel<DROP, MD_, WM_>, hipFuncAttributeMaxDynamicSharedMemorySize, AS2F_LDS); \
@@ -1946,7 +1950,7 @@ static int attn_fwd_launch(const AttnArgs& a, hipStream_t st) {
 // Words (u32) per (n, h) of the dropout bit mask a2v_attention_fwd writes and a2v_attention_bwd reads for this (dtype, S, HD), or 0
 // where the kernels regenerate the decisions from the counter hash instead (the pointer is then ignored).
 extern "C" int a2v_attention_dropmask_words(int dtype, int S, int HD) {
-  return (dtype == A2V_BF16 && HD == 64 && S <= AS2_ROWS && g_a2v_attn_seq2) ? AS2_ROWS * 4 * 2 : 0;
+  return (dtype == A2V_BF16 && HD == 64 && as2_takes(S)) ? AS2_ROWS * 4 * 2 : 0;
 }
 
 extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, unsigned* dropmask, const int* pos,
@@ -3224,7 +3228,7 @@ static int attn_bwd_launch(const AttnBwdArgs& a_in, const void* out, float* delt
       A2V_CHECK_LAUNCH();
       return A2V_OK;
     }
-    if (a.S <= AS2_ROWS && g_a2v_attn_seq2) {              // round 6: two barrier-free roles over one 40-KB LDS image pair (a2v_attn_seq2.h)
+    if (as2_takes(a.S)) {                                   // round 6: persistent ten-wave kernel, two register-resident roles (a2v_attn_seq2.h)
       const bool dr = a.drop.thresh != 0;
       const dim3 pgrid(1, a.H, a.N);                        // (the d alibi_scale partials: one slot per (n, h), as the one-shot kernels)
       set_part(pgrid);

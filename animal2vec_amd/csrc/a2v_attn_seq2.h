@@ -53,19 +53,6 @@ __device__ __forceinline__ void as2_dma_piece(const bf16* __restrict__ base, lon
   __builtin_amdgcn_global_load_lds((af_gbl_cvoid_t*)((const char*)base + off), (af_lds_void_t*)(img + piece * 1024), 16, 0, 0);
 }
 
-// The workgroups of a launch are identical, start together and finish together: left alone, every CU's three resident workgroups
-// fetch at the same time, then compute at the same time, then store at the same time -- load, math and store times ADD (measured:
-// 110 + 170 + 69 us for the forward).  The first workgroup each CU slot receives (dispatch order: 256 CUs get one workgroup each, then
-// a second, then a third) therefore starts `sleeps` x slot x ~4 us late; the offset between a CU's workgroups then persists, since
-// each retiring workgroup is replaced at once by one of the same length.
-__device__ __forceinline__ void as2_stagger(int sleeps) {
-  const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  if (sleeps > 0 && lin >= 256 && lin < 768) {
-    const int nsl = (lin >> 8) * sleeps;
-    for (int i = 0; i < nsl; ++i) __builtin_amdgcn_s_sleep(127);
-  }
-}
-
 __device__ __forceinline__ unsigned as2_pack2(float lo, float hi) {     // two fp32 -> packed bf16 pair (RNE), one instruction
   unsigned r;
   asm(A2V_ASM_CVT_PK " %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));

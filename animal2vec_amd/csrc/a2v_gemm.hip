@@ -742,7 +742,6 @@ extern int g_a2v_attn_msum;
 extern int g_a2v_attn_band;
 extern int g_a2v_attn_fwd32;
 extern int g_a2v_attn_seq2;
-extern int g_a2v_attn_dbg;
 extern "C" int a2v_debug_set(int key, int value) {
   if (key == 0) { g_a2v_gemm_variant = value; return A2V_OK; }
   if (key == 1) { g_a2v_gemm_p8 = value; return A2V_OK; }     // 256x256 8-phase kernel on / off
@@ -772,7 +771,6 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 13) { g_a2v_conv_dec = value; return A2V_OK; }   // decoder grouped-conv kernel (a2v_conv_dec.hip) on / off
   { extern int g_a2v_dec_bpw; if (key == 38) { g_a2v_dec_bpw = value; return A2V_OK; } }   // conv_dec_kernel: 64-row blocks per workgroup (0 auto)
   if (key == 37) { g_a2v_wgrad_sparse = value; return A2V_OK; }  // row-sparse pos-conv weight gradients on / off
-  if (key == 40) { g_a2v_attn_dbg = value; return A2V_OK; }    // timing experiments on the round-6 attention forward (0 in product runs)
   if (key == 39) { g_a2v_attn_seq2 = value; return A2V_OK; }   // S <= 160 bf16 attention forward + backward: round-6 five-wave kernels on / off
   if (key == 36) { g_a2v_attn_fwd32 = value; return A2V_OK; }  // long-sequence attention forward: 32 x 32 x 16 kernel on / off
   if (key == 19) { g_a2v_attn_band = value; return A2V_OK; }  // long-sequence attention forward: ALiBi band limit on / off

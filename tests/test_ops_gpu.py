@@ -1389,7 +1389,7 @@ def _unpack_dropmask(dm, N, H, S):
 
 
 @pytest.mark.parametrize("S", [37, 96, 140, 152, 155, 160])
-def test_attention_seq2_dropout_mask_path(ops, S):
+def test_attention_seq2_dropout_mask_path(ops, S, request):
     """Round-6 whole-sequence kernels (bf16, HD 64, S <= 160): the forward's bit mask IS the counter hash's decision; a backward that
     reads the mask, one that re-hashes, and the round-5 kernels agree; forward / backward against the fp32 reference with that mask."""
     dtype, hd = torch.bfloat16, 64
@@ -1408,6 +1408,8 @@ def test_attention_seq2_dropout_mask_path(ops, S):
     ref.backward(do)
     qd, dod = dev(qkv.detach(), dtype), dev(do, dtype)
     args = (pos.cuda(), slopes.cuda(), sc.detach().cuda(), H)
+    ops.debug_set(39, 2)                                  # every S <= 160 through the round-6 kernels (default: 145 .. 160 only)
+    request.addfinalizer(lambda: ops.debug_set(39, 1))
     out, lse = ops.attention_fwd(qd, *args, drop=(p_, seed))
     dm = getattr(lse, "_a2v_dropmask", None)
     assert dm is not None, "the whole-sequence forward did not return a dropout mask"
@@ -1433,10 +1435,67 @@ def test_attention_seq2_dropout_mask_path(ops, S):
         assert getattr(lse5, "_a2v_dropmask", None) is None
         d5, dal5, _ = bwd(lse5)
     finally:
-        ops.debug_set(39, 1)
+        ops.debug_set(39, 2)
     assert rel_err(out.float(), out5.float()) < 4e-3 and rel_err(lse[0], lse5[0]) < 1e-5 and rel_err(lse[1], lse5[1]) < 1e-4
     assert rel_err(d_mask.float(), d5.float()) < 8e-3
     assert rel_err(dal_mask, dal5) < 2e-2
+
+
+@pytest.mark.parametrize("S,drop", [(152, True), (147, False), (160, True)])
+def test_attention_seq2_many_sequences(ops, S, drop):
+    """The round-6 kernels are PERSISTENT: one workgroup per CU walks several (n, h) sequences through alternating LDS buffers and
+    constant sets.  Only a launch with more than 256 sequences exercises that (every other test here has at most 12): 44 x 16 = 704
+    sequences -- two or three per workgroup -- against the round-5 one-shot kernels on the same inputs (independently held to the
+    fp32 reference above), forward outputs, log-sum-exp, all three gradients, the fused bias gradient and d alibi_scale; and every
+    sequence against the fp32 reference for a sample of rows."""
+    dtype, hd, N, H = torch.bfloat16, 64, 44, 16
+    g = torch.Generator().manual_seed(17)
+    qkv = torch.randn(N, S, 3 * H * hd, generator=g).to(dtype)
+    pos = torch.stack([torch.randperm(2000, generator=g)[:S].sort()[0] for _ in range(N)]).int()
+    slopes = torch.tensor(O.alibi_slopes(H))
+    sc = torch.rand(H, generator=g) + 0.5
+    do = torch.randn(N, S, H * hd, generator=g).to(dtype)
+    qd, dod = qkv.cuda(), do.cuda()
+    args = (pos.cuda(), slopes.cuda(), sc.cuda(), H)
+    dr = (0.1, 777) if drop else None
+
+    def both():
+        out, lse = ops.attention_fwd(qd, *args, drop=dr)
+        dal = torch.zeros(H, device="cuda")
+        bg = torch.zeros(3 * H * hd, device="cuda")
+        d = ops.attention_bwd(qd, out, dod, lse, *args, dal, drop=dr, bias_grad=bg)
+        torch.cuda.synchronize()
+        return out, lse, d, dal, bg
+    o6, l6, d6, a6, b6 = both()
+    assert (getattr(l6, "_a2v_dropmask", None) is not None) == drop
+    ops.debug_set(39, 0)
+    try:
+        o5, l5, d5, a5, b5 = both()
+    finally:
+        ops.debug_set(39, 1)
+    assert torch.isfinite(o6.float()).all() and torch.isfinite(d6.float()).all()
+    assert rel_err(o6.float(), o5.float()) < 4e-3 and rel_err(l6[0], l5[0]) < 1e-5 and rel_err(l6[1], l5[1]) < 1e-4
+    # per sequence: no (n, h) may be off (a stale buffer or constant set would hit whole sequences, not the norm of the tensor)
+    e = ((o6.float() - o5.float()).view(N, S, H, hd).pow(2).sum((1, 3)) / o5.float().view(N, S, H, hd).pow(2).sum((1, 3))).sqrt()
+    assert float(e.max()) < 8e-3, (float(e.max()), int(e.argmax()))
+    W = 3 * H * hd
+    eg = ((d6.float() - d5.float()).view(N, S, 3, H, hd).pow(2).sum((1, 4)) / d5.float().view(N, S, 3, H, hd).pow(2).sum((1, 4))).sqrt()
+    assert float(eg.max()) < 2e-2, (float(eg.max()), int(eg.argmax()))
+    assert rel_err(d6.float(), d5.float()) < 8e-3
+    assert rel_err(b6, d6.float().sum((0, 1))) < 1e-4 and rel_err(b6, b5) < 5e-3
+    assert rel_err(a6, a5) < 2e-2
+    # a sample of sequences against the fp32 reference (with the kernel's own mask)
+    keep = None
+    if drop:
+        keep = ops.dropout_mask2d(N * H * S, S, dr[0], dr[1]).view(N, H, S, S).float().cpu()
+    for n in (0, 17, 43):
+        q, k, v = qkv[n:n + 1].float().reshape(1, S, 3, H, hd).permute(2, 0, 3, 1, 4)
+        bias = O.alibi_bias_from_positions(pos[n:n + 1].long(), H, sc.view(1, 1, H, 1, 1))
+        att = ((q * hd ** -0.5) @ k.transpose(-2, -1) + bias).softmax(-1)
+        if drop:
+            att = att * keep[n:n + 1] / (1 - dr[0])
+        ref = (att @ v).transpose(1, 2).reshape(1, S, H * hd)
+        assert rel_err(o6[n:n + 1].float().cpu(), ref) < tol(dtype, 2), n
 
 
 def test_attention_dropout_mask_statistics(ops):

@@ -1223,8 +1223,8 @@ def test_fp16_teacher_option():
                           dec=rel_err(dbg["decoder_out"].float(), fx["out.decoder_out"]))
         eng.close()
     parity_report("fp16_teacher_option", torch.bfloat16, [(errs[True]["worst"], "worst, fp16 teacher"), (errs[False]["worst"], "worst, bf16 teacher")],
-                  targets=errs[True]["targets"], targets_bf16_teacher=errs[False]["targets"], median=errs[True]["med"],
-                  median_bf16_teacher=errs[False]["med"])
+                  targets=errs[True]["targets"], targets_bf16_teacher=errs[False]["targets"], grad_median=errs[True]["med"],
+                  grad_median_bf16_teacher=errs[False]["med"])
     assert errs[True]["targets"] < 1e-2 and errs[True]["targets"] < 0.5 * errs[False]["targets"], errs
     assert errs[True]["med"] < 3.5e-2 and errs[True]["worst"] < 1e-1 and errs[True]["dec"] < 2.5e-2, errs
 
