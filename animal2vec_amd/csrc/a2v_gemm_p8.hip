@@ -100,6 +100,19 @@ extern "C" int a2v_diag_p8_stamps2(unsigned long long* host_out, int* n_out) {
 #define P8_ST2R(slot_)
 #endif
 
+#if defined(P8_ST_AUX) && P8_ST_AUX > 1
+#if P8_ST_AUX == 2
+#define P8_ST_AUXS " sc1"
+#elif P8_ST_AUX == 3
+#define P8_ST_AUXS " sc0 sc1"
+#else
+#define P8_ST_AUXS " nt sc1"
+#endif
+template <typename V> __device__ __forceinline__ void p8_store_aux(V* p, V v) {
+  if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off" P8_ST_AUXS :: "v"(p), "v"(v) : "memory");
+  else asm volatile("global_store_dwordx2 %0, %1, off" P8_ST_AUXS :: "v"(p), "v"(v) : "memory");
+}
+#endif
 struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
   int m0, n0;        // first output row / column of the tile
@@ -626,7 +639,21 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       p8_u32x4 rq[D8 ? 1 : RQ];              // (a native vector: asm operands cannot be members of the HIP uint4 struct)
       p8_u32x2 rq8[D8 ? RQ : 1];
 #define P8_DROW(i_) ((i_) < 4 ? rlo + (i_) * 16 : rhi + ((i_) - 4) * 16)
-#define P8_ST16(base_, eo_, val_) *(p8_u32x4*)((base_) + (eo_)) = (val_)
+      // P8_ST_AUX (experiment builds): cache-policy bits on the epilogue's output stores -- 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1
+#ifndef P8_ST_AUX
+#define P8_STV(ptr_, val_) (*(ptr_) = (val_))
+#elif P8_ST_AUX == 1
+#define P8_STV(ptr_, val_) __builtin_nontemporal_store((val_), (ptr_))
+#else
+#define P8_STV(ptr_, val_) p8_store_aux((ptr_), (val_))
+#endif
+#define P8_ST16(base_, eo_, val_) P8_STV((p8_u32x4*)((base_) + (eo_)), (val_))
+#define P8_ST8BF(ptr_, v_)                                                                    \
+  {                                                                                           \
+    bf16x8 pk_;                                                                               \
+    _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) pk_[q_] = (bf16)(v_)[q_];               \
+    P8_STV((bf16x8*)(ptr_), pk_);                                                             \
+  }
       // (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, as the compiler's own loads here; s_nop: the base may have
       //  just been written by v_readfirstlane / v_readlane, and a VMEM instruction reading such an SGPR needs 5 wait states)
 #define P8_ROFF(k_) ((unsigned)(P8_DROW((k_) % NB) * (int)g.ldr + ((k_) / NB) * 128 + wc * 32 + fqe * 8) * 2u)
@@ -686,7 +713,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
                 g8[q >> 1] = dact8_put(dact8_put(g8[q >> 1], 2u * (q & 1), dd[0]), 2u * (q & 1) + 1u, dd[1]);
                 asm volatile("" : "+v"(v[2 * q]), "+v"(v[2 * q + 1]), "+v"(g8[q >> 1]));
               }
-              *(p8_u32x2*)(C2t8 + eo) = g8;
+              P8_STV((p8_u32x2*)(C2t8 + eo), g8);
             } else {
             p8_u32x4 gr;                             // gelu and gelu' from one evaluation; the derivative is what is kept,
 #pragma unroll                                       // packed pair by pair, the order pinned (interleaved, the eight
@@ -702,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
             P8_ST16(C2t, eo, gr);
             }
           } else {
-            if (flags & F_STORE_PRE) Vec8<bf16>::store(C2t + eo, v);
+            if (flags & F_STORE_PRE) P8_ST8BF(C2t + eo, v)
             if (flags & F_GELU) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
@@ -737,7 +764,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               for (int q = 0; q < 8; ++q) v[q] *= (flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
             }
           }
-          Vec8<bf16>::store(Ct + eo, v);
+          P8_ST8BF(Ct + eo, v)
           if (flags & F_COLSUM) {
             const float own = row >= rskip ? 1.f : 0.f;        // rows of the shifted tile's neighbour are summed there
 #pragma unroll
@@ -763,6 +790,8 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       }
 #undef P8_DROW
 #undef P8_ST16
+#undef P8_ST8BF
+#undef P8_STV
 #undef P8_ROFF
 #undef P8_RLOAD
 #undef P8_RN
