@@ -100,19 +100,6 @@ extern "C" int a2v_diag_p8_stamps2(unsigned long long* host_out, int* n_out) {
 #define P8_ST2R(slot_)
 #endif
 
-#if defined(P8_ST_AUX) && P8_ST_AUX > 1
-#if P8_ST_AUX == 2
-#define P8_ST_AUXS " sc1"
-#elif P8_ST_AUX == 3
-#define P8_ST_AUXS " sc0 sc1"
-#else
-#define P8_ST_AUXS " nt sc1"
-#endif
-template <typename V> __device__ __forceinline__ void p8_store_aux(V* p, V v) {
-  if constexpr (sizeof(V) == 16) asm volatile("global_store_dwordx4 %0, %1, off" P8_ST_AUXS :: "v"(p), "v"(v) : "memory");
-  else asm volatile("global_store_dwordx2 %0, %1, off" P8_ST_AUXS :: "v"(p), "v"(v) : "memory");
-}
-#endif
 struct P8Tile {      // byte offsets (from the tile's A / B base) of the 16-B chunks this thread stages
   unsigned al0, al1, ah0, ah1, bl0, bl1, bh0, bh1;
   int m0, n0;        // first output row / column of the tile
@@ -609,9 +596,13 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       // Addresses: a uniform 64-bit tile base (SGPRs) + a 32-bit per-lane element offset inside the tile's rows.
       const int fre = le & 15, fqe = le >> 4;
       const long long tile_off = (long long)T.mc * g.ldc + (long long)grp * g.c_goff + T.n0;
-      bf16* const Ct = C + tile_off;
-      bf16* const C2t = C2 + tile_off;
-      unsigned char* const C2t8 = (unsigned char*)g.C2 + tile_off;      // (F_DACT8: one byte per element)
+      // (tile bases made uniform explicitly, as Rt below: the raw-asm stores take them as SGPR pairs)
+#define P8_UNI_(ptr_) ((__typeof__(ptr_))(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(ptr_) >> 32)) << 32) | \
+                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(unsigned long long)(ptr_))))
+      bf16* const Ct = P8_UNI_(C + tile_off);
+      bf16* const C2t = P8_UNI_(C2 + tile_off);
+      unsigned char* const C2t8 = P8_UNI_((unsigned char*)g.C2 + tile_off);      // (F_DACT8: one byte per element)
+#undef P8_UNI_
       // (made uniform explicitly: the raw-asm loads below take it as an SGPR pair, and hipcc does not always prove that itself)
       const unsigned long long rt_ = (FX > 0 && (FX & F_DACT8) != 0)
           ? (unsigned long long)((const unsigned char*)g.R + ((long long)T.mc * g.ldr + (long long)grp * g.c_goff + T.n0))
@@ -639,20 +630,44 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
       p8_u32x4 rq[D8 ? 1 : RQ];              // (a native vector: asm operands cannot be members of the HIP uint4 struct)
       p8_u32x2 rq8[D8 ? RQ : 1];
 #define P8_DROW(i_) ((i_) < 4 ? rlo + (i_) * 16 : rhi + ((i_) - 4) * 16)
-      // P8_ST_AUX (experiment builds): cache-policy bits on the epilogue's output stores -- 1 nt, 2 sc1, 3 sc0 sc1, 4 nt sc1
+      // P8_ST_AUX (experiment builds): cache-policy bits on the output stores -- 0 plain stores (product), 1 nt, 2 sc1, 3 sc0 sc1,
+      // 4 nt sc1, 5 nt sc0, 6 nt sc0 sc1; non-zero = raw asm in the SGPR-base + 32-bit-offset form (the builtin nontemporal store
+      // only sets nt; the trailing s_nop 1: a VALU write of the data registers of a 16-byte store needs two wait states on gfx940+,
+      // and hipcc's hazard pass does not look inside asm).  Measured (profiles/r06_store_policy.txt): "nt sc1" (streaming, written
+      // through L2) takes 3-7 % off the K = 1024 launches run back to back on their own -- and ADDS 1-9 % to the same launches inside
+      // the training step (whole step -0.7 %), where the acknowledgement of a written-through store waits behind the memory traffic
+      // of the neighbouring kernels.  Not the product.
 #ifndef P8_ST_AUX
-#define P8_STV(ptr_, val_) (*(ptr_) = (val_))
-#elif P8_ST_AUX == 1
-#define P8_STV(ptr_, val_) __builtin_nontemporal_store((val_), (ptr_))
-#else
-#define P8_STV(ptr_, val_) p8_store_aux((ptr_), (val_))
+#define P8_ST_AUX 0
 #endif
-#define P8_ST16(base_, eo_, val_) P8_STV((p8_u32x4*)((base_) + (eo_)), (val_))
-#define P8_ST8BF(ptr_, v_)                                                                    \
+#if P8_ST_AUX == 0
+#define P8_STV(base_, boff_, val_) (*(__typeof__(val_)*)((char*)(base_) + (boff_)) = (val_))
+#else
+#if P8_ST_AUX == 1
+#define P8_ST_AUXS " nt"
+#elif P8_ST_AUX == 2
+#define P8_ST_AUXS " sc1"
+#elif P8_ST_AUX == 3
+#define P8_ST_AUXS " sc0 sc1"
+#elif P8_ST_AUX == 4
+#define P8_ST_AUXS " nt sc1"
+#elif P8_ST_AUX == 5
+#define P8_ST_AUXS " nt sc0"
+#else
+#define P8_ST_AUXS " nt sc0 sc1"
+#endif
+#define P8_STV(base_, boff_, val_)                                                                                              \
+  {                                                                                                                             \
+    if constexpr (sizeof(val_) == 16) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2" P8_ST_AUXS "\n\ts_nop 1" :: "v"(boff_), "v"(val_), "s"(base_) : "memory"); \
+    else asm volatile("s_nop 4\n\tglobal_store_dwordx2 %0, %1, %2" P8_ST_AUXS :: "v"(boff_), "v"(val_), "s"(base_) : "memory");  \
+  }
+#endif
+#define P8_ST16(base_, eo_, val_) P8_STV(base_, (eo_) * 2u, val_)
+#define P8_ST8BF(base_, eo_, v_)                                                              \
   {                                                                                           \
     bf16x8 pk_;                                                                               \
     _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) pk_[q_] = (bf16)(v_)[q_];               \
-    P8_STV((bf16x8*)(ptr_), pk_);                                                             \
+    P8_STV(base_, (eo_) * 2u, pk_);                                                           \
   }
       // (uniform 64-bit base in SGPRs + a 32-bit byte offset per lane, as the compiler's own loads here; s_nop: the base may have
       //  just been written by v_readfirstlane / v_readlane, and a VMEM instruction reading such an SGPR needs 5 wait states)
@@ -713,7 +728,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
                 g8[q >> 1] = dact8_put(dact8_put(g8[q >> 1], 2u * (q & 1), dd[0]), 2u * (q & 1) + 1u, dd[1]);
                 asm volatile("" : "+v"(v[2 * q]), "+v"(v[2 * q + 1]), "+v"(g8[q >> 1]));
               }
-              P8_STV((p8_u32x2*)(C2t8 + eo), g8);
+              P8_STV(C2t8, eo, g8);
             } else {
             p8_u32x4 gr;                             // gelu and gelu' from one evaluation; the derivative is what is kept,
 #pragma unroll                                       // packed pair by pair, the order pinned (interleaved, the eight
@@ -729,7 +744,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
             P8_ST16(C2t, eo, gr);
             }
           } else {
-            if (flags & F_STORE_PRE) P8_ST8BF(C2t + eo, v)
+            if (flags & F_STORE_PRE) P8_ST8BF(C2t, eo, v)
             if (flags & F_GELU) {
 #pragma unroll
               for (int q = 0; q < 8; ++q) v[q] = gelu_f(v[q]);
@@ -764,7 +779,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
               for (int q = 0; q < 8; ++q) v[q] *= (flags & F_DACT) ? h[q] : gelu_grad_f(h[q]);
             }
           }
-          P8_ST8BF(Ct + eo, v)
+          P8_ST8BF(Ct, eo, v)
           if (flags & F_COLSUM) {
             const float own = row >= rskip ? 1.f : 0.f;        // rows of the shifted tile's neighbour are summed there
 #pragma unroll
