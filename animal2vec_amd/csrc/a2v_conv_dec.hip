@@ -55,7 +55,7 @@ extern "C" int a2v_diag_cd_stamps(unsigned long long* host_out) {
 }
 #endif
 template <int CI, int CO, int GPW>
-__global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_per_wg, int y_fastest) {
+__global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int nW, int front) {
   using GM = CdGeom<CI, CO, GPW>;
   constexpr int CD_GW = GM::GW, CD_PITCH = GM::PITCH, CD_SLAB_BYTES = GM::SLAB_BYTES, CD_CHUNKS = GM::CHUNKS, CD_NLD = GM::NLD;
   constexpr int CD_KSTEPS = GM::KSTEPS, TCH = GM::TCH, KCH = GM::KCH, NJ = GM::NJ, RCH = GM::RCH;
@@ -64,16 +64,18 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
   const int fr = lane & 15, fq = lane >> 4;
   const ConvA& a = g.a;
   const int T = a.T_out;
-  const int rows_per_wg = blocks_per_wg * CD_ROWS;
-  const int cpc = (T + rows_per_wg - 1) / rows_per_wg;           // row chunks per clip
-  // (y_fastest: 1-D grid, the workgroups that share a row chunk -- one per 8 (4) groups -- are dispatched together)
+  // Work order (round 6): the (clip, 64-row block) pairs form ONE sequence over the whole activation tensor and workgroup wl of the
+  // nW that share a channel slice takes blocks wl, wl + nW, wl + 2 nW, ...: at any moment the nW x ny resident workgroups read (and
+  // write) one contiguous window of nW x 64 rows that moves through the tensor -- an in-order front, as the streaming LayerNorm
+  // kernels (a2v_norm.hip) -- instead of 256 separate streams 3 MB apart (a workgroup used to own 32 consecutive blocks of one clip).
+  // front = 0 keeps that older order (a2v_debug_set(38, -1)): workgroup wl owns the blocks [wl * bpw, (wl + 1) * bpw), bpw = nW here.
   const int ny = g.G / CD_GW;
-  const int bx = y_fastest ? (int)(blockIdx.x / (unsigned)ny) : (int)blockIdx.x;
-  const int by = y_fastest ? (int)(blockIdx.x % (unsigned)ny) : (int)blockIdx.y;
-  const int clip = bx / cpc;
-  const int t_begin = (bx - clip * cpc) * rows_per_wg;
-  const int t_end = min(T, t_begin + rows_per_wg);
-  const int nblk = (t_end - t_begin + CD_ROWS - 1) / CD_ROWS;
+  const int by = (int)(blockIdx.x % (unsigned)ny);                // the workgroups that share a row block are dispatched together
+  const int wl = (int)(blockIdx.x / (unsigned)ny);
+  const int nbc = (T + CD_ROWS - 1) / CD_ROWS;                    // blocks per clip; the last one starts at T - 64 (see block_pos)
+  const int total = (g.M / T) * nbc;
+  const int gb0 = front ? wl : wl * nW, gstep = front ? nW : 1;
+  const int nblk = front ? (total - wl + nW - 1) / nW : min(nW, total - gb0);
   const int g0 = by * CD_GW;                                      // first group of this workgroup
 
   // ---- weights of this wave's two groups as MFMA fragments.  K-chunk q = 4 s + fq of step s is channels [8 (q % 6), +8)
@@ -108,10 +110,13 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
     const int tap = q / TCH, c0 = (q - TCH * tap) * 8;
     return (fr_ + tap) * CD_PITCH + c0 * 2;
   };
-  const bf16* const xb = (const bf16*)a.ptr + (long long)(clip / a.bdiv) * a.bstride + (long long)g0 * a.goff;
-  // Every block is a full 64 rows: the last one of a chunk starts at t_end - 64 and recomputes rows its predecessor (or the
-  // previous chunk's workgroup) also writes -- same operands, same order, same bits (the launcher refuses C overlapping R).
-  auto block_t0 = [&](int blk) { return min(t_begin + blk * CD_ROWS, t_end - CD_ROWS); };
+  // Every block is a full 64 rows: the last one of a clip starts at T - 64 and recomputes rows its predecessor also writes -- same
+  // operands, same order, same bits (the launcher refuses C overlapping R).  (uniform: scalar registers)
+  auto block_pos = [&](int blk, int& clip_, int& t0_) {
+    const int gb = gb0 + blk * gstep;
+    clip_ = gb / nbc;
+    t0_ = min((gb - clip_ * nbc) * CD_ROWS, T - CD_ROWS);
+  };
   // The next slab is fetched by raw-asm loads from clamped addresses into AGPRs (slab rows block_t0 - pad + [0, 70); rows outside the
   // clip and chunks past the slab are zeroed when the registers are stashed) and waited for by hand: vmcnt(N), N = the vector-memory
   // operations certainly issued after the fetch -- the block's unconditional stores and, with a residual, its residual loads.  As
@@ -120,12 +125,17 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
   // bounded the kernel -- profiles/r05_dec_bench.txt; tests/test_abi.py checks that nothing names the AGPRs before the wait.)
   typedef unsigned cd_u32x4 __attribute__((ext_vector_type(4)));
   cd_u32x4 rga[CD_NLD];
-  const unsigned long long xb64_ = (unsigned long long)xb;       // made uniform explicitly (the asm takes it as an SGPR pair); formed here,
-  const bf16* const xb_u = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb64_ >> 32)) << 32) |   // far from its first use
-                                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb64_));
   const unsigned xpitch_b = (unsigned)a.pitch * 2u;              // (a slab row of a 10 s clip is < 4 MiB from the clip's base)
   auto fetch_asm = [&](int blk) {
-    const int t0 = block_t0(blk) - a.pad;
+    int clip_, t0_;
+    block_pos(blk, clip_, t0_);
+    const int t0 = t0_ - a.pad;
+    // the clip's base, made uniform explicitly (the asm takes it as an SGPR pair; s_nop 4: a VMEM instruction reading an SGPR that
+    // v_readfirstlane has just written needs five wait states, and hipcc's hazard pass does not look inside asm)
+    const unsigned long long xb64_ = (unsigned long long)((const bf16*)a.ptr + (long long)clip_ * a.bstride + (long long)g0 * a.goff);
+    const bf16* const xb_u = (const bf16*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xb64_ >> 32)) << 32) |
+                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)xb64_));
+    asm volatile("s_nop 4" :: "s"(xb_u));
 #pragma unroll
     for (int u = 0; u < CD_NLD; ++u) {
       int idx = tid + 256 * u;
@@ -139,7 +149,9 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
     }
   };
   auto stash_asm = [&](char* buf, int blk) {
-    const int t0 = block_t0(blk) - a.pad;
+    int clip_, t0_;
+    block_pos(blk, clip_, t0_);
+    const int t0 = t0_ - a.pad;
 #pragma unroll
     for (int u = 0; u < CD_NLD; ++u) {
       const int idx = tid + 256 * u;
@@ -182,10 +194,12 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
     CD_STAMP_AT(0)
     if (blk + 1 < nblk) fetch_asm(blk + 1);           // in flight under this block's MFMAs
     CD_STAMP_AT(4)
+    int clip, t0c;
+    block_pos(blk, clip, t0c);
 #pragma unroll
     for (int gi = 0; gi < GPW; ++gi) {
       const int grp = g0 + GPW * wid + gi;
-      const long long m0 = (long long)clip * T + block_t0(blk) + fr;       // row of i = 0
+      const long long m0 = (long long)clip * T + t0c + fr;       // row of i = 0
       Raw8<bf16> h8[4][NJ / 2];
       uint2 h4[4];
       if (g.flags & F_RES) {
@@ -302,7 +316,7 @@ __global__ __launch_bounds__(256) void conv_dec_kernel(GemmArgs g, int blocks_pe
 }
 
 int g_a2v_conv_dec = 1;     // a2v_debug_set(13, v): decoder grouped conv through this kernel on / off
-int g_a2v_dec_bpw = 0;      // a2v_debug_set(38, v): 64-row blocks per workgroup (0: 32, fewer for small batches)
+int g_a2v_dec_bpw = 0;      // a2v_debug_set(38, v): 0 in-order front, one workgroup per CU; v > 0: v workgroups per channel slice; -1: the older order
 template <int CI, int CO, int GPW>
 static void conv_dec_go(const GemmArgs& g, hipStream_t stream) {
   using GM = CdGeom<CI, CO, GPW>;
@@ -313,17 +327,31 @@ static void conv_dec_go(const GemmArgs& g, hipStream_t stream) {
     attr = true;
   }
   const int nclips = g.M / a.T_out;
-  // rows per workgroup: long enough that the weight fragments a wave loads are a small share of its traffic, short
-  // enough for a few rounds over the CUs
-  int bpw = 32;                                        // (round 5 sweep, 768 clones x 2000 frames: 8 / 16 / 32 blocks = 1405 / 1331 / 1277 us)
-  while (bpw > 4 && (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS) * (g.G / GM::GW) < 512) bpw >>= 1;
-  if (g_a2v_dec_bpw > 0) bpw = g_a2v_dec_bpw;
-  extern int g_a2v_slab_order;
-  const long long nx = (long long)nclips * cdiv(a.T_out, bpw * CD_ROWS);
   const int ny = g.G / GM::GW;
-  const int yf = (g_a2v_slab_order & 2) && nx * ny < (1ll << 31) ? 1 : 0;
-  dim3 grid(yf ? (unsigned)(nx * ny) : (unsigned)nx, yf ? 1 : ny, 1);
-  hipLaunchKernelGGL((conv_dec_kernel<CI, CO, GPW>), grid, dim3(256), GM::LDS, stream, g, bpw, yf);
+  const int total = nclips * cdiv(a.T_out, CD_ROWS);                 // 64-row blocks of the tensor
+  static int cus_dev[A2V_MAX_DEVICES]; int& cus = cus_dev[a2v_device()];
+  if (!cus) {
+    hipDeviceProp_t p;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipGetDeviceProperties(&p, dev);
+    cus = p.multiProcessorCount > 0 ? p.multiProcessorCount : 256;
+  }
+  if (g_a2v_dec_bpw >= 0) {
+    // in-order front: one resident workgroup per CU (512 registers per lane), nW of them per channel slice; few blocks -> fewer
+    // workgroups, each with at least four blocks behind the weight fragments it loads (66 KB per wave)
+    int nW = cus / ny > 0 ? cus / ny : 1;
+    if (g_a2v_dec_bpw > 0) nW = g_a2v_dec_bpw;
+    while (nW > 1 && total < 4 * nW) nW >>= 1;
+    if (nW > total) nW = total;
+    hipLaunchKernelGGL((conv_dec_kernel<CI, CO, GPW>), dim3((unsigned)(nW * ny)), dim3(256), GM::LDS, stream, g, nW, 1);
+    return;
+  }
+  // the older order (a2v_debug_set(38, -1)): a workgroup owns bpw consecutive blocks (round 5 sweep, 768 clones x 2000 frames:
+  // 8 / 16 / 32 blocks = 1405 / 1331 / 1277 us)
+  int bpw = 32;
+  while (bpw > 4 && (long long)cdiv(total, bpw) * ny < 512) bpw >>= 1;
+  hipLaunchKernelGGL((conv_dec_kernel<CI, CO, GPW>), dim3((unsigned)(cdiv(total, bpw) * ny)), dim3(256), GM::LDS, stream, g, bpw, 0);
 }
 bool a2v_launch_conv_dec48(const GemmArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;

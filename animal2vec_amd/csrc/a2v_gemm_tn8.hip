@@ -17,6 +17,10 @@ __device__ __forceinline__ void t8_glds16(const char* gsrc, char* lds_dst) {
   __builtin_amdgcn_global_load_lds((t8_gbl_cvoid_t*)gsrc, (t8_lds_void_t*)lds_dst, 16, 0, 0);
 }
 
+// T8_EXP (timing builds, wrong results; tools/tn_probe.py): 1 no MFMA, 2 no LDS-DMA in the K loop, 3 no fragment reads, 4 no atomics
+#ifndef T8_EXP
+#define T8_EXP 0
+#endif
 #define T8_BUF 65536                  // one K-tile: P_lo, P_hi, Q_lo, Q_hi (16 KiB half-tiles: 64 rows x 256 B)
 #define T8_PLO 0
 #define T8_PHI 16384
@@ -91,7 +95,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
 
   // stage one half-tile of K-tile kt of unit U: 2 LDS-DMA per thread; rows >= M come from the zero page
 #define T8_STAGE(ub, ld2, U, kt, hi, lds_off)                                                       \
-  {                                                                                                 \
+  if (T8_EXP != 2) {                                                                                \
     const char* kb_ = U.ub + ((long long)(kt) * 64 * U.ld2 + (hi) * 256);                           \
     const int mr_ = U.mbeg + (kt) * 64;                                                             \
     t8_glds16(mr_ + mrow0 < g.M ? kb_ + ((unsigned)mrow0 * U.ld2 + sc0) : zsrc, dst0 + (lds_off));  \
@@ -116,8 +120,9 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
 #define T8_FRAG(dst, addr, off)                                                                          \
   {                                                                                                      \
     t8_i2 lo_, hi_;                                                                                      \
+    if (T8_EXP == 3) { asm volatile("" : "=v"(lo_) : "v"(addr)); asm volatile("" : "=v"(hi_) : "v"(addr)); } else {  \
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo_) : "v"(addr), "n"(off));               \
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(addr), "n"((off) + 1024));      \
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi_) : "v"(addr), "n"((off) + 1024)); }    \
     union { struct { t8_i2 a, b; } s; bf16x8 v; } u_;                                                    \
     u_.s.a = lo_; u_.s.b = hi_;                                                                          \
     dst = u_.v;                                                                                          \
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-    acc[(ibase) + i][(jbase) + j] =                                                                      \
+    if (T8_EXP != 1) acc[(ibase) + i][(jbase) + j] =                                                     \
         A2V_MFMA_16x16x32(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                         \
   __builtin_amdgcn_s_barrier();
@@ -217,7 +222,8 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
           for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-              atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * U.ldw + hb * 128 + j * 16, acc[ha * 4 + i][hb * 2 + j][r]);
+              if (T8_EXP != 4) atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * U.ldw + hb * 128 + j * 16, acc[ha * 4 + i][hb * 2 + j][r]);
+              else asm volatile("" :: "v"(acc[ha * 4 + i][hb * 2 + j][r]));
     U = Un;
   }
   if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
