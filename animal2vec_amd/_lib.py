@@ -15,6 +15,8 @@ LIB_PATH = os.environ.get("A2V_LIB_PATH") or os.path.join(_HERE, "liba2v_hip.so"
 F32, BF16, BF16X3, BF16X3S = 0, 1, 2, 3
 EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_X3IMG = 1, 2, 4, 8, 16, 32, 64, 128, 256
 EPI_DACT8 = 512
+EPI_QKNORM = 1024
+ERR_UNSUPPORTED = -4
 
 _p, _i, _ll, _f, _u = C.c_void_p, C.c_int, C.c_longlong, C.c_float, C.c_uint
 
@@ -32,7 +34,7 @@ SIGNATURES = {
     "a2v_conv_wgrad_kept": [_p, _i, _i, _p, _ll, _ll, _i, _i, _i, _i, _i, _i, _i, _i, _p, _i, _p, _ll, _i, _p, _ll, _ll, _i, _i, _i,
                             _i, _p],
     "a2v_linear_wgrad_pair": [_i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p, _ll, _p, _ll, _p, _ll, _i, _i, _p],
-    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
     "a2v_attention_dropmask_words": [_i, _i, _i],
     "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
     "a2v_attention_bwd_fused_bias": [_i, _i, _i],
@@ -85,6 +87,10 @@ ABI12_SIGNATURES = {
     "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
     "a2v_attention_bwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
 }
+# ABI 14: a2v_attention_fwd takes `qk_norms` (one more pointer, after dropmask); a2v_conv_gemm knows A2V_EPI_QKNORM.
+ABI13_SIGNATURES = {
+    "a2v_attention_fwd": [_i, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _f, _f, _u, _p],
+}
 RESTYPES = {"a2v_query_workspace": C.c_size_t}      # everything else returns int
 
 _lib = None
@@ -113,6 +119,8 @@ def _load_path(path: str, what: str) -> C.CDLL:
             if name in ABI13_ENTRIES:
                 continue
             argtypes = ABI12_SIGNATURES.get(name, argtypes)
+        elif abi == 13 and os.environ.get("A2V_LIB_PATH"):
+            argtypes = ABI13_SIGNATURES.get(name, argtypes)
         try:
             fn = getattr(lib, name)
         except AttributeError as e:

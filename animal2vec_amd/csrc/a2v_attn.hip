@@ -57,6 +57,8 @@ struct AttnArgs {
                                   // the backward centres |pos_i - pos_j| on it when it forms d alibi_scale (see AttnBwdArgs::mdist)
   float band_nats;                // ALiBi band limit: keys whose softmax weight is provably below exp(-band_nats) of the row sum are not visited
   unsigned* dropmask;             // (N,H,160,4,2) u32 or nullptr: the whole-sequence forward (S <= 160, bf16, HD 64) writes its dropout decisions here (a2v_attn_seq2.h)
+  const float* qk_norm;           // host side only: (N, 3 H HD / 32) squared-norm maxima of the 32-column segments of q | k | v as the qkv product's
+                                  // F_QKNORM epilogue left them, or nullptr (then attn_qk_bound_kernel reads q and k again)
 };
 
 struct AttnBwdArgs {
@@ -1501,6 +1503,24 @@ __global__ __launch_bounds__(256) void attn_qk_bound_kernel(const T* __restrict_
     }
   }
 }
+// The same bound from the qkv product's own epilogue (F_QKNORM, a2v_gemm_p8.hip): per clip and 32-column segment the maximum over the
+// rows of the segment's squared norm.  A head row is two segments a, b:  |q_i . k_j| <= |q_a,i| |k_a,j| + |q_b,i| |k_b,j| <=
+// sqrt(max_i q_a,i^2 max_j k_a,j^2) + sqrt(max_i q_b,i^2 max_j k_b,j^2) =: B' -- a bound as before (Cauchy-Schwarz per segment; the
+// maxima of a and b may sit in different rows, which is all it loses).  The forward kernels read (q2, k2) per (n, h) from
+// A2V_QKB_SPLIT slots and form sqrt(max q2 * max k2): slot 0 gets (B'^2, 1), the others zero.
+__global__ __launch_bounds__(256) void attn_qk_norm_fold_kernel(const float* __restrict__ norms, float* __restrict__ bound, int N, int H) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;          // over (SPLIT, N, H, 2)
+  if (idx >= A2V_QKB_SPLIT * N * H * 2) return;
+  const int which = idx & 1, h = (idx >> 1) % H, n = ((idx >> 1) / H) % N, z = (idx >> 1) / (H * N);
+  float v = 0.f;
+  if (z == 0) {
+    const float* const q = norms + (long long)n * (6 * H) + 2 * h;
+    const float* const k = q + 2 * H;
+    const float b = sqrtf(q[0] * k[0]) + sqrtf(q[1] * k[1]);
+    v = which ? 1.f : b * b;
+  }
+  bound[idx] = v;
+}
 int g_a2v_attn_band = 1;     // a2v_debug_set(19, v): ALiBi band limit of the long-sequence forward (positions = arange) on / off;
                              // v >= 8: on, with exp(-v) as the bf16 kernel's weight bound (experiments)
 #define A2V_BAND_NATS_BF16 20.f  // bf16 kernels: 2000 keys x e^-20 = 4e-6 of the row sum, 500 times below the bf16 rounding of P itself (2^-9)
@@ -1538,7 +1558,8 @@ static void attn_fwd_bf16_launch(const AttnArgs& a_in, hipStream_t st) {
       char* const ws = (g_a2v_attn_band && !a.pos && (long long)a.N * a.H * 2 * A2V_QKB_SPLIT <= A2V_QKB_MAX) ? a2v_stream_ws(st) : nullptr;
       if (ws) {
         float* const bp = (float*)(ws + A2V_WS_QKB);
-        hipLaunchKernelGGL((attn_qk_bound_kernel<64>), dim3(A2V_QKB_SPLIT, a.N), dim3(256), 0, st, (const bf16*)a.qkv, bp, a.S, a.H);
+        if (a.qk_norm) hipLaunchKernelGGL(attn_qk_norm_fold_kernel, dim3((A2V_QKB_SPLIT * a.N * a.H * 2 + 255) / 256), dim3(256), 0, st, a.qk_norm, bp, a.N, a.H);
+        else hipLaunchKernelGGL((attn_qk_bound_kernel<64>), dim3(A2V_QKB_SPLIT, a.N), dim3(256), 0, st, (const bf16*)a.qkv, bp, a.S, a.H);
         a.qk_bound = bp;
       }
     }
@@ -1953,12 +1974,12 @@ extern "C" int a2v_attention_dropmask_words(int dtype, int S, int HD) {
   return (dtype == A2V_BF16 && HD == 64 && as2_takes(S)) ? AS2_ROWS * 4 * 2 : 0;
 }
 
-extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, unsigned* dropmask, const int* pos,
-                                 const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
+extern "C" int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, unsigned* dropmask, const float* qk_norms,
+                                 const int* pos, const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
                                  float drop_p, unsigned drop_seed, hipStream_t stream) {
   if (N <= 0 || S <= 0 || H <= 0 || !slopes || !alibi_scale || drop_p < 0.f || drop_p >= 1.f) return A2V_ERR_ARG;
   AttnArgs a{qkv, out, lse, pos, slopes, alibi_scale, N, S, H, scale, make_drop(drop_p, drop_seed), 0, nullptr, mdist, 32.f,
-             a2v_attention_dropmask_words(dtype, S, HD) ? dropmask : nullptr};
+             a2v_attention_dropmask_words(dtype, S, HD) ? dropmask : nullptr, (dtype == A2V_BF16 && HD == 64) ? qk_norms : nullptr};
   if (dtype == A2V_BF16) {
     a.band_nats = g_a2v_attn_band >= 8 ? (float)g_a2v_attn_band : A2V_BAND_NATS_BF16;
     const bool dr = a.drop.thresh != 0;

@@ -881,4 +881,4 @@ extern "C" int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols,
   return A2V_OK;
 }
 
-extern "C" int a2v_abi_version(void) { return 13; }
+extern "C" int a2v_abi_version(void) { return 14; }

@@ -38,7 +38,12 @@ struct GemmArgs {
 };
 
 enum { F_BIAS = 1, F_GELU = 2, F_RES = 4, F_GELU_BWD = 8, F_STORE_PRE = 16, F_COLSUM = 32, F_DROPOUT = 64, F_DACT = 128, F_X3IMG = 256,
-       F_DACT8 = 512 };    // F_DACT8 (bf16, with F_DACT): the derivative tensor (C2 when stored, R when multiplied) is uint8, a2v_common.h dact8_*
+       F_DACT8 = 512, F_QKNORM = 1024 };
+// F_DACT8 (bf16, with F_DACT): the derivative tensor (C2 when stored, R when multiplied) is uint8, a2v_common.h dact8_*
+// F_QKNORM (bf16, with F_BIAS only, the persistent kernel's fixed flavour or nothing): `colsum` is instead a [M / T_out][N / 32] fp32 table
+// (zeroed by the caller) that receives, by atomic maximum, max over the T_out rows of each clip of the squared norm of every 32-column
+// segment of the output -- what the long-sequence attention forward's ALiBi band limit needs of q and k (a2v_attn.hip), taken from the
+// accumulators instead of a second pass over the qkv tensor.
 // F_X3IMG (dtype A2V_BF16X3 on the persistent kernel only): C is written as the bf16 [hi | lo | hi] split image of the result (row pitch
 // ldc >= 3 N bf16 elements) instead of fp32 -- for a result that only further products read (the Mlp's hidden activation)
 // F_DACT (with F_GELU | F_STORE_PRE): C2 receives gelu'(acc + bias) instead of the pre-activation -- both come out of one

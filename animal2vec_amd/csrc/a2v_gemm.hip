@@ -483,6 +483,15 @@ static int conv_gemm_impl(const int* rowidx, int dtype, const void* A, long long
     A2V_CHECK_LAUNCH();
     return A2V_OK;
   }
+  if (flags & F_QKNORM) {
+    // row-norm maxima per clip and 32-column segment (include/a2v.h: A2V_EPI_QKNORM) into `colsum`: one fixed flavour of the persistent
+    // kernel forms them, nothing else does -- a launch it does not take is refused, never run without them
+    if (dtype != A2V_BF16 || flags != (F_BIAS | F_QKNORM) || rowidx || rowmask || G != 1 || taps != 1 || stride != 1 || !colsum ||
+        N % 32 || T_in != T_out || M % T_out || !g_a2v_gemm_p8 || !a2v_launch_nt_bf16_p8(g, stream))
+      return A2V_ERR_UNSUPPORTED;
+    A2V_CHECK_LAUNCH();
+    return A2V_OK;
+  }
   if ((flags & F_X3IMG) && (dtype != A2V_BF16X3 || rowidx || !a2v_launch_nt_x3_p8(g, stream))) return A2V_ERR_UNSUPPORTED;
   if (flags & F_X3IMG) {
     A2V_CHECK_LAUNCH();

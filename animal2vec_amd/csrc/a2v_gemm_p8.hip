@@ -138,7 +138,8 @@ __host__ __device__ constexpr int p8_later(int /*k*/, int b0, int b1, int RQ, in
 #define P8_FX_PLAIN 256                                         /* no flag at all (proj input gradient); bit 8 marks "fixed" */
 #define P8_FX_FC1_8 (P8_FX_FC1 | F_DACT8)                       /* fc1 forward, the kept derivative in 8 bits (a2v_common.h dact8_*) */
 #define P8_FX_FC2D_8 (P8_FX_FC2D | F_DACT8)                     /* fc2 input gradient reading it */
-#define P8_FXM 0x2FF                                            /* the epilogue flags a fixed flavour encodes (bit 8 is the marker above) */
+#define P8_FX_BQ (F_BIAS | F_QKNORM)                            /* the teacher's qkv: + the row-norm maxima of the attention's band limit */
+#define P8_FXM 0x6FF                                            /* the epilogue flags a fixed flavour encodes (bit 8 is the marker above) */
 // O32 (dtype A2V_BF16X3 of the C ABI): bf16 operands, fp32 C / C2 / R.  The caller hands over SPLIT operand images --
 // A3 = [A_hi | A_lo | A_hi], B3 = [B_hi | B_hi | B_lo] along K (a2v_split_bf16), so that this ordinary bf16 product over 3 K
 // is A_hi B_hi + A_lo B_hi + A_hi B_lo: every product exact, fp32 accumulation, 2^-17-relative operands -- and gets fp32-grade
@@ -611,6 +612,15 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
                                            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)rt_));
       const int rskip = T.m0 - T.mc;                        // the shifted last m-tile: rows below m0 belong to its neighbour
       const int rlo = wr * 64 + fre, rhi = 128 + wr * IH * 16 + fre;
+      // F_QKNORM: the tile's rows belong to clip qk_c0 below in-tile row qk_rb and to clip qk_c0 + 1 from there on (a clip is
+      // a.T_out >= BM rows: at most one boundary per tile; uniform values)
+      constexpr bool QKN = FX > 0 && (FX & F_QKNORM) != 0;
+      int qk_c0 = 0, qk_rb = 0x7fffffff;
+      if constexpr (QKN) {
+        qk_c0 = T.mc / a.T_out;
+        qk_rb = (qk_c0 + 1) * a.T_out - T.mc;
+      }
+      const bool qk_split = qk_rb < BM;
       // Residual / pre-activation rows are fetched RQ row blocks ahead of their use, across both column halves (2 NB row blocks
       // form one sequence).  Loads, stores, atomics and the LDS-DMA share ONE in-order counter (vmcnt): the data of a load issued
       // behind a store is only there once that store is acknowledged.  hipcc, which must assume the two kinds complete out of
@@ -704,6 +714,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #pragma unroll
         for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(bias8[i]));     // consumed here (see the staged form below)
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float qm0 = 0.f, qm1 = 0.f;              // F_QKNORM: running maxima of this lane's rows, first / second clip of the tile
 #pragma unroll
         for (int i = 0; i < 4 + IH; ++i) {
           const int row = P8_DROW(i);
@@ -713,6 +724,29 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
           const unsigned eo = (unsigned)(row * (int)g.ldc + cl);
 #pragma unroll
           for (int q = 0; q < 8; ++q) v[q] += bias8[q];
+          if constexpr (QKN) {
+            // squared norm of the row's 32-column segment: 8 columns here, the other 24 in the lanes fq ^ 1, 2, 3 of the same fr
+            // (v_permlane32_swap / v_permlane16_swap: no LDS round trip); fp32 values before the bf16 rounding -- the consumer's
+            // 1 % margin covers (1 + 2^-9)^2
+            float sq = v[0] * v[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) sq = fmaf(v[q], v[q], sq);
+            {
+              const unsigned u_ = __float_as_uint(sq);
+              auto r_ = __builtin_amdgcn_permlane32_swap(u_, u_, false, false);
+              sq = __uint_as_float(r_[0]) + __uint_as_float(r_[1]);
+              const unsigned x_ = __float_as_uint(sq);
+              auto t_ = __builtin_amdgcn_permlane16_swap(x_, x_, false, false);
+              sq = __uint_as_float(t_[0]) + __uint_as_float(t_[1]);
+            }
+            if (qk_split) {
+              const bool second = row >= qk_rb;
+              qm0 = fmaxf(qm0, second ? 0.f : sq);
+              qm1 = fmaxf(qm1, second ? sq : 0.f);
+            } else {
+              qm0 = fmaxf(qm0, sq);
+            }
+          }
           // (not at the 256-row tile: its register allocation has no room for this branch -- 8 spills, reloaded inside the tile
           //  seam; the launcher gives the flavour 224- or 192-row tiles)
           if ((IH < 4 || FX > 0) && (flags & (F_DACT | F_GELU | F_STORE_PRE)) == (F_DACT | F_GELU | F_STORE_PRE)) {
@@ -786,6 +820,17 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
             for (int q = 0; q < 8; ++q) cs[q] = fmaf(own, Cvt<bf16>::to(Cvt<bf16>::from(v[q])), cs[q]);
           }
           __builtin_amdgcn_sched_barrier(0);       // one row block at a time: interleaved, the blocks' temporaries spill
+        }
+        if constexpr (QKN) {                   // maximum over the 16 rows in fr (DPP), then one atomic maximum per clip and segment
+#define P8_DPP_MAX(x_, ctrl_) x_ = fmaxf(x_, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x_), ctrl_, 0xF, 0xF, true)))
+          P8_DPP_MAX(qm0, 0xB1); P8_DPP_MAX(qm0, 0x4E); P8_DPP_MAX(qm0, 0x141); P8_DPP_MAX(qm0, 0x140);
+          if (qk_split) { P8_DPP_MAX(qm1, 0xB1); P8_DPP_MAX(qm1, 0x4E); P8_DPP_MAX(qm1, 0x141); P8_DPP_MAX(qm1, 0x140); }
+#undef P8_DPP_MAX
+          if (le == 0) {                       // (non-negative floats order as their bit patterns)
+            unsigned* const nt_ = (unsigned*)g.colsum + (long long)qk_c0 * (g.N / 32) + (T.n0 + cl) / 32;
+            atomicMax(nt_, __float_as_uint(qm0));
+            if (qk_split) atomicMax(nt_ + g.N / 32, __float_as_uint(qm1));
+          }
         }
         if (flags & F_COLSUM) {                // rows live in fr (the 16 lanes of a DPP row) and in i (in-lane)
 #pragma unroll
@@ -1000,7 +1045,7 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
     (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<2, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
 #define P8_ATTRF(F_) (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<4, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS); \
   (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_p8_kernel<3, true, F_>, hipFuncAttributeMaxDynamicSharedMemorySize, P8_LDS);
-    P8_ATTRF(P8_FX_FC1_8) P8_ATTRF(P8_FX_FC2D_8) P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R) P8_ATTRF(P8_FX_B) P8_ATTRF(P8_FX_BG) P8_ATTRF(P8_FX_PLAIN)
+    P8_ATTRF(P8_FX_FC1_8) P8_ATTRF(P8_FX_FC2D_8) P8_ATTRF(P8_FX_FC1) P8_ATTRF(P8_FX_FC2D) P8_ATTRF(P8_FX_BR) P8_ATTRF(P8_FX_BRD) P8_ATTRF(P8_FX_R) P8_ATTRF(P8_FX_B) P8_ATTRF(P8_FX_BG) P8_ATTRF(P8_FX_PLAIN) P8_ATTRF(P8_FX_BQ)
 #undef P8_ATTRF
 #undef P8_ATTR
   }
@@ -1012,12 +1057,13 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   // (DACT only qualifies a pre-activation store or a GELU backward: alone it changes nothing)
   const int eff = (g.flags & (F_STORE_PRE | F_GELU_BWD)) ? g.flags : (g.flags & ~F_DACT);
   if (direct && g_a2v_p8_fx && !out32)
-    for (int f : {(int)P8_FX_FC1_8, (int)P8_FX_FC2D_8, (int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R, (int)P8_FX_B, (int)P8_FX_BG})
+    for (int f : {(int)P8_FX_FC1_8, (int)P8_FX_FC2D_8, (int)P8_FX_FC1, (int)P8_FX_FC2D, (int)P8_FX_BR, (int)P8_FX_BRD, (int)P8_FX_R, (int)P8_FX_B, (int)P8_FX_BG, (int)P8_FX_BQ})
       if (eff == f) fx = f;
   if (direct && g_a2v_p8_fx && eff == 0 && !out32) fx = P8_FX_PLAIN;
   const bool fx1 = fx == P8_FX_FC1 || fx == P8_FX_FC1_8;
   for (int ih = (dact_store && direct && !fx1 && !out32) ? 3 : 4; ih >= 2; --ih) {
     if (g_a2v_p8_ih && ih != g_a2v_p8_ih && !(dact_store && direct && !fx1 && g_a2v_p8_ih == 4)) continue;
+    if ((g.flags & F_QKNORM) && ih < 3 && best >= 0) continue;       // (its fixed flavour exists at 256 and 224 rows)
     const int bm = 128 + 32 * ih;
     const long long nt = (long long)cdiv(g.M, bm) * (g.N / 256);
     // what one CU executes = rounds x the time of one tile; a shorter tile is NOT proportionally cheaper (same LDS traffic for B,
@@ -1030,6 +1076,10 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
   // the 8-bit derivative tensor exists in the two fixed flavours only (256- / 224-row tiles): anything else goes to the 128 x 128 kernels
   const bool d8 = (g.flags & F_DACT8) != 0;
   if (d8 && !((fx == P8_FX_FC1_8 || fx == P8_FX_FC2D_8) && best_ih >= 3)) return false;
+  // the row-norm maxima exist in one fixed flavour only, over whole clips of at least a tile's rows; nothing else can honour the flag
+  const bool qkn = (g.flags & F_QKNORM) != 0;
+  if (qkn && !(fx == P8_FX_BQ && best_ih >= 3 && g.colsum && a.T_out >= 256 && g.M % a.T_out == 0 && g.N % 32 == 0)) return false;
+  if (qkn) allow_tail = false;               // (the 128 x 128 kernel that takes a split-off last round does not form them)
   // A last round with few tiles leaves most CUs idle for a whole tile time (M = 768 x 151 kept frames, N = 1024: 7.08 rounds of
   // 256-row tiles -- 12 % of the launch for 1 % of the work).  The rows of that round go to the 128 x 128 LDS-DMA kernel instead: a
   // quarter of the work per tile, spread over four times as many CUs, issued right behind this launch.
@@ -1092,6 +1142,7 @@ static bool p8_launch_impl(const GemmArgs& g, hipStream_t stream, bool out32, bo
     else if (best_ih >= 3 && fx == P8_FX_R) P8_GOF(P8_FX_R)
     else if (best_ih >= 3 && fx == P8_FX_B) P8_GOF(P8_FX_B)
     else if (best_ih >= 3 && fx == P8_FX_BG) P8_GOF(P8_FX_BG)
+    else if (best_ih >= 3 && fx == P8_FX_BQ) P8_GOF(P8_FX_BQ)
     else if (best_ih >= 3 && fx == P8_FX_PLAIN) P8_GOF(P8_FX_PLAIN)
 #undef P8_GOF
     else if (best_ih == 4) P8_GO(4, true); else if (best_ih == 3) P8_GO(3, true); else P8_GO(2, true);

@@ -214,7 +214,13 @@ class Engine:
         N, S, D = x.shape
         eps = self.cfg.norm_eps
         x2 = x.view(N * S, D)
-        qkv = ops.linear(x2, pk.w[prefix + "attn.qkv.weight"], params[prefix + "attn.qkv.bias"])
+        # (long sequences in frame order -- the teacher's 2000 frames, finetuning: the qkv product's epilogue also leaves the row-norm
+        #  maxima the attention forward's ALiBi band limit is made of, ops.linear_qknorm)
+        qkn = None
+        if pos is None and S >= 512 and x.dtype != torch.float32:
+            qkv, qkn = ops.linear_qknorm(x2, pk.w[prefix + "attn.qkv.weight"], params[prefix + "attn.qkv.bias"], S)
+        else:
+            qkv = ops.linear(x2, pk.w[prefix + "attn.qkv.weight"], params[prefix + "attn.qkv.bias"])
         c = self.cfg
         p_att, p_proj, p_mlp, p_act = dp if dp is not None else (c.attention_dropout, c.encoder_dropout, c.post_mlp_drop, 0.0)
 
@@ -226,7 +232,7 @@ class Engine:
         d_att, d_proj, d_mlp = mk(p_att, 0), mk(p_proj, 1), mk(p_mlp, 2)
         d_act1, d_act2 = mk(p_act, 3), mk(p_act, 3, 0x632BE5AB)
         att, lse = ops.attention_fwd(qkv.view(N, S, 3 * D), pos, self.store.alibi_slopes, alibi_scale, H,
-                                     need_lse=save is not None, drop=d_att)
+                                     need_lse=save is not None, drop=d_att, qk_norms=qkn)
         att2 = att.view(N * S, D)        # (the object kept for the backward: in the bf16x3 mode its split image rides on it)
         s1 = ops.linear(att2, pk.w[prefix + "attn.proj.weight"], params[prefix + "attn.proj.bias"], res=x2, drop=d_proj)
         x1, m1, r1 = ops.layernorm_fwd(s1, params[prefix + "norm1.weight"], params[prefix + "norm1.bias"], eps,

@@ -11,7 +11,7 @@ from typing import List, Optional, Sequence
 import torch
 
 from . import _lib
-from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_DACT8, EPI_X3IMG, check
+from ._lib import BF16, BF16X3, BF16X3S, F32, EPI_BIAS, EPI_GELU, EPI_RES, EPI_GELU_BWD, EPI_STORE_PRE, EPI_COLSUM, EPI_DROPOUT, EPI_DACT, EPI_DACT8, EPI_X3IMG, EPI_QKNORM, ERR_UNSUPPORTED, check
 
 
 _HALF = False       # inside half_library(): calls go to liba2v_hip_f16.so, whose 16-bit type is IEEE half (the teacher's forward)
@@ -108,7 +108,8 @@ def _drop(drop):
 # ----------------------------------------------------------------------------------------------
 def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, Cg, Cv=0, a_pitch, a_bstride,
               a_goff=0, rowmask=None, bdiv=1, ldb, b_gstride=0, ldc, c_goff=0, bias=None, res=None, ldr=0,
-              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False, x3=None, x3img=False):
+              gelu=False, gelu_bwd=False, pre_out=None, colsum=None, drop=None, rowidx=None, dact=False, x3=None, x3img=False,
+              qknorm=None):
     """drop = (p, seed) applies dropout to (acc + bias [gelu]) before the residual add.
     rowidx (int32, M entries): GEMM row m reads the im2col row of flat index rowidx[m]; out stays compact.
     x3=True: x and w are bf16 split images (split_bf16), out / res / pre_out fp32 (include/a2v.h: A2V_BF16X3);
@@ -136,6 +137,10 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
         flags |= EPI_DROPOUT
     if x3img:                          # out is the bf16 [hi | lo | hi] image of the result (pitch ldc), include/a2v.h: A2V_EPI_X3IMG
         flags |= EPI_X3IMG
+    if qknorm is not None:             # include/a2v.h: A2V_EPI_QKNORM -- the table rides in the colsum argument
+        assert colsum is None
+        flags |= EPI_QKNORM
+        colsum = qknorm
     dp, ds = (drop if drop is not None and drop[0] > 0 else (0.0, 0))
     dtype_code = dt(x) if x3 is None else (BF16X3S if x3 == "stacked" else BF16X3)
     args = (dtype_code, ptr(x), a_pitch, a_bstride, a_goff, T_in, T_out, stride, pad, taps, Cg, Cv,
@@ -143,6 +148,8 @@ def conv_gemm(x, w, out, *, M, N, K, G=1, T_in, T_out, stride=1, pad=0, taps=1, 
             ptr(res), ldr if res is not None else 0, ptr(bias), ptr(colsum), M, N, K, G, flags,
             dp, ds & 0xFFFFFFFF, stream())
     rc = _L().a2v_conv_gemm(*args) if rowidx is None else _L().a2v_conv_gemm_rows(ptr(rowidx), *args)
+    if qknorm is not None and rc == ERR_UNSUPPORTED:
+        return None                    # (no kernel forms the table for this call: linear_qknorm repeats it without)
     check(rc, "a2v_conv_gemm")
     return out
 
@@ -156,6 +163,7 @@ X3_OUT_IMAGE = os.environ.get("A2V_X3_OUT_IMAGE", "1") != "0"         # the Mlp'
 X3_DH_IMAGE = os.environ.get("A2V_X3_DH_IMAGE", "1") != "0"           # the fc2 input gradient leaves its epilogue as a split image only (A/B switch)
 DROPMASK = os.environ.get("A2V_DROPMASK", "1") != "0"                # attention dropout: forward writes a bit mask, backward reads it (0: both hash)
 X3_ATTN_BWD = os.environ.get("A2V_X3_ATTN_BWD", "1") != "0"          # whole-sequence attention backward with split products (A/B switch)
+QKNORM = os.environ.get("A2V_QKNORM", "1") != "0"                   # the teacher's qkv product also forms the row-norm maxima of its attention's band limit (A/B switch)
 DACT8 = os.environ.get("A2V_DACT8", "1") != "0"     # bf16 mode: the Mlp's kept gelu' in 8 bits (A/B switch; include/a2v.h: A2V_EPI_DACT8)
 X3_WGRAD = False         # the engine of a bf16x3 run switches the weight-gradient products over too (they have no weight operand)
 X3_KEEP = False          # set by the engine during the student's saving forward: operand images stay on the activations for the backward
@@ -288,6 +296,24 @@ def linear(x, w, bias=None, *, out=None, res=None, gelu=False, gelu_bwd_aux=None
     return conv_gemm(x, w, out, M=M, N=N, K=K, T_in=M, T_out=M, Cg=K, a_pitch=x.stride(0), a_bstride=0,
                      ldb=w.stride(0), ldc=out.stride(0), bias=bias, res=r, ldr=r.stride(0) if r is not None else 0,
                      gelu=gelu, gelu_bwd=gelu_bwd_aux is not None, pre_out=pre_out, colsum=colsum, drop=drop, dact=dact)
+
+
+def linear_qknorm(x, w, bias, S):
+    """The qkv Linear of a long-sequence attention layer (x: N clips x S rows, row-major): out = x @ w^T + bias, and -- where the
+    library's persistent GEMM takes the product -- the (N, w.shape[0] / 32) fp32 table of per-clip maxima of the squared norms of the
+    output's 32-column segments (include/a2v.h: A2V_EPI_QKNORM), which attention_fwd(qk_norms=...) turns into its ALiBi band limit
+    instead of reading q and k again.  -> (out, table or None)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if (QKNORM and _L()._a2v_abi >= 14 and x.dtype == w.dtype and dt(x) == BF16 and x.dtype != torch.float32 and bias is not None
+            and M % S == 0 and S >= 512 and N % 256 == 0 and x.stride(1) == 1 and w.stride(1) == 1):
+        out = _E(M, N, dtype=x.dtype, device=w.device)
+        table = torch.zeros(M // S, N // 32, dtype=torch.float32, device=w.device)
+        r = conv_gemm(x, w, out, M=M, N=N, K=K, T_in=S, T_out=S, Cg=K, a_pitch=x.stride(0), a_bstride=S * x.stride(0),
+                      ldb=w.stride(0), ldc=out.stride(0), bias=bias, qknorm=table)
+        if r is not None:
+            return out, table
+    return linear(x, w, bias), None
 
 
 def conv1d_cl(x, w_packed, bias, *, k, stride, pad, groups, T_out, n_out, out=None, rowmask=None, bdiv=1,
@@ -475,7 +501,7 @@ def conv1d_cl_wgrad(x, dy, gw_packed, *, k, stride, pad, groups, T_out, rowmask=
 # ----------------------------------------------------------------------------------------------
 #                                         attention
 # ----------------------------------------------------------------------------------------------
-def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None):
+def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None, qk_norms=None):
     """qkv (N,S,3*H*HD) -> out (N,S,H*HD), lse (2,N,H,S): [0] the log-sum-exp, [1] the mean attended distance
     sum_j P_ij |pos_i - pos_j| of every row (what attention_bwd centres the ALiBi distance on; include/a2v.h)"""
     N, S, W = qkv.shape
@@ -492,8 +518,9 @@ def attention_fwd(qkv, pos, slopes, alibi_scale, H, *, need_lse=True, drop=None)
         words = _L().a2v_attention_dropmask_words(code, S, HD)
         if words:
             dm = _E(N * H * words, dtype=torch.int32, device=qkv.device)
+    abi14 = _L()._a2v_abi >= 14
     rc = _L().a2v_attention_fwd(code, ptr(qkv), ptr(out), ptr(lse), ptr(lse[1]) if need_lse else None, *((ptr(dm),) if abi13 else ()),
-                                ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)), stream())
+                                *((ptr(qk_norms),) if abi14 else ()), ptr(pos), ptr(slopes), ptr(alibi_scale), N, S, H, HD, HD ** -0.5, *(_drop(drop)), stream())
     check(rc, "a2v_attention_fwd")
     if dm is not None:
         lse._a2v_dropmask = dm

@@ -69,6 +69,13 @@ typedef struct ihipStream_t* a2v_stream_t; /* == hipStream_t */
                              * output bytes and a third of the fc2 input-gradient launch's extra input bytes less; the bf16 throughput mode's
                              * default (A2V_DACT8=0 keeps bf16), never used by the fp32 / bf16x3 parity modes.  Other uses: A2V_ERR_UNSUPPORTED */
 
+#define A2V_EPI_QKNORM 1024 /* (ABI 14) dtype A2V_BF16, flags == BIAS | QKNORM, plain Linear products over whole clips (G = 1, taps = 1, T_in = T_out = the
+                             * clip's rows >= 256, M % T_out == 0, a_bstride = T_out * a_pitch, N % 256 == 0): `colsum` is a caller-zeroed
+                             * (M / T_out, N / 32) fp32 table that receives, per clip and 32-column segment of the output, the maximum over the
+                             * clip's rows of the segment's squared norm -- for a qkv product, what a2v_attention_fwd(qk_norms) needs.  Only the
+                             * persistent 256-row kernel forms it: any call it does not take returns A2V_ERR_UNSUPPORTED and has done nothing
+                             * (repeat it without the flag and pass qk_norms = NULL). */
+
 /* ---------------------------------------------------------------- implicit-GEMM (MFMA) family
  * C[m][g*c_goff + n] = epi( sum_kk A_g[m][kk] * Bw[g][n][kk] ),  kk = tap*Cg + ci,
  * A_g[m=(b,t)][kk] = X[b / bdiv][t*stride - pad + tap][g*a_goff + ci]   (0 outside [0,T_in), 0 for
@@ -151,10 +158,15 @@ int a2v_linear_wgrad_pair(int dtype, int M, const void* xa, long long lda, const
  * W u32 words per (n, h) -- N*H*W words, caller-owned like every buffer -- which a2v_attention_bwd reads instead of re-hashing
  * every score (layout: csrc/a2v_attn_seq2.h).  NULL in either call, or W = 0: both calls regenerate the same decisions from the
  * counter hash of (drop_seed, row, key), so a mask-less backward after a masked forward (and vice versa) is still exact. */
+/* qk_norms (ABI 14) or NULL: the (N, 3*H*HD/32) fp32 table the qkv product left through A2V_EPI_QKNORM (HD = 64, bf16, pos = NULL, S >= 512:
+ * the EMA teacher's and the finetune path's full-length sequences).  The forward's ALiBi band limit -- key tiles whose softmax weight is
+ * provably below e^-20 of the row sum are not visited -- needs max_i |q_i|^2 and max_j |k_j|^2 of every (n, h); with the table they come
+ * from the product's accumulators (Cauchy-Schwarz per 32-column segment, two segments per head row: a bound as before), without it
+ * from a pass over q and k.  Ignored where no band limit applies. */
 int a2v_attention_dropmask_words(int dtype, int S, int HD);
-int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, unsigned* dropmask, const int* pos,
-                      const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale, float drop_p,
-                      unsigned drop_seed, a2v_stream_t stream);
+int a2v_attention_fwd(int dtype, const void* qkv, void* out, float* lse, float* mdist, unsigned* dropmask, const float* qk_norms,
+                      const int* pos, const float* slopes, const float* alibi_scale, int N, int S, int H, int HD, float scale,
+                      float drop_p, unsigned drop_seed, a2v_stream_t stream);
 /* delta (N,H,S) fp32 scratch; dqkv receives dK,dV; dalibi (H) fp32 accumulates d loss / d alibi_scale.
  * dQ: when a2v_attention_bwd_direct_dq(dtype, S, HD) is 1 (bf16 with S <= 192 -- the student's kept-token sequences --
  * or bf16 with HD = 64 at any S -- the two-pass long-sequence kernels of the finetune path)
@@ -408,7 +420,8 @@ int a2v_split_bf16(const float* x, void* out, long long M, int K, long long ldx,
 int a2v_maskinfo(const unsigned char* mask, int* ids_keep, int* ids_restore, int* rows_bad, int N, int T, int K,
                  a2v_stream_t stream);
 
-/* 13: a2v_attention_fwd / a2v_attention_bwd take `dropmask` (one more pointer each, after mdist; NULL = the ABI-12 arithmetic); + a2v_attention_dropmask_words;
+/* 14: a2v_attention_fwd takes `qk_norms` (one more pointer, after dropmask; NULL = the ABI-13 behaviour); + epilogue flag A2V_EPI_QKNORM of a2v_conv_gemm.
+ * 13: a2v_attention_fwd / a2v_attention_bwd take `dropmask` (one more pointer each, after mdist; NULL = the ABI-12 arithmetic); + a2v_attention_dropmask_words;
  *     a2v_debug_set key 39 (round-6 whole-sequence attention kernels on / off).
  * 12: + a2v_conv_sparse_in, a2v_conv_wgrad_kept.
  * 11: + epilogue flag A2V_EPI_DACT8 of a2v_conv_gemm; a2v_debug_set keys 30-34 (LayerNorm launch forms); no signature changed.

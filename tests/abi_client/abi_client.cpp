@@ -107,7 +107,7 @@ int main() {
     int* dpos = dev(pos);
     float* dlse = nullptr;
     CK(hipMalloc(&dlse, (size_t)Nb * H * S * 4));
-    A2V(a2v_attention_fwd(A2V_F32, dq, dout, dlse, nullptr, nullptr, dpos, dsl, dasc, Nb, S, H, HD, 1.0f / std::sqrt((float)HD), 0.f, 0u, st));
+    A2V(a2v_attention_fwd(A2V_F32, dq, dout, dlse, nullptr, nullptr, nullptr, dpos, dsl, dasc, Nb, S, H, HD, 1.0f / std::sqrt((float)HD), 0.f, 0u, st));
     CK(hipStreamSynchronize(st));
     CK(hipMemcpy(out.data(), dout, out.size() * 4, hipMemcpyDeviceToHost));
     std::vector<double> ref(out.size());

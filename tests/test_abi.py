@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
         assert len(_lib.SIGNATURES[name]) == nargs, (name, len(_lib.SIGNATURES[name]), nargs)
     assert set(_lib.SIGNATURES) == set(decls)
-    assert lib.a2v_abi_version() == 13
+    assert lib.a2v_abi_version() == 14
 
 
 def test_fp16_twin_library_exports_the_same_abi():
@@ -167,7 +167,7 @@ def test_p8_tile_claim_register_is_untouched_until_its_wait(tmp_path):
         if "ELb1ELi" in m.group(1) and not o32:
             tail0 = [i for i in range(mfma[-1], len(lines)) if lines[i].startswith("s_waitcnt vmcnt(0)")]
             assert len(tail0) <= 5, (m.group(1), len(tail0))
-    assert checked == 29         # three tile heights x (two epilogue forms + the fp32-output form) + ten fixed flavours x two tile heights
+    assert checked == 31         # three tile heights x (two epilogue forms + the fp32-output form) + eleven fixed flavours x two tile heights
     # the fixed-flavour instantiations exist because the generic 256-row epilogue has no registers to spare: none of them may spill
     for m in re.finditer(r"\.amdhsa_kernel (_Z\d+gemm_nt_bf16_p8_kernelILi[34]ELb1ELi([1-9]\d*)E\w*)(.*?)\.end_amdhsa_kernel", s, re.S):
         scratch = int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", m.group(3)).group(1))
@@ -251,7 +251,7 @@ def test_p8_fixed_flavour_seam_wait_is_covered_by_the_epilogue(tmp_path):
         n = _min_vmem_to_back_edge(lines, w8[0])
         assert n is not None and n >= e, (m.group(1), "epilogue issues", n, "certain vector-memory operations, the seam wait assumes", e)
         seen += 1
-    assert seen == 20            # ten fixed flavours x two tile heights
+    assert seen == 22            # eleven fixed flavours x two tile heights
 
 
 def test_conv_dec_counted_fetch_registers_are_untouched_until_their_wait(tmp_path):

@@ -894,6 +894,59 @@ def test_attention_alibi_band_limit_changes_nothing(ops, S):
         assert (l1 - l0).abs().max() < 1e-5, sc
 
 
+@pytest.mark.parametrize("S,nclip", [(512, 4), (600, 4), (2000, 2)])
+def test_linear_qknorm_table_and_band_limit(ops, S, nclip):
+    """ABI 14: the qkv product of a long-sequence layer run with A2V_EPI_QKNORM leaves, per clip and 32-column segment, the maximum over
+    the clip's rows of the segment's squared norm (from the fp32 accumulators, clips that start inside a 256- / 224-row tile included);
+    the output itself is the plain Linear's bit for bit; and the attention forward fed with the table gives the all-tiles result bit
+    for bit, as it does with the bound from its own pass over q and k (test_attention_alibi_band_limit_changes_nothing)."""
+    H, hd, D = 4, 64, 256
+    M, N3 = nclip * S, 3 * H * hd
+    x = dev(rnd(M, D, dtype=torch.bfloat16, seed=5), torch.bfloat16)
+    w = dev(rnd(N3, D, dtype=torch.bfloat16, seed=6) * (1.5 * D ** -0.5), torch.bfloat16)
+    b = dev(rnd(N3, dtype=torch.float32, seed=7) * 0.1, torch.float32)
+    out, table = ops.linear_qknorm(x, w, b, S)
+    assert table is not None, "the persistent kernel must take this product (M >= 1024, N % 256 == 0, K % 128 == 0)"
+    ref = ops.linear(x, w, b)
+    assert torch.equal(out, ref)
+    full = x.float() @ w.float().t() + b
+    want = (full.view(nclip, S, N3 // 32, 32) ** 2).sum(-1).amax(1)
+    assert table.shape == want.shape
+    assert rel_err(table, want) < 1e-4
+    assert ((table - want) / want).abs().max() < 2e-3           # every entry (fp32 sums in another order)
+    # consumer: the bound made of the table (Cauchy-Schwarz per 32-column segment, summed over a head's two segments) is never
+    # below the largest |q_i . k_j| of its (clip, head)
+    qk = full.view(nclip, S, 3, H, hd)
+    t4 = table.view(nclip, 3, H, 2)
+    bnd = (t4[:, 0] * t4[:, 1]).sqrt().sum(-1)                     # (clip, H)
+    scores = torch.einsum("nihd,njhd->nhij", qk[:, :, 0], qk[:, :, 1]).abs().amax((2, 3))
+    assert (bnd >= scores * (1 - 1e-3)).all()
+    slopes = torch.tensor(O.alibi_slopes(H)).cuda()
+    for sc in ([1.0, 1.0, 1.0, 1.0], [40.0, 3.0, 0.0, -1.0]):
+        scd = torch.tensor(sc).cuda()
+        o1, l1 = ops.attention_fwd(out.view(nclip, S, N3), None, slopes, scd, H, need_lse=True, qk_norms=table)
+        ops.debug_set(19, 0)
+        o0, l0 = ops.attention_fwd(out.view(nclip, S, N3), None, slopes, scd, H, need_lse=True)
+        ops.debug_set(19, 1)
+        assert torch.equal(o1, o0), sc
+        assert (l1 - l0).abs().max() < 1e-5, sc
+
+
+def test_linear_qknorm_refused_where_no_kernel_forms_it(ops):
+    """a product the persistent kernel does not take (M < 1024 here) is refused with the flag -- never run without the table -- and
+    ops.linear_qknorm falls back to the plain Linear + the attention's own pass"""
+    x = dev(rnd(2 * 300, 256, dtype=torch.bfloat16, seed=1), torch.bfloat16)
+    w = dev(rnd(768, 256, dtype=torch.bfloat16, seed=2) * 0.1, torch.bfloat16)
+    b = dev(rnd(768, dtype=torch.float32, seed=3), torch.float32)
+    out = torch.empty(600, 768, dtype=torch.bfloat16, device="cuda")
+    table = torch.zeros(2, 24, device="cuda")
+    r = ops.conv_gemm(x, w, out, M=600, N=768, K=256, T_in=300, T_out=300, Cg=256, a_pitch=256, a_bstride=300 * 256, ldb=256, ldc=768,
+                      bias=b, qknorm=table)
+    assert r is None and float(table.abs().max()) == 0.0
+    o2, t2 = ops.linear_qknorm(x, w, b, 300)
+    assert t2 is None and torch.equal(o2, ops.linear(x, w, b))
+
+
 @pytest.mark.parametrize("S,kind,drop", [(2000, "arange", None), (1100, "arange", None), (700, "kept", None), (700, "kept", (0.1, 77)),
                                          (640, "arange", (0.1, 5))])
 def test_attention_fwd32_matches_the_16x16_kernel(ops, S, kind, drop):
