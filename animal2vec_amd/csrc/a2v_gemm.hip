@@ -738,6 +738,7 @@ extern int g_a2v_p8_fx;
 extern int g_a2v_conv_strided;
 extern int g_a2v_p8_tail;
 extern int g_a2v_p8_tmode;
+extern int g_a2v_wgrad_slab_split;
 extern int g_a2v_p8_stagger;
 extern int g_a2v_p8_dynamic;
 extern int g_a2v_attn_long;
@@ -763,6 +764,7 @@ extern "C" int a2v_debug_set(int key, int value) {
   if (key == 20) { g_a2v_p8_fx = value; return A2V_OK; }    // 0: no fixed-flavour p8 epilogues
   if (key == 21) { g_a2v_conv_strided = value; return A2V_OK; }
   if (key == 22) { g_a2v_p8_tail = value; return A2V_OK; }        // persistent NT kernel: nearly empty last round -> 128 x 128 kernel   // dense strided convs on the 8-phase GEMMs on / off
+  if (key == 40) { g_a2v_wgrad_slab_split = value; return A2V_OK; }   // pos-conv weight gradient: kk tiles over two workgroups per CU on / off
   if (key == 23) { g_a2v_p8_tmode = value; return A2V_OK; }   // persistent NT kernel: tile order (0: 8 m-tiles x all n-tiles, 1: W-stationary n-groups)
 #ifdef A2V_W2      // experiment library only (python -m animal2vec_amd.build --variant w2 -DA2V_W2): profiles/r04_w2_experiment.txt
   { extern int g_a2v_gemm_w2; if (key == 25) { g_a2v_gemm_w2 = value; return A2V_OK; } }   // 256 x 128 two-per-CU NT kernel: 0 off, 1 K <= 1024, 2 all

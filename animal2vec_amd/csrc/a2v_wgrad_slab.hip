@@ -31,8 +31,13 @@ __device__ __forceinline__ bf16x8 ws_frag(const char* p) {      // rows r .. r+3
 #define WS_P_BYTES (64 * WS_PITCH)
 #define WS_STAGE (WS_P_BYTES + WS_SLAB_ROWS * WS_PITCH)
 
+// CPW = 5 (round 6 experiment, a2v_debug_set(40, 1); NOT the default): the kk tiles of a 19-20-tap convolution split over TWO workgroups
+// (blockIdx.z = 0 / 1: tiles [z * 40, z * 40 + 40)), 80 accumulator registers per lane instead of 160, two workgroups per CU (4 waves
+// per SIMD), so that one's staging / barrier / restart runs under the other's MFMAs.  Measured: SLOWER -- 488 -> 543 us per launch at
+// 96 x 2000 rows, whole step -0.5 % (tools/gpu/r06_wgs.sh): each A fragment now feeds 5 kk tiles instead of 10 (LDS reads per MFMA
+// +29 %), both workgroups stage the same tiles, and 128 registers cost a spilled pointer reloaded in the step loop.
 template <int CPW, bool MASKED>
-__global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int clips_per_unit) {
+__global__ __launch_bounds__(512, CPW == 5 ? 4 : 1) void conv_wgrad_slab_kernel(WgradArgs g, int clips_per_unit) {
   __shared__ __attribute__((aligned(16))) char smem[2 * WS_STAGE];
   if (g.skip_if && *g.skip_if) return;                   // (launched behind conv_wgrad_sparse_kernel: only runs if that one could not)
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
 
   const int gq = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
   const int lane_base = (8 * gq + q) * WS_PITCH + 8 * p;
-  const int ct0 = wid * CPW;
+  const int ct0 = wid * CPW + (int)blockIdx.z * 8 * CPW;
   for (int st = 0; st < nsteps; ++st) {
     const int buf = st & 1;
     // (unconditional, the last step re-fetches itself: with the loads and their consuming stores behind `if (st + 1 < nsteps)` the
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
   const int fr = lane & 15, fq = lane >> 4;
 #pragma unroll
   for (int j = 0; j < CPW; ++j) {
-    const int c = wid * CPW + j;
+    const int c = wid * CPW + (int)blockIdx.z * 8 * CPW + j;
     if (c >= CT) continue;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -192,6 +197,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_slab_kernel(WgradArgs g, int c
   }
 }
 
+int g_a2v_wgrad_slab_split = 0;     // a2v_debug_set(40, v): 19-20 taps: kk tiles split over two workgroups per CU (0: one workgroup, all tiles)
 bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
   if (a.Cg != 64 || a.stride != 1 || a.T_in != a.T_out || a.taps < 2 || a.taps > 20 || g.N > 64 || g.N % 8 || a.Cv % 8 ||
@@ -207,6 +213,10 @@ bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream) {
   if (a.taps * 4 <= 32) {
     if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<4, true>), grid, dim3(512), 0, stream, g, cpu);
     else hipLaunchKernelGGL((conv_wgrad_slab_kernel<4, false>), grid, dim3(512), 0, stream, g, cpu);
+  } else if (g_a2v_wgrad_slab_split) {
+    const dim3 grid2(units, g.G, 2);
+    if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<5, true>), grid2, dim3(512), 0, stream, g, cpu);
+    else hipLaunchKernelGGL((conv_wgrad_slab_kernel<5, false>), grid2, dim3(512), 0, stream, g, cpu);
   } else {
     if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<10, true>), grid, dim3(512), 0, stream, g, cpu);
     else hipLaunchKernelGGL((conv_wgrad_slab_kernel<10, false>), grid, dim3(512), 0, stream, g, cpu);
