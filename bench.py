@@ -311,6 +311,26 @@ def _cpu_leg(model_name, L, K, threads, budget_s):
     print(json.dumps(dict(threads=threads, warmup_s=round(warm, 3), runs_s=[round(t, 3) for t in times])), flush=True)
 
 
+def _host_memory_available():
+    """bytes this process may still allocate: min(MemAvailable, cgroup limit - cgroup usage)"""
+    avail = float("inf")
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = float(ln.split()[1]) * 1024
+    except OSError:
+        pass
+    for lim, cur in (("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory.current"),
+                     ("/sys/fs/cgroup/memory/memory.limit_in_bytes", "/sys/fs/cgroup/memory/memory.usage_in_bytes")):
+        try:
+            l_ = open(lim).read().strip()
+            if l_ != "max":
+                avail = min(avail, float(l_) - float(open(cur).read().strip()))
+        except (OSError, ValueError):
+            pass
+    return avail if avail != float("inf") else 0.0
+
+
 def cpu_baseline(model_name, L, K, sample_rate=8000, thread_legs=(16, 32, 64), procs=4, leg_timeout=90):
     """The oracle timed on this box's host cores (SURVEY 8d / BASELINE.md 4: 1 warm-up + median of 3, thread counts stated).
     Legs, each a child process so that torch's thread pool is sized before anything runs and the leg is bounded:
@@ -351,8 +371,10 @@ def cpu_baseline(model_name, L, K, sample_rate=8000, thread_legs=(16, 32, 64), p
             legs.append(dict(threads=threads, audio_s_per_s=None, note=f"no timed run finished within {leg_timeout} s"))
         except Exception as e:                                   # a failed leg must not lose the GPU measurement
             legs.append(dict(threads=threads, audio_s_per_s=None, note=f"leg failed: {type(e).__name__}: {e}"))
-    # ---- k processes x 16 threads, one clip each, at the same time
-    k = max(1, min(procs, ncpu // 16))
+    # ---- k processes x 16 threads, one clip each, at the same time (13 GB resident each at the large model: k is also bounded by
+    # the memory this process may use -- MemAvailable and the cgroup's limit -- at 20 GB per process, so that a wider leg asked for
+    # with --cpu-procs can never take the bench itself down)
+    k = max(1, min(procs, ncpu // 16, int(_host_memory_available() // (20 << 30)) or 1))
     if k > 1:
         try:
             ps = [subprocess.Popen(cmd(16, 25.0), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env(16)) for _ in range(k)]
@@ -553,6 +575,8 @@ def main():
                     help="dtype of the gradient buckets on the links (ddp.GradSync): bf16 halves the all-reduce bytes, as the reference's "
                          "fp16 recipe does, for two conversion passes over the flat gradient; fp32 (default) reduces the buffer in place")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
+    ap.add_argument("--cpu-procs", type=int, default=4, help="concurrent one-clip oracle processes x 16 threads of the cpu_baseline leg "
+                    "(bounded by cores / 16 and by the host memory this process may use; 16 = the whole 256-core host, about a minute longer)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--parity-leg", default="auto", choices=["auto", "skip"],
                     help="auto: also time the fp32 parity mode on a bounded sample (rank 0 at N = 1) -> `parity_mode` in the line")
@@ -743,7 +767,8 @@ def main():
             "roofline": roof,
         }
         if args.cpu_baseline == "auto" and world == 1:
-            line["cpu_baseline"] = cpu_baseline(args.model, L, K, cfg.audio.sample_rate)
+            line["cpu_baseline"] = cpu_baseline(args.model, L, K, cfg.audio.sample_rate, procs=args.cpu_procs,
+                                                leg_timeout=90 if args.cpu_procs <= 4 else 240)
         else:
             line["cpu_baseline"] = None
         # the mode that carries the north-star's 1e-3 (the bf16 headline above is held to bf16-level bounds), timed on a
