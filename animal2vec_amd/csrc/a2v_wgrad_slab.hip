@@ -31,7 +31,7 @@ __device__ __forceinline__ bf16x8 ws_frag(const char* p) {      // rows r .. r+3
 #define WS_P_BYTES (64 * WS_PITCH)
 #define WS_STAGE (WS_P_BYTES + WS_SLAB_ROWS * WS_PITCH)
 
-// CPW = 5 (round 6 experiment, a2v_debug_set(40, 1); NOT the default): the kk tiles of a 19-20-tap convolution split over TWO workgroups
+// CPW = 5 (round 6 experiment: builds with -DA2V_WGRAD_SPLIT + a2v_debug_set(40, 1); not in the product library): the kk tiles of a 19-20-tap convolution split over TWO workgroups
 // (blockIdx.z = 0 / 1: tiles [z * 40, z * 40 + 40)), 80 accumulator registers per lane instead of 160, two workgroups per CU (4 waves
 // per SIMD), so that one's staging / barrier / restart runs under the other's MFMAs.  Measured: SLOWER -- 488 -> 543 us per launch at
 // 96 x 2000 rows, whole step -0.5 % (tools/gpu/r06_wgs.sh): each A fragment now feeds 5 kk tiles instead of 10 (LDS reads per MFMA
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(512, CPW == 5 ? 4 : 1) void conv_wgrad_slab_kernel(
   }
 }
 
-int g_a2v_wgrad_slab_split = 0;     // a2v_debug_set(40, v): 19-20 taps: kk tiles split over two workgroups per CU (0: one workgroup, all tiles)
+int g_a2v_wgrad_slab_split = 0;     // a2v_debug_set(40, v), -DA2V_WGRAD_SPLIT builds only: 19-20 taps: kk tiles split over two workgroups per CU
 bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream) {
   const ConvA& a = g.a;
   if (a.Cg != 64 || a.stride != 1 || a.T_in != a.T_out || a.taps < 2 || a.taps > 20 || g.N > 64 || g.N % 8 || a.Cv % 8 ||
@@ -213,10 +213,12 @@ bool a2v_launch_wgrad_slab(const WgradArgs& g, hipStream_t stream) {
   if (a.taps * 4 <= 32) {
     if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<4, true>), grid, dim3(512), 0, stream, g, cpu);
     else hipLaunchKernelGGL((conv_wgrad_slab_kernel<4, false>), grid, dim3(512), 0, stream, g, cpu);
+#ifdef A2V_WGRAD_SPLIT     /* experiment builds only (python -m animal2vec_amd.build --variant wgs -DA2V_WGRAD_SPLIT): the 128-register form spills */
   } else if (g_a2v_wgrad_slab_split) {
     const dim3 grid2(units, g.G, 2);
     if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<5, true>), grid2, dim3(512), 0, stream, g, cpu);
     else hipLaunchKernelGGL((conv_wgrad_slab_kernel<5, false>), grid2, dim3(512), 0, stream, g, cpu);
+#endif
   } else {
     if (a.rowmask) hipLaunchKernelGGL((conv_wgrad_slab_kernel<10, true>), grid, dim3(512), 0, stream, g, cpu);
     else hipLaunchKernelGGL((conv_wgrad_slab_kernel<10, false>), grid, dim3(512), 0, stream, g, cpu);
