@@ -127,6 +127,7 @@ def test_cpu_baseline_median_and_best_leg(monkeypatch):
     monkeypatch.setattr(subprocess, "run", fake_run)
     monkeypatch.setattr(subprocess, "Popen", FakePopen)
     monkeypatch.setattr(os, "cpu_count", lambda: 256)
+    monkeypatch.setattr(bench, "_host_memory_available", lambda: float(1 << 40))
     c = bench.cpu_baseline("large", 80000, 152)
     assert [l["threads"] for l in c["legs"]] == [16, 32, 64, 64] and c["legs"][2]["audio_s_per_s"] is None
     assert abs(c["legs"][0]["audio_s_per_s"] - 10.0 / 9.0) < 1e-3 and abs(c["legs"][1]["audio_s_per_s"] - 1.25) < 1e-3
@@ -134,6 +135,12 @@ def test_cpu_baseline_median_and_best_leg(monkeypatch):
     assert multi["processes"] == 4 and abs(multi["audio_s_per_s"] - 4.0) < 1e-3
     assert c["value"] == multi["audio_s_per_s"] and c["cores"] == 64 and c["host_cores"] == 256 and c["kind"] == "port"
     assert "warm-up" in c["sample"] and "median" in c["sample"]
+    # the concurrent leg is bounded by the memory the process may use (20 GB per oracle process): --cpu-procs 16 on a 256-core host
+    # with 50 GB to spare runs two
+    monkeypatch.setattr(bench, "_host_memory_available", lambda: 50.0 * (1 << 30))
+    c2 = bench.cpu_baseline("large", 80000, 152, procs=16)
+    assert c2["legs"][3]["processes"] == 2 and c2["legs"][3]["threads"] == 32
+    monkeypatch.setattr(bench, "_host_memory_available", lambda: float(1 << 40))
     # a small host: thread legs collapse to what exists, no multi-process leg
     monkeypatch.setattr(os, "cpu_count", lambda: 8)
     per_thread_median[8] = 20.0
