@@ -337,7 +337,11 @@ int a2v_dropout_mask2d(unsigned char* keep, long long rows, int cols, float drop
  *   35 launch order of the grouped-conv kernels: bit 0 conv_nt_slab2_kernel group-fastest, bit 2 conv_dec_kernel halves together
  *      (round-5 experiment, no gain: profiles/r05_conv_order_ab.txt; default 0)
  *   37 row-sparse weight gradients of the positional encoder's first / last layer (a2v_wgrad_sparse.hip) on (1, default) / off (0)
- *   38 conv_dec_kernel: 64-row blocks per workgroup (0 auto: 32, fewer for small batches)
+ *   38 conv_dec_kernel work order (round 6): 0 (default) the 64-row blocks of the whole tensor as one in-order front, one workgroup per
+ *      CU; v > 0: v workgroups per channel slice; -1 the older order (a workgroup owns 32 consecutive blocks)
+ *   39 whole-sequence bf16 attention for S <= 160 (round 6, a2v_attn_seq2.h): 1 (default) the persistent ten-wave kernels for
+ *      S = 145 .. 160, 2 for every S <= 160, 0 the round-5 kernels
+ *   40 experiment builds with -DA2V_WGRAD_SPLIT only: pos-conv weight gradient with its kk tiles over two workgroups per CU
  *   36 bf16 attention forward for S >= 512, head dimension 64: the 32 x 32 x 16 MFMA kernel of round 5 (1, default) / the
  *      16 x 16 x 32 kernel (0)
  *   (19 also switches the bf16x3 attention forward's band limit, round 4)
