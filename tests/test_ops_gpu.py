@@ -1873,6 +1873,15 @@ def test_conv_decoder_kernel(ops, B, T, CI, CO):
     assert rel_err(dx.float(), xr.grad.transpose(1, 2) + res) < tol(dtype, 2)
     # K is accumulated as (tap, channel) here and as tap-major 64-wide steps there: same products, fp32 sums in another order
     assert rel_err(y.float(), y0.float()) < 4e-3 and rel_err(dx.float(), dx0.float()) < 4e-3
+    # the work order does not touch the arithmetic: the in-order front with three workgroups per channel slice (a workgroup then
+    # walks several blocks of different clips, stride 3) and the older order (a workgroup owns consecutive blocks) give the same bits
+    for order in (3, -1):
+        lib.a2v_debug_set(38, order)
+        try:
+            yo, dxo = run()
+        finally:
+            lib.a2v_debug_set(38, 0)
+        assert torch.equal(yo, y) and torch.equal(dxo, dx), order
 
 
 # ------------------------------------------------------------------------------------------ bf16x3 parity mode
