@@ -2,8 +2,9 @@
 //
 //     W[n][kk] += sum_m dY[m][n] * X[m][kk]        (fp32 accumulate into the flat gradient buffer)
 //
-// Same machine as a2v_gemm_p8.hip (8 waves, 4 phases per 64-row K-tile, one LDS-DMA half-tile per phase, counted
-// vmcnt(6), persistent stream across work units) with the reduction running over ROWS: both operands are staged
+// Same machine as a2v_gemm_p8.hip (8 waves, LDS-DMA half-tiles, counted vmcnt(6), persistent stream across work units) -- since round 6
+// with TWO phases of 32 MFMAs per 64-row K-tile on 64 x 64 wave tiles (half the fragment reads of the four-phase form) -- with the
+// reduction running over ROWS: both operands are staged
 // row-major as [64 m][128 cols] half-tiles (256-B rows, 32-B blocks XOR-swizzled by f(m) = (m & 3) | ((m >> 3) & 1) << 2,
 // the swizzle applied to the LDS-DMA source address) and every MFMA fragment is a ds_read_b64_tr_b16 pair.
 // A work unit is (output tile, M chunk); units = tiles x ceil(CUs / tiles), a unit's result leaves with fp32
@@ -108,14 +109,18 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
   const int f = q | ((gq & 1) << 2);
   const int lds0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
   const int rowb = lds0 + (8 * gq + q) * 256 + 8 * p;
-  int pa[4], qa[2];
+  // Wave (wr, wc) owns rows (n) ha * 128 + wr * 64 + [0, 64) of both A halves and columns (kk) wc * 64 + [0, 64): ONE Q half (lo for wc < 2,
+  // hi above), whose eight fragments are read once per K-tile and kept across both phases; a 64 x 64 wave tile takes 8 fragments per 16
+  // MFMAs where the 64 x 32 tile of the four-phase form took 12 -- 24 instead of 48 fragments (48 instead of 96 ds_read_b64_tr_b16) per
+  // wave and K-tile.
+  int pa[4], qa[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) pa[i] = rowb + (((wr * 4 + i) ^ f) << 5);
 #pragma unroll
-  for (int j = 0; j < 2; ++j) qa[j] = rowb + (((wc * 2 + j) ^ f) << 5);
+  for (int j = 0; j < 4; ++j) qa[j] = rowb + ((((wc & 1) * 4 + j) ^ f) << 5) + (wc >> 1) * (T8_QHI - T8_QLO);
 
   f32x4 acc[8][4];
-  bf16x8 fa[4][2], fbl[2][2], fbh[2][2];
+  bf16x8 fa[4][2], fb[4][2];
   typedef __attribute__((ext_vector_type(2))) int t8_i2;
 #define T8_FRAG(dst, addr, off)                                                                          \
   {                                                                                                      \
@@ -132,43 +137,40 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
     const int ad_ = (cur) ? pa[i] + T8_BUF : pa[i];                                                      \
     T8_FRAG(fa[i][0], ad_, (half_off)) T8_FRAG(fa[i][1], ad_, (half_off) + 8192)                         \
   }
-#define T8_READ_B(fb, cur, half_off)                                                                     \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+#define T8_READ_B(cur)                                                                                   \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                        \
     const int ad_ = (cur) ? qa[j] + T8_BUF : qa[j];                                                      \
-    T8_FRAG(fb[j][0], ad_, (half_off)) T8_FRAG(fb[j][1], ad_, (half_off) + 8192)                         \
+    T8_FRAG(fb[j][0], ad_, T8_QLO) T8_FRAG(fb[j][1], ad_, T8_QLO + 8192)                                 \
   }
-#define T8_TIE4(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1])
-#define T8_LGKM0                                                                                         \
-  asm volatile("s_waitcnt lgkmcnt(0)"                                                                    \
-               : T8_TIE4(fa), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), T8_TIE4(fbl), T8_TIE4(fbh));
-#define T8_MFMA(ibase, jbase, fb)                                                                        \
+#define T8_TIE8(x) "+v"(x[0][0]), "+v"(x[0][1]), "+v"(x[1][0]), "+v"(x[1][1]), "+v"(x[2][0]), "+v"(x[2][1]), "+v"(x[3][0]), "+v"(x[3][1])
+#define T8_LGKM0 asm volatile("s_waitcnt lgkmcnt(0)" : T8_TIE8(fa), T8_TIE8(fb));
+#define T8_MFMA(ibase)                                                                                   \
   T8_LGKM0            /* before the barrier: the other wave group may re-stage what was just read one phase later */ \
   __builtin_amdgcn_s_barrier();                                                                          \
   __builtin_amdgcn_s_setprio(1);                                                                         \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                       \
   _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                          \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                          \
-    if (T8_EXP != 1) acc[(ibase) + i][(jbase) + j] =                                                     \
-        A2V_MFMA_16x16x32(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                          \
+    if (T8_EXP != 1) acc[(ibase) + i][j] = A2V_MFMA_16x16x32(fa[i][ks], fb[j][ks], acc[(ibase) + i][j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                         \
   __builtin_amdgcn_s_barrier();
 
   // one K-tile held in buffer `cur`; U1 / k1: unit and K index of the K-tile after it (P_hi goes to `oth`),
   // U2 / k2: of the one after that (P_lo, Q_lo, Q_hi re-stage `cur`)
+  // (two phases of 32 MFMAs per wave: phase 1 = P_lo x this wave's Q half, phase 2 = P_hi x the same Q fragments.  P_lo, Q_lo and Q_hi
+  //  are dead behind phase 1's "reads done" barrier and are re-staged for K-tile t + 2 during phase 2; P_hi of K-tile t + 1 goes to the
+  //  other buffer during phase 1.  The counted wait leaves the six DMAs of phase 2 in flight.)
 #define T8_KTILE(cur, oth, U1, k1, U2, k2)                                                               \
-  T8_READ_B(fbl, cur, T8_QLO)                                                                            \
+  T8_READ_B(cur)                                                                                         \
   T8_READ_A(cur, T8_PLO)                                                                                 \
   T8_STAGE(pb, ldp2, U1, k1, 1, (oth) + T8_PHI)                                      \
-  T8_MFMA(0, 0, fbl)                                                                                     \
-  T8_READ_B(fbh, cur, T8_QHI)                                                                            \
-  T8_STAGE(pb, ldp2, U2, k2, 0, (cur) + T8_PLO)                                      \
-  T8_MFMA(0, 2, fbh)                                                                                     \
+  T8_MFMA(0)                                                                                             \
   T8_READ_A(cur, T8_PHI)                                                                                 \
+  T8_STAGE(pb, ldp2, U2, k2, 0, (cur) + T8_PLO)                                      \
   T8_STAGE(qb, ldq2, U2, k2, 0, (cur) + T8_QLO)                                      \
-  T8_MFMA(4, 2, fbh)                                                                                     \
   T8_STAGE(qb, ldq2, U2, k2, 1, (cur) + T8_QHI)                                      \
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                                       \
-  T8_MFMA(4, 0, fbl)
+  T8_MFMA(4)
 
   int seq = blockIdx.x;
   T8Unit U = make_unit(seq);
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
     int le;                                          // (again from the hardware: lane-derived addresses stay out of the K loop's live set)
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(le));
     const int fre = le & 15, fqe = le >> 4;
-    float* const wt = U.wb + (long long)(wr * 64 + fqe * 4) * U.ldw + wc * 32 + fre;
+    float* const wt = U.wb + (long long)(wr * 64 + fqe * 4) * U.ldw + wc * 64 + fre;
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
@@ -219,11 +221,9 @@ __global__ __launch_bounds__(512) void gemm_tn_bf16_p8_kernel(T8Args g, int chun
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-          for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              if (T8_EXP != 4) atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * U.ldw + hb * 128 + j * 16, acc[ha * 4 + i][hb * 2 + j][r]);
-              else asm volatile("" :: "v"(acc[ha * 4 + i][hb * 2 + j][r]));
+          for (int j = 0; j < 4; ++j)
+            if (T8_EXP != 4) atomicAdd(wt + (long long)(ha * 128 + i * 16 + r) * U.ldw + j * 16, acc[ha * 4 + i][j][r]);
+            else asm volatile("" :: "v"(acc[ha * 4 + i][j][r]));
     U = Un;
   }
   if (stagger && wr == 0) __builtin_amdgcn_s_barrier();         // pairs with the wr = 1 group's last barrier
