@@ -268,16 +268,27 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #define P8_LGKM0                                                                                        \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                  \
                : P8_TIE4(fa), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]), P8_TIE4(fbl), P8_TIE4(fbh));
-#define P8_MFMA(ibase, jbase, fb, NI)                                                                  \
-  P8_LGKM0            /* before the barrier: the other wave group may re-stage what was just read one phase later */ \
-  __builtin_amdgcn_s_barrier();                                                                        \
-  __builtin_amdgcn_s_setprio(1);                                                                       \
+#define P8_MFMA_BODY(ibase, jbase, fb, NI)                                                             \
   _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                     \
   _Pragma("unroll") for (int i = 0; i < (NI); ++i)                                                     \
   _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                        \
     acc[(ibase) + i][(jbase) + j] = DS                                                                 \
         ? A2V_MFMA_16x16x32(fb[j][ks], fa[i][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0) \
-        : A2V_MFMA_16x16x32(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0); \
+        : A2V_MFMA_16x16x32(fa[i][ks], fb[j][ks], acc[(ibase) + i][(jbase) + j], 0, 0, 0);
+#define P8_MFMA(ibase, jbase, fb, NI)                                                                  \
+  P8_LGKM0            /* before the barrier: the other wave group may re-stage what was just read one phase later */ \
+  __builtin_amdgcn_s_barrier();                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                       \
+  P8_MFMA_BODY(ibase, jbase, fb, NI)                                                                   \
+  __builtin_amdgcn_s_setprio(0);                                                                       \
+  __builtin_amdgcn_s_barrier();
+// both B halves' fragments against one A half: 32 MFMAs between one pair of barriers (P8_TWO_PHASE)
+#define P8_MFMA2(ibase, NI)                                                                            \
+  P8_LGKM0                                                                                             \
+  __builtin_amdgcn_s_barrier();                                                                        \
+  __builtin_amdgcn_s_setprio(1);                                                                       \
+  P8_MFMA_BODY(ibase, 0, fbl, NI)                                                                      \
+  P8_MFMA_BODY(ibase, 2, fbh, NI)                                                                      \
   __builtin_amdgcn_s_setprio(0);                                                                       \
   __builtin_amdgcn_s_barrier();
 
@@ -292,6 +303,7 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
 #define P8_BH1(T_) (DS ? T_.bh0 + d64b_ : T_.bh1)
 // PH1 = the phase-1 stage of A_hi(T1, k1) (absent in a tile's first K-tile: staged before the seam, below), PH4X = an extra stage in
 // phase 4 (the seam's last K-tile), WAITN = the counted wait of phase 4.
+#ifndef P8_TWO_PHASE
 #define P8_KTILE_X(cur, oth, T1, k1, T2, k2, PH1, PH4X, WAITN)                                          \
   unsigned d64a_ = d64a, d64b_ = d64b;                                                                 \
   asm volatile("" : "+s"(d64a_), "+s"(d64b_));                                                         \
@@ -314,6 +326,26 @@ __global__ __launch_bounds__(512) void gemm_nt_bf16_p8_kernel(GemmArgs g, int st
   PH4X                                                                                                 \
   asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");                                        \
   P8_MFMA(4, 0, fbl, IH)
+#else
+// Experiment builds (-DP8_TWO_PHASE): two phases of 32 MFMAs -- the lower A half, then the upper one, each against the fragments of BOTH B
+// halves (read once, in phase 1) -- with the four-phase form's column ownership and epilogue (profiles/r06_nt_two_phase.txt)
+#define P8_KTILE_X(cur, oth, T1, k1, T2, k2, PH1, PH4X, WAITN)                                          \
+  unsigned d64a_ = d64a, d64b_ = d64b;                                                                 \
+  asm volatile("" : "+s"(d64a_), "+s"(d64b_));                                                         \
+  P8_READ_B(fbl, cur, P8_BLO)                                                                          \
+  P8_READ_B(fbh, cur, P8_BHI)                                                                          \
+  __builtin_amdgcn_sched_barrier(0);                                                                   \
+  P8_READ_A(cur, P8_ALO)                                                                               \
+  PH1                                                                                                  \
+  P8_MFMA2(0, 4)                                                                                       \
+  P8_READ_AH(cur)                                                                                      \
+  P8_STAGE(abase, T2.al0, P8_AL1(T2), k2, (cur) + P8_ALO)                                              \
+  P8_STAGE(bbase, T2.bl0, P8_BL1(T2), k2, (cur) + P8_BLO)                                              \
+  P8_STAGE(bbase, T2.bh0, P8_BH1(T2), k2, (cur) + P8_BHI)                                              \
+  PH4X                                                                                                 \
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");                                        \
+  P8_MFMA2(4, IH)
+#endif
 #define P8_KTILE(cur, oth, T1, k1, T2, k2) \
   P8_KTILE_X(cur, oth, T1, k1, T2, k2, P8_STAGE2(abase, T1.ah0, P8_AH1(T1), k1, (oth) + P8_AHI, ah_second), , 6)
 // The tile seam and vmcnt.  Loads, stores, atomics and LDS-DMA retire through ONE in-order counter, so a counted wait for a DMA
